@@ -1,0 +1,870 @@
+// cat_amd/csrc/crf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the CTC-CRF loss and
+// the C-ABI entry point that launches them.  No MFMA: this is a sparse sum-product recursion.
+//
+// What is computed (semantics of the reference):
+//   denominator  den_calculate.cu:63-261   alpha/beta over the den graph, logZ, arc posteriors -> labels
+//   numerator    gpu_ctc_kernels.h:87-458  CTC alpha/beta on log-probs (blank 0), label posteriors
+//   combine      ctc_crf/__init__.py:78-87 grad = c_den*gamma_den - c_ctc*gamma_ctc, loss likewise
+//
+// How (the MI355X design):
+//   * arithmetic is LINEAR domain with an exact per-frame power-of-two rescale (integer exponent
+//     bookkeeping) instead of per-arc log1p(exp()) (den_calculate.cu:29-35): no transcendental in
+//     any recursion, the only exp() is one per (b,t,v) in crf_prep_kernel.
+//   * 3 launches instead of ~3T+7 (den_calculate.cu:443-476): prep -> chains -> grad (+ finalize).
+//   * crf_chain_kernel<ROLE> runs the FOUR independent recursions of every utterance (den forward,
+//     den backward, ctc forward, ctc backward) as concurrent persistent workgroups on forked HIP
+//     streams, one workgroup (one CU) per utterance and recursion, the whole time loop in-kernel, state vectors in LDS, arcs streamed as coalesced 16-byte ELL elements.
+//   * the den graph is factored through "pairs" p = (destination state, label):
+//       forward   q_t[p]   = sum_{arcs k in p} a_t[src_k] * w_k          (one LDS gather + FMA per arc)
+//                 a_{t+1}[dst_p] += e_t[lab_p] * q_t[p]                   (one LDS atomic per pair)
+//       backward  b_t[s]   = sum_{arcs k out of s} w_k * z_t[pair_k],  z_t[p] = e_t[lab_p]*b_{t+1}[dst_p]
+//     so the per-arc work has no label lookup, and the posterior needs no arc pass at all:
+//       gamma_den[t][v] = e_t[v] * sum_{p: lab_p = v} q_t[p] * b_{t+1}[dst_p] / Z
+//     (crf_grad_kernel: two coalesced streams q_t, b_{t+1}[dst_p] -- the "algorithmic bytes").
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+
+#include "../../include/ctc_crf_hip.h"
+#include "crf_internal.h"
+
+namespace crf {
+
+constexpr int kEpRegs = 8;    // ep row prefetch registers per thread  -> V  <= 8 * 1024
+constexpr int kCtcRegs = 4;   // ctc states per thread                  -> 2L+1 <= 4 * 1024
+constexpr int kGradThreads = 256;
+constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
+
+struct LossParams {
+    GraphDev g;
+    const float *logp;
+    const int *labels, *lab_off, *lx, *ly;
+    int B, T, V;
+    int Sc;       // row stride of the ctc per-frame stores: 2*max_label_len+1 rounded up to 64
+    float c_den, c_ctc;
+    // workspace
+    float *ep, *mx;               // [B*T*V] exp(logp - mx), [B*T] row max
+    float *Q, *BP;                // [B*T*Pr] q_t[p], b_{t+1}[dst_p]  (scaled)
+    int *EQ, *EB;                 // [B*T] their binary exponents
+    float *CA, *CB;               // [B*T*Sc] ctc forward (incl. emission) / backward (excl.)  (scaled)
+    int *ECA, *ECB;
+    float *den_zs, *ctc_zc;       // [B] scaled partition sums
+    int *den_ez, *ctc_ez;         // [B] their exponents
+    float *cost_alpha, *cost_beta, *cost_ctc;  // [B]
+    int *invalid;                 // [B]
+    // outputs
+    float *grad, *loss, *out_den, *out_beta, *out_ctc;
+    int *out_invalid;
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// exact power-of-two rescale that brings m into [2^kScaleExp, 2^(kScaleExp+1))
+__device__ __forceinline__ int rescale_exp(float m) {
+    if (!(m > 0.f)) return 0;
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+    int k = kScaleExp - e;
+    return k < -100 ? -100 : (k > 100 ? 100 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
+
+// ---------------------------------------------------------------------------------------------
+// prep: e[b][t][v] = exp(logp[b][t][v] - max_v), mx[b][t] = max_v   (one wave per frame)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= (int64_t)p.B * p.T) return;
+    const int b = (int)(f / p.T), t = (int)(f % p.T);
+    if (t >= p.lx[b]) return;
+    const float *row = p.logp + f * p.V;
+    float m = -INFINITY;
+    for (int v = lane; v < p.V; v += 64) m = fmaxf(m, row[v]);
+    m = wave_max(m);
+    if (m == -INFINITY) m = 0.f;
+    float *er = p.ep + f * p.V;
+    for (int v = lane; v < p.V; v += 64) er[v] = expf(row[v] - m);
+    if (lane == 0) p.mx[f] = m;
+}
+
+// block-wide helpers for the 1024-thread chain workgroups --------------------------------------
+__device__ __forceinline__ float block_sum(float v, float *red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kChainWaves; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ double block_sum_d(double v, double *red, int tid) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < kChainWaves; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ double mx_total(const LossParams &p, int b, int lx, double *red, int tid) {
+    double part = 0.0;
+    for (int t = tid; t < lx; t += kChainThreads) part += (double)p.mx[(int64_t)b * p.T + t];
+    return block_sum_d(part, red, tid);
+}
+__device__ __forceinline__ float frame_max(const float *wm) {
+    float m = wm[0];
+#pragma unroll
+    for (int i = 1; i < kChainWaves; ++i) m = fmaxf(m, wm[i]);
+    return m;
+}
+__device__ __forceinline__ float to_log(float zs, int e, double mxs) {
+    return zs > 0.f ? (float)(log((double)zs) - (double)e * 0.6931471805599453 + mxs) : -INFINITY;
+}
+
+// LDS carve (floats) shared by host sizing and the kernels
+__host__ __device__ inline int rup64(int x) { return (x + 63) & ~63; }
+
+// ---------------------------------------------------------------------------------------------
+// denominator forward.  LDS: X[3][Sp] | EP[2][Vp] | wmax[2][16] | red (16 doubles)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void den_forward(const LossParams &p, int b, float *lds) {
+    const GraphDev &g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = g.S, V = p.V, Pr = g.Pr, lx = p.lx[b];
+    const int Sp = rup64(S), Vp = rup64(V);
+    float *X = lds;
+    float *EP = X + 3 * Sp;
+    float *wm = EP + 2 * Vp;
+    double *red = (double *)(wm + 2 * kChainWaves);
+    const int64_t bt0 = (int64_t)b * p.T;
+
+    for (int s = tid; s < 3 * Sp; s += kChainThreads) X[s] = (s < S) ? g.start_lin[s] * pow2f(kScaleExp) : 0.f;
+    if (lx > 0)
+        for (int v = tid; v < V; v += kChainThreads) EP[v] = p.ep[bt0 * V + v];
+    int E = kScaleExp;
+    __syncthreads();
+
+    const int sl0 = g.fwd.wave_off[wave], sl1 = g.fwd.wave_off[wave + 1];
+    for (int t = 0; t < lx; ++t) {
+        float *Xc = X + (t % 3) * Sp, *Xn = X + ((t + 1) % 3) * Sp, *Xz = X + ((t + 2) % 3) * Sp;
+        const float *EPc = EP + (t & 1) * Vp;
+        // next frame's emission row -> registers now, LDS at the end of the frame
+        float epn[kEpRegs];
+        if (t + 1 < lx) {
+            const float *er = p.ep + (bt0 + t + 1) * V;
+#pragma unroll
+            for (int i = 0; i < kEpRegs; ++i) {
+                int v = tid + i * kChainThreads;
+                epn[i] = v < V ? er[v] : 0.f;
+            }
+        }
+        float m = 0.f;
+        for (int s = tid; s < S; s += kChainThreads) m = fmaxf(m, Xc[s]);
+        m = wave_max(m);
+        if (lane == 0) wm[(t & 1) * kChainWaves + wave] = m;
+        __syncthreads();
+        const int k = rescale_exp(frame_max(wm + (t & 1) * kChainWaves));
+        const float sc = pow2f(k);
+        E += k;
+        if (tid == 0) p.EQ[bt0 + t] = E;
+        for (int s = tid; s < Sp; s += kChainThreads) Xz[s] = 0.f;
+        float *Qrow = p.Q + (bt0 + t) * Pr;
+        for (int i = sl0; i < sl1; ++i) {
+            const int j = g.fwd.wave_slices[i];
+            const uint4 *a = g.fwd.arcs + g.fwd.slice_off[j] + lane;
+            const int w2 = g.fwd.slice_w2[j];
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 4
+            for (int kk = 0; kk < w2; ++kk) {
+                const uint4 e = a[(int64_t)kk * kWave];
+                acc0 = fmaf(Xc[e.x], __uint_as_float(e.y), acc0);
+                acc1 = fmaf(Xc[e.z], __uint_as_float(e.w), acc1);
+            }
+            const float q = (acc0 + acc1) * sc;
+            const int r = j * kWave + lane;
+            Qrow[r] = q;
+            const int d = g.pair_dst[r];
+            if (d >= 0) atomicAdd(&Xn[d], EPc[g.pair_lab[r]] * q);
+        }
+        if (t + 1 < lx) {
+            float *EPn = EP + ((t + 1) & 1) * Vp;
+#pragma unroll
+            for (int i = 0; i < kEpRegs; ++i) {
+                int v = tid + i * kChainThreads;
+                if (v < V) EPn[v] = epn[i];
+            }
+        }
+        __syncthreads();
+    }
+    const float *Xf = X + (lx % 3) * Sp;
+    float part = 0.f;
+    for (int s = tid; s < S; s += kChainThreads) part += Xf[s] * g.end_lin[s];
+    const float zs = block_sum(part, (float *)red, tid);
+    const double mxs = mx_total(p, b, lx, red, tid);
+    if (tid == 0) {
+        p.den_zs[b] = zs;
+        p.den_ez[b] = E;
+        p.cost_alpha[b] = to_log(zs, E, mxs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// denominator backward.  LDS: Z[2][Pr] | BPst[2][Pr] | EP[2][Vp] | wmax[2][16] | red
+// iteration i handles frame t = lx-1-i:  b_t[s] = sc * sum_k w_k * Z[cur][pair_k]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void den_backward(const LossParams &p, int b, float *lds) {
+    const GraphDev &g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = g.S, V = p.V, Pr = g.Pr, lx = p.lx[b];
+    const int Vp = rup64(V);
+    float *Z = lds;
+    float *BPst = Z + 2 * Pr;
+    float *EP = BPst + 2 * Pr;
+    float *wm = EP + 2 * Vp;
+    double *red = (double *)(wm + 2 * kChainWaves);
+    const int64_t bt0 = (int64_t)b * p.T;
+    int F = kScaleExp;
+    float zpart = 0.f;
+
+    for (int r = tid; r < 4 * Pr; r += kChainThreads) Z[r] = 0.f;
+    if (lx > 0) {
+        for (int v = tid; v < V; v += kChainThreads) {
+            EP[v] = p.ep[(bt0 + lx - 1) * V + v];
+            if (lx > 1) EP[Vp + v] = p.ep[(bt0 + lx - 2) * V + v];
+        }
+        __syncthreads();
+        float *BProw = p.BP + (bt0 + lx - 1) * Pr;
+        for (int r = tid; r < Pr; r += kChainThreads) {
+            const int d = g.pair_dst[r];
+            const float bv = d >= 0 ? g.end_lin[d] * pow2f(kScaleExp) : 0.f;
+            BProw[r] = bv;
+            Z[r] = EP[g.pair_lab[r]] * bv;
+        }
+        if (tid == 0) p.EB[bt0 + lx - 1] = F;
+    } else {
+        for (int s = tid; s < S; s += kChainThreads) zpart += g.start_lin[s] * g.end_lin[s] * pow2f(kScaleExp);
+    }
+    __syncthreads();
+
+    const int sl0 = g.bwd.wave_off[wave], sl1 = g.bwd.wave_off[wave + 1];
+    for (int i = 0; i < lx; ++i) {
+        const int t = lx - 1 - i;
+        const float *Zc = Z + (i & 1) * Pr;
+        float *Zn = Z + ((i + 1) & 1) * Pr;
+        float *BPc = BPst + (i & 1) * Pr;
+        const float *EPn = EP + ((i + 1) & 1) * Vp;  // e_{t-1}
+        float epn[kEpRegs];
+        if (t >= 2) {
+            const float *er = p.ep + (bt0 + t - 2) * V;
+#pragma unroll
+            for (int q = 0; q < kEpRegs; ++q) {
+                int v = tid + q * kChainThreads;
+                epn[q] = v < V ? er[v] : 0.f;
+            }
+        }
+        float m = 0.f;
+        for (int r = tid; r < Pr; r += kChainThreads) m = fmaxf(m, Zc[r]);
+        m = wave_max(m);
+        if (lane == 0) wm[(i & 1) * kChainWaves + wave] = m;
+        if (i > 0) {  // b_{t+1}[dst_p], staged by the previous iteration -> BP[b][t]
+            const float *BPp = BPst + ((i - 1) & 1) * Pr;
+            float *BProw = p.BP + (bt0 + t) * Pr;
+            for (int r = tid; r < Pr; r += kChainThreads) BProw[r] = BPp[r];
+            if (tid == 0) p.EB[bt0 + t] = F;
+        }
+        __syncthreads();
+        const int k = rescale_exp(frame_max(wm + (i & 1) * kChainWaves));
+        const float sc = pow2f(k);
+        F += k;
+        for (int ii = sl0; ii < sl1; ++ii) {
+            const int j = g.bwd.wave_slices[ii];
+            const uint4 *a = g.bwd.arcs + g.bwd.slice_off[j] + lane;
+            const int w2 = g.bwd.slice_w2[j];
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 4
+            for (int kk = 0; kk < w2; ++kk) {
+                const uint4 e = a[(int64_t)kk * kWave];
+                acc0 = fmaf(Zc[e.x], __uint_as_float(e.y), acc0);
+                acc1 = fmaf(Zc[e.z], __uint_as_float(e.w), acc1);
+            }
+            const float bv = (acc0 + acc1) * sc;
+            const int s = g.bwd_row_state[j * kWave + lane];
+            if (s >= 0) {
+                if (t == 0) {
+                    zpart += g.start_lin[s] * bv;
+                } else {
+                    for (int pi = g.st_pair_off[s]; pi < g.st_pair_off[s + 1]; ++pi) {
+                        const int r = g.st_pairs[pi];
+                        BPc[r] = bv;
+                        Zn[r] = EPn[g.pair_lab[r]] * bv;
+                    }
+                }
+            }
+        }
+        if (t >= 2) {
+            float *EPw = EP + (i & 1) * Vp;
+#pragma unroll
+            for (int q = 0; q < kEpRegs; ++q) {
+                int v = tid + q * kChainThreads;
+                if (v < V) EPw[v] = epn[q];
+            }
+        }
+        __syncthreads();
+    }
+    const float zb = block_sum(zpart, (float *)red, tid);
+    const double mxs = mx_total(p, b, lx, red, tid);
+    if (tid == 0) p.cost_beta[b] = to_log(zb, F, mxs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CTC numerator chains.  LDS: Abuf[2][Sxp] | lab[Sxp] (int) | wmax[2][16] | red
+// validity rule L + repeats <= T_b: gpu_ctc.h:161-174
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ctc_setup(const LossParams &p, int b, int *lab, float *red, int L, int lx, int tid) {
+    const int *ul = p.labels + p.lab_off[b];
+    const int Sx = 2 * L + 1;
+    float rep = 0.f;
+    for (int s = tid; s < Sx; s += kChainThreads) lab[s] = (s & 1) ? ul[s >> 1] : 0;
+    for (int i = tid + 1; i < L; i += kChainThreads) rep += (ul[i] == ul[i - 1]) ? 1.f : 0.f;
+    const int repeats = (int)(block_sum(rep, red, tid) + 0.5f);  // also orders the lab[] writes
+    return lx > 0 && L + repeats <= lx;
+}
+
+__device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
+    float *A = lds;
+    int *lab = (int *)(A + 2 * Sxp);
+    float *wm = (float *)(lab + Sxp);
+    double *red = (double *)(wm + 2 * kChainWaves);
+    const int64_t bt0 = (int64_t)b * p.T;
+    const bool valid = ctc_setup(p, b, lab, (float *)red, L, lx, tid);
+    if (!valid) {
+        if (tid == 0) {
+            const bool empty_ok = (lx <= 0 && L == 0);
+            p.ctc_zc[b] = 0.f; p.ctc_ez[b] = 0; p.cost_ctc[b] = 0.f; p.invalid[b] = empty_ok ? 0 : 1;
+        }
+        return;
+    }
+    int mylab[kCtcRegs];
+    bool skip[kCtcRegs];
+#pragma unroll
+    for (int i = 0; i < kCtcRegs; ++i) {
+        const int s = tid + i * kChainThreads;
+        mylab[i] = s < Sx ? lab[s] : 0;
+        skip[i] = s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2];
+    }
+    int E = kScaleExp;
+    {   // t = 0 (gpu_ctc_kernels.h:146-152)
+        const float *er = p.ep + bt0 * V;
+        float *CArow = p.CA + bt0 * p.Sc;
+#pragma unroll
+        for (int i = 0; i < kCtcRegs; ++i) {
+            const int s = tid + i * kChainThreads;
+            if (s < Sxp) {
+                const float v = (s < 2 && s < Sx) ? er[mylab[i]] * pow2f(kScaleExp) : 0.f;
+                A[s] = v;
+                if (s < Sx) CArow[s] = v;
+            }
+        }
+        if (tid == 0) p.ECA[bt0] = E;
+    }
+    __syncthreads();
+    for (int t = 1; t < lx; ++t) {
+        const float *Ac = A + ((t - 1) & 1) * Sxp;
+        float *An = A + (t & 1) * Sxp;
+        const float *er = p.ep + (bt0 + t) * V;
+        float em[kCtcRegs];
+#pragma unroll
+        for (int i = 0; i < kCtcRegs; ++i) em[i] = (tid + i * kChainThreads < Sx) ? er[mylab[i]] : 0.f;
+        float m = 0.f;
+        for (int s = tid; s < Sx; s += kChainThreads) m = fmaxf(m, Ac[s]);
+        m = wave_max(m);
+        if (lane == 0) wm[(t & 1) * kChainWaves + wave] = m;
+        __syncthreads();
+        const int k = rescale_exp(frame_max(wm + (t & 1) * kChainWaves));
+        const float sc = pow2f(k);
+        E += k;
+        float *CArow = p.CA + (bt0 + t) * p.Sc;
+#pragma unroll
+        for (int i = 0; i < kCtcRegs; ++i) {
+            const int s = tid + i * kChainThreads;
+            if (s < Sx) {
+                float a = Ac[s];
+                if (s >= 1) a += Ac[s - 1];
+                if (skip[i]) a += Ac[s - 2];
+                const float v = sc * em[i] * a;
+                An[s] = v;
+                CArow[s] = v;
+            }
+        }
+        if (tid == 0) p.ECA[bt0 + t] = E;
+        __syncthreads();
+    }
+    const float *Af = A + ((lx - 1) & 1) * Sxp;
+    const double mxs = mx_total(p, b, lx, red, tid);
+    if (tid == 0) {
+        const float zc = Af[Sx - 1] + (Sx > 1 ? Af[Sx - 2] : 0.f);
+        const bool ok = zc > 0.f;
+        p.ctc_zc[b] = ok ? zc : 0.f;
+        p.ctc_ez[b] = E;
+        p.cost_ctc[b] = ok ? to_log(zc, E, mxs) : 0.f;
+        p.invalid[b] = ok ? 0 : 1;
+    }
+}
+
+// backward, EXCLUDING the emission at t:  Bx_t[s] = sum_{s' in {s,s+1,s+2*}} e_{t+1}[l'_s'] Bx_{t+1}[s']
+// LDS holds Y_t[s] = e_t[l'_s] * Bx_t[s]; Bx_t itself only goes to HBM (CB).
+__device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *lds) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
+    float *Y = lds;
+    int *lab = (int *)(Y + 2 * Sxp);
+    float *wm = (float *)(lab + Sxp);
+    double *red = (double *)(wm + 2 * kChainWaves);
+    const int64_t bt0 = (int64_t)b * p.T;
+    if (!ctc_setup(p, b, lab, (float *)red, L, lx, tid)) return;
+    int mylab[kCtcRegs];
+    bool skip[kCtcRegs];
+#pragma unroll
+    for (int i = 0; i < kCtcRegs; ++i) {
+        const int s = tid + i * kChainThreads;
+        mylab[i] = s < Sx ? lab[s] : 0;
+        skip[i] = (s + 2 < Sx) && lab[s + 2] != 0 && lab[s + 2] != mylab[i];
+    }
+    int F = kScaleExp;
+    {   // t = lx-1
+        const float *er = p.ep + (bt0 + lx - 1) * V;
+        float *CBrow = p.CB + (bt0 + lx - 1) * p.Sc;
+#pragma unroll
+        for (int i = 0; i < kCtcRegs; ++i) {
+            const int s = tid + i * kChainThreads;
+            if (s < Sxp) {
+                const float bx = (s < Sx && s >= Sx - 2) ? pow2f(kScaleExp) : 0.f;
+                Y[s] = s < Sx ? er[mylab[i]] * bx : 0.f;
+                Y[Sxp + s] = 0.f;
+                if (s < Sx) CBrow[s] = bx;
+            }
+        }
+        if (tid == 0) p.ECB[bt0 + lx - 1] = F;
+    }
+    __syncthreads();
+    for (int i = 1; i < lx; ++i) {
+        const int t = lx - 1 - i;
+        const float *Yc = Y + ((i - 1) & 1) * Sxp;
+        float *Yn = Y + (i & 1) * Sxp;
+        const float *er = p.ep + (bt0 + t) * V;
+        float em[kCtcRegs];
+#pragma unroll
+        for (int q = 0; q < kCtcRegs; ++q) em[q] = (tid + q * kChainThreads < Sx) ? er[mylab[q]] : 0.f;
+        float m = 0.f;
+        for (int s = tid; s < Sx; s += kChainThreads) m = fmaxf(m, Yc[s]);
+        m = wave_max(m);
+        if (lane == 0) wm[(i & 1) * kChainWaves + wave] = m;
+        __syncthreads();
+        const int k = rescale_exp(frame_max(wm + (i & 1) * kChainWaves));
+        const float sc = pow2f(k);
+        F += k;
+        float *CBrow = p.CB + (bt0 + t) * p.Sc;
+#pragma unroll
+        for (int q = 0; q < kCtcRegs; ++q) {
+            const int s = tid + q * kChainThreads;
+            if (s < Sx) {
+                float a = Yc[s];
+                if (s + 1 < Sx) a += Yc[s + 1];
+                if (skip[q]) a += Yc[s + 2];
+                const float bx = sc * a;
+                CBrow[s] = bx;
+                Yn[s] = em[q] * bx;
+            }
+        }
+        if (tid == 0) p.ECB[bt0 + t] = F;
+        __syncthreads();
+    }
+}
+
+// One kernel per recursion so each keeps its own (small) set of live kernel arguments in SGPRs; the
+// four launches are issued on forked HIP streams and run concurrently (crf_loss_fwd_bwd).
+template <int ROLE>
+__global__ __launch_bounds__(kChainThreads) void crf_chain_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = (int)blockIdx.x;
+    if (ROLE == 0) den_forward(p, b, lds);
+    else if (ROLE == 1) den_backward(p, b, lds);
+    else if (ROLE == 2) ctc_forward(p, b, lds);
+    else ctc_backward(p, b, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// grad: one workgroup per (utterance, kGradFrames consecutive frames)
+// LDS: prod[Pr] | csum[NC] | gd[Vp] | gc[Vp]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const GraphDev &g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.y, V = p.V, Vp = rup64(V);
+    const int lx = p.lx[b];
+    const bool do_den = p.c_den != 0.f, do_ctc = p.c_ctc != 0.f;
+    const int Pr = do_den ? g.Pr : 0, NC = do_den ? g.NC : 0;
+    float *prod = lds;
+    float *csum = prod + Pr;
+    float *gd = csum + rup64(NC);
+    float *gc = gd + Vp;
+    const int64_t bt0 = (int64_t)b * p.T;
+    float zs = 0.f, zc = 0.f;
+    int ez = 0, ezc = 0, Sx = 0;
+    const int *ul = nullptr;
+    if (do_den) { zs = p.den_zs[b]; ez = p.den_ez[b]; }
+    if (do_ctc) { zc = p.ctc_zc[b]; ezc = p.ctc_ez[b]; Sx = 2 * p.ly[b] + 1; ul = p.labels + p.lab_off[b]; }
+    const float inv = zs > 0.f ? 1.f / zs : 0.f;
+    const float invc = zc > 0.f ? 1.f / zc : 0.f;
+
+    const int t0 = blockIdx.x * kGradFrames;
+    for (int t = t0; t < t0 + kGradFrames && t < p.T; ++t) {
+        float *row = p.grad + (bt0 + t) * V;
+        if (t >= lx) {
+            for (int v = tid; v < V; v += kGradThreads) row[v] = 0.f;
+            continue;
+        }
+        if (do_den) {
+            const float *Qr = p.Q + (bt0 + t) * Pr, *Br = p.BP + (bt0 + t) * Pr;
+            for (int r = tid; r < Pr; r += kGradThreads) prod[r] = Qr[r] * Br[r];
+            __syncthreads();
+            for (int c = tid; c < NC; c += kGradThreads) {
+                float s = 0.f;
+                for (int j = g.chunk_off[c]; j < g.chunk_off[c + 1]; ++j) s += prod[g.perm[j]];
+                csum[c] = s;
+            }
+            __syncthreads();
+            const int e = ez - p.EQ[bt0 + t] - p.EB[bt0 + t];
+            const float *er = p.ep + (bt0 + t) * V;
+            for (int v = tid; v < V; v += kGradThreads) {
+                float s = 0.f;
+                if (v <= g.max_label)
+                    for (int c = g.lab_chunk_off[v]; c < g.lab_chunk_off[v + 1]; ++c) s += csum[c];
+                gd[v] = er[v] * (ldexpf(s, e) * inv);
+            }
+        }
+        float fc = 0.f;
+        if (do_ctc) {
+            for (int v = tid; v < V; v += kGradThreads) gc[v] = 0.f;
+            __syncthreads();
+            if (zc > 0.f) {
+                const float *Ar = p.CA + (bt0 + t) * p.Sc, *Br = p.CB + (bt0 + t) * p.Sc;
+                float blank = 0.f;
+                for (int s = tid; s < Sx; s += kGradThreads) {
+                    const float pr = Ar[s] * Br[s];
+                    if (s & 1) atomicAdd(&gc[ul[s >> 1]], pr);
+                    else blank += pr;
+                }
+                blank = wave_sum(blank);
+                if (lane == 0) atomicAdd(&gc[0], blank);
+                fc = ldexpf(invc, ezc - p.ECA[bt0 + t] - p.ECB[bt0 + t]);
+            }
+        }
+        __syncthreads();
+        for (int v = tid; v < V; v += kGradThreads) {
+            float o = 0.f;
+            if (do_den) o = p.c_den * gd[v];
+            if (do_ctc) o -= p.c_ctc * (gc[v] * fc);
+            row[v] = o;
+        }
+        __syncthreads();
+    }
+}
+
+// loss = sum_b(c_den*logZ_b - c_ctc*logp_b); copies the per-utterance costs out (one workgroup)
+__global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double part = 0.0;
+    for (int b = tid; b < p.B; b += 256) {
+        double c = 0.0;
+        if (p.c_den != 0.f) {
+            c += (double)p.c_den * (double)p.cost_alpha[b];
+            if (p.out_den) p.out_den[b] = p.cost_alpha[b];
+            if (p.out_beta) p.out_beta[b] = p.cost_beta[b];
+        }
+        if (p.c_ctc != 0.f) {
+            c -= (double)p.c_ctc * (double)p.cost_ctc[b];
+            if (p.out_ctc) p.out_ctc[b] = p.cost_ctc[b];
+            if (p.out_invalid) p.out_invalid[b] = p.invalid[b];
+        }
+        part += c;
+    }
+    part = wave_sum_d(part);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) p.loss[0] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct WsLayout {
+    int64_t off_ep, off_mx, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, total;
+};
+static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, int64_t Sc) {
+    WsLayout w{};
+    int64_t o = 0;
+    const int64_t Pr = h ? h->dev.Pr : 0;
+    w.off_ep = o; o = al(o + B * T * V * 4);
+    w.off_mx = o; o = al(o + B * T * 4);
+    w.off_Q = o; o = al(o + B * T * Pr * 4);
+    w.off_BP = o; o = al(o + B * T * Pr * 4);
+    w.off_EQ = o; o = al(o + B * T * 4);
+    w.off_EB = o; o = al(o + B * T * 4);
+    w.off_CA = o; o = al(o + B * T * Sc * 4);
+    w.off_CB = o; o = al(o + B * T * Sc * 4);
+    w.off_ECA = o; o = al(o + B * T * 4);
+    w.off_ECB = o; o = al(o + B * T * 4);
+    w.off_pb = o; o = al(o + 16 * B * 4);
+    w.total = o;
+    return w;
+}
+
+static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role) {
+    const size_t tail = 2 * kChainWaves + 2 * kChainWaves + 16;  // wmax + 16 doubles + slack
+    size_t fl;
+    if (role == 0) fl = (size_t)3 * rup64(h->dev.S) + 2 * rup64(V) + tail;
+    else if (role == 1) fl = (size_t)4 * h->dev.Pr + 2 * rup64(V) + tail;
+    else fl = (size_t)3 * Sc + tail;
+    return fl * sizeof(float);
+}
+
+// Side streams + events used to run the four recursions concurrently (fork/join around the
+// caller's stream).  One set per device, created on first use.
+struct DevCtx {
+    bool init = false;
+    hipStream_t side[3]{};
+    hipEvent_t fork{}, join[3]{};
+};
+static DevCtx g_ctx[64];
+static std::mutex g_ctx_mu;
+
+static int get_ctx(DevCtx **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) { set_error("hipGetDevice failed"); return CRF_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    DevCtx &c = g_ctx[dev];
+    if (!c.init) {
+        for (int i = 0; i < 3; ++i) {
+            if ((e = hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking)) != hipSuccess ||
+                (e = hipEventCreateWithFlags(&c.join[i], hipEventDisableTiming)) != hipSuccess) {
+                set_error(std::string("stream/event create: ") + hipGetErrorString(e));
+                return CRF_ERR_HIP;
+            }
+        }
+        if ((e = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming)) != hipSuccess) {
+            set_error(std::string("event create: ") + hipGetErrorString(e));
+            return CRF_ERR_HIP;
+        }
+        c.init = true;
+    }
+    *out = &c;
+    return CRF_OK;
+}
+
+// optional per-kernel timing (crf_profile_enable / crf_profile_read)
+struct Prof {
+    bool on = false, have = false;
+    hipEvent_t ev[16]{};  // start/stop per slot 0..6, [14],[15] whole call
+    bool made = false, used[8]{};
+};
+static thread_local Prof g_prof;
+static void prof_mark(int slot, bool stop, hipStream_t st) {
+    if (!g_prof.on) return;
+    if (!g_prof.made) {
+        for (auto &e : g_prof.ev) (void)hipEventCreate(&e);
+        g_prof.made = true;
+    }
+    (void)hipEventRecord(g_prof.ev[2 * slot + (stop ? 1 : 0)], st);
+    g_prof.used[slot] = true;
+}
+
+template <int ROLE>
+static int launch_chain(const LossParams &p, size_t lds, hipStream_t st) {
+    static std::atomic<size_t> lds_set{0};  // dynamic LDS above 64 KiB must be opted into; only raised
+    hipError_t e;
+    if (lds > lds_set.load()) {
+        if ((e = hipFuncSetAttribute((const void *)crf_chain_kernel<ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
+            set_error(std::string("hipFuncSetAttribute(chain): ") + hipGetErrorString(e));
+            return CRF_ERR_HIP;
+        }
+        lds_set = lds;
+    }
+    prof_mark(1 + ROLE, false, st);
+    hipLaunchKernelGGL(crf_chain_kernel<ROLE>, dim3((unsigned)p.B), dim3(kChainThreads), lds, st, p);
+    prof_mark(1 + ROLE, true, st);
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return CRF_OK;
+}
+
+}  // namespace crf
+
+using namespace crf;
+
+extern "C" {
+
+int64_t crf_workspace_bytes(const crf_graph *g, int64_t B, int64_t T, int64_t V, int64_t max_label_len) {
+    const int64_t Sc = rup64((int)(2 * max_label_len + 1));
+    return ws_layout(g ? g->h : nullptr, B, T, V, Sc).total;
+}
+
+int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *labels, const int32_t *lab_off,
+                     const int32_t *lx, const int32_t *ly, int64_t B, int64_t T, int64_t V,
+                     int64_t max_label_len, float c_den, float c_ctc, float *grad, float *loss,
+                     float *costs_den, float *costs_beta, float *costs_ctc, int32_t *invalid, void *ws,
+                     int64_t ws_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool den = c_den != 0.f, ctc = c_ctc != 0.f;
+    if (!logp || !lx || !grad || !loss || !ws) { set_error("null argument"); return CRF_ERR_ARG; }
+    if (B <= 0 || T <= 0 || V <= 0 || B * T > INT32_MAX) { set_error("bad B/T/V"); return CRF_ERR_ARG; }
+    if (!den && !ctc) { set_error("c_den and c_ctc are both zero"); return CRF_ERR_ARG; }
+    if (den && (!g || !g->h)) { set_error("denominator requested without a graph"); return CRF_ERR_ARG; }
+    if (ctc && (!labels || !lab_off || !ly || max_label_len < 0)) { set_error("numerator requested without labels"); return CRF_ERR_ARG; }
+    const HostGraph *h = den ? g->h : nullptr;
+    if (den && V <= h->dev.max_label) {
+        set_error("den_lm has label " + std::to_string(h->dev.max_label) + " but log_probs has only V=" + std::to_string(V) + " classes");
+        return CRF_ERR_ARG;
+    }
+    if (V > kEpRegs * kChainThreads) { set_error("V > 8192 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
+    const int Sc = rup64((int)(2 * (ctc ? max_label_len : 0) + 1));
+    if (ctc && 2 * max_label_len + 1 > kCtcRegs * kChainThreads) { set_error("label length > 2047 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
+    const WsLayout w = ws_layout(h, B, T, V, Sc);
+    if (ws_bytes < w.total) { set_error("workspace too small: need " + std::to_string(w.total)); return CRF_ERR_WORKSPACE; }
+    size_t lds_chain = 0;
+    if (den) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0), chain_lds_bytes(h, (int)V, Sc, 1));
+    if (ctc) lds_chain = std::max(lds_chain, chain_lds_bytes(h, (int)V, Sc, 2));
+    const size_t lds_grad = ((den ? (size_t)h->dev.Pr + rup64(h->dev.NC) : 0) + 2 * (size_t)rup64((int)V)) * sizeof(float);
+    if (lds_chain > 160 * 1024 || lds_grad > 160 * 1024) {
+        set_error("graph too large for the LDS-resident kernels of this build (states=" + std::to_string(h ? h->S : 0) + ")");
+        return CRF_ERR_UNSUPPORTED;
+    }
+
+    LossParams p{};
+    if (den) p.g = h->dev;
+    p.logp = logp; p.labels = labels; p.lab_off = lab_off; p.lx = lx; p.ly = ly;
+    p.B = (int)B; p.T = (int)T; p.V = (int)V; p.Sc = Sc;
+    p.c_den = c_den; p.c_ctc = c_ctc;
+    char *base = (char *)ws;
+    p.ep = (float *)(base + w.off_ep); p.mx = (float *)(base + w.off_mx);
+    p.Q = (float *)(base + w.off_Q); p.BP = (float *)(base + w.off_BP);
+    p.EQ = (int *)(base + w.off_EQ); p.EB = (int *)(base + w.off_EB);
+    p.CA = (float *)(base + w.off_CA); p.CB = (float *)(base + w.off_CB);
+    p.ECA = (int *)(base + w.off_ECA); p.ECB = (int *)(base + w.off_ECB);
+    float *pb = (float *)(base + w.off_pb);
+    p.den_zs = pb; p.ctc_zc = pb + B; p.den_ez = (int *)(pb + 2 * B); p.ctc_ez = (int *)(pb + 3 * B);
+    p.cost_alpha = pb + 4 * B; p.cost_beta = pb + 5 * B; p.cost_ctc = pb + 6 * B; p.invalid = (int *)(pb + 7 * B);
+    p.grad = grad; p.loss = loss; p.out_den = costs_den; p.out_beta = costs_beta; p.out_ctc = costs_ctc;
+    p.out_invalid = invalid;
+
+    hipError_t e;
+#define LAUNCH_CHECK(what)                                                                         \
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string(what) + ": " + hipGetErrorString(e)); return CRF_ERR_HIP; }
+
+    const int64_t frames = B * T;
+    for (bool &u : g_prof.used) u = false;
+    prof_mark(7, false, stream);
+    prof_mark(0, false, stream);
+    hipLaunchKernelGGL(crf_prep_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
+    prof_mark(0, true, stream);
+    LAUNCH_CHECK("crf_prep_kernel");
+
+    static std::atomic<size_t> lds_set_grad{0};
+    if (lds_grad > lds_set_grad.load()) {
+        if ((e = hipFuncSetAttribute((const void *)crf_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad)) != hipSuccess) {
+            set_error(std::string("hipFuncSetAttribute(grad): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+        }
+        lds_set_grad = lds_grad;
+    }
+    // fork: the four recursions are independent; den forward (the longest) stays on the caller's
+    // stream, the others go to side streams and are joined before the grad pass.
+    static const bool serial = getenv("CRF_SERIAL_CHAINS") && atoi(getenv("CRF_SERIAL_CHAINS")) != 0;
+    DevCtx *cx = nullptr;
+    int rc;
+    if (!serial) {
+        if ((rc = get_ctx(&cx))) return rc;
+        if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess) { set_error("hipEventRecord(fork)"); return CRF_ERR_HIP; }
+    }
+    bool used[3] = {false, false, false};
+    auto side = [&](int i) -> hipStream_t {
+        if (serial) return stream;
+        used[i] = true;
+        (void)hipStreamWaitEvent(cx->side[i], cx->fork, 0);
+        return cx->side[i];
+    };
+    if (den) {
+        if ((rc = launch_chain<0>(p, chain_lds_bytes(h, (int)V, Sc, 0), stream))) return rc;
+        if ((rc = launch_chain<1>(p, chain_lds_bytes(h, (int)V, Sc, 1), side(0)))) return rc;
+    }
+    if (ctc) {
+        if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream))) return rc;
+        if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2)))) return rc;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (used[i]) {
+            if ((e = hipEventRecord(cx->join[i], cx->side[i])) != hipSuccess ||
+                (e = hipStreamWaitEvent(stream, cx->join[i], 0)) != hipSuccess) {
+                set_error(std::string("join: ") + hipGetErrorString(e));
+                return CRF_ERR_HIP;
+            }
+        }
+    prof_mark(5, false, stream);
+    hipLaunchKernelGGL(crf_grad_kernel, dim3((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B), dim3(kGradThreads), lds_grad, stream, p);
+    prof_mark(5, true, stream);
+    LAUNCH_CHECK("crf_grad_kernel");
+    prof_mark(6, false, stream);
+    hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
+    prof_mark(6, true, stream);
+    prof_mark(7, true, stream);
+    g_prof.have = g_prof.on;
+    LAUNCH_CHECK("crf_finalize_kernel");
+#undef LAUNCH_CHECK
+    return CRF_OK;
+}
+
+void crf_profile_enable(int on) { g_prof.on = on != 0; if (!on) g_prof.have = false; }
+
+int crf_profile_read(float *ms_out, int n) {
+    if (!ms_out || n <= 0 || !g_prof.have) return 0;
+    int w = 0;
+    for (int s = 0; s < 8 && s < n; ++s, ++w) {
+        ms_out[s] = -1.f;
+        if (!g_prof.used[s]) continue;
+        if (hipEventSynchronize(g_prof.ev[2 * s + 1]) != hipSuccess) continue;
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[2 * s], g_prof.ev[2 * s + 1]) == hipSuccess) ms_out[s] = ms;
+    }
+    return w;
+}
+
+}  // extern "C"

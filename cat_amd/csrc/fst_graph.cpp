@@ -1,0 +1,355 @@
+// cat_amd/csrc/fst_graph.cpp -- host side of the denominator graph: OpenFst-binary reader (no OpenFst)
+// and the "graph compiler" that turns the arc list into the tables the gfx950 kernels stream.
+//
+// Replaces reference src/ctc_crf/gpu_den/fst_read.cc:11-62 (ReadFst on top of OpenFst 1.6.7, which
+// is not vendored) and the table construction + upload of Init, den_calculate.cu:288-392.
+// Conventions are the reference's (fst_read.cc:40-60): label = ilabel-1, weight = -cost,
+// end_weight = -Final, start_weight[start] = 0.  Epsilon input labels are rejected (the reference
+// would read logits[-1], fst_read.cc:55-56).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+#include "../../include/ctc_crf_hip.h"
+#include "crf_internal.h"
+
+namespace crf {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const char *last_error_cstr() { return g_err.c_str(); }
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+            return CRF_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+namespace {
+struct Cursor {
+    const unsigned char *p;
+    size_t n, off = 0;
+    bool ok = true;
+    template <typename T>
+    T get() {
+        T v{};
+        if (off + sizeof(T) > n) { ok = false; return v; }
+        memcpy(&v, p + off, sizeof(T));
+        off += sizeof(T);
+        return v;
+    }
+    std::string str() {
+        int32_t len = get<int32_t>();
+        if (!ok || len < 0 || off + (size_t)len > n) { ok = false; return {}; }
+        std::string s((const char *)p + off, (size_t)len);
+        off += (size_t)len;
+        return s;
+    }
+    void skip_symtab() {  // OpenFst SymbolTable binary: magic, name, available_key, size, entries
+        get<int32_t>(); str(); get<int64_t>();
+        int64_t cnt = get<int64_t>();
+        for (int64_t i = 0; ok && i < cnt; ++i) { str(); get<int64_t>(); }
+    }
+};
+}  // namespace
+
+int read_fst_file(const char *path, int64_t *S, std::vector<int32_t> *src, std::vector<int32_t> *dst,
+                  std::vector<int32_t> *lab, std::vector<float> *w, std::vector<float> *start_w,
+                  std::vector<float> *end_w) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error(std::string("cannot open den_lm: ") + path); return CRF_ERR_IO; }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> buf((size_t)std::max(0L, sz));
+    size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    if (got != buf.size()) { set_error(std::string("short read: ") + path); return CRF_ERR_IO; }
+    Cursor c{buf.data(), buf.size()};
+    if (c.get<uint32_t>() != 0x7eb2fdd6u) { set_error(std::string(path) + ": not an OpenFst binary (bad magic)"); return CRF_ERR_FORMAT; }
+    std::string fsttype = c.str(), arctype = c.str();
+    if (fsttype != "vector" || arctype != "standard") {
+        set_error(std::string(path) + ": need fst type vector/standard, got " + fsttype + "/" + arctype);
+        return CRF_ERR_FORMAT;
+    }
+    c.get<int32_t>();  // version
+    int32_t flags = c.get<int32_t>();
+    c.get<uint64_t>();  // properties
+    int64_t start = c.get<int64_t>();
+    int64_t ns = c.get<int64_t>();
+    c.get<int64_t>();  // narcs (0 in VectorFst headers; arcs are counted per state)
+    if (flags & 1) c.skip_symtab();
+    if (flags & 2) c.skip_symtab();
+    if (!c.ok || ns <= 0 || ns > INT32_MAX || start < 0 || start >= ns) {
+        set_error(std::string(path) + ": corrupt header / no start state");
+        return CRF_ERR_FORMAT;
+    }
+    *S = ns;
+    start_w->assign((size_t)ns, -INFINITY);
+    end_w->assign((size_t)ns, -INFINITY);
+    (*start_w)[(size_t)start] = 0.f;
+    for (int64_t s = 0; s < ns; ++s) {
+        float fin = c.get<float>();
+        int64_t na = c.get<int64_t>();
+        if (!c.ok || na < 0) { set_error(std::string(path) + ": truncated state record"); return CRF_ERR_FORMAT; }
+        if (fin != INFINITY) (*end_w)[(size_t)s] = -fin;
+        for (int64_t k = 0; k < na; ++k) {
+            int32_t il = c.get<int32_t>();
+            c.get<int32_t>();
+            float cost = c.get<float>();
+            int32_t nx = c.get<int32_t>();
+            if (!c.ok) { set_error(std::string(path) + ": truncated arc record"); return CRF_ERR_FORMAT; }
+            if (il <= 0) { set_error(std::string(path) + ": epsilon / negative input label on an arc (den_lm must be epsilon-free)"); return CRF_ERR_FORMAT; }
+            if (nx < 0 || nx >= ns) { set_error(std::string(path) + ": arc to a non-existent state"); return CRF_ERR_FORMAT; }
+            src->push_back((int32_t)s); dst->push_back(nx); lab->push_back(il - 1); w->push_back(-cost);
+        }
+    }
+    if (src->size() > (size_t)INT32_MAX) { set_error("too many arcs"); return CRF_ERR_UNSUPPORTED; }
+    return CRF_OK;
+}
+
+namespace {
+
+struct EllHost {
+    std::vector<uint4> arcs;
+    std::vector<int> slice_off, slice_w2, wave_off, wave_slices;
+    std::vector<int> row_of;  // row position -> original row id (-1 padding)
+    int64_t padded_arcs = 0;
+};
+
+// rows[r] = list of (idx, w).  Rows are sorted by degree (descending, stable) and cut into slices
+// of 64; each slice is as wide as its first (longest) row, rounded up to an even arc count.
+EllHost build_ell(const std::vector<std::vector<std::pair<int, float>>> &rows) {
+    EllHost e;
+    const int R = (int)rows.size();
+    std::vector<int> order(R);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rows[a].size() > rows[b].size(); });
+    const int nsl = (R + kWave - 1) / kWave;
+    e.row_of.assign((size_t)nsl * kWave, -1);
+    for (int i = 0; i < R; ++i) e.row_of[i] = order[i];
+    e.slice_off.resize(nsl);
+    e.slice_w2.resize(nsl);
+    for (int j = 0; j < nsl; ++j) {
+        int wmax = (int)rows[order[(size_t)j * kWave]].size();
+        int w2 = (wmax + 1) / 2;
+        e.slice_off[j] = (int)e.arcs.size();
+        e.slice_w2[j] = w2;
+        e.arcs.resize(e.arcs.size() + (size_t)w2 * kWave, uint4{0u, 0u, 0u, 0u});
+        for (int lane = 0; lane < kWave; ++lane) {
+            int r = e.row_of[(size_t)j * kWave + lane];
+            if (r < 0) continue;
+            const auto &row = rows[r];
+            for (size_t k = 0; k < row.size(); ++k) {
+                uint4 &a = e.arcs[(size_t)e.slice_off[j] + (k / 2) * kWave + lane];
+                uint32_t wb;
+                memcpy(&wb, &row[k].second, 4);
+                if (k & 1) { a.z = (uint32_t)row[k].first; a.w = wb; }
+                else { a.x = (uint32_t)row[k].first; a.y = wb; }
+            }
+        }
+        e.padded_arcs += (int64_t)w2 * 2 * kWave;
+    }
+    // longest-processing-time assignment of slices (already sorted by width) to the waves
+    std::vector<int64_t> load(kChainWaves, 0);
+    std::vector<std::vector<int>> lists(kChainWaves);
+    for (int j = 0; j < nsl; ++j) {
+        int best = 0;
+        for (int wv = 1; wv < kChainWaves; ++wv)
+            if (load[wv] < load[best]) best = wv;
+        lists[best].push_back(j);
+        load[best] += e.slice_w2[j] + 4;  // +4: per-slice fixed cost (row epilogue)
+    }
+    e.wave_off.assign(kChainWaves + 1, 0);
+    for (int wv = 0; wv < kChainWaves; ++wv) {
+        e.wave_off[wv + 1] = e.wave_off[wv] + (int)lists[wv].size();
+        for (int j : lists[wv]) e.wave_slices.push_back(j);
+    }
+    return e;
+}
+
+template <typename T>
+int upload(HostGraph *h, const std::vector<T> &v, const T **out) {
+    void *d = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&d, bytes));
+    h->allocs.push_back(d);
+    if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)d;
+    return CRF_OK;
+}
+
+int upload_ell(HostGraph *h, const EllHost &e, EllDev *d) {
+    int rc;
+    if ((rc = upload(h, e.arcs, &d->arcs))) return rc;
+    if ((rc = upload(h, e.slice_off, &d->slice_off))) return rc;
+    if ((rc = upload(h, e.slice_w2, &d->slice_w2))) return rc;
+    if ((rc = upload(h, e.wave_off, &d->wave_off))) return rc;
+    if ((rc = upload(h, e.wave_slices, &d->wave_slices))) return rc;
+    d->nslices = (int)e.slice_off.size();
+    return CRF_OK;
+}
+
+}  // namespace
+
+int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, const int32_t *lab,
+                  const float *w, const float *start_w, const float *end_w, int device, HostGraph **out) {
+    if (S <= 0 || S > INT32_MAX / 4 || A < 0 || A > INT32_MAX / 4) { set_error("graph size out of range"); return CRF_ERR_UNSUPPORTED; }
+    int max_label = 0;
+    for (int64_t k = 0; k < A; ++k) {
+        if (src[k] < 0 || src[k] >= S || dst[k] < 0 || dst[k] >= S) { set_error("arc endpoint out of range"); return CRF_ERR_ARG; }
+        if (lab[k] < 0) { set_error("negative label (epsilon ilabel) on an arc"); return CRF_ERR_FORMAT; }
+        max_label = std::max(max_label, (int)lab[k]);
+    }
+    // 1. pairs = distinct (dst, label)
+    std::map<std::pair<int, int>, int> pair_id;  // (label, dst) -> temp id, ordered => deterministic
+    for (int64_t k = 0; k < A; ++k) pair_id.emplace(std::make_pair((int)lab[k], (int)dst[k]), 0);
+    const int P = (int)pair_id.size();
+    {
+        int i = 0;
+        for (auto &kv : pair_id) kv.second = i++;
+    }
+    std::vector<int> tmp_dst(P), tmp_lab(P);
+    for (auto &kv : pair_id) { tmp_lab[kv.second] = kv.first.first; tmp_dst[kv.second] = kv.first.second; }
+    std::vector<std::vector<std::pair<int, float>>> frows(P);
+    std::vector<int> arc_tmp_pair((size_t)A);
+    for (int64_t k = 0; k < A; ++k) {
+        int tp = pair_id[{(int)lab[k], (int)dst[k]}];
+        arc_tmp_pair[(size_t)k] = tp;
+        frows[tp].push_back({(int)src[k], expf(w[k])});
+    }
+    EllHost fe = build_ell(frows);
+    const int Pr = (int)fe.row_of.size();
+    std::vector<int> pid_of_tmp(P), pair_dst(Pr, -1), pair_lab(Pr, 0);
+    for (int r = 0; r < Pr; ++r)
+        if (fe.row_of[r] >= 0) { pid_of_tmp[fe.row_of[r]] = r; pair_dst[r] = tmp_dst[fe.row_of[r]]; pair_lab[r] = tmp_lab[fe.row_of[r]]; }
+    // 2. backward rows = states, arcs carry the pair id of (dst, label)
+    std::vector<std::vector<std::pair<int, float>>> brows((size_t)S);
+    for (int64_t k = 0; k < A; ++k) brows[src[k]].push_back({pid_of_tmp[arc_tmp_pair[(size_t)k]], expf(w[k])});
+    EllHost be = build_ell(brows);
+    const int Sr = (int)be.row_of.size();
+    // 3. pairs of each destination state
+    std::vector<int> st_pair_off((size_t)S + 1, 0), st_pairs(P);
+    for (int r = 0; r < Pr; ++r) if (pair_dst[r] >= 0) st_pair_off[(size_t)pair_dst[r] + 1]++;
+    for (int64_t s = 0; s < S; ++s) st_pair_off[s + 1] += st_pair_off[s];
+    {
+        std::vector<int> fill(st_pair_off.begin(), st_pair_off.end() - 1);
+        for (int r = 0; r < Pr; ++r) if (pair_dst[r] >= 0) st_pairs[fill[pair_dst[r]]++] = r;
+    }
+    // 4. grad-pass tables: pair ids sorted by (label, pair id); chunks of <= kChunk within a label
+    std::vector<int> perm;
+    perm.reserve(P);
+    for (int r = 0; r < Pr; ++r) if (pair_dst[r] >= 0) perm.push_back(r);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return pair_lab[a] < pair_lab[b]; });
+    std::vector<int> chunk_off{0}, lab_chunk_off((size_t)max_label + 2, 0);
+    {
+        size_t i = 0;
+        for (int v = 0; v <= max_label; ++v) {
+            lab_chunk_off[v] = (int)chunk_off.size() - 1;
+            size_t j = i;
+            while (j < perm.size() && pair_lab[perm[j]] == v) ++j;
+            for (size_t c = i; c < j; c += kChunk) chunk_off.push_back((int)std::min(j, c + kChunk));
+            i = j;
+        }
+        lab_chunk_off[(size_t)max_label + 1] = (int)chunk_off.size() - 1;
+    }
+    std::vector<float> start_lin((size_t)S), end_lin((size_t)S);
+    for (int64_t s = 0; s < S; ++s) { start_lin[s] = expf(start_w[s]); end_lin[s] = expf(end_w[s]); }
+
+    auto *h = new HostGraph();
+    h->device = device; h->S = S; h->A = A; h->P = P;
+    h->fwd_padded_arcs = fe.padded_arcs; h->bwd_padded_arcs = be.padded_arcs;
+    for (auto &r : frows) h->max_in_deg = std::max(h->max_in_deg, (int)r.size());
+    for (auto &r : brows) h->max_out_deg = std::max(h->max_out_deg, (int)r.size());
+    int prev = 0;
+    hipError_t e0 = hipGetDevice(&prev);
+    if (e0 != hipSuccess || hipSetDevice(device) != hipSuccess) {
+        set_error(std::string("cannot select device ") + std::to_string(device));
+        delete h;
+        return CRF_ERR_HIP;
+    }
+    GraphDev &d = h->dev;
+    d.S = (int)S; d.A = (int)A; d.P = P; d.Pr = Pr; d.Sr = Sr; d.max_label = max_label;
+    d.NC = (int)chunk_off.size() - 1;
+    int rc = CRF_OK;
+    do {
+        if ((rc = upload_ell(h, fe, &d.fwd))) break;
+        if ((rc = upload_ell(h, be, &d.bwd))) break;
+        if ((rc = upload(h, pair_dst, &d.pair_dst))) break;
+        if ((rc = upload(h, pair_lab, &d.pair_lab))) break;
+        if ((rc = upload(h, be.row_of, &d.bwd_row_state))) break;
+        if ((rc = upload(h, st_pair_off, &d.st_pair_off))) break;
+        if ((rc = upload(h, st_pairs, &d.st_pairs))) break;
+        if ((rc = upload(h, start_lin, &d.start_lin))) break;
+        if ((rc = upload(h, end_lin, &d.end_lin))) break;
+        if ((rc = upload(h, perm, &d.perm))) break;
+        if ((rc = upload(h, chunk_off, &d.chunk_off))) break;
+        if ((rc = upload(h, lab_chunk_off, &d.lab_chunk_off))) break;
+    } while (0);
+    (void)hipSetDevice(prev);
+    if (rc) {
+        for (void *p : h->allocs) (void)hipFree(p);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return CRF_OK;
+}
+
+}  // namespace crf
+
+extern "C" {
+
+int crf_graph_create_from_arcs(int64_t S, int64_t A, const int32_t *src, const int32_t *dst,
+                               const int32_t *lab, const float *w, const float *start_w,
+                               const float *end_w, int device, crf_graph **out) {
+    if (!out || !start_w || !end_w || (A > 0 && (!src || !dst || !lab || !w))) { crf::set_error("null argument"); return CRF_ERR_ARG; }
+    crf::HostGraph *h = nullptr;
+    int rc = crf::compile_graph(S, A, src, dst, lab, w, start_w, end_w, device, &h);
+    if (rc) return rc;
+    *out = new crf_graph{h};
+    return CRF_OK;
+}
+
+int crf_graph_create(const char *fst_path, int device, crf_graph **out) {
+    if (!fst_path || !out) { crf::set_error("null argument"); return CRF_ERR_ARG; }
+    int64_t S = 0;
+    std::vector<int32_t> src, dst, lab;
+    std::vector<float> w, sw, ew;
+    int rc = crf::read_fst_file(fst_path, &S, &src, &dst, &lab, &w, &sw, &ew);
+    if (rc) return rc;
+    return crf_graph_create_from_arcs(S, (int64_t)src.size(), src.data(), dst.data(), lab.data(), w.data(),
+                                      sw.data(), ew.data(), device, out);
+}
+
+void crf_graph_destroy(crf_graph *g) {
+    if (!g) return;
+    if (g->h) {
+        int prev = 0;
+        bool sw = hipGetDevice(&prev) == hipSuccess && hipSetDevice(g->h->device) == hipSuccess;
+        for (void *p : g->h->allocs) (void)hipFree(p);
+        if (sw) (void)hipSetDevice(prev);
+        delete g->h;
+    }
+    delete g;
+}
+
+int crf_graph_dims(const crf_graph *g, int64_t *S, int64_t *A, int64_t *P, int64_t *max_label) {
+    if (!g || !g->h) { crf::set_error("null graph"); return CRF_ERR_ARG; }
+    if (S) *S = g->h->S;
+    if (A) *A = g->h->A;
+    if (P) *P = g->h->P;
+    if (max_label) *max_label = g->h->dev.max_label;
+    return CRF_OK;
+}
+
+const char *crf_last_error(void) { return crf::last_error_cstr(); }
+const char *crf_version(void) { return "ctc_crf_hip 0.1.0 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+"""cat_amd/ctc_crf/_C.py -- ctypes binding of libctc_crf_hip.so, mirroring the reference's pybind module
+``ctc_crf._C`` (src/ctc_crf/binding.cpp:120-126: gpu_den, gpu_ctc, init_env, release_env).
+
+There is NO CPU fallback and no PyTorch fallback: if the HIP library is missing the import fails,
+and every call goes through the C ABI of include/ctc_crf_hip.h.
+"""
+import ctypes
+import os
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libctc_crf_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the gfx950 HIP library has not been built. "
+        "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `python -m cat_amd.build`) first; "
+        "there is no CPU fallback for the CTC-CRF loss.")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+_i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
+_lib.crf_graph_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(_vp)]
+_lib.crf_graph_create.restype = ctypes.c_int
+_lib.crf_graph_create_from_arcs.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(_vp)]
+_lib.crf_graph_create_from_arcs.restype = ctypes.c_int
+_lib.crf_graph_destroy.argtypes = [_vp]
+_lib.crf_graph_destroy.restype = None
+_lib.crf_graph_dims.argtypes = [_vp] + [ctypes.POINTER(_i64)] * 4
+_lib.crf_graph_dims.restype = ctypes.c_int
+_lib.crf_workspace_bytes.argtypes = [_vp, _i64, _i64, _i64, _i64]
+_lib.crf_workspace_bytes.restype = _i64
+_lib.crf_loss_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _f32,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
+_lib.crf_loss_fwd_bwd.restype = ctypes.c_int
+_lib.crf_profile_enable.argtypes = [ctypes.c_int]
+_lib.crf_profile_enable.restype = None
+_lib.crf_profile_read.argtypes = [ctypes.POINTER(_f32), ctypes.c_int]
+_lib.crf_profile_read.restype = ctypes.c_int
+_lib.crf_last_error.restype = ctypes.c_char_p
+_lib.crf_version.restype = ctypes.c_char_p
+
+EXPORTED_SYMBOLS = (
+    "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims",
+    "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_profile_enable", "crf_profile_read",
+    "crf_last_error", "crf_version",
+)
+
+PROFILE_SLOTS = ("prep", "den_fwd_chain", "den_bwd_chain", "ctc_fwd_chain", "ctc_bwd_chain", "grad",
+                 "finalize", "call")
+
+
+def profile_enable(on: bool) -> None:
+    _lib.crf_profile_enable(1 if on else 0)
+
+
+def profile_read() -> Dict[str, float]:
+    """Per-kernel HIP-event durations (ms) of the last loss_fwd_bwd call on this thread."""
+    buf = (_f32 * 8)()
+    n = _lib.crf_profile_read(buf, 8)
+    return {PROFILE_SLOTS[i]: float(buf[i]) for i in range(n)}
+
+
+def version() -> str:
+    return _lib.crf_version().decode()
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"ctc_crf_hip error {rc}: {_lib.crf_last_error().decode()}")
+
+
+# process-global graphs, one per device -- the reference keeps one graph per process in globals
+# indexed by DEVICE_HASH[cudaGetDevice()] (den_calculate.cu:263-273, 436-438)
+_GRAPHS: Dict[int, int] = {}
+
+
+def graph_dims(handle: int):
+    S, A, P, ML = _i64(), _i64(), _i64(), _i64()
+    _check(_lib.crf_graph_dims(_vp(handle), S, A, P, ML))
+    return dict(S=S.value, A=A.value, P=P.value, max_label=ML.value)
+
+
+def init_env(fst_name: str, gpus: torch.Tensor) -> None:
+    """binding.cpp:51-56 ``init_env`` -> Init(): load den_lm once per listed GPU."""
+    for dev in [int(i) for i in gpus.tolist()]:
+        out = _vp()
+        _check(_lib.crf_graph_create(os.fsencode(fst_name), dev, ctypes.byref(out)))
+        if dev in _GRAPHS:  # the reference leaks on a second Init; we replace
+            _lib.crf_graph_destroy(_vp(_GRAPHS.pop(dev)))
+        _GRAPHS[dev] = out.value
+
+
+def release_env(gpus: torch.Tensor) -> None:
+    """binding.cpp:58-63 ``release_env`` -> Release()."""
+    for dev in [int(i) for i in gpus.tolist()]:
+        h = _GRAPHS.pop(dev, None)
+        if h is not None:
+            _lib.crf_graph_destroy(_vp(h))
+
+
+def graph_for(device: torch.device) -> int:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    h = _GRAPHS.get(idx)
+    if h is None:
+        raise RuntimeError(
+            f"no denominator graph loaded on cuda:{idx}: create ctc_crf.CRFContext(den_lm, {idx}) first "
+            "(reference: cat/ctc/train.py:137-141)")
+    return h
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return _vp(0) if t is None else _vp(t.data_ptr())
+
+
+def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch.Tensor,
+                 ly: Optional[torch.Tensor], c_den: float, c_ctc: float, graph: Optional[int],
+                 want_costs: bool = False):
+    """One call of the hot path (include/ctc_crf_hip.h ``crf_loss_fwd_bwd``).
+
+    logits [N,T,V] f32 on the GPU, contiguous; labels/lx/ly int32 on CPU (as CAT passes them,
+    cat/ctc/train.py:176-190) or on the GPU.  Returns (loss[1], grad[N,T,V], extras dict).
+    """
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 3
+    dev = logits.device
+    N, T, V = logits.shape
+    lx32 = lx.to(torch.int32)
+    if c_ctc != 0.0:
+        ly32 = ly.to(torch.int32)
+        ly_cpu = ly32.cpu()
+        max_l = int(ly_cpu.max()) if N > 0 else 0
+        off = (torch.cumsum(ly_cpu, 0, dtype=torch.int32) - ly_cpu).to(torch.int32)
+        lab32 = labels.to(torch.int32).reshape(-1)
+        if lab32.numel() == 0:
+            lab32 = torch.zeros(1, dtype=torch.int32)
+        # one H2D copy for all integer metadata (the reference issues ~5, gpu_ctc.h:143-229)
+        meta = torch.cat([lx32.cpu().reshape(-1), ly_cpu.reshape(-1), off.reshape(-1), lab32.cpu()]).to(dev, non_blocking=True)
+        lx_d, ly_d, off_d, lab_d = meta[:N], meta[N:2 * N], meta[2 * N:3 * N], meta[3 * N:]
+    else:
+        max_l = 0
+        lx_d = lx32.to(dev, non_blocking=True)
+        ly_d = off_d = lab_d = None
+        meta = lx_d
+    gh = _vp(graph) if (graph and c_den != 0.0) else _vp(0)
+    ws_bytes = _lib.crf_workspace_bytes(gh, N, T, V, max_l)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    grad = torch.empty_like(logits)
+    out = torch.empty(1 + 3 * N, dtype=torch.float32, device=dev)
+    invalid = torch.empty(N, dtype=torch.int32, device=dev) if c_ctc != 0.0 else None
+    loss, c_alpha, c_beta, c_ctc_t = out[:1], out[1:1 + N], out[1 + N:1 + 2 * N], out[1 + 2 * N:]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        rc = _lib.crf_loss_fwd_bwd(gh, _ptr(logits), _ptr(lab_d), _ptr(off_d), _ptr(lx_d), _ptr(ly_d),
+                                   N, T, V, max_l, c_den, c_ctc, _ptr(grad), _ptr(loss), _ptr(c_alpha),
+                                   _ptr(c_beta), _ptr(c_ctc_t), _ptr(invalid), _ptr(ws), ws_bytes, _vp(stream))
+    _check(rc)
+    del meta
+    extras = dict(costs_alpha=c_alpha, costs_beta=c_beta, costs_ctc=c_ctc_t, invalid=invalid) if want_costs else {}
+    return loss, grad, extras
+
+
+def gpu_den(logits: torch.Tensor, grad_net: torch.Tensor, input_lengths: torch.Tensor,
+            costs_alpha: torch.Tensor, costs_beta: torch.Tensor) -> None:
+    """Same signature and in-place outputs as the reference's ``_C.gpu_den`` (binding.cpp:65-84)."""
+    _, g, ex = loss_fwd_bwd(logits.contiguous(), None, input_lengths, None, 1.0, 0.0, graph_for(logits.device), True)
+    grad_net.copy_(g)
+    costs_alpha.copy_(ex["costs_alpha"])
+    costs_beta.copy_(ex["costs_beta"])
+
+
+def gpu_ctc(probs: torch.Tensor, grads: torch.Tensor, labels: torch.Tensor, label_sizes: torch.Tensor,
+            sizes: torch.Tensor, minibatch_size: int, costs: torch.Tensor, blank_label: int = 0) -> None:
+    """Same signature as the reference's ``_C.gpu_ctc`` (binding.cpp:86-117): probs/grads are
+    [T,N,V] (the reference's transposed layout, __init__.py:70), costs is a CPU tensor receiving
+    +loglike.  Our kernels work on [N,T,V] directly, so this mirror transposes at the edge."""
+    assert blank_label == 0 and probs.size(1) == minibatch_size
+    # c_ctc = -1  ->  grad = +gamma_ctc, exactly what the reference's kernel writes (:431-435)
+    _, g, ex = loss_fwd_bwd(probs.transpose(0, 1).contiguous(), labels, sizes, label_sizes, 0.0, -1.0, None, True)
+    grads.copy_(g.transpose(0, 1))
+    costs.copy_(ex["costs_ctc"].to(costs.device))

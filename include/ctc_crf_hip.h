@@ -1,0 +1,114 @@
+/*
+ * include/ctc_crf_hip.h -- C ABI of libctc_crf_hip.so, the MI355X-native (gfx950) CTC-CRF loss.
+ *
+ * This is the drop-in boundary for the reference's native layer L0:
+ * plain pointers and sizes, no torch types.  It deliberately does NOT keep the reference's C
+ * symbols (binding.cpp:20-49: Init / Release / compute_alpha / compute_beta_and_grad, and
+ * gpu_ctc/ctc.h:76-109: compute_ctc_loss / get_workspace_size) because those bake in the
+ * per-frame-launch design (separate alpha and beta entry points, [32]-striped grad_storage,
+ * host-resident labels with two stream syncs).  Each entry point below names the reference
+ * interface it replaces.
+ *
+ * Conventions
+ *   - every pointer named *_dev is device memory on the graph's device; all work is enqueued on
+ *     `stream` (a hipStream_t passed as void*); nothing here synchronises the host.
+ *   - return value: 0 = CRF_OK, otherwise a crf_status; crf_last_error() gives the message
+ *     (the reference printf()s and exit(1)s, den_calculate.cu:16-25, or drops the status,
+ *     binding.cpp:111).
+ *   - log_probs: [B][T][V] float32, contiguous (the reference's `logits`, ctc_crf/__init__.py:61);
+ *     labels: flattened int32 without padding, blank = 0; lx/ly: int32 [B].
+ */
+#ifndef CTC_CRF_HIP_H_
+#define CTC_CRF_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    CRF_OK = 0,
+    CRF_ERR_IO = 1,          /* cannot open / parse the FST file                      */
+    CRF_ERR_FORMAT = 2,      /* not an OpenFst vector/standard binary, or epsilon ilabel */
+    CRF_ERR_ARG = 3,         /* bad argument (null pointer, V <= max label, ...)      */
+    CRF_ERR_HIP = 4,         /* a HIP runtime call failed                             */
+    CRF_ERR_WORKSPACE = 5,   /* workspace too small                                   */
+    CRF_ERR_UNSUPPORTED = 6  /* graph / label length exceeds what this build handles  */
+} crf_status;
+
+typedef struct crf_graph crf_graph; /* opaque: the denominator graph, resident on one GPU */
+
+/* Replaces Init(fst_name, n_gpus, gpus) (den_calculate.cu:288-392) + ReadFst (fst_read.cc:11-62),
+ * for ONE device: reads an OpenFst vector/standard binary without OpenFst, applies the same
+ * conventions (label = ilabel-1, weight = -cost, end_weight = -Final), builds the device arc
+ * tables and uploads them.  Unlike the reference there is no process-global state: any number of
+ * graphs may coexist; one is created per (den_lm, device). */
+int crf_graph_create(const char *fst_path, int device, crf_graph **out);
+
+/* Same, from arc arrays already in reference conventions (lab = ilabel-1, w = -cost, log domain;
+ * start_w/end_w = -inf for non-start / non-final states). */
+int crf_graph_create_from_arcs(int64_t num_states, int64_t num_arcs, const int32_t *src,
+                               const int32_t *dst, const int32_t *lab, const float *w,
+                               const float *start_w, const float *end_w, int device,
+                               crf_graph **out);
+
+/* Replaces Release(n_gpus, gpus) (den_calculate.cu:394-425). */
+void crf_graph_destroy(crf_graph *g);
+
+/* Replaces the globals DEN_NUM_STATES / DEN_NUM_ARCS (binding.cpp:14-15).  `num_pairs` is the
+ * number of distinct (destination state, label) pairs, the unit the kernels store per frame. */
+int crf_graph_dims(const crf_graph *g, int64_t *num_states, int64_t *num_arcs, int64_t *num_pairs,
+                   int64_t *max_label);
+
+/* Replaces get_workspace_size (ctc.h:99-109) and the torch::empty temporaries of gpu_den
+ * (binding.cpp:77-79): bytes of device scratch crf_loss_fwd_bwd needs.  `g` may be NULL when
+ * c_den == 0 (plain CTC).  `max_label_len` >= max(ly). */
+int64_t crf_workspace_bytes(const crf_graph *g, int64_t B, int64_t T, int64_t V, int64_t max_label_len);
+
+/* The hot path.  Replaces, in one call and with no host synchronisation:
+ *   gpu_ctc  (binding.cpp:86-117  -> compute_ctc_loss, ctc_entrypoint.cu:29-60)
+ *   gpu_den  (binding.cpp:65-84   -> compute_alpha + compute_beta_and_grad, den_calculate.cu:427-481)
+ *   and the combine of _CTC_CRF.forward (ctc_crf/__init__.py:78-87).
+ *
+ *   grad_dev[b][t][v]  = c_den * gamma_den[b][t][v] - c_ctc * gamma_ctc[b][t][v]   (0 for t >= lx[b])
+ *   loss_dev[0]        = sum_b ( c_den * logZ_den[b] - c_ctc * logp_ctc[b] )
+ *   costs_den_dev[b]   = logZ_den[b]   (the reference's costs_alpha_den; may be NULL)
+ *   costs_beta_dev[b]  = logZ_den[b] computed from the backward recursion (costs_beta_den; may be NULL)
+ *   costs_ctc_dev[b]   = logp_ctc[b]   (+loglike, as the modified warp-ctc returns; may be NULL)
+ *
+ * CTC-CRF loss:  c_den = s, c_ctc = s*(1+lamb), s = 1/B if size_average else 1.
+ * gpu_den alone: c_den = 1, c_ctc = 0.     gpu_ctc / WARP_CTC_LOSS: c_den = 0, c_ctc = s (g may be NULL).
+ *
+ * labels_dev: flattened labels; label_off_dev[b] = start of utterance b in it (int32 [B]).
+ * Utterances the reference treats as invalid (L + repeats > T, gpu_ctc.h:166-174, where it returns
+ * uninitialised memory) contribute logp_ctc = 0 and gamma_ctc = 0 and set invalid_dev[b] = 1
+ * (invalid_dev may be NULL). */
+int crf_loss_fwd_bwd(const crf_graph *g, const float *log_probs_dev, const int32_t *labels_dev,
+                     const int32_t *label_off_dev, const int32_t *lx_dev, const int32_t *ly_dev,
+                     int64_t B, int64_t T, int64_t V, int64_t max_label_len, float c_den, float c_ctc,
+                     float *grad_dev, float *loss_dev, float *costs_den_dev, float *costs_beta_dev,
+                     float *costs_ctc_dev, int32_t *invalid_dev, void *workspace_dev,
+                     int64_t workspace_bytes, void *stream);
+
+/* Diagnostics (no reference counterpart; the reference has no profiler hooks).
+ * crf_profile_enable(1): every following crf_loss_fwd_bwd on this thread brackets each of its
+ * kernel launches with HIP events on the stream the kernel is launched on.
+ * crf_profile_read synchronises on those events and returns, for the LAST call, up to `n`
+ * durations in milliseconds in the fixed order
+ *   [0] prep  [1] den forward chain  [2] den backward chain  [3] ctc forward chain
+ *   [4] ctc backward chain  [5] grad  [6] finalize  [7] whole call (first launch .. last launch)
+ * (-1 for kernels that were not launched).  Returns the number of slots written. */
+void crf_profile_enable(int on);
+int crf_profile_read(float *ms_out, int n);
+
+/* Message for the last non-zero status returned on this thread. */
+const char *crf_last_error(void);
+
+/* Library version string, e.g. "ctc_crf_hip 0.1.0 (gfx950)". */
+const char *crf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTC_CRF_HIP_H_ */

@@ -1,0 +1,269 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via the reference-shaped Python surface)
+against the CPU oracle, the committed golden vectors, the reference's own denominator kernels when
+oracle/_ref is present, and size-independent invariants at BASELINE sizes.
+
+Tolerance: BASELINE.json north_star states loss and grad within 1e-4 relative."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import fst_io
+from tests.util import graph_to_file, make_batch, rel_err, small_synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def crf():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctc_crf
+    return ctc_crf
+
+
+def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True):
+    ctx = crf.CRFContext(den_lm, 0)
+    x = torch.tensor(logits, device="cuda:0", requires_grad=True)
+    crit = crf.CTC_CRF_LOSS(lamb=lamb, size_average=size_average)
+    loss = crit(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32),
+                torch.tensor(ly, dtype=torch.int32))
+    loss.backward()
+    out = float(loss.item()), x.grad.detach().cpu().numpy()
+    del ctx
+    return out
+
+
+def test_fixture_kat(crf, golden_dir):
+    """Exactly src/ctc_crf/test/main.py:15-35 (the reference's only test), with the value pinned."""
+    k = json.load(open(os.path.join(golden_dir, "kat_fixture.json")))
+    logits = np.log(np.array(k["probs"], dtype=np.float32))[None]
+    loss, grad = run_hip(crf, os.path.join(golden_dir, "den_lm_fixture.fst"), logits, k["labels"], [5], [3], lamb=k["lamb"])
+    assert abs(loss - k["loss"]) <= TOL * abs(k["loss"])
+    assert rel_err(grad[0], np.array(k["grad"])) <= TOL
+
+
+def test_fixture_costs_and_gpu_den_gpu_ctc(crf, golden_dir):
+    """The _C-level mirrors (binding.cpp:65-117 signatures) against the brute-force KAT."""
+    k = json.load(open(os.path.join(golden_dir, "kat_fixture.json")))
+    core = crf._C
+    ctx = crf.CRFContext(os.path.join(golden_dir, "den_lm_fixture.fst"), 0)
+    logits = torch.tensor(np.log(np.array(k["probs"], dtype=np.float32))[None], device="cuda:0")
+    gd = torch.zeros_like(logits)
+    ca, cb = torch.zeros(1, device="cuda:0"), torch.zeros(1, device="cuda:0")
+    core.gpu_den(logits, gd, torch.tensor([5], dtype=torch.int32).cuda(), ca, cb)
+    assert abs(ca.item() - k["logZ_den"]) <= TOL * abs(k["logZ_den"])
+    assert abs(cb.item() - k["logZ_den"]) <= TOL * abs(k["logZ_den"])
+    assert rel_err(gd[0].cpu().numpy(), np.array(k["gamma_den"])) <= TOL
+    act = logits.transpose(0, 1).contiguous()
+    gc = torch.zeros_like(act)
+    cc = torch.zeros(1)
+    core.gpu_ctc(act, gc, torch.tensor(k["labels"], dtype=torch.int32), torch.tensor([3], dtype=torch.int32),
+                 torch.tensor([5], dtype=torch.int32), 1, cc, 0)
+    assert abs(cc.item() - k["logp_ctc"]) <= TOL * abs(k["logp_ctc"])
+    assert rel_err(gc.transpose(0, 1)[0].cpu().numpy(), np.array(k["gamma_ctc"])) <= TOL
+    del ctx
+
+
+def test_random_golden(crf, golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "kat_random.json")))
+    core = crf._C
+    for c in cases:
+        ctx = crf.CRFContext(os.path.join(golden_dir, c["fst"]), 0)
+        lg = torch.tensor(np.array(c["logits"], dtype=np.float32)[None], device="cuda:0")
+        T = lg.shape[1]
+        gd = torch.zeros_like(lg)
+        ca, cb = torch.zeros(1, device="cuda:0"), torch.zeros(1, device="cuda:0")
+        core.gpu_den(lg, gd, torch.tensor([T], dtype=torch.int32).cuda(), ca, cb)
+        assert abs(ca.item() - c["logZ_den"]) <= TOL * max(1.0, abs(c["logZ_den"])), c["fst"]
+        assert abs(cb.item() - c["logZ_den"]) <= TOL * max(1.0, abs(c["logZ_den"])), c["fst"]
+        assert rel_err(gd[0].cpu().numpy(), np.array(c["gamma_den"])) <= TOL, c["fst"]
+        del ctx
+
+
+@pytest.mark.parametrize("seed,B,T,vocab,hist,fan", [(0, 3, 20, 8, 16, 4), (1, 5, 37, 12, 40, 6), (2, 2, 64, 72, 128, 16)])
+def test_synth_vs_oracle_ragged(crf, tmp_path, seed, B, T, vocab, hist, fan):
+    g, p = small_synth(tmp_path, vocab, hist, fan, seed)
+    logits, labels, lx, ly = make_batch(g, B, T, vocab, seed=seed, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+    for b in range(B):  # rows past lx[b] are exactly zero (copy_grad returns early, den_calculate.cu:239)
+        assert np.all(grad[b, lx[b]:] == 0.0)
+
+
+def test_edge_cases(crf, tmp_path):
+    """repeats, L = 0, L + repeats == T (no slack), lx < T, and an invalid utterance (L + repeats > T)."""
+    g, p = small_synth(tmp_path, 6, 8, 3, 3)
+    rng = np.random.default_rng(5)
+    B, T, V = 5, 9, 6
+    x = rng.normal(size=(B, T, V)) * 2
+    logits = (x - np.log(np.exp(x).sum(-1, keepdims=True))).astype(np.float32)
+    labs = [[1, 1, 2], [], [3, 3, 3, 3, 3], [2, 4, 2, 4], [1, 1, 1, 1, 1, 1]]
+    lx = np.array([9, 7, 9, 4, 9], dtype=np.int32)  # utt 2: L+rep = 9 == T; utt 4: 6+5 = 11 > 9 invalid
+    ly = np.array([len(l) for l in labs], dtype=np.int32)
+    labels = np.array([v for l in labs for v in l], dtype=np.int32)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.3, size_average=False)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.3, size_average=False)
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
+def test_peaked_inputs(crf, tmp_path):
+    """Near one-hot posteriors (log-probs down to about -60): stresses the linear-domain rescaling that
+    replaces the reference's per-arc log-add (den_calculate.cu:29-35)."""
+    g, p = small_synth(tmp_path, 10, 24, 5, 7)
+    B, T, V = 3, 50, 10
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(B, T, V)) * 20.0
+    logits = (x - x.max(-1, keepdims=True))
+    logits = (logits - np.log(np.exp(logits).sum(-1, keepdims=True))).astype(np.float32)
+    _, labels, lx, ly = make_batch(g, B, T, V, seed=3, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
+    assert np.isfinite(loss)
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
+def test_warp_ctc_loss_vs_torch(crf):
+    """WARP_CTC_LOSS (reference __init__.py:128-144) against torch's own CPU ctc_loss."""
+    rng = np.random.default_rng(2)
+    B, T, V = 4, 30, 11
+    x = torch.tensor(rng.normal(size=(B, T, V)), dtype=torch.float32).log_softmax(-1)
+    ly = torch.tensor([5, 0, 9, 3], dtype=torch.int32)
+    lx = torch.tensor([30, 12, 25, 30], dtype=torch.int32)
+    labels = torch.tensor(rng.integers(1, V, size=int(ly.sum())), dtype=torch.int32)
+    xg = x.cuda().requires_grad_(True)
+    loss = crf.WARP_CTC_LOSS(size_average=False)(xg, labels, lx, ly)
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.ctc_loss(xr.transpose(0, 1), labels.long(), lx.long(), ly.long(), blank=0, reduction="sum")
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= TOL * abs(ref.item())
+    # torch returns d/d(logits-before-log_softmax) = softmax - gamma ; ours is -gamma on the log-probs
+    mask = (torch.arange(T)[None, :] < lx[:, None]).float()[..., None]
+    gamma_ref = (x.exp() * mask - xr.grad)
+    assert rel_err(-xg.grad.cpu().numpy(), gamma_ref.numpy()) <= 5e-4
+
+
+def _default_graph(tmp_path_factory):
+    d = tmp_path_factory.mktemp("denlm")
+    p = os.path.join(str(d), "den_lm_v72.fst")
+    from cat_amd.den_lm import synth_den_lm
+    return synth_den_lm(72, 2048, 24, 0, path=p), p
+
+
+@pytest.fixture(scope="module")
+def default_graph(tmp_path_factory):
+    return _default_graph(tmp_path_factory)
+
+
+def test_config2_slice_vs_oracle(crf, default_graph):
+    """BASELINE config #2 graph and shapes (V=72, S=4097, T=500), on a 3-utterance slice the fp64
+    oracle finishes in seconds."""
+    g, p = default_graph
+    logits, labels, lx, ly = make_batch(g, 3, 500, 72, seed=0, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
+def test_full_size_invariants(crf, default_graph):
+    """B=32, T=500, V=72 (config #2, full) -- size-independent properties:
+    both posterior matrices sum to 1 per frame for t < lx and are 0 after; logZ from the forward
+    and from the backward recursion agree; per-utterance results do not depend on batch position."""
+    g, p = default_graph
+    B, T, V = 32, 500, 72
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=1, ragged=True)
+    core = crf._C
+    ctx = crf.CRFContext(p, 0)
+    x = torch.tensor(logits, device="cuda:0")
+    _, gden, ex = core.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, core.graph_for(x.device), True)
+    gden = gden.cpu().numpy()
+    ca, cb = ex["costs_alpha"].cpu().numpy(), ex["costs_beta"].cpu().numpy()
+    assert np.allclose(ca, cb, rtol=2e-5, atol=0)
+    _, gctc, ex2 = core.loss_fwd_bwd(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
+    gctc = gctc.cpu().numpy()
+    assert int(ex2["invalid"].sum().item()) == 0
+    for b in range(B):
+        n = int(lx[b])
+        assert np.allclose(gden[b, :n].sum(-1), 1.0, atol=2e-4)
+        assert np.allclose(gctc[b, :n].sum(-1), 1.0, atol=2e-4)
+        assert np.all(gden[b, n:] == 0) and np.all(gctc[b, n:] == 0)
+    assert gden.min() >= 0 and gctc.min() >= 0
+    # permutation invariance: utterance 5 alone == utterance 5 inside the batch
+    _, g5, ex5 = core.loss_fwd_bwd(x[5:6].contiguous(), None, torch.tensor(lx[5:6]), None, 1.0, 0.0, core.graph_for(x.device), True)
+    assert np.allclose(g5.cpu().numpy()[0], gden[5], rtol=1e-5, atol=1e-7)
+    del ctx
+
+
+def _ref_den(p, logits, lx):
+    """The reference's own kernels (den_calculate.cu, compiled for gfx950 into oracle/_ref)."""
+    so = os.path.join(os.path.dirname(oracle.__file__), "_ref", "libden_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libden_ref.so not built (needs /root/reference at build time)")
+    lib = ctypes.CDLL(so)
+    B, T, V = logits.shape
+    gpus = (ctypes.c_int * 1)(0)
+    lib.Init(os.fsencode(p), 1, gpus)
+    S = ctypes.c_int.in_dll(lib, "DEN_NUM_STATES").value
+    x = torch.tensor(logits, device="cuda:0")
+    lxd = torch.tensor(lx, dtype=torch.int32, device="cuda:0")
+    alpha = torch.empty((T + 1) * B * S, device="cuda:0")
+    beta = torch.empty(2 * B * S, device="cuda:0")
+    gs = torch.empty(32 * B * V, device="cuda:0")
+    grad = torch.zeros(B, T, V, device="cuda:0")
+    ca, cb = torch.zeros(B, device="cuda:0"), torch.zeros(B, device="cuda:0")
+    vp = ctypes.c_void_p
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lib.compute_alpha(vp(alpha.data_ptr()), vp(x.data_ptr()), B, T, S, V, vp(lxd.data_ptr()), vp(ca.data_ptr()), st)
+    lib.compute_beta_and_grad(vp(beta.data_ptr()), vp(alpha.data_ptr()), vp(x.data_ptr()), vp(ca.data_ptr()),
+                              vp(gs.data_ptr()), vp(grad.data_ptr()), B, T, S, V, vp(lxd.data_ptr()), vp(cb.data_ptr()), st)
+    torch.cuda.synchronize()
+    out = grad.cpu().numpy(), ca.cpu().numpy()
+    lib.Release(1, gpus)
+    return out
+
+
+def test_denominator_vs_reference_kernels(crf, tmp_path):
+    """gpu_den of this repo vs the REFERENCE'S OWN CUDA kernels built for gfx950 (oracle/Makefile `ref`)."""
+    g, p = small_synth(tmp_path, 72, 256, 16, 4)
+    logits, _, lx, _ = make_batch(g, 4, 120, 72, seed=4, ragged=True)
+    gref, cref = _ref_den(p, logits, lx)
+    core = crf._C
+    ctx = crf.CRFContext(p, 0)
+    x = torch.tensor(logits, device="cuda:0")
+    _, gd, ex = core.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, core.graph_for(x.device), True)
+    assert np.allclose(ex["costs_alpha"].cpu().numpy(), cref, rtol=TOL, atol=0)
+    assert rel_err(gd.cpu().numpy(), gref) <= TOL
+    del ctx
+
+
+def test_functional_and_errors(crf, golden_dir, tmp_path):
+    k = json.load(open(os.path.join(golden_dir, "kat_fixture.json")))
+    lp = torch.tensor(np.log(np.array(k["probs"], dtype=np.float32))[None], device="cuda:0", requires_grad=True)
+    loss = crf.ctc_crf_loss(lp, torch.tensor(k["labels"]), torch.tensor([5]), torch.tensor([3]),
+                            os.path.join(golden_dir, "den_lm_fixture.fst"), lamb=k["lamb"])
+    assert loss.shape == (1,) and abs(loss.item() - k["loss"]) <= TOL * abs(k["loss"])
+    (2.0 * loss).backward()  # backward multiplies the saved grads by grad_output (__init__.py:92-94)
+    assert rel_err(lp.grad[0].cpu().numpy(), 2.0 * np.array(k["grad"])) <= TOL
+    with pytest.raises(RuntimeError):
+        crf.CRFContext(os.path.join(str(tmp_path), "missing.fst"), 0)
+    with pytest.raises(RuntimeError):
+        crf.CRFContext(os.path.join(golden_dir, "den_lm_fixture.fst"), 99)
+    bad = os.path.join(str(tmp_path), "bad.fst")
+    open(bad, "wb").write(b"not an fst at all")
+    with pytest.raises(RuntimeError):
+        crf.CRFContext(bad, 0)
+    with pytest.raises(AssertionError):  # dtype asserts of CTC_CRF_LOSS.forward (__init__.py:116-124)
+        crf.CTC_CRF_LOSS()(lp.double(), torch.tensor([1], dtype=torch.int32), torch.tensor([5], dtype=torch.int32),
+                           torch.tensor([1], dtype=torch.int32))
