@@ -13,7 +13,10 @@ constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kChainWaves = 16;    // waves per chain workgroup (1024 threads = one full CU)
 constexpr int kChainThreads = kChainWaves * kWave;
 constexpr int kChunk = 32;         // pairs per grad-pass chunk
-constexpr int kScaleExp = 40;      // per-frame rescale target: max entry in [2^40, 2^41)
+constexpr int kScaleExp = 20;      // den per-frame rescale target: max entry in [2^20, 2^21)
+constexpr int kEpExp = 64;         // den emission factors are stored as exp(logp - rowmax) * 2^64, so
+                                   // they stay normal fp32 numbers down to e^-131 below the row max
+constexpr int kScaleExpD = 40;     // ctc (fp64) per-frame rescale target
 
 // One direction of the recursion as sliced-ELL: rows are grouped in slices of 64 (one wave), rows
 // sorted by degree so a slice pads only to its own widest row; two arcs per 16-byte element

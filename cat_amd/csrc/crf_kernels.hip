@@ -50,9 +50,10 @@ struct LossParams {
     float *ep, *mx;               // [B*T*V] exp(logp - mx), [B*T] row max
     float *Q, *BP;                // [B*T*Pr] q_t[p], b_{t+1}[dst_p]  (scaled)
     int *EQ, *EB;                 // [B*T] their binary exponents
-    float *CA, *CB;               // [B*T*Sc] ctc forward (incl. emission) / backward (excl.)  (scaled)
+    double *CA, *CB;              // [B*T*Sc] ctc forward (incl. emission) / backward (excl.)  (scaled, fp64)
     int *ECA, *ECB;
-    float *den_zs, *ctc_zc;       // [B] scaled partition sums
+    float *den_zs;                // [B] scaled partition sums
+    double *ctc_zc;
     int *den_ez, *ctc_ez;         // [B] their exponents
     float *cost_alpha, *cost_beta, *cost_ctc;  // [B]
     int *invalid;                 // [B]
@@ -77,6 +78,33 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// fp64 twin of rescale_exp / pow2f for the numerator chains
+__device__ __forceinline__ int rescale_exp_d(double m) {
+    if (!(m > 0.0)) return 0;
+    int e = (int)(((unsigned long long)__double_as_longlong(m) >> 52) & 0x7ffull) - 1023;
+    int k = kScaleExpD - e;
+    return k < -900 ? -900 : (k > 900 ? 900 : k);
+}
+__device__ __forceinline__ double pow2d(int k) { return __longlong_as_double((long long)(k + 1023) << 52); }
+// exp(d) * 2^add for d <= 0 without intermediate underflow: d = k ln2 + r, result = exp(r) * 2^(k+add)
+__device__ __forceinline__ float exp_scaled(float d, int add) {
+    const float k = rintf(d * 1.4426950408889634f);
+    float r = fmaf(-k, 0.693145751953125f, d);
+    r = fmaf(-k, 1.428606765330187e-06f, r);
+    return ldexpf(expf(r), (int)k + add);
+}
+__device__ __forceinline__ double exp_scaled_d(float d) {
+    const float k = rintf(d * 1.4426950408889634f);
+    float r = fmaf(-k, 0.693145751953125f, d);
+    r = fmaf(-k, 1.428606765330187e-06f, r);
+    return ldexp((double)expf(r), (int)k);
+}
+
 // exact power-of-two rescale that brings m into [2^kScaleExp, 2^(kScaleExp+1))
 __device__ __forceinline__ int rescale_exp(float m) {
     if (!(m > 0.f)) return 0;
@@ -87,7 +115,7 @@ __device__ __forceinline__ int rescale_exp(float m) {
 __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
 
 // ---------------------------------------------------------------------------------------------
-// prep: e[b][t][v] = exp(logp[b][t][v] - max_v), mx[b][t] = max_v   (one wave per frame)
+// prep: e[b][t][v] = exp(logp[b][t][v] - max_v) * 2^kEpExp, mx[b][t] = max_v   (one wave per frame)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     const int lane = threadIdx.x & 63;
@@ -101,7 +129,7 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     m = wave_max(m);
     if (m == -INFINITY) m = 0.f;
     float *er = p.ep + f * p.V;
-    for (int v = lane; v < p.V; v += 64) er[v] = expf(row[v] - m);
+    for (int v = lane; v < p.V; v += 64) er[v] = exp_scaled(row[v] - m, kEpExp);
     if (lane == 0) p.mx[f] = m;
 }
 
@@ -186,8 +214,9 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
         __syncthreads();
         const int k = rescale_exp(frame_max(wm + (t & 1) * kChainWaves));
         const float sc = pow2f(k);
-        E += k;
+        E += k;                       // exponent of q_t
         if (tid == 0) p.EQ[bt0 + t] = E;
+        E += kEpExp;                  // a_{t+1} = sum e'_t q_t carries the 2^kEpExp of e'_t
         for (int s = tid; s < Sp; s += kChainThreads) Xz[s] = 0.f;
         float *Qrow = p.Q + (bt0 + t) * Pr;
         for (int i = sl0; i < sl1; ++i) {
@@ -297,7 +326,7 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
         __syncthreads();
         const int k = rescale_exp(frame_max(wm + (i & 1) * kChainWaves));
         const float sc = pow2f(k);
-        F += k;
+        F += k + kEpExp;              // Z_t = e'_t b_{t+1} carries the 2^kEpExp of e'_t
         for (int ii = sl0; ii < sl1; ++ii) {
             const int j = g.bwd.wave_slices[ii];
             const uint4 *a = g.bwd.arcs + g.bwd.slice_off[j] + lane;
@@ -339,33 +368,57 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
 }
 
 // ---------------------------------------------------------------------------------------------
-// CTC numerator chains.  LDS: Abuf[2][Sxp] | lab[Sxp] (int) | wmax[2][16] | red
+// CTC numerator chains, in fp64: a forced alignment may have to pass through frames where the
+// label is e^-100 below the row max, so the numerator gets the e^+-700 range of doubles (it is
+// ~1% of the work).  Emissions are formed in-kernel as exp(logp - rowmax) in double.
+// LDS: Abuf[2][Sxp] (double) | wmax[2][16] (double) | red[16] (double) | lab[Sxp] (int)
 // validity rule L + repeats <= T_b: gpu_ctc.h:161-174
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool ctc_setup(const LossParams &p, int b, int *lab, float *red, int L, int lx, int tid) {
+struct CtcLds {
+    double *A, *wm, *red;
+    int *lab;
+};
+__device__ __forceinline__ CtcLds ctc_carve(float *lds, int Sxp) {
+    CtcLds c;
+    c.A = (double *)lds;
+    c.wm = c.A + 2 * Sxp;
+    c.red = c.wm + 2 * kChainWaves;
+    c.lab = (int *)(c.red + kChainWaves);
+    return c;
+}
+__device__ __forceinline__ bool ctc_setup(const LossParams &p, int b, const CtcLds &c, int L, int lx, int tid) {
     const int *ul = p.labels + p.lab_off[b];
     const int Sx = 2 * L + 1;
     float rep = 0.f;
-    for (int s = tid; s < Sx; s += kChainThreads) lab[s] = (s & 1) ? ul[s >> 1] : 0;
+    for (int s = tid; s < Sx; s += kChainThreads) c.lab[s] = (s & 1) ? ul[s >> 1] : 0;
     for (int i = tid + 1; i < L; i += kChainThreads) rep += (ul[i] == ul[i - 1]) ? 1.f : 0.f;
-    const int repeats = (int)(block_sum(rep, red, tid) + 0.5f);  // also orders the lab[] writes
+    const int repeats = (int)(block_sum(rep, (float *)c.red, tid) + 0.5f);  // also orders the lab[] writes
+    __syncthreads();
     return lx > 0 && L + repeats <= lx;
+}
+__device__ __forceinline__ double frame_max_d(const double *wm) {
+    double m = wm[0];
+#pragma unroll
+    for (int i = 1; i < kChainWaves; ++i) m = fmax(m, wm[i]);
+    return m;
+}
+__device__ __forceinline__ float to_log_d(double zs, int e, double mxs) {
+    return zs > 0.0 ? (float)(log(zs) - (double)e * 0.6931471805599453 + mxs) : -INFINITY;
 }
 
 __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
-    float *A = lds;
-    int *lab = (int *)(A + 2 * Sxp);
-    float *wm = (float *)(lab + Sxp);
-    double *red = (double *)(wm + 2 * kChainWaves);
+    const CtcLds c = ctc_carve(lds, Sxp);
+    double *A = c.A, *wm = c.wm;
+    const int *lab = c.lab;
     const int64_t bt0 = (int64_t)b * p.T;
-    const bool valid = ctc_setup(p, b, lab, (float *)red, L, lx, tid);
+    const bool valid = ctc_setup(p, b, c, L, lx, tid);
     if (!valid) {
         if (tid == 0) {
             const bool empty_ok = (lx <= 0 && L == 0);
-            p.ctc_zc[b] = 0.f; p.ctc_ez[b] = 0; p.cost_ctc[b] = 0.f; p.invalid[b] = empty_ok ? 0 : 1;
+            p.ctc_zc[b] = 0.0; p.ctc_ez[b] = 0; p.cost_ctc[b] = 0.f; p.invalid[b] = empty_ok ? 0 : 1;
         }
         return;
     }
@@ -377,16 +430,18 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         mylab[i] = s < Sx ? lab[s] : 0;
         skip[i] = s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2];
     }
-    int E = kScaleExp;
+    int E = kScaleExpD;
     {   // t = 0 (gpu_ctc_kernels.h:146-152)
-        const float *er = p.ep + bt0 * V;
-        float *CArow = p.CA + bt0 * p.Sc;
+        const float *lr = p.logp + bt0 * V;
+        const float m0 = p.mx[bt0];
+        double *CArow = p.CA + bt0 * p.Sc;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
             const int s = tid + i * kChainThreads;
             if (s < Sxp) {
-                const float v = (s < 2 && s < Sx) ? er[mylab[i]] * pow2f(kScaleExp) : 0.f;
+                const double v = (s < 2 && s < Sx) ? exp_scaled_d(lr[mylab[i]] - m0) * pow2d(kScaleExpD) : 0.0;
                 A[s] = v;
+                A[Sxp + s] = 0.0;
                 if (s < Sx) CArow[s] = v;
             }
         }
@@ -394,29 +449,30 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
     }
     __syncthreads();
     for (int t = 1; t < lx; ++t) {
-        const float *Ac = A + ((t - 1) & 1) * Sxp;
-        float *An = A + (t & 1) * Sxp;
-        const float *er = p.ep + (bt0 + t) * V;
-        float em[kCtcRegs];
+        const double *Ac = A + ((t - 1) & 1) * Sxp;
+        double *An = A + (t & 1) * Sxp;
+        const float *lr = p.logp + (bt0 + t) * V;
+        const float mt = p.mx[bt0 + t];
+        double em[kCtcRegs];
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) em[i] = (tid + i * kChainThreads < Sx) ? er[mylab[i]] : 0.f;
-        float m = 0.f;
-        for (int s = tid; s < Sx; s += kChainThreads) m = fmaxf(m, Ac[s]);
-        m = wave_max(m);
+        for (int i = 0; i < kCtcRegs; ++i) em[i] = (tid + i * kChainThreads < Sx) ? exp_scaled_d(lr[mylab[i]] - mt) : 0.0;
+        double m = 0.0;
+        for (int s = tid; s < Sx; s += kChainThreads) m = fmax(m, Ac[s]);
+        m = wave_max_d(m);
         if (lane == 0) wm[(t & 1) * kChainWaves + wave] = m;
         __syncthreads();
-        const int k = rescale_exp(frame_max(wm + (t & 1) * kChainWaves));
-        const float sc = pow2f(k);
+        const int k = rescale_exp_d(frame_max_d(wm + (t & 1) * kChainWaves));
+        const double sc = pow2d(k);
         E += k;
-        float *CArow = p.CA + (bt0 + t) * p.Sc;
+        double *CArow = p.CA + (bt0 + t) * p.Sc;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
             const int s = tid + i * kChainThreads;
             if (s < Sx) {
-                float a = Ac[s];
+                double a = Ac[s];
                 if (s >= 1) a += Ac[s - 1];
                 if (skip[i]) a += Ac[s - 2];
-                const float v = sc * em[i] * a;
+                const double v = sc * em[i] * a;
                 An[s] = v;
                 CArow[s] = v;
             }
@@ -424,14 +480,14 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         if (tid == 0) p.ECA[bt0 + t] = E;
         __syncthreads();
     }
-    const float *Af = A + ((lx - 1) & 1) * Sxp;
-    const double mxs = mx_total(p, b, lx, red, tid);
+    const double *Af = A + ((lx - 1) & 1) * Sxp;
+    const double mxs = mx_total(p, b, lx, c.red, tid);
     if (tid == 0) {
-        const float zc = Af[Sx - 1] + (Sx > 1 ? Af[Sx - 2] : 0.f);
-        const bool ok = zc > 0.f;
-        p.ctc_zc[b] = ok ? zc : 0.f;
+        const double zc = Af[Sx - 1] + (Sx > 1 ? Af[Sx - 2] : 0.0);
+        const bool ok = zc > 0.0;
+        p.ctc_zc[b] = ok ? zc : 0.0;
         p.ctc_ez[b] = E;
-        p.cost_ctc[b] = ok ? to_log(zc, E, mxs) : 0.f;
+        p.cost_ctc[b] = ok ? to_log_d(zc, E, mxs) : 0.f;
         p.invalid[b] = ok ? 0 : 1;
     }
 }
@@ -442,12 +498,11 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
-    float *Y = lds;
-    int *lab = (int *)(Y + 2 * Sxp);
-    float *wm = (float *)(lab + Sxp);
-    double *red = (double *)(wm + 2 * kChainWaves);
+    const CtcLds c = ctc_carve(lds, Sxp);
+    double *Y = c.A, *wm = c.wm;
+    const int *lab = c.lab;
     const int64_t bt0 = (int64_t)b * p.T;
-    if (!ctc_setup(p, b, lab, (float *)red, L, lx, tid)) return;
+    if (!ctc_setup(p, b, c, L, lx, tid)) return;
     int mylab[kCtcRegs];
     bool skip[kCtcRegs];
 #pragma unroll
@@ -456,17 +511,18 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         mylab[i] = s < Sx ? lab[s] : 0;
         skip[i] = (s + 2 < Sx) && lab[s + 2] != 0 && lab[s + 2] != mylab[i];
     }
-    int F = kScaleExp;
+    int F = kScaleExpD;
     {   // t = lx-1
-        const float *er = p.ep + (bt0 + lx - 1) * V;
-        float *CBrow = p.CB + (bt0 + lx - 1) * p.Sc;
+        const float *lr = p.logp + (bt0 + lx - 1) * V;
+        const float ml = p.mx[bt0 + lx - 1];
+        double *CBrow = p.CB + (bt0 + lx - 1) * p.Sc;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
             const int s = tid + i * kChainThreads;
             if (s < Sxp) {
-                const float bx = (s < Sx && s >= Sx - 2) ? pow2f(kScaleExp) : 0.f;
-                Y[s] = s < Sx ? er[mylab[i]] * bx : 0.f;
-                Y[Sxp + s] = 0.f;
+                const double bx = (s < Sx && s >= Sx - 2) ? pow2d(kScaleExpD) : 0.0;
+                Y[s] = s < Sx ? exp_scaled_d(lr[mylab[i]] - ml) * bx : 0.0;
+                Y[Sxp + s] = 0.0;
                 if (s < Sx) CBrow[s] = bx;
             }
         }
@@ -475,29 +531,30 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     __syncthreads();
     for (int i = 1; i < lx; ++i) {
         const int t = lx - 1 - i;
-        const float *Yc = Y + ((i - 1) & 1) * Sxp;
-        float *Yn = Y + (i & 1) * Sxp;
-        const float *er = p.ep + (bt0 + t) * V;
-        float em[kCtcRegs];
+        const double *Yc = Y + ((i - 1) & 1) * Sxp;
+        double *Yn = Y + (i & 1) * Sxp;
+        const float *lr = p.logp + (bt0 + t) * V;
+        const float mt = p.mx[bt0 + t];
+        double em[kCtcRegs];
 #pragma unroll
-        for (int q = 0; q < kCtcRegs; ++q) em[q] = (tid + q * kChainThreads < Sx) ? er[mylab[q]] : 0.f;
-        float m = 0.f;
-        for (int s = tid; s < Sx; s += kChainThreads) m = fmaxf(m, Yc[s]);
-        m = wave_max(m);
+        for (int q = 0; q < kCtcRegs; ++q) em[q] = (tid + q * kChainThreads < Sx) ? exp_scaled_d(lr[mylab[q]] - mt) : 0.0;
+        double m = 0.0;
+        for (int s = tid; s < Sx; s += kChainThreads) m = fmax(m, Yc[s]);
+        m = wave_max_d(m);
         if (lane == 0) wm[(i & 1) * kChainWaves + wave] = m;
         __syncthreads();
-        const int k = rescale_exp(frame_max(wm + (i & 1) * kChainWaves));
-        const float sc = pow2f(k);
+        const int k = rescale_exp_d(frame_max_d(wm + (i & 1) * kChainWaves));
+        const double sc = pow2d(k);
         F += k;
-        float *CBrow = p.CB + (bt0 + t) * p.Sc;
+        double *CBrow = p.CB + (bt0 + t) * p.Sc;
 #pragma unroll
         for (int q = 0; q < kCtcRegs; ++q) {
             const int s = tid + q * kChainThreads;
             if (s < Sx) {
-                float a = Yc[s];
+                double a = Yc[s];
                 if (s + 1 < Sx) a += Yc[s + 1];
                 if (skip[q]) a += Yc[s + 2];
-                const float bx = sc * a;
+                const double bx = sc * a;
                 CBrow[s] = bx;
                 Yn[s] = em[q] * bx;
             }
@@ -536,13 +593,14 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
     float *gd = csum + rup64(NC);
     float *gc = gd + Vp;
     const int64_t bt0 = (int64_t)b * p.T;
-    float zs = 0.f, zc = 0.f;
+    float zs = 0.f;
+    double zc = 0.0;
     int ez = 0, ezc = 0, Sx = 0;
     const int *ul = nullptr;
     if (do_den) { zs = p.den_zs[b]; ez = p.den_ez[b]; }
     if (do_ctc) { zc = p.ctc_zc[b]; ezc = p.ctc_ez[b]; Sx = 2 * p.ly[b] + 1; ul = p.labels + p.lab_off[b]; }
     const float inv = zs > 0.f ? 1.f / zs : 0.f;
-    const float invc = zc > 0.f ? 1.f / zc : 0.f;
+    const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
 
     const int t0 = blockIdx.x * kGradFrames;
     for (int t = t0; t < t0 + kGradFrames && t < p.T; ++t) {
@@ -561,7 +619,7 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
                 csum[c] = s;
             }
             __syncthreads();
-            const int e = ez - p.EQ[bt0 + t] - p.EB[bt0 + t];
+            const int e = ez - p.EQ[bt0 + t] - p.EB[bt0 + t] - kEpExp;  // er[] carries 2^kEpExp
             const float *er = p.ep + (bt0 + t) * V;
             for (int v = tid; v < V; v += kGradThreads) {
                 float s = 0.f;
@@ -570,28 +628,27 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
                 gd[v] = er[v] * (ldexpf(s, e) * inv);
             }
         }
-        float fc = 0.f;
         if (do_ctc) {
             for (int v = tid; v < V; v += kGradThreads) gc[v] = 0.f;
             __syncthreads();
-            if (zc > 0.f) {
-                const float *Ar = p.CA + (bt0 + t) * p.Sc, *Br = p.CB + (bt0 + t) * p.Sc;
+            if (zc > 0.0) {
+                const double *Ar = p.CA + (bt0 + t) * p.Sc, *Br = p.CB + (bt0 + t) * p.Sc;
+                const double fc = ldexp(invc, ezc - p.ECA[bt0 + t] - p.ECB[bt0 + t]);
                 float blank = 0.f;
                 for (int s = tid; s < Sx; s += kGradThreads) {
-                    const float pr = Ar[s] * Br[s];
+                    const float pr = (float)(Ar[s] * Br[s] * fc);  // a posterior, in [0,1]
                     if (s & 1) atomicAdd(&gc[ul[s >> 1]], pr);
                     else blank += pr;
                 }
                 blank = wave_sum(blank);
                 if (lane == 0) atomicAdd(&gc[0], blank);
-                fc = ldexpf(invc, ezc - p.ECA[bt0 + t] - p.ECB[bt0 + t]);
             }
         }
         __syncthreads();
         for (int v = tid; v < V; v += kGradThreads) {
             float o = 0.f;
             if (do_den) o = p.c_den * gd[v];
-            if (do_ctc) o -= p.c_ctc * (gc[v] * fc);
+            if (do_ctc) o -= p.c_ctc * gc[v];
             row[v] = o;
         }
         __syncthreads();
@@ -641,11 +698,11 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_BP = o; o = al(o + B * T * Pr * 4);
     w.off_EQ = o; o = al(o + B * T * 4);
     w.off_EB = o; o = al(o + B * T * 4);
-    w.off_CA = o; o = al(o + B * T * Sc * 4);
-    w.off_CB = o; o = al(o + B * T * Sc * 4);
+    w.off_CA = o; o = al(o + B * T * Sc * 8);
+    w.off_CB = o; o = al(o + B * T * Sc * 8);
     w.off_ECA = o; o = al(o + B * T * 4);
     w.off_ECB = o; o = al(o + B * T * 4);
-    w.off_pb = o; o = al(o + 16 * B * 4);
+    w.off_pb = o; o = al(o + 16 * B * 8);
     w.total = o;
     return w;
 }
@@ -655,7 +712,7 @@ static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role) {
     size_t fl;
     if (role == 0) fl = (size_t)3 * rup64(h->dev.S) + 2 * rup64(V) + tail;
     else if (role == 1) fl = (size_t)4 * h->dev.Pr + 2 * rup64(V) + tail;
-    else fl = (size_t)3 * Sc + tail;
+    else fl = (size_t)2 * (2 * Sc + 3 * kChainWaves) + Sc + 16;  // doubles counted as 2 floats
     return fl * sizeof(float);
 }
 
@@ -779,11 +836,12 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     p.ep = (float *)(base + w.off_ep); p.mx = (float *)(base + w.off_mx);
     p.Q = (float *)(base + w.off_Q); p.BP = (float *)(base + w.off_BP);
     p.EQ = (int *)(base + w.off_EQ); p.EB = (int *)(base + w.off_EB);
-    p.CA = (float *)(base + w.off_CA); p.CB = (float *)(base + w.off_CB);
+    p.CA = (double *)(base + w.off_CA); p.CB = (double *)(base + w.off_CB);
     p.ECA = (int *)(base + w.off_ECA); p.ECB = (int *)(base + w.off_ECB);
-    float *pb = (float *)(base + w.off_pb);
-    p.den_zs = pb; p.ctc_zc = pb + B; p.den_ez = (int *)(pb + 2 * B); p.ctc_ez = (int *)(pb + 3 * B);
-    p.cost_alpha = pb + 4 * B; p.cost_beta = pb + 5 * B; p.cost_ctc = pb + 6 * B; p.invalid = (int *)(pb + 7 * B);
+    p.ctc_zc = (double *)(base + w.off_pb);
+    float *pb = (float *)(p.ctc_zc + B);
+    p.den_zs = pb; p.den_ez = (int *)(pb + B); p.ctc_ez = (int *)(pb + 2 * B);
+    p.cost_alpha = pb + 3 * B; p.cost_beta = pb + 4 * B; p.cost_ctc = pb + 5 * B; p.invalid = (int *)(pb + 6 * B);
     p.grad = grad; p.loss = loss; p.out_den = costs_den; p.out_beta = costs_beta; p.out_ctc = costs_ctc;
     p.out_invalid = invalid;
 

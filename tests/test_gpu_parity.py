@@ -115,21 +115,44 @@ def test_edge_cases(crf, tmp_path):
     assert rel_err(grad, ref["grad"]) <= TOL
 
 
+def _peaked(B, T, V, scale, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(B, T, V)) * scale
+    x = x - x.max(-1, keepdims=True)
+    return (x - np.log(np.exp(x).sum(-1, keepdims=True))).astype(np.float32)
+
+
 def test_peaked_inputs(crf, tmp_path):
-    """Near one-hot posteriors (log-probs down to about -60): stresses the linear-domain rescaling that
-    replaces the reference's per-arc log-add (den_calculate.cu:29-35)."""
+    """Near one-hot posteriors (log-probs down to about -100 below the row max): stresses the
+    linear-domain rescaling that replaces the reference's per-arc log-add (den_calculate.cu:29-35)."""
     g, p = small_synth(tmp_path, 10, 24, 5, 7)
     B, T, V = 3, 50, 10
-    rng = np.random.default_rng(11)
-    x = rng.normal(size=(B, T, V)) * 20.0
-    logits = (x - x.max(-1, keepdims=True))
-    logits = (logits - np.log(np.exp(logits).sum(-1, keepdims=True))).astype(np.float32)
+    logits = _peaked(B, T, V, 20.0, 11)
     _, labels, lx, ly = make_batch(g, B, T, V, seed=3, ragged=True)
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
     loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
     assert np.isfinite(loss)
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
+
+
+def test_numerator_extreme_range(crf):
+    """Forced alignments through labels ~400 nats below the row max: the numerator runs in fp64
+    (range e^+-700) exactly so that this matches the log-domain reference semantics."""
+    B, T, V = 3, 40, 9
+    logits = _peaked(B, T, V, 80.0, 5)
+    rng = np.random.default_rng(6)
+    ly = np.array([4, 7, 0], dtype=np.int32)
+    lx = np.array([40, 33, 21], dtype=np.int32)
+    labels = rng.integers(1, V, size=int(ly.sum())).astype(np.int32)
+    gref, cref, valid = oracle.ctc(logits, labels, lx, ly)
+    assert valid.all() and cref.min() < -300
+    core = crf._C
+    _, g, ex = core.loss_fwd_bwd(torch.tensor(logits, device="cuda:0"), torch.tensor(labels), torch.tensor(lx),
+                                 torch.tensor(ly), 0.0, -1.0, None, True)
+    assert np.allclose(ex["costs_ctc"].cpu().numpy(), cref, rtol=TOL, atol=0)
+    assert int(ex["invalid"].sum().item()) == 0
+    assert rel_err(g.cpu().numpy(), gref) <= TOL
 
 
 def test_warp_ctc_loss_vs_torch(crf):
