@@ -42,9 +42,8 @@ struct GraphDev {
     int max_label;  // largest label on any arc
     EllDev fwd;     // rows = pairs,  arc idx = source state,       w = exp(weight)
     EllDev bwd;     // rows = states, arc idx = pair of that arc,   w = exp(weight)
-    const int *pair_dst;     // [Pr] destination state of pair (-1 = padding row)
-    const int *pair_lab;     // [Pr] label of pair
-    const int *bwd_row_state;// [Sr] state of each backward row (-1 = padding)
+    const int2 *pair_meta;   // [Pr] {destination state (-1 = padding row), label} of each pair
+    const int4 *bwd_row_meta;// [Sr] per backward row {state (-1 = padding), #pairs into it, first pair, its label}
     const int *st_pair_off;  // [S+1] CSR: pairs whose destination is state s
     const int *st_pairs;     // [P]
     const float *start_lin;  // [S] exp(start_weight)
@@ -61,7 +60,7 @@ struct HostGraph {
     GraphDev dev{};
     std::vector<void *> allocs;  // device allocations to free
     // statistics for diagnostics / DESIGN.md
-    int64_t fwd_padded_arcs = 0, bwd_padded_arcs = 0;
+    int64_t fwd_padded_arcs = 0, bwd_padded_arcs = 0, fwd_conflicts = 0, bwd_conflicts = 0;
     int max_in_deg = 0, max_out_deg = 0;
 };
 

@@ -169,6 +169,78 @@ __device__ __forceinline__ float to_log(float zs, int e, double mxs) {
     return zs > 0.f ? (float)(log((double)zs) - (double)e * 0.6931471805599453 + mxs) : -INFINITY;
 }
 
+// Sum of one ELL row per lane: sum_k x[idx_k] * w_k over n 16-byte elements (2 arcs each) that are
+// kWave elements apart.  n is wave-uniform; the host pads n to a multiple of 4 whenever n > 2, so
+// the stream is consumed in groups of four elements with the NEXT group already in flight (4 KiB per
+// wave, 64 KiB per CU): the L2 latency of the arc stream overlaps the LDS gathers of the group
+// that has landed.  hipcc folds a source-level prefetch loop back into load->wait->use, so the
+// group loads are issued from inline asm (invisible to its scheduler) and waited for explicitly; two
+// register sets alternate.  Loads return in order, so compiler-issued loads/stores in between only
+// make either side's waits more conservative (cdna_hip_programming.md 5.7).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ell_consume(const u32x4 &c, const float *x, float &acc0, float &acc1) {
+    acc0 = fmaf(x[c.x], __uint_as_float(c.y), acc0);
+    acc1 = fmaf(x[c.z], __uint_as_float(c.w), acc1);
+}
+#define CRF_LOADG(R, P)                                                                                        \
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"           \
+                 "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"   \
+                 : "=&v"(R##0), "=&v"(R##1), "=&v"(R##2), "=&v"(R##3) : "v"(P) : "memory")
+#define CRF_WAITG(N, R) \
+    asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(R##0), "+v"(R##1), "+v"(R##2), "+v"(R##3) : : "memory")
+#define CRF_USEG(R)                      \
+    ell_consume(R##0, x, acc0, acc1);    \
+    ell_consume(R##1, x, acc0, acc1);    \
+    ell_consume(R##2, x, acc0, acc1);    \
+    ell_consume(R##3, x, acc0, acc1)
+
+__device__ __forceinline__ float ell_row_sum(const uint4 *a4, int n, const float *x) {
+    const u32x4 *a = (const u32x4 *)a4;
+    float acc0 = 0.f, acc1 = 0.f;
+    if (n <= 2) {
+        if (n > 0) {
+            const u32x4 c0 = a[0];
+            if (n > 1) {
+                const u32x4 c1 = a[kWave];
+                ell_consume(c1, x, acc0, acc1);
+            }
+            ell_consume(c0, x, acc0, acc1);
+        }
+        return acc0 + acc1;
+    }
+    // Double buffer: the loads of group g+1 are in flight while group g is gathered and summed.
+    // Every group is waited for BEFORE the loop back-edge, so whatever register copies hipcc inserts
+    // for the loop-carried set only ever touch data that has landed (cdna_hip_programming.md 5.7:
+    // an asm load's destination counts as written at the end of the statement).
+    const int ng = n >> 2;
+    u32x4 A0, A1, A2, A3, B0, B1, B2, B3;
+    const u32x4 *p = a;
+    CRF_LOADG(A, p);
+    CRF_WAITG(0, A);
+    int g = 1;
+#pragma unroll 1
+    for (; g + 1 < ng; g += 2) {
+        p += 4 * kWave;
+        CRF_LOADG(B, p);
+        CRF_USEG(A);
+        p += 4 * kWave;
+        CRF_WAITG(0, B);
+        CRF_LOADG(A, p);
+        CRF_USEG(B);
+        CRF_WAITG(0, A);
+    }
+    if (g < ng) {
+        p += 4 * kWave;
+        CRF_LOADG(B, p);
+        CRF_USEG(A);
+        CRF_WAITG(0, B);
+        CRF_USEG(B);
+    } else {
+        CRF_USEG(A);
+    }
+    return acc0 + acc1;
+}
+
 // LDS carve (floats) shared by host sizing and the kernels
 __host__ __device__ inline int rup64(int x) { return (x + 63) & ~63; }
 
@@ -220,21 +292,14 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
         for (int s = tid; s < Sp; s += kChainThreads) Xz[s] = 0.f;
         float *Qrow = p.Q + (bt0 + t) * Pr;
         for (int i = sl0; i < sl1; ++i) {
-            const int j = g.fwd.wave_slices[i];
-            const uint4 *a = g.fwd.arcs + g.fwd.slice_off[j] + lane;
-            const int w2 = g.fwd.slice_w2[j];
-            float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 4
-            for (int kk = 0; kk < w2; ++kk) {
-                const uint4 e = a[(int64_t)kk * kWave];
-                acc0 = fmaf(Xc[e.x], __uint_as_float(e.y), acc0);
-                acc1 = fmaf(Xc[e.z], __uint_as_float(e.w), acc1);
-            }
-            const float q = (acc0 + acc1) * sc;
+            const int j = __builtin_amdgcn_readfirstlane(g.fwd.wave_slices[i]);
+            const int off = __builtin_amdgcn_readfirstlane(g.fwd.slice_off[j]);
+            const int w2 = __builtin_amdgcn_readfirstlane(g.fwd.slice_w2[j]);
             const int r = j * kWave + lane;
+            const int2 meta = g.pair_meta[r];  // {dst, label}; issued before the arc stream
+            const float q = ell_row_sum(g.fwd.arcs + off + lane, w2, Xc) * sc;
             Qrow[r] = q;
-            const int d = g.pair_dst[r];
-            if (d >= 0) atomicAdd(&Xn[d], EPc[g.pair_lab[r]] * q);
+            if (meta.x >= 0) atomicAdd(&Xn[meta.x], EPc[meta.y] * q);
         }
         if (t + 1 < lx) {
             float *EPn = EP + ((t + 1) & 1) * Vp;
@@ -286,10 +351,10 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
         __syncthreads();
         float *BProw = p.BP + (bt0 + lx - 1) * Pr;
         for (int r = tid; r < Pr; r += kChainThreads) {
-            const int d = g.pair_dst[r];
+            const int d = g.pair_meta[r].x;
             const float bv = d >= 0 ? g.end_lin[d] * pow2f(kScaleExp) : 0.f;
             BProw[r] = bv;
-            Z[r] = EP[g.pair_lab[r]] * bv;
+            Z[r] = EP[g.pair_meta[r].y] * bv;
         }
         if (tid == 0) p.EB[bt0 + lx - 1] = F;
     } else {
@@ -328,26 +393,23 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
         const float sc = pow2f(k);
         F += k + kEpExp;              // Z_t = e'_t b_{t+1} carries the 2^kEpExp of e'_t
         for (int ii = sl0; ii < sl1; ++ii) {
-            const int j = g.bwd.wave_slices[ii];
-            const uint4 *a = g.bwd.arcs + g.bwd.slice_off[j] + lane;
-            const int w2 = g.bwd.slice_w2[j];
-            float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll 4
-            for (int kk = 0; kk < w2; ++kk) {
-                const uint4 e = a[(int64_t)kk * kWave];
-                acc0 = fmaf(Zc[e.x], __uint_as_float(e.y), acc0);
-                acc1 = fmaf(Zc[e.z], __uint_as_float(e.w), acc1);
-            }
-            const float bv = (acc0 + acc1) * sc;
-            const int s = g.bwd_row_state[j * kWave + lane];
+            const int j = __builtin_amdgcn_readfirstlane(g.bwd.wave_slices[ii]);
+            const int off = __builtin_amdgcn_readfirstlane(g.bwd.slice_off[j]);
+            const int w2 = __builtin_amdgcn_readfirstlane(g.bwd.slice_w2[j]);
+            const int4 meta = g.bwd_row_meta[j * kWave + lane];  // {state, #pairs into it, first pair, its label}
+            const float bv = ell_row_sum(g.bwd.arcs + off + lane, w2, Zc) * sc;
+            const int s = meta.x;
             if (s >= 0) {
                 if (t == 0) {
                     zpart += g.start_lin[s] * bv;
+                } else if (meta.y == 1) {
+                    BPc[meta.z] = bv;
+                    Zn[meta.z] = EPn[meta.w] * bv;
                 } else {
                     for (int pi = g.st_pair_off[s]; pi < g.st_pair_off[s + 1]; ++pi) {
                         const int r = g.st_pairs[pi];
                         BPc[r] = bv;
-                        Zn[r] = EPn[g.pair_lab[r]] * bv;
+                        Zn[r] = EPn[g.pair_meta[r].y] * bv;
                     }
                 }
             }

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -121,12 +122,14 @@ struct EllHost {
     std::vector<int> slice_off, slice_w2, wave_off, wave_slices;
     std::vector<int> row_of;  // row position -> original row id (-1 padding)
     int64_t padded_arcs = 0;
+    int64_t conflict_cycles = 0;  // gathers that land on an already-used bank (extra LDS cycles)
 };
 
 // rows[r] = list of (idx, w).  Rows are sorted by degree (descending, stable) and cut into slices
 // of 64; each slice is as wide as its first (longest) row, rounded up to an even arc count.
 EllHost build_ell(const std::vector<std::vector<std::pair<int, float>>> &rows) {
     EllHost e;
+    const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
     const int R = (int)rows.size();
     std::vector<int> order(R);
     std::iota(order.begin(), order.end(), 0);
@@ -139,21 +142,69 @@ EllHost build_ell(const std::vector<std::vector<std::pair<int, float>>> &rows) {
     for (int j = 0; j < nsl; ++j) {
         int wmax = (int)rows[order[(size_t)j * kWave]].size();
         int w2 = (wmax + 1) / 2;
+        if (w2 > 2) w2 = (w2 + 3) & ~3;  // ell_row_sum streams groups of four elements
         e.slice_off[j] = (int)e.arcs.size();
         e.slice_w2[j] = w2;
         e.arcs.resize(e.arcs.size() + (size_t)w2 * kWave, uint4{0u, 0u, 0u, 0u});
+        // Column assignment.  Column c of the slice is ONE ds_read_b32 gather per wave, serviced in
+        // two 32-lane halves over 32 banks (bank = idx mod 32, MI355X_MICROARCH.md LDS table).  The
+        // order of a row's arcs is free, so pick it greedily per column: lanes with the fewest arcs
+        // left choose first, each takes the arc whose bank is least used in its half (equal idx =
+        // broadcast, free).  Summation order changes, the sum is the same up to fp32 rounding.
+        std::vector<std::vector<std::pair<int, float>>> rem(kWave);
         for (int lane = 0; lane < kWave; ++lane) {
             int r = e.row_of[(size_t)j * kWave + lane];
-            if (r < 0) continue;
-            const auto &row = rows[r];
-            for (size_t k = 0; k < row.size(); ++k) {
-                uint4 &a = e.arcs[(size_t)e.slice_off[j] + (k / 2) * kWave + lane];
-                uint32_t wb;
-                memcpy(&wb, &row[k].second, 4);
-                if (k & 1) { a.z = (uint32_t)row[k].first; a.w = wb; }
-                else { a.x = (uint32_t)row[k].first; a.y = wb; }
+            if (r >= 0) rem[lane] = rows[r];
+        }
+        for (int c = 0; c < 2 * w2; ++c) {
+            for (int half = 0; half < 2; ++half) {
+                int used[32];
+                int occupant[32];
+                for (int b = 0; b < 32; ++b) { used[b] = 0; occupant[b] = -1; }
+                int lanes[32];
+                for (int l = 0; l < 32; ++l) lanes[l] = half * 32 + l;
+                std::stable_sort(lanes, lanes + 32, [&](int a, int b) { return rem[a].size() < rem[b].size(); });
+                for (int li = 0; li < 32; ++li) {
+                    const int lane = lanes[li];
+                    auto &rv = rem[lane];
+                    if (rv.empty()) continue;
+                    size_t best = 0;
+                    int best_cost = 1 << 30;
+                    for (size_t k = 0; k < (arrange ? rv.size() : (size_t)1); ++k) {
+                        const int bank = rv[k].first & 31;
+                        const int cost = (occupant[bank] == rv[k].first) ? 0 : used[bank];
+                        if (cost < best_cost) { best_cost = cost; best = k; if (cost == 0) break; }
+                    }
+                    const auto arc = rv[best];
+                    rv.erase(rv.begin() + (long)best);
+                    const int bank = arc.first & 31;
+                    if (occupant[bank] != arc.first) { used[bank]++; if (occupant[bank] < 0) occupant[bank] = arc.first; }
+                    e.conflict_cycles += (best_cost > 0) ? 1 : 0;
+                    uint4 &a = e.arcs[(size_t)e.slice_off[j] + (size_t)(c / 2) * kWave + lane];
+                    uint32_t wb;
+                    memcpy(&wb, &arc.second, 4);
+                    if (c & 1) { a.z = (uint32_t)arc.first; a.w = wb; }
+                    else { a.x = (uint32_t)arc.first; a.y = wb; }
+                }
             }
         }
+        // padding arcs have weight 0; give them the index the first lane of their half reads in the same
+        // column, so the padded gather is a broadcast and costs no extra bank cycle
+        for (int c = 0; c < 2 * w2; ++c)
+            for (int half = 0; half < 2; ++half) {
+                uint32_t bidx = 0;
+                bool have = false;
+                for (int l = 0; l < 32 && !have; ++l) {
+                    const uint4 &a = e.arcs[(size_t)e.slice_off[j] + (size_t)(c / 2) * kWave + half * 32 + l];
+                    const uint32_t wbits = (c & 1) ? a.w : a.y;
+                    if (wbits != 0u) { bidx = (c & 1) ? a.z : a.x; have = true; }
+                }
+                for (int l = 0; l < 32; ++l) {
+                    uint4 &a = e.arcs[(size_t)e.slice_off[j] + (size_t)(c / 2) * kWave + half * 32 + l];
+                    if (c & 1) { if (a.w == 0u) a.z = bidx; }
+                    else { if (a.y == 0u) a.x = bidx; }
+                }
+            }
         e.padded_arcs += (int64_t)w2 * 2 * kWave;
     }
     // longest-processing-time assignment of slices (already sorted by width) to the waves
@@ -259,14 +310,35 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
         }
         lab_chunk_off[(size_t)max_label + 1] = (int)chunk_off.size() - 1;
     }
+    std::vector<int2> pair_meta(Pr);
+    for (int r = 0; r < Pr; ++r) pair_meta[r] = int2{pair_dst[r], pair_lab[r]};
+    std::vector<int4> bwd_row_meta(Sr);
+    for (int r = 0; r < Sr; ++r) {
+        const int st = be.row_of[r];
+        int4 m{-1, 0, 0, 0};
+        if (st >= 0) {
+            m.x = st;
+            m.y = st_pair_off[(size_t)st + 1] - st_pair_off[st];
+            if (m.y > 0) { m.z = st_pairs[st_pair_off[st]]; m.w = pair_lab[m.z]; }
+        }
+        bwd_row_meta[r] = m;
+    }
     std::vector<float> start_lin((size_t)S), end_lin((size_t)S);
     for (int64_t s = 0; s < S; ++s) { start_lin[s] = expf(start_w[s]); end_lin[s] = expf(end_w[s]); }
 
     auto *h = new HostGraph();
     h->device = device; h->S = S; h->A = A; h->P = P;
     h->fwd_padded_arcs = fe.padded_arcs; h->bwd_padded_arcs = be.padded_arcs;
+    h->fwd_conflicts = fe.conflict_cycles; h->bwd_conflicts = be.conflict_cycles;
     for (auto &r : frows) h->max_in_deg = std::max(h->max_in_deg, (int)r.size());
     for (auto &r : brows) h->max_out_deg = std::max(h->max_out_deg, (int)r.size());
+    GraphDev &d0 = h->dev;
+    d0.S = (int)S; d0.A = (int)A; d0.P = P; d0.Pr = Pr; d0.Sr = Sr; d0.max_label = max_label;
+    d0.NC = (int)chunk_off.size() - 1;
+    if (device < 0) {  // host-only compile (diagnostics / CPU tests): tables are built, nothing is uploaded
+        *out = h;
+        return CRF_OK;
+    }
     int prev = 0;
     hipError_t e0 = hipGetDevice(&prev);
     if (e0 != hipSuccess || hipSetDevice(device) != hipSuccess) {
@@ -281,9 +353,8 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     do {
         if ((rc = upload_ell(h, fe, &d.fwd))) break;
         if ((rc = upload_ell(h, be, &d.bwd))) break;
-        if ((rc = upload(h, pair_dst, &d.pair_dst))) break;
-        if ((rc = upload(h, pair_lab, &d.pair_lab))) break;
-        if ((rc = upload(h, be.row_of, &d.bwd_row_state))) break;
+        if ((rc = upload(h, pair_meta, &d.pair_meta))) break;
+        if ((rc = upload(h, bwd_row_meta, &d.bwd_row_meta))) break;
         if ((rc = upload(h, st_pair_off, &d.st_pair_off))) break;
         if ((rc = upload(h, st_pairs, &d.st_pairs))) break;
         if ((rc = upload(h, start_lin, &d.start_lin))) break;
@@ -346,6 +417,15 @@ int crf_graph_dims(const crf_graph *g, int64_t *S, int64_t *A, int64_t *P, int64
     if (A) *A = g->h->A;
     if (P) *P = g->h->P;
     if (max_label) *max_label = g->h->dev.max_label;
+    return CRF_OK;
+}
+
+int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
+    if (!g || !g->h || !out) { crf::set_error("null argument"); return CRF_ERR_ARG; }
+    const crf::HostGraph *h = g->h;
+    const int64_t v[10] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
+                           h->fwd_conflicts, h->bwd_conflicts, (int64_t)h->max_in_deg * 100000 + h->max_out_deg};
+    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
     return CRF_OK;
 }
 

@@ -30,6 +30,8 @@ _lib.crf_graph_destroy.argtypes = [_vp]
 _lib.crf_graph_destroy.restype = None
 _lib.crf_graph_dims.argtypes = [_vp] + [ctypes.POINTER(_i64)] * 4
 _lib.crf_graph_dims.restype = ctypes.c_int
+_lib.crf_graph_stats.argtypes = [_vp, ctypes.POINTER(_i64), ctypes.c_int]
+_lib.crf_graph_stats.restype = ctypes.c_int
 _lib.crf_workspace_bytes.argtypes = [_vp, _i64, _i64, _i64, _i64]
 _lib.crf_workspace_bytes.restype = _i64
 _lib.crf_loss_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _f32,
@@ -43,7 +45,7 @@ _lib.crf_last_error.restype = ctypes.c_char_p
 _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
-    "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims",
+    "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
     "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_profile_enable", "crf_profile_read",
     "crf_last_error", "crf_version",
 )
@@ -81,6 +83,22 @@ def graph_dims(handle: int):
     S, A, P, ML = _i64(), _i64(), _i64(), _i64()
     _check(_lib.crf_graph_dims(_vp(handle), S, A, P, ML))
     return dict(S=S.value, A=A.value, P=P.value, max_label=ML.value)
+
+
+def graph_stats(handle: int):
+    buf = (_i64 * 10)()
+    _check(_lib.crf_graph_stats(_vp(handle), buf, 10))
+    k = ("S", "A", "P", "Pr", "Sr", "fwd_ell_arcs", "bwd_ell_arcs", "fwd_bank_conflicts", "bwd_bank_conflicts", "deg")
+    d = dict(zip(k, [int(x) for x in buf]))
+    d["max_in_deg"], d["max_out_deg"] = d["deg"] // 100000, d.pop("deg") % 100000
+    return d
+
+
+def compile_graph_host_only(fst_name: str) -> int:
+    """Compile the tables on the host only (device = -1): diagnostics and CPU-side tests."""
+    out = _vp()
+    _check(_lib.crf_graph_create(os.fsencode(fst_name), -1, ctypes.byref(out)))
+    return out.value
 
 
 def init_env(fst_name: str, gpus: torch.Tensor) -> None:

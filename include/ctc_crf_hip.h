@@ -61,6 +61,13 @@ void crf_graph_destroy(crf_graph *g);
 int crf_graph_dims(const crf_graph *g, int64_t *num_states, int64_t *num_arcs, int64_t *num_pairs,
                    int64_t *max_label);
 
+/* Diagnostics of the compiled tables: out[0..9] = states, arcs, pairs, padded pair rows, padded state
+ * rows, forward ELL arcs incl. padding, backward ELL arcs incl. padding, forward / backward LDS
+ * gathers that share a bank with an earlier lane of their half-wave (extra LDS cycles per frame),
+ * max_in_degree*100000 + max_out_degree.  A graph created with device < 0 is compiled on the host
+ * only (no GPU needed) and can be used with crf_graph_dims / crf_graph_stats / crf_graph_destroy. */
+int crf_graph_stats(const crf_graph *g, int64_t *out, int n);
+
 /* Replaces get_workspace_size (ctc.h:99-109) and the torch::empty temporaries of gpu_den
  * (binding.cpp:77-79): bytes of device scratch crf_loss_fwd_bwd needs.  `g` may be NULL when
  * c_den == 0 (plain CTC).  `max_label_len` >= max(ly). */

@@ -13,7 +13,7 @@ import torch
 
 import oracle
 from oracle import fst_io
-from tests.util import graph_to_file, make_batch, rel_err, small_synth
+from tests.util import graph_to_file, make_batch, post_err, rel_err, small_synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -60,6 +60,7 @@ def test_fixture_costs_and_gpu_den_gpu_ctc(crf, golden_dir):
     assert abs(ca.item() - k["logZ_den"]) <= TOL * abs(k["logZ_den"])
     assert abs(cb.item() - k["logZ_den"]) <= TOL * abs(k["logZ_den"])
     assert rel_err(gd[0].cpu().numpy(), np.array(k["gamma_den"])) <= TOL
+    assert post_err(gd[0].cpu().numpy(), np.array(k["gamma_den"])) <= TOL
     act = logits.transpose(0, 1).contiguous()
     gc = torch.zeros_like(act)
     cc = torch.zeros(1)
@@ -196,7 +197,21 @@ def test_config2_slice_vs_oracle(crf, default_graph):
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
     loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
-    assert rel_err(grad, ref["grad"]) <= TOL
+    e = rel_err(grad, ref["grad"])
+    print(f"config-2 slice: loss rel err {abs(loss - ref['loss']) / abs(ref['loss']):.2e}, grad err {e:.2e}")
+    assert e <= TOL
+    # the two posterior matrices separately, entry by entry
+    core = crf._C
+    ctx = crf.CRFContext(p, 0)
+    x = torch.tensor(logits, device="cuda:0")
+    _, gd, _ = core.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, core.graph_for(x.device), True)
+    _, gc, _ = core.loss_fwd_bwd(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
+    gdo, _, _ = oracle.den(fst_io.read_fst(p), logits, lx)
+    gco, _, _ = oracle.ctc(logits, labels, lx, ly)
+    pe_d, pe_c = post_err(gd.cpu().numpy(), gdo), post_err(gc.cpu().numpy(), gco)
+    print(f"posterior entry-wise rel err: den {pe_d:.2e}, ctc {pe_c:.2e}")
+    assert pe_d <= TOL and pe_c <= TOL
+    del ctx
 
 
 def test_full_size_invariants(crf, default_graph):
@@ -258,16 +273,24 @@ def _ref_den(p, logits, lx):
 
 
 def test_denominator_vs_reference_kernels(crf, tmp_path):
-    """gpu_den of this repo vs the REFERENCE'S OWN CUDA kernels built for gfx950 (oracle/Makefile `ref`)."""
+    """gpu_den of this repo vs the REFERENCE'S OWN CUDA kernels built for gfx950 (oracle/Makefile `ref`),
+    both judged against the fp64 oracle: the reference's fp32 log-domain arithmetic drifts with T
+    (each alpha is rounded at ulp(|alpha|) ~ 3e-5 per frame), so it is held to 2e-2 and ours to 1e-4;
+    ours must be the closer of the two."""
     g, p = small_synth(tmp_path, 72, 256, 16, 4)
     logits, _, lx, _ = make_batch(g, 4, 120, 72, seed=4, ragged=True)
     gref, cref = _ref_den(p, logits, lx)
+    gor, cor, _ = oracle.den(fst_io.read_fst(p), logits, lx)
     core = crf._C
     ctx = crf.CRFContext(p, 0)
     x = torch.tensor(logits, device="cuda:0")
     _, gd, ex = core.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, core.graph_for(x.device), True)
-    assert np.allclose(ex["costs_alpha"].cpu().numpy(), cref, rtol=TOL, atol=0)
-    assert rel_err(gd.cpu().numpy(), gref) <= TOL
+    ours, cours = gd.cpu().numpy(), ex["costs_alpha"].cpu().numpy()
+    e_ref, e_ours = rel_err(gref, gor), rel_err(ours, gor)
+    print(f"reference kernels vs fp64 oracle: {e_ref:.2e}; this repo vs fp64 oracle: {e_ours:.2e}")
+    assert np.allclose(cref, cor, rtol=1e-4) and np.allclose(cours, cor, rtol=TOL)
+    assert e_ref <= 2e-2 and e_ours <= TOL and e_ours <= e_ref
+    assert rel_err(ours, gref) <= 2e-2
     del ctx
 
 
