@@ -1,0 +1,84 @@
+"""CPU tests (no GPU): the C-ABI library loads, exports every symbol include/*.h declares, and its
+host-side logic (FST reader, graph compiler, error paths) behaves -- no compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import fst_io
+from cat_amd.den_lm import synth_den_lm
+from tests.conftest import ROOT
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ctc_crf_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(crf_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctc_crf
+    core = ctc_crf._C
+    lib = ctypes.CDLL(core.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 11
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ctc_crf_hip.h but not exported"
+    assert set(syms) == set(core.EXPORTED_SYMBOLS)
+    assert "gfx950" in core.version()
+
+
+def test_python_surface_matches_reference_names():
+    """The names CAT imports (cat/ctc/train.py:118,137) and the _C-level mirrors (binding.cpp:120-126)."""
+    import ctc_crf
+    for n in ("CTC_CRF_LOSS", "WARP_CTC_LOSS", "CRFContext", "_CTC_CRF", "_WARP_CTC_GPU", "ctc_crf_loss", "__version__"):
+        assert hasattr(ctc_crf, n)
+    for n in ("gpu_den", "gpu_ctc", "init_env", "release_env"):
+        assert hasattr(ctc_crf._C, n)
+    crit = ctc_crf.CTC_CRF_LOSS()
+    assert crit.lamb == 0.1 and crit.size_average is True
+
+
+def test_error_paths_without_gpu(tmp_path):
+    import ctc_crf
+    core = ctc_crf._C
+    out = ctypes.c_void_p()
+    rc = core._lib.crf_graph_create(os.fsencode(os.path.join(str(tmp_path), "nope.fst")), 0, ctypes.byref(out))
+    assert rc == 1 and b"cannot open" in core._lib.crf_last_error()
+    bad = os.path.join(str(tmp_path), "bad.fst")
+    open(bad, "wb").write(b"\x00" * 64)
+    assert core._lib.crf_graph_create(os.fsencode(bad), 0, ctypes.byref(out)) == 2
+    with pytest.raises(RuntimeError):
+        ctc_crf.CRFContext(os.path.join(str(tmp_path), "nope.fst"), 0)  # same message path as the reference (:154-156)
+    # a truncated but otherwise valid file
+    p = os.path.join(str(tmp_path), "t.fst")
+    synth_den_lm(8, 10, 3, seed=0, path=p)
+    data = open(p, "rb").read()
+    open(p, "wb").write(data[: len(data) // 2])
+    assert core._lib.crf_graph_create(os.fsencode(p), -1, ctypes.byref(out)) == 2
+
+
+def test_graph_compiler_host_only(tmp_path, golden_dir):
+    """crf_graph_create(device=-1) builds all tables on the host: check them against the oracle's reader."""
+    import ctc_crf
+    core = ctc_crf._C
+    h = core.compile_graph_host_only(os.path.join(golden_dir, "den_lm_fixture.fst"))
+    d = core.graph_dims(h)
+    assert (d["S"], d["A"], d["P"], d["max_label"]) == (9, 24, 9, 4)  # every state has one in-label -> P == S
+    core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+    p = os.path.join(str(tmp_path), "big.fst")
+    g = synth_den_lm(72, 2048, 24, seed=0, path=p)
+    r = fst_io.read_fst(p)
+    h = core.compile_graph_host_only(p)
+    st = core.graph_stats(h)
+    assert st["S"] == r["S"] == 4097 and st["A"] == r["A"] == g["A"]
+    pairs = len(set(zip(r["dst"].tolist(), r["lab"].tolist())))
+    assert st["P"] == pairs
+    assert st["max_in_deg"] == np.bincount(r["dst"]).max() and st["max_out_deg"] == np.bincount(r["src"]).max()
+    assert st["A"] <= st["fwd_ell_arcs"] <= 1.35 * st["A"] and st["A"] <= st["bwd_ell_arcs"] <= 1.35 * st["A"]
+    assert st["fwd_bank_conflicts"] < 0.1 * st["A"]  # the column assignment leaves < 10% of gathers on a shared bank
+    core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+    ws = core._lib.crf_workspace_bytes(ctypes.c_void_p(0), 4, 100, 72, 10)
+    assert ws > 4 * 100 * 72 * 4

@@ -264,8 +264,18 @@ def _ref_den(p, logits, lx):
     st = vp(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     lib.compute_alpha(vp(alpha.data_ptr()), vp(x.data_ptr()), B, T, S, V, vp(lxd.data_ptr()), vp(ca.data_ptr()), st)
+    torch.cuda.synchronize()
+    # alpha_lld_kernal (den_calculate.cu:122-161) reduces its last 64 partial sums through shared memory
+    # with no barrier and no volatile (:150-154, "warp-synchronous"); built with hipcc -O2 for wave64 the
+    # values are kept in registers and logZ comes out wrong by O(1) nats.  The forward recursion itself is
+    # fine, so logZ is re-reduced here from the reference's OWN alpha buffer (row lx[b] already has
+    # end_weight added by alpha_last_kernel) and handed to compute_beta_and_grad, which takes it as input.
+    ca_kernel = ca.clone()
+    al = alpha.view(B, T + 1, S)
+    ca = torch.stack([torch.logsumexp(al[b, int(lx[b])], 0) for b in range(B)]).contiguous()
     lib.compute_beta_and_grad(vp(beta.data_ptr()), vp(alpha.data_ptr()), vp(x.data_ptr()), vp(ca.data_ptr()),
                               vp(gs.data_ptr()), vp(grad.data_ptr()), B, T, S, V, vp(lxd.data_ptr()), vp(cb.data_ptr()), st)
+    print("reference alpha_lld_kernal logZ:", ca_kernel.cpu().numpy(), "re-reduced from its alpha:", ca.cpu().numpy())
     torch.cuda.synchronize()
     out = grad.cpu().numpy(), ca.cpu().numpy()
     lib.Release(1, gpus)
