@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("fst_graph.cpp", "crf_kernels.hip")]
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("fst_graph.cpp", "res_layout.cpp", "crf_kernels.hip")]
 DEPS = SRCS + [os.path.join(HERE, "csrc", "crf_internal.h"), os.path.join(os.path.dirname(HERE), "include", "ctc_crf_hip.h")]
 OUT = os.path.join(HERE, "lib", "libctc_crf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -31,6 +31,48 @@ struct EllDev {
     int nslices;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident layout of one recursion direction, split over K compute units per utterance.
+// Each CU owns a set of rows; a thread keeps the arcs of its rows in VGPRs for the whole kernel
+// (kResNCH chunks of kResW arcs: per chunk 2 words of packed 16-bit LDS byte offsets + 4 weights).
+// Rows are grouped in slices of 64 equal-length rows (one per lane); a wave's slices are laid end to
+// end along the chunk axis and a per-wave bit mask marks the chunk after which a slice (row) ends.
+// Row ids are numbered CU by CU, wave by wave, slice by slice, lane by lane, so a wave's row results
+// are 64 consecutive floats of the per-frame HBM row.
+// ---------------------------------------------------------------------------------------------
+constexpr int kResThreads = 512;
+constexpr int kResWaves = kResThreads / kWave;
+constexpr int kResW = 4;
+constexpr int kResNCH = 30;
+constexpr int kResWords = kResNCH * 6;
+constexpr int kResMaxK = 4;
+
+struct ResDirDev {
+    const unsigned *arcs;    // [K][kResWords][kResThreads]
+    const uint4 *wave_info;  // [K][kResWaves] {slice-end mask, chunks used, first row id, unused}
+    const int4 *row_meta;    // [R] fwd {x index of dst state | -1 pad, label, 0, 0}
+                             //     bwd {#pairs into the state | -1 pad, first z index, its label, csr begin}
+    const int *cu_row_off;   // [K+1] row-id range of each CU
+    const int *own_off;      // [K+1] range of gather-vector indices PRODUCED by each CU
+    int R;                   // rows incl. padding = row stride of the per-frame HBM store
+    int G;                   // gather-vector length (fwd: states, bwd: pairs)
+};
+struct ResDev {
+    int K;                    // 0 = resident layout not available (graph too large): streaming kernels
+    ResDirDev f, b;
+    const float *x_start;     // [S] exp(start weight), forward x-index order
+    const float *x_end;       // [S] exp(end weight),   forward x-index order
+    const int *z_lab;         // [P] label of each z entry (backward z-index order)
+    const float *z_end;       // [P] exp(end weight) of the pair's destination state
+    const float *brow_start;  // [Rb] exp(start weight) of the row's state
+    const float *brow_end;    // [Rb] exp(end weight) of the row's state
+    const int2 *bcsr;         // {z index, label} lists for states entered with more than one label
+    const int *gq, *gb;       // [NR] grad pass over label-sorted forward (sub-)rows: index into the Q row / BP row
+    const int *chunk_off;     // [NC+1] chunks (<= kChunk entries, one label each) of that list
+    const int *lab_chunk_off; // [max_label+2]
+    int NC;
+};
+
 // The denominator graph as the kernels see it (all pointers device memory).
 // A "pair" is a distinct (destination state, label); pairs are numbered in forward-ELL row order.
 struct GraphDev {
@@ -52,7 +94,10 @@ struct GraphDev {
     const int *chunk_off;    // [NC+1] ranges of perm, each <= kChunk and within one label
     const int *lab_chunk_off;// [max_label+2] chunk range of each label
     int NC;
+    ResDev res;
 };
+
+struct ResBuildStats { int K = 0; int64_t slots_f = 0, slots_b = 0, conflicts_f = 0, conflicts_b = 0; };
 
 struct HostGraph {
     int device = 0;
@@ -62,6 +107,8 @@ struct HostGraph {
     // statistics for diagnostics / DESIGN.md
     int64_t fwd_padded_arcs = 0, bwd_padded_arcs = 0, fwd_conflicts = 0, bwd_conflicts = 0;
     int max_in_deg = 0, max_out_deg = 0;
+    ResBuildStats res_stats;
+    int res_rows_cu_f = 0, res_rows_cu_b = 0;  // max rows of one CU (LDS carve of the resident kernels)
 };
 
 void set_error(const std::string &msg);
@@ -69,6 +116,13 @@ void set_error(const std::string &msg);
 // Builds pairs, both ELL tables and the grad-pass chunk tables, and uploads them to `device`.
 int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, const int32_t *lab,
                   const float *w, const float *start_w, const float *end_w, int device, HostGraph **out);
+// Builds the resident layout (smallest K in {1,2,4} that fits the register budget) into h->dev.res and
+// uploads it (unless h->device < 0).  Returns CRF_OK with res.K == 0 when the graph does not fit.
+int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
+                   const std::vector<std::vector<std::pair<int, float>>> &in_arcs_of_pair,
+                   const std::vector<std::vector<std::pair<int, float>>> &out_arcs_of_state,
+                   const std::vector<float> &start_lin, const std::vector<float> &end_lin,
+                   const std::vector<int> &label_sorted_pairs);
 int read_fst_file(const char *path, int64_t *S, std::vector<int32_t> *src, std::vector<int32_t> *dst,
                   std::vector<int32_t> *lab, std::vector<float> *w, std::vector<float> *start_w,
                   std::vector<float> *end_w);

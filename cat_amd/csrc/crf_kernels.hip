@@ -44,11 +44,23 @@ struct LossParams {
     const float *logp;
     const int *labels, *lab_off, *lx, *ly;
     int B, T, V;
+    int res_lds_rows_f, res_lds_rows_b;  // max rows per CU (LDS carve of the resident kernels)
     int Sc;       // row stride of the ctc per-frame stores: 2*max_label_len+1 rounded up to 64
     float c_den, c_ctc;
     // workspace
     float *ep, *mx;               // [B*T*V] exp(logp - mx), [B*T] row max
-    float *Q, *BP;                // [B*T*Pr] q_t[p], b_{t+1}[dst_p]  (scaled)
+    float *Q, *BP;                // [B*T*Rq] q_t[row], [B*T*Rb] b_{t+1}[row]  (scaled)
+    int Rq, Rb;                   // their row strides
+    const int *gq, *gb;           // label-sorted pair list -> index into a Q row / a BP row
+    const int *gchunk, *glab;     // its chunks (<= kChunk entries of one label) and per-label chunk ranges
+    int gNC;
+    int res;                      // 1: register-resident den kernels (g.res), 0: streaming kernels
+    int b0;                       // first utterance of this launch (resident kernels with K > 1 run in groups)
+    unsigned long long *xch;      // [2][B][2][G] tagged granules for the K-way exchange of the state vector
+    float *cb_part;               // [B][kResMaxK] partial backward partition sums
+    double *cb_mxs;               // [B]
+    int *cb_F;                    // [B]
+    int *err;                     // [1] set if an exchange timed out
     int *EQ, *EB;                 // [B*T] their binary exponents
     double *CA, *CB;              // [B*T*Sc] ctc forward (incl. emission) / backward (excl.)  (scaled, fp64)
     int *ECA, *ECB;
@@ -626,6 +638,278 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     }
 }
 
+// =============================================================================================
+// Register-resident denominator recursions (crf_internal.h: ResDev, res_layout.cpp).
+// A recursion of one utterance runs on K compute units; each thread holds its arcs in VGPRs, so a
+// frame is: max-reduce -> kResNCH x (4 LDS gathers + 4 FMA), row epilogue at every slice end ->
+// barrier -> (K > 1) all-gather of the new state vector through tagged 8-byte granules in L2.
+// =============================================================================================
+constexpr int kEpRegsR = 2;   // emission-row prefetch registers (V <= 2*512 for the resident kernels)
+constexpr int kPoll = 8;      // granules polled concurrently per thread
+
+__device__ __forceinline__ float res_block_sum(float v, float *red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kResWaves; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ double res_mx_total(const LossParams &p, int b, int lx, double *red, int tid) {
+    double part = 0.0;
+    for (int t = tid; t < lx; t += kResThreads) part += (double)p.mx[(int64_t)b * p.T + t];
+    part = wave_sum_d(part);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < kResWaves; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float res_frame_max(const float *wm) {
+    float m = wm[0];
+#pragma unroll
+    for (int i = 1; i < kResWaves; ++i) m = fmaxf(m, wm[i]);
+    return m;
+}
+
+// All-gather of a state vector of G floats held in LDS (`v`): this CU produced [lo,hi); the others are
+// fetched from the peers' publications.  Granule = {tag << 32 | float bits}, one aligned 8-byte
+// agent-scope store / load each (the data is the flag; cdna_hip_programming.md G16 R2).  Slots
+// alternate per frame; a peer can be at most one exchange ahead, so two slots suffice.
+__device__ __forceinline__ void res_exchange(unsigned long long *slot, float *v, int G, int lo, int hi,
+                                             unsigned tag, int *err, int tid) {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    gu64 *gs = (gu64 *)slot;
+    for (int i = lo + tid; i < hi; i += kResThreads)
+        __hip_atomic_store(gs + i, ((unsigned long long)tag << 32) | __float_as_uint(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int base = 0; base < G; base += kPoll * kResThreads) {
+        unsigned pending = 0;
+#pragma unroll
+        for (int q = 0; q < kPoll; ++q) {
+            const int i = base + q * kResThreads + tid;
+            if (i < G && (i < lo || i >= hi)) pending |= 1u << q;
+        }
+        for (unsigned spins = 0; pending; ++spins) {
+            unsigned long long gv[kPoll];
+#pragma unroll
+            for (int q = 0; q < kPoll; ++q)
+                if (pending >> q & 1) gv[q] = __hip_atomic_load(gs + base + q * kResThreads + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 0; q < kPoll; ++q)
+                if ((pending >> q & 1) && (unsigned)(gv[q] >> 32) == tag) {
+                    v[base + q * kResThreads + tid] = __uint_as_float((unsigned)gv[q]);
+                    pending &= ~(1u << q);
+                }
+            if (spins > (1u << 22)) {  // ~seconds: a peer died or was never scheduled -- give up loudly, never hang
+                *err = 1;
+                break;
+            }
+            if (pending && spins > 4) __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
+#define CRF_RES_GATHER4(c)                                                                        \
+    {                                                                                             \
+        const unsigned i01 = A[6 * (c)], i23 = A[6 * (c) + 1];                                    \
+        acc = fmaf(*(const float *)(xb + (i01 & 0xffffu)), __uint_as_float(A[6 * (c) + 2]), acc); \
+        acc1 = fmaf(*(const float *)(xb + (i01 >> 16)), __uint_as_float(A[6 * (c) + 3]), acc1);   \
+        acc = fmaf(*(const float *)(xb + (i23 & 0xffffu)), __uint_as_float(A[6 * (c) + 4]), acc); \
+        acc1 = fmaf(*(const float *)(xb + (i23 >> 16)), __uint_as_float(A[6 * (c) + 5]), acc1);   \
+    }
+
+template <int DIR>
+__global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ResDev &R = p.g.res;
+    const ResDirDev &L = DIR == 0 ? R.f : R.b;
+    const int K = R.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = p.b0 + (int)(blockIdx.x / (unsigned)K), k = (int)(blockIdx.x % (unsigned)K);
+    const int V = p.V, lx = p.lx[b], G = L.G;
+    const int Gp = rup64(G), Vp = rup64(V);
+    const int64_t bt0 = (int64_t)b * p.T;
+    const int NB = 3;  // gather source / accumulated next vector / being zeroed, rotated every frame
+    const int rows_cu_max = DIR == 0 ? p.res_lds_rows_f : p.res_lds_rows_b;
+    float *X = lds;                                  // [NB][Gp] state vectors
+    int4 *RM = (int4 *)(X + NB * Gp);                // [rows_cu_max] row metadata of this CU
+    float *EP = (float *)(RM + rows_cu_max);         // [2][Vp]
+    float *wm = EP + 2 * Vp;                         // [2][kResWaves]
+    double *red = (double *)(wm + 2 * kResWaves);    // [kResWaves]
+
+    // ---- one-time: arcs -> registers, row metadata -> LDS
+    unsigned A[kResWords];
+    {
+        const unsigned *src = L.arcs + (size_t)k * kResWords * kResThreads + tid;
+#pragma unroll
+        for (int i = 0; i < kResWords; ++i) A[i] = src[(size_t)i * kResThreads];
+    }
+    const uint4 wi = L.wave_info[k * kResWaves + wave];
+    const unsigned ends = __builtin_amdgcn_readfirstlane(wi.x);
+    const int nch = __builtin_amdgcn_readfirstlane(wi.y);
+    const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
+    const int cu_row0 = L.cu_row_off[k], cu_rows = L.cu_row_off[k + 1] - cu_row0;
+    const int own_lo = L.own_off[k], own_hi = L.own_off[k + 1];
+    for (int r = tid; r < cu_rows; r += kResThreads) RM[r] = L.row_meta[cu_row0 + r];
+    unsigned long long *xch = p.xch + ((size_t)DIR * p.B + b) * 2 * (size_t)G;
+
+    if (DIR == 0) {
+        // ================= forward =================
+        for (int s = tid; s < 3 * Gp; s += kResThreads) X[s] = (s < G) ? R.x_start[s] * pow2f(kScaleExp) : 0.f;
+        if (lx > 0)
+            for (int v = tid; v < V; v += kResThreads) EP[v] = p.ep[bt0 * V + v];
+        int E = kScaleExp;
+        __syncthreads();
+        for (int t = 0; t < lx; ++t) {
+            const float *Xc = X + (t % 3) * Gp;
+            float *Xn = X + ((t + 1) % 3) * Gp, *Xz = X + ((t + 2) % 3) * Gp;
+            const float *EPc = EP + (t & 1) * Vp;
+            float epn[kEpRegsR];
+            if (t + 1 < lx) {
+                const float *er = p.ep + (bt0 + t + 1) * V;
+#pragma unroll
+                for (int i = 0; i < kEpRegsR; ++i) { const int v = tid + i * kResThreads; epn[i] = v < V ? er[v] : 0.f; }
+            }
+            float m = 0.f;
+            for (int s = tid; s < G; s += kResThreads) m = fmaxf(m, Xc[s]);
+            m = wave_max(m);
+            if (lane == 0) wm[(t & 1) * kResWaves + wave] = m;
+            __syncthreads();
+            const int ksc = rescale_exp(res_frame_max(wm + (t & 1) * kResWaves));
+            const float sc = pow2f(ksc);
+            E += ksc;
+            if (tid == 0 && k == 0) p.EQ[bt0 + t] = E;
+            E += kEpExp;
+            for (int s = tid; s < Gp; s += kResThreads) Xz[s] = 0.f;
+            float *Qrow = p.Q + (bt0 + t) * p.Rq;
+            const char *xb = (const char *)Xc;
+            float acc = 0.f, acc1 = 0.f;
+            int rid = row0 + lane;
+#pragma unroll
+            for (int c = 0; c < kResNCH; ++c) {
+                if (c < nch) {
+                    CRF_RES_GATHER4(c);
+                    if (ends >> c & 1u) {
+                        const float q = (acc + acc1) * sc;
+                        Qrow[rid] = q;
+                        const int4 mt = RM[rid - cu_row0];
+                        if (mt.x >= 0) atomicAdd(&Xn[mt.x], EPc[mt.y] * q);
+                        acc = 0.f; acc1 = 0.f;
+                        rid += kWave;
+                    }
+                }
+            }
+            if (t + 1 < lx) {
+                float *EPn = EP + ((t + 1) & 1) * Vp;
+#pragma unroll
+                for (int i = 0; i < kEpRegsR; ++i) { const int v = tid + i * kResThreads; if (v < V) EPn[v] = epn[i]; }
+            }
+            __syncthreads();
+            if (K > 1) {
+                res_exchange(xch + (size_t)((t + 1) & 1) * G, Xn, G, own_lo, own_hi, (unsigned)(t + 1), p.err, tid);
+                __syncthreads();
+            }
+        }
+        if (k == 0) {
+            const float *Xf = X + (lx % 3) * Gp;
+            float part = 0.f;
+            for (int s = tid; s < G; s += kResThreads) part += Xf[s] * R.x_end[s];
+            const float zs = res_block_sum(part, (float *)red, tid);
+            const double mxs = res_mx_total(p, b, lx, red, tid);
+            if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); }
+        }
+    } else {
+        // ================= backward =================
+        int F = kScaleExp;
+        float zpart = 0.f;
+        for (int r = tid; r < 3 * Gp; r += kResThreads) X[r] = 0.f;
+        if (lx > 0) {
+            for (int v = tid; v < V; v += kResThreads) {
+                EP[v] = p.ep[(bt0 + lx - 1) * V + v];
+                if (lx > 1) EP[Vp + v] = p.ep[(bt0 + lx - 2) * V + v];
+            }
+            __syncthreads();
+            for (int z = tid; z < G; z += kResThreads) X[z] = EP[R.z_lab[z]] * (R.z_end[z] * pow2f(kScaleExp));
+            float *BProw = p.BP + (bt0 + lx - 1) * p.Rb;
+            for (int r = tid; r < cu_rows; r += kResThreads) BProw[cu_row0 + r] = R.brow_end[cu_row0 + r] * pow2f(kScaleExp);
+            if (tid == 0 && k == 0) p.EB[bt0 + lx - 1] = F;
+        } else {
+            for (int r = tid; r < cu_rows; r += kResThreads) zpart += R.brow_start[cu_row0 + r] * R.brow_end[cu_row0 + r] * pow2f(kScaleExp);
+        }
+        __syncthreads();
+        for (int i = 0; i < lx; ++i) {
+            const int t = lx - 1 - i;
+            const float *Zc = X + (i % 3) * Gp;
+            float *Zn = X + ((i + 1) % 3) * Gp, *Zz = X + ((i + 2) % 3) * Gp;
+            const float *EPn = EP + ((i + 1) & 1) * Vp;  // e'_{t-1}
+            float epn[kEpRegsR];
+            if (t >= 2) {
+                const float *er = p.ep + (bt0 + t - 2) * V;
+#pragma unroll
+                for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; epn[q] = v < V ? er[v] : 0.f; }
+            }
+            for (int z = tid; z < Gp; z += kResThreads) Zz[z] = 0.f;
+            float m = 0.f;
+            for (int z = tid; z < G; z += kResThreads) m = fmaxf(m, Zc[z]);
+            m = wave_max(m);
+            if (lane == 0) wm[(i & 1) * kResWaves + wave] = m;
+            __syncthreads();
+            const int ksc = rescale_exp(res_frame_max(wm + (i & 1) * kResWaves));
+            const float sc = pow2f(ksc);
+            F += ksc + kEpExp;
+            if (t > 0 && tid == 0 && k == 0) p.EB[bt0 + t - 1] = F;
+            float *BProw = p.BP + (bt0 + (t > 0 ? t - 1 : 0)) * p.Rb;
+            const char *xb = (const char *)Zc;
+            float acc = 0.f, acc1 = 0.f;
+            int rid = row0 + lane;
+#pragma unroll
+            for (int c = 0; c < kResNCH; ++c) {
+                if (c < nch) {
+                    CRF_RES_GATHER4(c);
+                    if (ends >> c & 1u) {
+                        const float bv = (acc + acc1) * sc;
+                        const int4 mt = RM[rid - cu_row0];
+                        if (t == 0) {
+                            if (mt.x >= 0) zpart += R.brow_start[rid] * bv;
+                        } else {
+                            BProw[rid] = bv;
+                            // a state's sub-rows add their partial b into z_{t-1} (LDS float atomics)
+                            if (mt.x == 1) {
+                                atomicAdd(&Zn[mt.y], EPn[mt.z] * bv);
+                            } else if (mt.x > 1) {
+                                for (int q = 0; q < mt.x; ++q) { const int2 zl = R.bcsr[mt.w + q]; atomicAdd(&Zn[zl.x], EPn[zl.y] * bv); }
+                            }
+                        }
+                        acc = 0.f; acc1 = 0.f;
+                        rid += kWave;
+                    }
+                }
+            }
+            if (t >= 2) {
+                float *EPw = EP + (i & 1) * Vp;
+#pragma unroll
+                for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; if (v < V) EPw[v] = epn[q]; }
+            }
+            __syncthreads();
+            if (K > 1 && t > 0) {
+                res_exchange(xch + (size_t)((i + 1) & 1) * G, Zn, G, own_lo, own_hi, (unsigned)(i + 1), p.err, tid);
+                __syncthreads();
+            }
+        }
+        const float zb = res_block_sum(zpart, (float *)red, tid);
+        if (tid == 0) p.cb_part[(size_t)b * kResMaxK + k] = zb;
+        if (k == 0) {
+            const double mxs = res_mx_total(p, b, lx, red, tid);
+            if (tid == 0) { p.cb_F[b] = F; p.cb_mxs[b] = mxs; }
+        }
+    }
+}
+
 // One kernel per recursion so each keeps its own (small) set of live kernel arguments in SGPRs; the
 // four launches are issued on forked HIP streams and run concurrently (crf_loss_fwd_bwd).
 template <int ROLE>
@@ -649,9 +933,10 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
     const int b = blockIdx.y, V = p.V, Vp = rup64(V);
     const int lx = p.lx[b];
     const bool do_den = p.c_den != 0.f, do_ctc = p.c_ctc != 0.f;
-    const int Pr = do_den ? g.Pr : 0, NC = do_den ? g.NC : 0;
-    float *prod = lds;
-    float *csum = prod + Pr;
+    const int Rq = do_den ? p.Rq : 0, Rb = do_den ? p.Rb : 0, NC = do_den ? p.gNC : 0;
+    float *Qs = lds;               // [Rq] staged q_t row
+    float *Bs = Qs + rup64(Rq);    // [Rb] staged b_{t+1} row
+    float *csum = Bs + rup64(Rb);
     float *gd = csum + rup64(NC);
     float *gc = gd + Vp;
     const int64_t bt0 = (int64_t)b * p.T;
@@ -672,12 +957,13 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
             continue;
         }
         if (do_den) {
-            const float *Qr = p.Q + (bt0 + t) * Pr, *Br = p.BP + (bt0 + t) * Pr;
-            for (int r = tid; r < Pr; r += kGradThreads) prod[r] = Qr[r] * Br[r];
+            const float *Qr = p.Q + (bt0 + t) * Rq, *Br = p.BP + (bt0 + t) * Rb;
+            for (int r = tid; r < Rq; r += kGradThreads) Qs[r] = Qr[r];
+            for (int r = tid; r < Rb; r += kGradThreads) Bs[r] = Br[r];
             __syncthreads();
             for (int c = tid; c < NC; c += kGradThreads) {
                 float s = 0.f;
-                for (int j = g.chunk_off[c]; j < g.chunk_off[c + 1]; ++j) s += prod[g.perm[j]];
+                for (int j = p.gchunk[c]; j < p.gchunk[c + 1]; ++j) s += Qs[p.gq[j]] * Bs[p.gb[j]];
                 csum[c] = s;
             }
             __syncthreads();
@@ -686,7 +972,7 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
             for (int v = tid; v < V; v += kGradThreads) {
                 float s = 0.f;
                 if (v <= g.max_label)
-                    for (int c = g.lab_chunk_off[v]; c < g.lab_chunk_off[v + 1]; ++c) s += csum[c];
+                    for (int c = p.glab[v]; c < p.glab[v + 1]; ++c) s += csum[c];
                 gd[v] = er[v] * (ldexpf(s, e) * inv);
             }
         }
@@ -725,6 +1011,11 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
     for (int b = tid; b < p.B; b += 256) {
         double c = 0.0;
         if (p.c_den != 0.f) {
+            if (p.res) {  // backward partition sum = sum of the K per-CU partials
+                float zb = 0.f;
+                for (int k = 0; k < p.g.res.K; ++k) zb += p.cb_part[(size_t)b * kResMaxK + k];
+                p.cost_beta[b] = to_log(zb, p.cb_F[b], p.cb_mxs[b]);
+            }
             c += (double)p.c_den * (double)p.cost_alpha[b];
             if (p.out_den) p.out_den[b] = p.cost_alpha[b];
             if (p.out_beta) p.out_beta[b] = p.cost_beta[b];
@@ -746,27 +1037,45 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
 // host side
 // ---------------------------------------------------------------------------------------------
 struct WsLayout {
-    int64_t off_ep, off_mx, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, total;
+    int64_t off_ep, off_mx, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_xch, total;
+    int64_t xch_bytes;
+    int64_t Rq, Rb;
+    bool res;
 };
 static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+// the register-resident kernels are used whenever the graph fits them (res.K > 0) and V fits their
+// emission-row prefetch; CRF_NO_RESIDENT=1 at graph creation forces the streaming kernels
+static bool use_resident(const HostGraph *h, int64_t V) {
+    return h && h->dev.res.K > 0 && V <= (int64_t)kEpRegsR * kResThreads;
+}
 
 static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, int64_t Sc) {
     WsLayout w{};
     int64_t o = 0;
-    const int64_t Pr = h ? h->dev.Pr : 0;
+    w.res = use_resident(h, V);
+    w.Rq = h ? (w.res ? h->dev.res.f.R : h->dev.Pr) : 0;
+    w.Rb = h ? (w.res ? h->dev.res.b.R : h->dev.Pr) : 0;
     w.off_ep = o; o = al(o + B * T * V * 4);
     w.off_mx = o; o = al(o + B * T * 4);
-    w.off_Q = o; o = al(o + B * T * Pr * 4);
-    w.off_BP = o; o = al(o + B * T * Pr * 4);
+    w.off_Q = o; o = al(o + B * T * w.Rq * 4);
+    w.off_BP = o; o = al(o + B * T * w.Rb * 4);
     w.off_EQ = o; o = al(o + B * T * 4);
     w.off_EB = o; o = al(o + B * T * 4);
     w.off_CA = o; o = al(o + B * T * Sc * 8);
     w.off_CB = o; o = al(o + B * T * Sc * 8);
     w.off_ECA = o; o = al(o + B * T * 4);
     w.off_ECB = o; o = al(o + B * T * 4);
-    w.off_pb = o; o = al(o + 16 * B * 8);
+    w.off_pb = o; o = al(o + 32 * B * 8);
+    w.xch_bytes = (w.res && h->dev.res.K > 1) ? al(B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) * 8) : 0;
+    w.off_xch = o; o = al(o + w.xch_bytes + 256);
     w.total = o;
     return w;
+}
+
+static size_t res_lds_bytes(const HostGraph *h, int V, int dir, int rows_cu_max) {
+    const int G = dir == 0 ? h->dev.res.f.G : h->dev.res.b.G;
+    return ((size_t)3 * rup64(G) + (size_t)rows_cu_max * 4 + 2 * (size_t)rup64(V) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
 }
 
 static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role) {
@@ -847,6 +1156,23 @@ static int launch_chain(const LossParams &p, size_t lds, hipStream_t st) {
     return CRF_OK;
 }
 
+template <int DIR>
+static int launch_res(LossParams p, size_t lds, int b0, int nb, hipStream_t st) {
+    static std::atomic<size_t> lds_set{0};
+    hipError_t e;
+    if (lds > lds_set.load()) {
+        if ((e = hipFuncSetAttribute((const void *)crf_res_chain_kernel<DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
+            set_error(std::string("hipFuncSetAttribute(res chain): ") + hipGetErrorString(e));
+            return CRF_ERR_HIP;
+        }
+        lds_set = lds;
+    }
+    p.b0 = b0;
+    hipLaunchKernelGGL(crf_res_chain_kernel<DIR>, dim3((unsigned)(nb * p.g.res.K)), dim3(kResThreads), lds, st, p);
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_res_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return CRF_OK;
+}
+
 }  // namespace crf
 
 using namespace crf;
@@ -880,10 +1206,12 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     if (ctc && 2 * max_label_len + 1 > kCtcRegs * kChainThreads) { set_error("label length > 2047 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
     const WsLayout w = ws_layout(h, B, T, V, Sc);
     if (ws_bytes < w.total) { set_error("workspace too small: need " + std::to_string(w.total)); return CRF_ERR_WORKSPACE; }
+    const bool res = den && w.res;
     size_t lds_chain = 0;
-    if (den) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0), chain_lds_bytes(h, (int)V, Sc, 1));
+    if (den && !res) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0), chain_lds_bytes(h, (int)V, Sc, 1));
+    if (res) lds_chain = std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b));
     if (ctc) lds_chain = std::max(lds_chain, chain_lds_bytes(h, (int)V, Sc, 2));
-    const size_t lds_grad = ((den ? (size_t)h->dev.Pr + rup64(h->dev.NC) : 0) + 2 * (size_t)rup64((int)V)) * sizeof(float);
+    const size_t lds_grad = ((den ? (size_t)rup64((int)w.Rq) + rup64((int)w.Rb) + rup64(std::max(h->dev.NC, h->dev.res.NC)) : 0) + 2 * (size_t)rup64((int)V)) * sizeof(float);
     if (lds_chain > 160 * 1024 || lds_grad > 160 * 1024) {
         set_error("graph too large for the LDS-resident kernels of this build (states=" + std::to_string(h ? h->S : 0) + ")");
         return CRF_ERR_UNSUPPORTED;
@@ -897,11 +1225,22 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     char *base = (char *)ws;
     p.ep = (float *)(base + w.off_ep); p.mx = (float *)(base + w.off_mx);
     p.Q = (float *)(base + w.off_Q); p.BP = (float *)(base + w.off_BP);
+    p.Rq = (int)w.Rq; p.Rb = (int)w.Rb; p.res = res ? 1 : 0;
+    if (den) {
+        p.gq = res ? h->dev.res.gq : h->dev.perm; p.gb = res ? h->dev.res.gb : h->dev.perm;
+        p.gchunk = res ? h->dev.res.chunk_off : h->dev.chunk_off; p.glab = res ? h->dev.res.lab_chunk_off : h->dev.lab_chunk_off;
+        p.gNC = res ? h->dev.res.NC : h->dev.NC;
+    }
+    if (res) { p.res_lds_rows_f = h->res_rows_cu_f; p.res_lds_rows_b = h->res_rows_cu_b; }
     p.EQ = (int *)(base + w.off_EQ); p.EB = (int *)(base + w.off_EB);
     p.CA = (double *)(base + w.off_CA); p.CB = (double *)(base + w.off_CB);
     p.ECA = (int *)(base + w.off_ECA); p.ECB = (int *)(base + w.off_ECB);
     p.ctc_zc = (double *)(base + w.off_pb);
-    float *pb = (float *)(p.ctc_zc + B);
+    p.cb_mxs = p.ctc_zc + B;
+    float *pb = (float *)(p.cb_mxs + B);
+    p.cb_part = pb + 8 * B; p.cb_F = (int *)(pb + 8 * B + (int64_t)kResMaxK * B);
+    p.xch = (unsigned long long *)(base + w.off_xch);
+    p.err = (int *)(base + w.off_xch + w.xch_bytes);
     p.den_zs = pb; p.den_ez = (int *)(pb + B); p.ctc_ez = (int *)(pb + 2 * B);
     p.cost_alpha = pb + 3 * B; p.cost_beta = pb + 4 * B; p.cost_ctc = pb + 5 * B; p.invalid = (int *)(pb + 6 * B);
     p.grad = grad; p.loss = loss; p.out_den = costs_den; p.out_beta = costs_beta; p.out_ctc = costs_ctc;
@@ -918,6 +1257,9 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     hipLaunchKernelGGL(crf_prep_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
     prof_mark(0, true, stream);
     LAUNCH_CHECK("crf_prep_kernel");
+    if (res) {  // exchange granules (tags) and the error word start at zero in every call
+        if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
+    }
 
     static std::atomic<size_t> lds_set_grad{0};
     if (lds_grad > lds_set_grad.load()) {
@@ -942,7 +1284,26 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         (void)hipStreamWaitEvent(cx->side[i], cx->fork, 0);
         return cx->side[i];
     };
-    if (den) {
+    if (res) {
+        // register-resident recursions: K CUs per utterance and direction, exchanging the state vector
+        // through L2 every frame.  With K > 1 every workgroup of a launch must be resident at once
+        // (its peers spin on it), so the batch goes in groups of at most CUs/(2K) utterances.
+        const int K = h->dev.res.K;
+        int ncu = 256;
+        int devid = 0;
+        if (hipGetDevice(&devid) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid);
+        const int grp = K > 1 ? std::max(1, ncu / (2 * K)) : (int)B;
+        hipStream_t sb = side(0);
+        prof_mark(1, false, stream);
+        prof_mark(2, false, sb);
+        for (int b0 = 0; b0 < (int)B; b0 += grp) {
+            const int nb = std::min(grp, (int)B - b0);
+            if ((rc = launch_res<0>(p, res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), b0, nb, stream))) return rc;
+            if ((rc = launch_res<1>(p, res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b), b0, nb, sb))) return rc;
+        }
+        prof_mark(1, true, stream);
+        prof_mark(2, true, sb);
+    } else if (den) {
         if ((rc = launch_chain<0>(p, chain_lds_bytes(h, (int)V, Sc, 0), stream))) return rc;
         if ((rc = launch_chain<1>(p, chain_lds_bytes(h, (int)V, Sc, 1), side(0)))) return rc;
     }

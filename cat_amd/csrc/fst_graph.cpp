@@ -332,10 +332,18 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     h->fwd_conflicts = fe.conflict_cycles; h->bwd_conflicts = be.conflict_cycles;
     for (auto &r : frows) h->max_in_deg = std::max(h->max_in_deg, (int)r.size());
     for (auto &r : brows) h->max_out_deg = std::max(h->max_out_deg, (int)r.size());
+    // canonical (label, dst)-ordered pair tables for the register-resident layout
+    std::vector<std::vector<std::pair<int, float>>> out_arcs_tmp((size_t)S);
+    for (int64_t k = 0; k < A; ++k) out_arcs_tmp[src[k]].push_back({arc_tmp_pair[(size_t)k], expf(w[k])});
+    std::vector<int> canon(P);
+    std::iota(canon.begin(), canon.end(), 0);
     GraphDev &d0 = h->dev;
     d0.S = (int)S; d0.A = (int)A; d0.P = P; d0.Pr = Pr; d0.Sr = Sr; d0.max_label = max_label;
     d0.NC = (int)chunk_off.size() - 1;
     if (device < 0) {  // host-only compile (diagnostics / CPU tests): tables are built, nothing is uploaded
+        h->device = -1;
+        int rcr = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon);
+        if (rcr) { delete h; return rcr; }
         *out = h;
         return CRF_OK;
     }
@@ -362,6 +370,7 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
         if ((rc = upload(h, perm, &d.perm))) break;
         if ((rc = upload(h, chunk_off, &d.chunk_off))) break;
         if ((rc = upload(h, lab_chunk_off, &d.lab_chunk_off))) break;
+        if ((rc = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon))) break;
     } while (0);
     (void)hipSetDevice(prev);
     if (rc) {
@@ -423,9 +432,11 @@ int crf_graph_dims(const crf_graph *g, int64_t *S, int64_t *A, int64_t *P, int64
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
     if (!g || !g->h || !out) { crf::set_error("null argument"); return CRF_ERR_ARG; }
     const crf::HostGraph *h = g->h;
-    const int64_t v[10] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
-                           h->fwd_conflicts, h->bwd_conflicts, (int64_t)h->max_in_deg * 100000 + h->max_out_deg};
-    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+    const int64_t v[16] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
+                           h->fwd_conflicts, h->bwd_conflicts, (int64_t)h->max_in_deg * 100000 + h->max_out_deg,
+                           h->res_stats.K, h->res_stats.slots_f, h->res_stats.slots_b, h->res_stats.conflicts_f,
+                           h->res_stats.conflicts_b, (int64_t)h->dev.res.f.R * 100000 + h->dev.res.b.R};
+    for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
     return CRF_OK;
 }
 

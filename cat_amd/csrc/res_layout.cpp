@@ -1,0 +1,337 @@
+// cat_amd/csrc/res_layout.cpp -- host-side builder of the REGISTER-RESIDENT layout of the denominator
+// graph (crf_internal.h: ResDev).  One recursion (forward or backward) of one utterance is split over
+// K compute units; every thread keeps its share of the arc list in VGPRs for the whole kernel, so the
+// per-frame work is LDS gathers + FMAs only and nothing is streamed from L2 (the streaming kernels of
+// crf_kernels.hip remain the fallback for graphs that do not fit).
+//
+// No reference counterpart: the reference keeps one flat arc array per direction in global memory and
+// re-reads it in every one of its T kernel launches (den_calculate.cu:309-355, 75-103, 189-227).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "../../include/ctc_crf_hip.h"
+#include "crf_internal.h"
+
+namespace crf {
+namespace {
+
+typedef std::vector<std::vector<std::pair<int, float>>> Rows;
+
+struct DirOut {
+    std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
+    std::vector<uint4> wave_info; // [K][kResWaves]
+    std::vector<int> row_of;      // rid -> input row (-1 padding)
+    std::vector<int> rid_of_row;  // input row -> rid
+    std::vector<int> cu_row_off;  // [K+1]
+    int64_t slots = 0, conflicts = 0;
+};
+
+inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / kResW)); }
+
+// rows[r] = arcs (gather index already renumbered, weight); row_cu[r] = owning CU.
+bool layout_dir(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o) {
+    const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
+    o->arcs.assign((size_t)K * kResWords * kResThreads, 0u);
+    o->wave_info.assign((size_t)K * kResWaves, uint4{0u, 0u, 0u, 0u});
+    o->rid_of_row.assign(rows.size(), -1);
+    o->row_of.clear();
+    o->cu_row_off.assign((size_t)K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        std::vector<int> mine;
+        for (size_t r = 0; r < rows.size(); ++r) if (row_cu[r] == k) mine.push_back((int)r);
+        std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return rows[a].size() > rows[b].size(); });
+        const int nsl = (int)((mine.size() + kWave - 1) / kWave);
+        std::vector<int> len(nsl);
+        for (int j = 0; j < nsl; ++j) len[j] = chunks_of(rows[mine[(size_t)j * kWave]].size());
+        // slices (sorted by length) -> waves with the register capacity as bin size: balanced
+        // longest-processing-time first; if that does not fit, best-fit-decreasing (tighter, less balanced)
+        std::vector<std::vector<int>> lists(kResWaves);
+        bool packed = false;
+        for (int mode = 0; mode < 2 && !packed; ++mode) {
+            std::vector<int> load(kResWaves, 0);
+            for (auto &l : lists) l.clear();
+            packed = true;
+            for (int j = 0; j < nsl && packed; ++j) {
+                int best = -1;
+                for (int w = 0; w < kResWaves; ++w) {
+                    if (load[w] + len[j] > kResNCH) continue;
+                    if (best < 0 || (mode == 0 ? load[w] < load[best] : load[w] > load[best])) best = w;
+                }
+                if (best < 0) { packed = false; break; }
+                lists[best].push_back(j);
+                load[best] += len[j];
+            }
+        }
+        if (!packed) return false;  // does not fit with this K
+        int rid = o->cu_row_off[k];
+        for (int w = 0; w < kResWaves; ++w) {
+            unsigned ends = 0;
+            int c0 = 0;
+            const int wave_row0 = rid;
+            for (int j : lists[w]) {
+                ends |= 1u << (c0 + len[j] - 1);
+                // remaining arcs per lane
+                std::vector<std::vector<std::pair<int, float>>> rem(kWave);
+                for (int lane = 0; lane < kWave; ++lane) {
+                    const size_t pos = (size_t)j * kWave + lane;
+                    int r = pos < mine.size() ? mine[pos] : -1;
+                    o->row_of.push_back(r);
+                    if (r >= 0) { o->rid_of_row[r] = rid + lane; rem[lane] = rows[r]; }
+                }
+                rid += kWave;
+                for (int ins = 0; ins < len[j] * kResW; ++ins) {
+                    const int c = c0 + ins / kResW, slot = ins % kResW;
+                    int off16[kWave];
+                    float wv[kWave];
+                    bool real[kWave];
+                    for (int half = 0; half < 2; ++half) {
+                        int used[32], occupant[32];
+                        for (int b = 0; b < 32; ++b) { used[b] = 0; occupant[b] = -1; }
+                        int lanes[32];
+                        for (int l = 0; l < 32; ++l) lanes[l] = half * 32 + l;
+                        std::stable_sort(lanes, lanes + 32, [&](int a, int b) { return rem[a].size() < rem[b].size(); });
+                        int first_real = -1;
+                        for (int li = 0; li < 32; ++li) {
+                            const int lane = lanes[li];
+                            auto &rv = rem[lane];
+                            real[lane] = false; off16[lane] = 0; wv[lane] = 0.f;
+                            if (rv.empty()) continue;
+                            size_t best = 0;
+                            int best_cost = 1 << 30;
+                            for (size_t q = 0; q < (arrange ? rv.size() : (size_t)1); ++q) {
+                                const int bank = rv[q].first & 31;
+                                const int cost = occupant[bank] == rv[q].first ? 0 : used[bank];
+                                if (cost < best_cost) { best_cost = cost; best = q; if (!cost) break; }
+                            }
+                            const auto arc = rv[best];
+                            rv.erase(rv.begin() + (long)best);
+                            const int bank = arc.first & 31;
+                            if (occupant[bank] != arc.first) { used[bank]++; if (occupant[bank] < 0) occupant[bank] = arc.first; }
+                            if (best_cost > 0) o->conflicts++;
+                            real[lane] = true; off16[lane] = arc.first * 4; wv[lane] = arc.second;
+                            if (first_real < 0) first_real = lane;
+                        }
+                        // padding gathers broadcast the address of a real lane of the same half
+                        for (int l = 0; l < 32; ++l) {
+                            const int lane = half * 32 + l;
+                            if (!real[lane]) off16[lane] = first_real >= 0 ? off16[first_real] : 0;
+                        }
+                    }
+                    for (int lane = 0; lane < kWave; ++lane) {
+                        const size_t t = (size_t)w * kWave + lane;
+                        unsigned &iw = o->arcs[((size_t)k * kResWords + (size_t)c * 6 + (slot >> 1)) * kResThreads + t];
+                        iw |= (unsigned)(off16[lane] & 0xffff) << ((slot & 1) * 16);
+                        unsigned wb;
+                        memcpy(&wb, &wv[lane], 4);
+                        o->arcs[((size_t)k * kResWords + (size_t)c * 6 + 2 + slot) * kResThreads + t] = wb;
+                    }
+                    o->slots += kWave;
+                }
+                c0 += len[j];
+            }
+            o->wave_info[(size_t)k * kResWaves + w] = uint4{ends, (unsigned)c0, (unsigned)wave_row0, 0u};
+        }
+        o->cu_row_off[(size_t)k + 1] = rid;
+    }
+    return true;
+}
+
+// balance states over K CUs by the chunk load of the rows keyed by each state
+std::vector<int> assign_owner(int S, int K, const std::vector<int64_t> &load) {
+    std::vector<int> order(S), owner(S, 0);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] > load[b]; });
+    std::vector<int64_t> tot(K, 0);
+    std::vector<int> cnt(K, 0);
+    for (int s : order) {
+        int best = 0;
+        for (int k = 1; k < K; ++k)
+            if (tot[k] < tot[best] || (tot[k] == tot[best] && cnt[k] < cnt[best])) best = k;
+        owner[s] = best; tot[best] += load[s]; cnt[best]++;
+    }
+    return owner;
+}
+
+template <typename T>
+int up(HostGraph *h, const std::vector<T> &v, const T **out) {
+    if (h->device < 0) { *out = nullptr; return CRF_OK; }
+    void *d = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) { set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    h->allocs.push_back(d);
+    if (!v.empty() && (e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)) != hipSuccess) {
+        set_error(std::string("hipMemcpy: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+    }
+    *out = (const T *)d;
+    return CRF_OK;
+}
+
+}  // namespace
+
+int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
+                   const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
+                   const std::vector<float> &end_lin, const std::vector<int> &label_sorted_pairs) {
+    ResDev &R = h->dev.res;
+    R = ResDev{};
+    if (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT"))) return CRF_OK;
+    if (S > 16383 || P > 16383) return CRF_OK;  // 16-bit LDS byte offsets
+    // Rows may be SPLIT into sub-rows (pieces of <= thr arcs, thr a multiple of the chunk width).
+    // Forward: a pair with many in-arcs becomes several sub-rows with the same (dst, label); everything
+    // downstream is linear in q (a_{t+1}[dst] += e'*q, gamma = sum q*b), so sub-rows are simply separate
+    // pairs.  Backward: a state's sub-rows produce partial b values that are summed by the LDS atomics
+    // into z_{t-1} and, in the grad pass, by listing every (forward sub-row, backward sub-row) product.
+    // Splitting evens out row lengths: less slice padding and a tight fit into the per-wave register budget.
+    const int max_lab = *std::max_element(pair_lab.begin(), pair_lab.end());
+    static const int kSplit[] = {1 << 30, 96, 64, 48, 32, 16, 8};
+    struct Dir { DirOut o; std::vector<int> sub_of; std::vector<int> owner; bool ok = false; };
+    auto try_dir = [&](const Rows &rows, const std::vector<int> &key, int K, std::vector<int> *gmap_out,
+                       const std::vector<int> &gkey, std::vector<int> *goff) -> Dir {
+        // gkey[g] = state whose owner produces gather-vector entry g; gmap_out = renumbering of g
+        Dir best;
+        // attempt 0: no splitting; attempt 1: split only the rows that would sit in a ragged last slice
+        // (fewer than 64 rows) of their CU into 2-chunk pieces, so that they fill leftover register space
+        // instead of claiming a whole slice; attempts 2..: global thresholds
+        std::vector<char> ragged(rows.size(), 0);
+        for (int attempt = 0; attempt < 1 + (int)(sizeof(kSplit) / sizeof(kSplit[0])); ++attempt) {
+            const int thr = attempt <= 1 ? (1 << 30) : kSplit[attempt - 1];
+            Dir d;
+            Rows sub;
+            std::vector<int> subkey;
+            for (size_t r = 0; r < rows.size(); ++r) {
+                const auto &a = rows[r];
+                const int rthr = (attempt == 1 && ragged[r]) ? 2 * kResW : thr;
+                const int parts = std::max(1, (int)((a.size() + (size_t)rthr - 1) / (size_t)rthr));
+                size_t per = (a.size() + parts - 1) / parts;
+                per = (per + kResW - 1) / kResW * kResW;
+                for (int q = 0; q < parts; ++q) {
+                    const size_t lo = std::min(a.size(), q * per), hi = std::min(a.size(), (q + 1) * per);
+                    if (q > 0 && lo >= hi) break;
+                    d.sub_of.push_back((int)r);
+                    sub.emplace_back(a.begin() + (long)lo, a.begin() + (long)hi);
+                    subkey.push_back(key[r]);
+                }
+            }
+            std::vector<int64_t> load(S, 0);
+            for (size_t r = 0; r < sub.size(); ++r) load[subkey[r]] += chunks_of(sub[r].size());
+            d.owner = assign_owner(S, K, load);
+            std::vector<int> gmap(gkey.size()), off(K + 1, 0);
+            for (int k = 0, n = 0; k < K; ++k) {
+                for (size_t g = 0; g < gkey.size(); ++g) if (d.owner[gkey[g]] == k) gmap[g] = n++;
+                off[k + 1] = n;
+            }
+            std::vector<int> cu(sub.size());
+            for (size_t r = 0; r < sub.size(); ++r) {
+                cu[r] = d.owner[subkey[r]];
+                for (auto &a : sub[r]) a.first = gmap[a.first];
+            }
+            if (!layout_dir(sub, cu, K, &d.o)) {
+                if (attempt == 0) {  // mark the rows of each CU's ragged last slice for attempt 1
+                    for (int k = 0; k < K; ++k) {
+                        std::vector<int> mine;
+                        for (size_t r = 0; r < sub.size(); ++r) if (cu[r] == k) mine.push_back((int)r);
+                        std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return sub[a].size() > sub[b].size(); });
+                        for (size_t i = mine.size() / kWave * kWave; i < mine.size(); ++i) ragged[d.sub_of[mine[i]]] = 1;
+                    }
+                }
+                continue;
+            }
+            d.ok = true;
+            *gmap_out = gmap;
+            *goff = off;
+            return d;
+        }
+        return best;
+    };
+    std::vector<int> fkey(P), state_id(S), gkey_f(S), gkey_b(P);
+    for (int p = 0; p < P; ++p) { fkey[p] = pair_dst[p]; gkey_b[p] = pair_dst[p]; }
+    std::iota(state_id.begin(), state_id.end(), 0);
+    gkey_f = state_id;
+    for (int K = 1; K <= kResMaxK; K *= 2) {
+        std::vector<int> xid, xoff, zid, zoff;
+        // forward rows are taken in label-sorted pair order so that sub-rows come out label-sorted
+        Rows fin(P);
+        std::vector<int> fin_key(P);
+        for (int j = 0; j < P; ++j) { fin[j] = in_arcs_of_pair[label_sorted_pairs[j]]; fin_key[j] = pair_dst[label_sorted_pairs[j]]; }
+        Dir F = try_dir(fin, fin_key, K, &xid, gkey_f, &xoff);
+        if (!F.ok) continue;
+        Dir Bk = try_dir(out_arcs_of_state, state_id, K, &zid, gkey_b, &zoff);
+        if (!Bk.ok) continue;
+        const DirOut &fo = F.o, &bo = Bk.o;
+        const int NRf = (int)F.sub_of.size(), NRb = (int)Bk.sub_of.size();
+        auto pair_of_sub = [&](int r) { return label_sorted_pairs[F.sub_of[r]]; };
+
+        // ---- row metadata and side tables
+        const int Rf = fo.cu_row_off[K], Rb = bo.cu_row_off[K];
+        std::vector<int4> fmeta(Rf, int4{-1, 0, 0, 0}), bmeta(Rb, int4{-1, 0, 0, 0});
+        for (int r = 0; r < Rf; ++r)
+            if (fo.row_of[r] >= 0) { const int p = pair_of_sub(fo.row_of[r]); fmeta[r] = int4{xid[pair_dst[p]], pair_lab[p], 0, 0}; }
+        std::vector<std::vector<int>> pairs_into(S), bsubs_of(S);
+        for (int p = 0; p < P; ++p) pairs_into[pair_dst[p]].push_back(p);
+        for (int r = 0; r < NRb; ++r) bsubs_of[Bk.sub_of[r]].push_back(r);
+        std::vector<int2> bcsr;
+        std::vector<float> brow_start(Rb, 0.f), brow_end(Rb, 0.f);
+        for (int r = 0; r < Rb; ++r) {
+            const int sr = bo.row_of[r];
+            if (sr < 0) continue;
+            const int s = Bk.sub_of[sr];
+            const auto &pl = pairs_into[s];
+            int4 m{(int)pl.size(), 0, 0, (int)bcsr.size()};
+            if (!pl.empty()) { m.y = zid[pl[0]]; m.z = pair_lab[pl[0]]; }
+            if (pl.size() > 1) for (int p : pl) bcsr.push_back(int2{zid[p], pair_lab[p]});
+            bmeta[r] = m;
+            brow_start[r] = start_lin[s];
+            brow_end[r] = (bsubs_of[s][0] == sr) ? end_lin[s] : 0.f;  // b_T[s] = end weight, counted once
+        }
+        std::vector<float> x_start(S), x_end(S), z_end(P);
+        std::vector<int> z_lab(P);
+        for (int s = 0; s < S; ++s) { x_start[xid[s]] = start_lin[s]; x_end[xid[s]] = end_lin[s]; }
+        for (int p = 0; p < P; ++p) { z_lab[zid[p]] = pair_lab[p]; z_end[zid[p]] = end_lin[pair_dst[p]]; }
+        // grad pass list: every (forward sub-row, backward sub-row of its dst state), label-sorted, cut into
+        // chunks of <= kChunk entries within one label
+        std::vector<int> gq, gb, glabel, gchunk{0}, glab((size_t)max_lab + 2, 0);
+        for (int r = 0; r < NRf; ++r) {
+            const int p = pair_of_sub(r);
+            for (int bs : bsubs_of[pair_dst[p]]) { gq.push_back(fo.rid_of_row[r]); gb.push_back(bo.rid_of_row[bs]); glabel.push_back(pair_lab[p]); }
+        }
+        {
+            const int NL = (int)gq.size();
+            int r = 0;
+            for (int v = 0; v <= max_lab; ++v) {
+                glab[v] = (int)gchunk.size() - 1;
+                int e = r;
+                while (e < NL && glabel[e] == v) ++e;
+                for (int c = r; c < e; c += kChunk) gchunk.push_back(std::min(e, c + kChunk));
+                r = e;
+            }
+            glab[(size_t)max_lab + 1] = (int)gchunk.size() - 1;
+        }
+        R.K = K;
+        R.f.R = Rf; R.f.G = S; R.b.R = Rb; R.b.G = P;
+        R.NC = (int)gchunk.size() - 1;
+        for (int k = 0; k < K; ++k) {
+            h->res_rows_cu_f = std::max(h->res_rows_cu_f, fo.cu_row_off[k + 1] - fo.cu_row_off[k]);
+            h->res_rows_cu_b = std::max(h->res_rows_cu_b, bo.cu_row_off[k + 1] - bo.cu_row_off[k]);
+        }
+        h->res_stats.K = K;
+        h->res_stats.slots_f = fo.slots; h->res_stats.slots_b = bo.slots;
+        h->res_stats.conflicts_f = fo.conflicts; h->res_stats.conflicts_b = bo.conflicts;
+        int rc;
+        if ((rc = up(h, fo.arcs, &R.f.arcs)) || (rc = up(h, fo.wave_info, &R.f.wave_info)) ||
+            (rc = up(h, fmeta, &R.f.row_meta)) || (rc = up(h, fo.cu_row_off, &R.f.cu_row_off)) ||
+            (rc = up(h, xoff, &R.f.own_off)) || (rc = up(h, bo.arcs, &R.b.arcs)) ||
+            (rc = up(h, bo.wave_info, &R.b.wave_info)) || (rc = up(h, bmeta, &R.b.row_meta)) ||
+            (rc = up(h, bo.cu_row_off, &R.b.cu_row_off)) || (rc = up(h, zoff, &R.b.own_off)) ||
+            (rc = up(h, x_start, &R.x_start)) || (rc = up(h, x_end, &R.x_end)) || (rc = up(h, z_lab, &R.z_lab)) ||
+            (rc = up(h, z_end, &R.z_end)) || (rc = up(h, brow_start, &R.brow_start)) ||
+            (rc = up(h, brow_end, &R.brow_end)) || (rc = up(h, bcsr, &R.bcsr)) || (rc = up(h, gq, &R.gq)) ||
+            (rc = up(h, gb, &R.gb)) || (rc = up(h, gchunk, &R.chunk_off)) || (rc = up(h, glab, &R.lab_chunk_off)))
+            return rc;
+        return CRF_OK;
+    }
+    return CRF_OK;  // K stays 0: not resident
+}
+
+}  // namespace crf
