@@ -117,6 +117,14 @@ __device__ __forceinline__ double exp_scaled_d(float d) {
     return ldexp((double)expf(r), (int)k);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
+// until every global store of the frame (the Q / BP rows) has been acknowledged by L2 -- about a
+// microsecond per frame on a 1500-frame dependency chain.  Nothing inside the frame loops reads
+// global data written by another wave of the same workgroup, so the LDS-only form is sufficient.
+__device__ __forceinline__ void sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // exact power-of-two rescale that brings m into [2^kScaleExp, 2^(kScaleExp+1))
 __device__ __forceinline__ int rescale_exp(float m) {
     if (!(m > 0.f)) return 0;
@@ -295,7 +303,7 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
         for (int s = tid; s < S; s += kChainThreads) m = fmaxf(m, Xc[s]);
         m = wave_max(m);
         if (lane == 0) wm[(t & 1) * kChainWaves + wave] = m;
-        __syncthreads();
+        sync_lds();
         const int k = rescale_exp(frame_max(wm + (t & 1) * kChainWaves));
         const float sc = pow2f(k);
         E += k;                       // exponent of q_t
@@ -311,7 +319,10 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
             const int2 meta = g.pair_meta[r];  // {dst, label}; issued before the arc stream
             const float q = ell_row_sum(g.fwd.arcs + off + lane, w2, Xc) * sc;
             Qrow[r] = q;
-            if (meta.x >= 0) atomicAdd(&Xn[meta.x], EPc[meta.y] * q);
+            if (meta.x >= 0) {  // sole contributor to its destination state: plain store; LDS float atomics
+                const float av = EPc[meta.y & 0xffff] * q;  // are lane-serial (~2.5 clk per lane)
+                if (meta.y >> 16) Xn[meta.x] = av; else atomicAdd(&Xn[meta.x], av);
+            }
         }
         if (t + 1 < lx) {
             float *EPn = EP + ((t + 1) & 1) * Vp;
@@ -321,7 +332,7 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
                 if (v < V) EPn[v] = epn[i];
             }
         }
-        __syncthreads();
+        sync_lds();
     }
     const float *Xf = X + (lx % 3) * Sp;
     float part = 0.f;
@@ -366,7 +377,7 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
             const int d = g.pair_meta[r].x;
             const float bv = d >= 0 ? g.end_lin[d] * pow2f(kScaleExp) : 0.f;
             BProw[r] = bv;
-            Z[r] = EP[g.pair_meta[r].y] * bv;
+            Z[r] = EP[g.pair_meta[r].y & 0xffff] * bv;
         }
         if (tid == 0) p.EB[bt0 + lx - 1] = F;
     } else {
@@ -400,7 +411,7 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
             for (int r = tid; r < Pr; r += kChainThreads) BProw[r] = BPp[r];
             if (tid == 0) p.EB[bt0 + t] = F;
         }
-        __syncthreads();
+        sync_lds();
         const int k = rescale_exp(frame_max(wm + (i & 1) * kChainWaves));
         const float sc = pow2f(k);
         F += k + kEpExp;              // Z_t = e'_t b_{t+1} carries the 2^kEpExp of e'_t
@@ -421,7 +432,7 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
                     for (int pi = g.st_pair_off[s]; pi < g.st_pair_off[s + 1]; ++pi) {
                         const int r = g.st_pairs[pi];
                         BPc[r] = bv;
-                        Zn[r] = EPn[g.pair_meta[r].y] * bv;
+                        Zn[r] = EPn[g.pair_meta[r].y & 0xffff] * bv;
                     }
                 }
             }
@@ -434,7 +445,7 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
                 if (v < V) EPw[v] = epn[q];
             }
         }
-        __syncthreads();
+        sync_lds();
     }
     const float zb = block_sum(zpart, (float *)red, tid);
     const double mxs = mx_total(p, b, lx, red, tid);
@@ -684,6 +695,9 @@ __device__ __forceinline__ void res_exchange(unsigned long long *slot, float *v,
                                              unsigned tag, int *err, int tid) {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     gu64 *gs = (gu64 *)slot;
+    // once any exchange of this launch has timed out nobody waits again: the run finishes (with the
+    // error word set and garbage results) instead of stacking timeouts
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     for (int i = lo + tid; i < hi; i += kResThreads)
         __hip_atomic_store(gs + i, ((unsigned long long)tag << 32) | __float_as_uint(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int base = 0; base < G; base += kPoll * kResThreads) {
@@ -704,22 +718,30 @@ __device__ __forceinline__ void res_exchange(unsigned long long *slot, float *v,
                     v[base + q * kResThreads + tid] = __uint_as_float((unsigned)gv[q]);
                     pending &= ~(1u << q);
                 }
-            if (spins > (1u << 22)) {  // ~seconds: a peer died or was never scheduled -- give up loudly, never hang
-                *err = 1;
+            if (spins > (1u << 20)) {  // ~1 s: a peer died or was never scheduled -- give up loudly, never hang
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
+            if ((spins & 1023u) == 1023u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             if (pending && spins > 4) __builtin_amdgcn_s_sleep(2);
         }
     }
 }
 
-#define CRF_RES_GATHER4(c)                                                                        \
-    {                                                                                             \
-        const unsigned i01 = A[6 * (c)], i23 = A[6 * (c) + 1];                                    \
-        acc = fmaf(*(const float *)(xb + (i01 & 0xffffu)), __uint_as_float(A[6 * (c) + 2]), acc); \
-        acc1 = fmaf(*(const float *)(xb + (i01 >> 16)), __uint_as_float(A[6 * (c) + 3]), acc1);   \
-        acc = fmaf(*(const float *)(xb + (i23 & 0xffffu)), __uint_as_float(A[6 * (c) + 4]), acc); \
-        acc1 = fmaf(*(const float *)(xb + (i23 >> 16)), __uint_as_float(A[6 * (c) + 5]), acc1);   \
+// Chunk sums in batches of kResBatch chunks: the 4*kResBatch gathers of a batch are one straight-line
+// block (no branch between them), so every wave keeps ~20 independent ds_read_b32 in flight -- with
+// only 2 waves per SIMD that, not occupancy, is what hides the LDS latency.  The (uniform) slice-end
+// branches sit between batches.  Unused chunks hold zero weights.
+constexpr int kResBatch = 5;
+static_assert(kResNCH % kResBatch == 0, "kResNCH must be a multiple of kResBatch");
+#define CRF_RES_BATCH(part, A, xb, c0)                                                                    \
+    _Pragma("unroll") for (int ci = 0; ci < kResBatch; ++ci) {                                            \
+        const int c = (c0) + ci;                                                                          \
+        const unsigned i01 = A[6 * c], i23 = A[6 * c + 1];                                                \
+        const float g0 = *(const float *)(xb + (i01 & 0xffffu)), g1 = *(const float *)(xb + (i01 >> 16)); \
+        const float g2 = *(const float *)(xb + (i23 & 0xffffu)), g3 = *(const float *)(xb + (i23 >> 16)); \
+        part[ci] = fmaf(g0, __uint_as_float(A[6 * c + 2]), g1 * __uint_as_float(A[6 * c + 3])) +          \
+                   fmaf(g2, __uint_as_float(A[6 * c + 4]), g3 * __uint_as_float(A[6 * c + 5]));           \
     }
 
 template <int DIR>
@@ -730,7 +752,15 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
     const int K = R.K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = p.b0 + (int)(blockIdx.x / (unsigned)K), k = (int)(blockIdx.x % (unsigned)K);
+    // Peers of one recursion are placed 8 block ids apart: the dispatcher is observed to put block x on
+    // XCD x % 8, so the K CUs that exchange a state vector every frame share one L2 (speed only; the
+    // protocol is placement-independent).
+    int b, k;
+    {
+        const int x = (int)blockIdx.x, total = (int)gridDim.x, full = total / (8 * K) * (8 * K);
+        if (x < full) { const int grp = x / (8 * K), within = x % (8 * K); k = within / 8; b = p.b0 + grp * 8 + within % 8; }
+        else { const int y = x - full; k = y % K; b = p.b0 + full / K + y / K; }
+    }
     const int V = p.V, lx = p.lx[b], G = L.G;
     const int Gp = rup64(G), Vp = rup64(V);
     const int64_t bt0 = (int64_t)b * p.T;
@@ -756,7 +786,8 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
     const int cu_row0 = L.cu_row_off[k], cu_rows = L.cu_row_off[k + 1] - cu_row0;
     const int own_lo = L.own_off[k], own_hi = L.own_off[k + 1];
     for (int r = tid; r < cu_rows; r += kResThreads) RM[r] = L.row_meta[cu_row0 + r];
-    unsigned long long *xch = p.xch + ((size_t)DIR * p.B + b) * 2 * (size_t)G;
+    // forward slots first ([B][2][S]), backward slots ([B][2][P]) after them
+    unsigned long long *xch = p.xch + (DIR == 0 ? 0 : (size_t)p.B * 2 * (size_t)R.f.G) + (size_t)b * 2 * (size_t)G;
 
     if (DIR == 0) {
         // ================= forward =================
@@ -779,7 +810,7 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
             for (int s = tid; s < G; s += kResThreads) m = fmaxf(m, Xc[s]);
             m = wave_max(m);
             if (lane == 0) wm[(t & 1) * kResWaves + wave] = m;
-            __syncthreads();
+            sync_lds();
             const int ksc = rescale_exp(res_frame_max(wm + (t & 1) * kResWaves));
             const float sc = pow2f(ksc);
             E += ksc;
@@ -788,19 +819,27 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
             for (int s = tid; s < Gp; s += kResThreads) Xz[s] = 0.f;
             float *Qrow = p.Q + (bt0 + t) * p.Rq;
             const char *xb = (const char *)Xc;
-            float acc = 0.f, acc1 = 0.f;
+            float acc = 0.f;
             int rid = row0 + lane;
 #pragma unroll
-            for (int c = 0; c < kResNCH; ++c) {
-                if (c < nch) {
-                    CRF_RES_GATHER4(c);
-                    if (ends >> c & 1u) {
-                        const float q = (acc + acc1) * sc;
-                        Qrow[rid] = q;
-                        const int4 mt = RM[rid - cu_row0];
-                        if (mt.x >= 0) atomicAdd(&Xn[mt.x], EPc[mt.y] * q);
-                        acc = 0.f; acc1 = 0.f;
-                        rid += kWave;
+            for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
+                if (c0 < nch) {
+                    float part[kResBatch];
+                    CRF_RES_BATCH(part, A, xb, c0);
+#pragma unroll
+                    for (int ci = 0; ci < kResBatch; ++ci) {
+                        acc += part[ci];
+                        if (ends >> (c0 + ci) & 1u) {
+                            const float q = acc * sc;
+                            Qrow[rid] = q;
+                            const int4 mt = RM[rid - cu_row0];
+                            if (mt.x >= 0) {  // sole contributor: plain store (LDS float atomics are lane-serial)
+                                const float av = EPc[mt.y] * q;
+                                if (mt.z) Xn[mt.x] = av; else atomicAdd(&Xn[mt.x], av);
+                            }
+                            acc = 0.f;
+                            rid += kWave;
+                        }
                     }
                 }
             }
@@ -809,10 +848,10 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
 #pragma unroll
                 for (int i = 0; i < kEpRegsR; ++i) { const int v = tid + i * kResThreads; if (v < V) EPn[v] = epn[i]; }
             }
-            __syncthreads();
+            sync_lds();
             if (K > 1) {
                 res_exchange(xch + (size_t)((t + 1) & 1) * G, Xn, G, own_lo, own_hi, (unsigned)(t + 1), p.err, tid);
-                __syncthreads();
+                sync_lds();
             }
         }
         if (k == 0) {
@@ -858,35 +897,41 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
             for (int z = tid; z < G; z += kResThreads) m = fmaxf(m, Zc[z]);
             m = wave_max(m);
             if (lane == 0) wm[(i & 1) * kResWaves + wave] = m;
-            __syncthreads();
+            sync_lds();
             const int ksc = rescale_exp(res_frame_max(wm + (i & 1) * kResWaves));
             const float sc = pow2f(ksc);
             F += ksc + kEpExp;
             if (t > 0 && tid == 0 && k == 0) p.EB[bt0 + t - 1] = F;
             float *BProw = p.BP + (bt0 + (t > 0 ? t - 1 : 0)) * p.Rb;
             const char *xb = (const char *)Zc;
-            float acc = 0.f, acc1 = 0.f;
+            float acc = 0.f;
             int rid = row0 + lane;
 #pragma unroll
-            for (int c = 0; c < kResNCH; ++c) {
-                if (c < nch) {
-                    CRF_RES_GATHER4(c);
-                    if (ends >> c & 1u) {
-                        const float bv = (acc + acc1) * sc;
-                        const int4 mt = RM[rid - cu_row0];
-                        if (t == 0) {
-                            if (mt.x >= 0) zpart += R.brow_start[rid] * bv;
-                        } else {
-                            BProw[rid] = bv;
-                            // a state's sub-rows add their partial b into z_{t-1} (LDS float atomics)
-                            if (mt.x == 1) {
-                                atomicAdd(&Zn[mt.y], EPn[mt.z] * bv);
-                            } else if (mt.x > 1) {
-                                for (int q = 0; q < mt.x; ++q) { const int2 zl = R.bcsr[mt.w + q]; atomicAdd(&Zn[zl.x], EPn[zl.y] * bv); }
+            for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
+                if (c0 < nch) {
+                    float part[kResBatch];
+                    CRF_RES_BATCH(part, A, xb, c0);
+#pragma unroll
+                    for (int ci = 0; ci < kResBatch; ++ci) {
+                        acc += part[ci];
+                        if (ends >> (c0 + ci) & 1u) {
+                            const float bv = acc * sc;
+                            const int4 mt = RM[rid - cu_row0];
+                            if (t == 0) {
+                                if (mt.x >= 0) zpart += R.brow_start[rid] * bv;
+                            } else {
+                                BProw[rid] = bv;
+                                // a state's sub-rows add their partial b into z_{t-1} (LDS float atomics)
+                                if (mt.x == 1) {
+                                    const float zv = EPn[mt.z & 0xffff] * bv;
+                                    if (mt.z >> 16) Zn[mt.y] = zv; else atomicAdd(&Zn[mt.y], zv);
+                                } else if (mt.x > 1) {
+                                    for (int q = 0; q < mt.x; ++q) { const int2 zl = R.bcsr[mt.w + q]; atomicAdd(&Zn[zl.x], EPn[zl.y] * bv); }
+                                }
                             }
+                            acc = 0.f;
+                            rid += kWave;
                         }
-                        acc = 0.f; acc1 = 0.f;
-                        rid += kWave;
                     }
                 }
             }
@@ -895,10 +940,10 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
 #pragma unroll
                 for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; if (v < V) EPw[v] = epn[q]; }
             }
-            __syncthreads();
+            sync_lds();
             if (K > 1 && t > 0) {
                 res_exchange(xch + (size_t)((i + 1) & 1) * G, Zn, G, own_lo, own_hi, (unsigned)(i + 1), p.err, tid);
-                __syncthreads();
+                sync_lds();
             }
         }
         const float zb = res_block_sum(zpart, (float *)red, tid);
@@ -1030,7 +1075,7 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
     part = wave_sum_d(part);
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
-    if (tid == 0) p.loss[0] = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (tid == 0) p.loss[0] = (p.res && *p.err) ? __builtin_nanf("") : (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1308,8 +1353,18 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if ((rc = launch_chain<1>(p, chain_lds_bytes(h, (int)V, Sc, 1), side(0)))) return rc;
     }
     if (ctc) {
-        if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream))) return rc;
-        if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2)))) return rc;
+        // The resident den kernels with K > 1 own every CU (one workgroup per CU, peers spin on each
+        // other), so the numerator recursions are queued BEHIND them on the same two streams instead of
+        // competing for CUs; otherwise all four recursions run side by side.
+        static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
+        const bool ctc_after = ctc_after_env >= 0 ? ctc_after_env != 0 : (res && h->dev.res.K > 1);
+        if (ctc_after) {
+            if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), stream))) return rc;
+            if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(0)))) return rc;
+        } else {
+            if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream))) return rc;
+            if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2)))) return rc;
+        }
     }
     for (int i = 0; i < 3; ++i)
         if (used[i]) {

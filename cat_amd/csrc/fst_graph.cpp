@@ -311,7 +311,11 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
         lab_chunk_off[(size_t)max_label + 1] = (int)chunk_off.size() - 1;
     }
     std::vector<int2> pair_meta(Pr);
-    for (int r = 0; r < Pr; ++r) pair_meta[r] = int2{pair_dst[r], pair_lab[r]};
+    // label | (1 << 16) when the pair is the only one into its destination state (plain LDS store)
+    for (int r = 0; r < Pr; ++r) {
+        const bool sole = pair_dst[r] >= 0 && st_pair_off[(size_t)pair_dst[r] + 1] - st_pair_off[pair_dst[r]] == 1;
+        pair_meta[r] = int2{pair_dst[r], pair_lab[r] | (sole ? 1 << 16 : 0)};
+    }
     std::vector<int4> bwd_row_meta(Sr);
     for (int r = 0; r < Sr; ++r) {
         const int st = be.row_of[r];

@@ -266,8 +266,13 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         // ---- row metadata and side tables
         const int Rf = fo.cu_row_off[K], Rb = bo.cu_row_off[K];
         std::vector<int4> fmeta(Rf, int4{-1, 0, 0, 0}), bmeta(Rb, int4{-1, 0, 0, 0});
+        std::vector<int> contrib(S, 0);  // forward (sub-)rows per destination state
+        for (int r = 0; r < NRf; ++r) contrib[pair_dst[pair_of_sub(r)]]++;
         for (int r = 0; r < Rf; ++r)
-            if (fo.row_of[r] >= 0) { const int p = pair_of_sub(fo.row_of[r]); fmeta[r] = int4{xid[pair_dst[p]], pair_lab[p], 0, 0}; }
+            if (fo.row_of[r] >= 0) {  // .z = 1: sole contributor to its destination -> plain LDS store
+                const int p = pair_of_sub(fo.row_of[r]);
+                fmeta[r] = int4{xid[pair_dst[p]], pair_lab[p], contrib[pair_dst[p]] == 1 ? 1 : 0, 0};
+            }
         std::vector<std::vector<int>> pairs_into(S), bsubs_of(S);
         for (int p = 0; p < P; ++p) pairs_into[pair_dst[p]].push_back(p);
         for (int r = 0; r < NRb; ++r) bsubs_of[Bk.sub_of[r]].push_back(r);
@@ -279,7 +284,8 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             const int s = Bk.sub_of[sr];
             const auto &pl = pairs_into[s];
             int4 m{(int)pl.size(), 0, 0, (int)bcsr.size()};
-            if (!pl.empty()) { m.y = zid[pl[0]]; m.z = pair_lab[pl[0]]; }
+            // .z = label | (1 << 16) when this is the state's only sub-row (plain LDS store of z)
+            if (!pl.empty()) { m.y = zid[pl[0]]; m.z = pair_lab[pl[0]] | (bsubs_of[s].size() == 1 ? 1 << 16 : 0); }
             if (pl.size() > 1) for (int p : pl) bcsr.push_back(int2{zid[p], pair_lab[p]});
             bmeta[r] = m;
             brow_start[r] = start_lin[s];

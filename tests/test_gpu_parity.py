@@ -27,8 +27,33 @@ def crf():
     return ctc_crf
 
 
-def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True):
-    ctx = crf.CRFContext(den_lm, 0)
+MODES = ["resident", "streaming"]
+
+
+class _mode:
+    """The denominator has two kernel families: register-resident (default whenever the graph fits) and
+    streaming (fallback).  CRF_NO_RESIDENT is read when a graph is created."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.get("CRF_NO_RESIDENT")
+        os.environ["CRF_NO_RESIDENT"] = "1" if self.mode == "streaming" else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("CRF_NO_RESIDENT", None)
+        else:
+            os.environ["CRF_NO_RESIDENT"] = self.old
+
+
+def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mode="resident"):
+    with _mode(mode):
+        ctx = crf.CRFContext(den_lm, 0)
+    want = 0 if mode == "streaming" else None
+    k = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))["res_K"]
+    assert (k == 0) if want == 0 else True
     x = torch.tensor(logits, device="cuda:0", requires_grad=True)
     crit = crf.CTC_CRF_LOSS(lamb=lamb, size_average=size_average)
     loss = crit(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32),
@@ -39,11 +64,12 @@ def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True):
     return out
 
 
-def test_fixture_kat(crf, golden_dir):
+@pytest.mark.parametrize("mode", MODES)
+def test_fixture_kat(crf, golden_dir, mode):
     """Exactly src/ctc_crf/test/main.py:15-35 (the reference's only test), with the value pinned."""
     k = json.load(open(os.path.join(golden_dir, "kat_fixture.json")))
     logits = np.log(np.array(k["probs"], dtype=np.float32))[None]
-    loss, grad = run_hip(crf, os.path.join(golden_dir, "den_lm_fixture.fst"), logits, k["labels"], [5], [3], lamb=k["lamb"])
+    loss, grad = run_hip(crf, os.path.join(golden_dir, "den_lm_fixture.fst"), logits, k["labels"], [5], [3], lamb=k["lamb"], mode=mode)
     assert abs(loss - k["loss"]) <= TOL * abs(k["loss"])
     assert rel_err(grad[0], np.array(k["grad"])) <= TOL
 
@@ -87,19 +113,21 @@ def test_random_golden(crf, golden_dir):
         del ctx
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("seed,B,T,vocab,hist,fan", [(0, 3, 20, 8, 16, 4), (1, 5, 37, 12, 40, 6), (2, 2, 64, 72, 128, 16)])
-def test_synth_vs_oracle_ragged(crf, tmp_path, seed, B, T, vocab, hist, fan):
+def test_synth_vs_oracle_ragged(crf, tmp_path, seed, B, T, vocab, hist, fan, mode):
     g, p = small_synth(tmp_path, vocab, hist, fan, seed)
     logits, labels, lx, ly = make_batch(g, B, T, vocab, seed=seed, ragged=True)
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
-    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode=mode)
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
     for b in range(B):  # rows past lx[b] are exactly zero (copy_grad returns early, den_calculate.cu:239)
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
-def test_edge_cases(crf, tmp_path):
+@pytest.mark.parametrize("mode", MODES)
+def test_edge_cases(crf, tmp_path, mode):
     """repeats, L = 0, L + repeats == T (no slack), lx < T, and an invalid utterance (L + repeats > T)."""
     g, p = small_synth(tmp_path, 6, 8, 3, 3)
     rng = np.random.default_rng(5)
@@ -111,7 +139,7 @@ def test_edge_cases(crf, tmp_path):
     ly = np.array([len(l) for l in labs], dtype=np.int32)
     labels = np.array([v for l in labs for v in l], dtype=np.int32)
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.3, size_average=False)
-    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.3, size_average=False)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.3, size_average=False, mode=mode)
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
 
@@ -189,20 +217,23 @@ def default_graph(tmp_path_factory):
     return _default_graph(tmp_path_factory)
 
 
-def test_config2_slice_vs_oracle(crf, default_graph):
+@pytest.mark.parametrize("mode", MODES)
+def test_config2_slice_vs_oracle(crf, default_graph, mode):
     """BASELINE config #2 graph and shapes (V=72, S=4097, T=500), on a 3-utterance slice the fp64
-    oracle finishes in seconds."""
+    oracle finishes in seconds.  In resident mode this graph runs on K=2 CUs per recursion, i.e. it
+    exercises the per-frame all-gather through L2."""
     g, p = default_graph
     logits, labels, lx, ly = make_batch(g, 3, 500, 72, seed=0, ragged=True)
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
-    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode=mode)
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     e = rel_err(grad, ref["grad"])
     print(f"config-2 slice: loss rel err {abs(loss - ref['loss']) / abs(ref['loss']):.2e}, grad err {e:.2e}")
     assert e <= TOL
     # the two posterior matrices separately, entry by entry
     core = crf._C
-    ctx = crf.CRFContext(p, 0)
+    with _mode(mode):
+        ctx = crf.CRFContext(p, 0)
     x = torch.tensor(logits, device="cuda:0")
     _, gd, _ = core.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, core.graph_for(x.device), True)
     _, gc, _ = core.loss_fwd_bwd(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
