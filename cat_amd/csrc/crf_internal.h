@@ -54,6 +54,9 @@ struct ResDirDev {
                              //     bwd {#pairs into the state | -1 pad, first z index, its label, csr begin}
     const int *cu_row_off;   // [K+1] row-id range of each CU
     const int *own_off;      // [K+1] range of gather-vector indices PRODUCED by each CU
+    const int *ex_cnt;       // [2K] per CU: [k] entries with a single contributing row (numbered first),
+                             //       [K+k] entries summed from several rows (next); the rest have no producer
+    int has_nx;              // some entry is summed from several (sub-)rows (LDS atomics, published after the barrier)
     int R;                   // rows incl. padding = row stride of the per-frame HBM store
     int G;                   // gather-vector length (fwd: states, bwd: pairs)
 };

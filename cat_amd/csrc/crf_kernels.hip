@@ -55,6 +55,7 @@ struct LossParams {
     const int *gchunk, *glab;     // its chunks (<= kChunk entries of one label) and per-label chunk ranges
     int gNC;
     int res;                      // 1: register-resident den kernels (g.res), 0: streaming kernels
+    int grad_phase;               // crf_grad_kernel: 0 = den and ctc in one pass, 1 = den part only (writes), 2 = ctc part only (subtracts)
     int b0;                       // first utterance of this launch (resident kernels with K > 1 run in groups)
     unsigned long long *xch;      // [2][B][2][G] tagged granules for the K-way exchange of the state vector
     float *cb_part;               // [B][kResMaxK] partial backward partition sums
@@ -687,45 +688,45 @@ __device__ __forceinline__ float res_frame_max(const float *wm) {
     return m;
 }
 
-// All-gather of a state vector of G floats held in LDS (`v`): this CU produced [lo,hi); the others are
-// fetched from the peers' publications.  Granule = {tag << 32 | float bits}, one aligned 8-byte
-// agent-scope store / load each (the data is the flag; cdna_hip_programming.md G16 R2).  Slots
-// alternate per frame; a peer can be at most one exchange ahead, so two slots suffice.
-__device__ __forceinline__ void res_exchange(unsigned long long *slot, float *v, int G, int lo, int hi,
-                                             unsigned tag, int *err, int tid) {
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-    gu64 *gs = (gu64 *)slot;
-    // once any exchange of this launch has timed out nobody waits again: the run finishes (with the
-    // error word set and garbage results) instead of stacking timeouts
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    for (int i = lo + tid; i < hi; i += kResThreads)
-        __hip_atomic_store(gs + i, ((unsigned long long)tag << 32) | __float_as_uint(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int base = 0; base < G; base += kPoll * kResThreads) {
+// Exchange of the state vector between the K CUs of one recursion.  Granule = {tag << 32 | float
+// bits}, ONE aligned 8-byte agent-scope store / load each: the data is the flag
+// (cdna_hip_programming.md G16 R2).  Slots alternate per frame; a peer can be at most one exchange
+// ahead, so two slots suffice.  Values are published from the row epilogues as soon as they are
+// final, so most of the hand-off latency overlaps the rest of the frame's gathers.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ void res_publish(gu64 *slot, int i, unsigned tag, float v) {
+    __hip_atomic_store(slot + i, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Fetch entries [lo,hi) published by a peer into LDS `v`; returns the largest value seen.
+__device__ __forceinline__ float res_fetch(gu64 *slot, float *v, int lo, int hi, unsigned tag, int *err, int tid) {
+    float mx = 0.f;
+    for (int base = lo; base < hi; base += kPoll * kResThreads) {
         unsigned pending = 0;
 #pragma unroll
-        for (int q = 0; q < kPoll; ++q) {
-            const int i = base + q * kResThreads + tid;
-            if (i < G && (i < lo || i >= hi)) pending |= 1u << q;
-        }
+        for (int q = 0; q < kPoll; ++q)
+            if (base + q * kResThreads + tid < hi) pending |= 1u << q;
         for (unsigned spins = 0; pending; ++spins) {
             unsigned long long gv[kPoll];
 #pragma unroll
             for (int q = 0; q < kPoll; ++q)
-                if (pending >> q & 1) gv[q] = __hip_atomic_load(gs + base + q * kResThreads + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pending >> q & 1) gv[q] = __hip_atomic_load(slot + base + q * kResThreads + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int q = 0; q < kPoll; ++q)
                 if ((pending >> q & 1) && (unsigned)(gv[q] >> 32) == tag) {
-                    v[base + q * kResThreads + tid] = __uint_as_float((unsigned)gv[q]);
+                    const float x = __uint_as_float((unsigned)gv[q]);
+                    v[base + q * kResThreads + tid] = x;
+                    mx = fmaxf(mx, x);
                     pending &= ~(1u << q);
                 }
-            if (spins > (1u << 20)) {  // ~1 s: a peer died or was never scheduled -- give up loudly, never hang
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            if ((spins & 1023u) == 1023u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            if (pending && spins > 4) __builtin_amdgcn_s_sleep(2);
+            if (!pending) break;
+            // a peer died or was never scheduled: give up loudly (error word -> NaN loss), never hang;
+            // once the word is set nobody waits again
+            if (spins > (1u << 20)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (spins > 2) __builtin_amdgcn_s_sleep(1);
         }
     }
+    return mx;
 }
 
 // Chunk sums in batches of kResBatch chunks: the 4*kResBatch gathers of a batch are one straight-line
@@ -764,13 +765,12 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
     const int V = p.V, lx = p.lx[b], G = L.G;
     const int Gp = rup64(G), Vp = rup64(V);
     const int64_t bt0 = (int64_t)b * p.T;
-    const int NB = 3;  // gather source / accumulated next vector / being zeroed, rotated every frame
     const int rows_cu_max = DIR == 0 ? p.res_lds_rows_f : p.res_lds_rows_b;
-    float *X = lds;                                  // [NB][Gp] state vectors
-    int4 *RM = (int4 *)(X + NB * Gp);                // [rows_cu_max] row metadata of this CU
+    float *X = lds;                                  // [3][Gp]: gather source / next vector / being zeroed
+    int4 *RM = (int4 *)(X + 3 * Gp);                 // [rows_cu_max] row metadata of this CU
     float *EP = (float *)(RM + rows_cu_max);         // [2][Vp]
-    float *wm = EP + 2 * Vp;                         // [2][kResWaves]
-    double *red = (double *)(wm + 2 * kResWaves);    // [kResWaves]
+    float *wm = EP + 2 * Vp;                         // [2][2][kResWaves] per-wave maxima (exclusive / shared entries)
+    double *red = (double *)(wm + 4 * kResWaves);    // [kResWaves]
 
     // ---- one-time: arcs -> registers, row metadata -> LDS
     unsigned A[kResWords];
@@ -784,76 +784,166 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
     const int nch = __builtin_amdgcn_readfirstlane(wi.y);
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
     const int cu_row0 = L.cu_row_off[k], cu_rows = L.cu_row_off[k + 1] - cu_row0;
-    const int own_lo = L.own_off[k], own_hi = L.own_off[k + 1];
+    // entries of the gather vector produced by CU j: [own_off[j], own_off[j+1]); the first ex_cnt[j] of
+    // them have a single contributing row ("exclusive": final in that row's epilogue), the rest are
+    // summed by LDS atomics and are final only after the frame barrier
+    const bool has_nx = L.has_nx != 0;
     for (int r = tid; r < cu_rows; r += kResThreads) RM[r] = L.row_meta[cu_row0 + r];
     // forward slots first ([B][2][S]), backward slots ([B][2][P]) after them
-    unsigned long long *xch = p.xch + (DIR == 0 ? 0 : (size_t)p.B * 2 * (size_t)R.f.G) + (size_t)b * 2 * (size_t)G;
+    gu64 *xch = (gu64 *)(p.xch + (DIR == 0 ? 0 : (size_t)p.B * 2 * (size_t)R.f.G) + (size_t)b * 2 * (size_t)G);
+    int E = kScaleExp;
+    float zpart = 0.f;
 
-    if (DIR == 0) {
-        // ================= forward =================
-        for (int s = tid; s < 3 * Gp; s += kResThreads) X[s] = (s < G) ? R.x_start[s] * pow2f(kScaleExp) : 0.f;
-        if (lx > 0)
-            for (int v = tid; v < V; v += kResThreads) EP[v] = p.ep[bt0 * V + v];
-        int E = kScaleExp;
-        __syncthreads();
-        for (int t = 0; t < lx; ++t) {
-            const float *Xc = X + (t % 3) * Gp;
-            float *Xn = X + ((t + 1) % 3) * Gp, *Xz = X + ((t + 2) % 3) * Gp;
-            const float *EPc = EP + (t & 1) * Vp;
-            float epn[kEpRegsR];
-            if (t + 1 < lx) {
-                const float *er = p.ep + (bt0 + t + 1) * V;
+    // ---- initial vector (complete on every CU, no exchange needed)
+    for (int s = tid; s < 3 * Gp; s += kResThreads) X[s] = 0.f;
+    if (lx > 0)
+        for (int v = tid; v < V; v += kResThreads) {
+            EP[v] = p.ep[(bt0 + (DIR == 0 ? 0 : lx - 1)) * V + v];
+            if (DIR == 1 && lx > 1) EP[Vp + v] = p.ep[(bt0 + lx - 2) * V + v];
+        }
+    __syncthreads();
+    {
+        float m0 = 0.f;
+        if (DIR == 0) {
+            for (int s = tid; s < G; s += kResThreads) { const float v = R.x_start[s] * pow2f(kScaleExp); X[s] = v; m0 = fmaxf(m0, v); }
+        } else if (lx > 0) {
+            for (int z = tid; z < G; z += kResThreads) { const float v = EP[R.z_lab[z]] * (R.z_end[z] * pow2f(kScaleExp)); X[z] = v; m0 = fmaxf(m0, v); }
+            float *BProw = p.BP + (bt0 + lx - 1) * p.Rb;
+            for (int r = tid; r < cu_rows; r += kResThreads) BProw[cu_row0 + r] = R.brow_end[cu_row0 + r] * pow2f(kScaleExp);
+            if (tid == 0 && k == 0) p.EB[bt0 + lx - 1] = E;
+        } else {
+            for (int r = tid; r < cu_rows; r += kResThreads) zpart += R.brow_start[cu_row0 + r] * R.brow_end[cu_row0 + r] * pow2f(kScaleExp);
+        }
+        m0 = wave_max(m0);
+        if (lane == 0) { wm[wave] = m0; wm[kResWaves + wave] = 0.f; }
+    }
+    __syncthreads();
+
+    for (int i = 0; i < lx; ++i) {
+        const int t = DIR == 0 ? i : lx - 1 - i;                     // frame whose emissions are consumed
+        const bool produce = DIR == 0 || t > 0;                      // a next vector exists
+        const float *Xc = X + (i % 3) * Gp;
+        float *Xn = X + ((i + 1) % 3) * Gp, *Xz = X + ((i + 2) % 3) * Gp;
+        const float *EPu = EP + (DIR == 0 ? (i & 1) : ((i + 1) & 1)) * Vp;   // e'_t (fwd) / e'_{t-1} (bwd)
+        const int tpre = DIR == 0 ? t + 1 : t - 2;                   // emission row to prefetch
+        const bool pre = DIR == 0 ? (t + 1 < lx) : (t >= 2);
+        float epn[kEpRegsR];
+        if (pre) {
+            const float *er = p.ep + (bt0 + tpre) * V;
 #pragma unroll
-                for (int i = 0; i < kEpRegsR; ++i) { const int v = tid + i * kResThreads; epn[i] = v < V ? er[v] : 0.f; }
-            }
-            float m = 0.f;
-            for (int s = tid; s < G; s += kResThreads) m = fmaxf(m, Xc[s]);
-            m = wave_max(m);
-            if (lane == 0) wm[(t & 1) * kResWaves + wave] = m;
-            sync_lds();
-            const int ksc = rescale_exp(res_frame_max(wm + (t & 1) * kResWaves));
-            const float sc = pow2f(ksc);
-            E += ksc;
+            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; epn[q] = v < V ? er[v] : 0.f; }
+        }
+        const float *wc = wm + (i & 1) * 2 * kResWaves;
+        float m = res_frame_max(wc);
+        if (has_nx) m = fmaxf(m, res_frame_max(wc + kResWaves));
+        const int ksc = rescale_exp(m);
+        const float sc = pow2f(ksc);
+        float *Orow;
+        if (DIR == 0) {
+            E += ksc;                         // exponent of q_t
             if (tid == 0 && k == 0) p.EQ[bt0 + t] = E;
-            E += kEpExp;
-            for (int s = tid; s < Gp; s += kResThreads) Xz[s] = 0.f;
-            float *Qrow = p.Q + (bt0 + t) * p.Rq;
-            const char *xb = (const char *)Xc;
-            float acc = 0.f;
-            int rid = row0 + lane;
+            E += kEpExp;                      // a_{t+1} = sum e'_t q_t carries the 2^kEpExp of e'_t
+            Orow = p.Q + (bt0 + t) * p.Rq;
+        } else {
+            E += ksc + kEpExp;                // z_t = e'_t b_{t+1} carries the 2^kEpExp of e'_t
+            if (t > 0 && tid == 0 && k == 0) p.EB[bt0 + t - 1] = E;
+            Orow = p.BP + (bt0 + (t > 0 ? t - 1 : 0)) * p.Rb;
+        }
+        for (int s = tid; s < Gp; s += kResThreads) Xz[s] = 0.f;
+        gu64 *slot = xch + (size_t)((i + 1) & 1) * G;
+        const unsigned tag = (unsigned)(i + 1);
+        const bool xchg = K > 1 && produce;
+        const char *xb = (const char *)Xc;
+        float acc = 0.f, mymax = 0.f;
+        int rid = row0 + lane;
 #pragma unroll
-            for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
-                if (c0 < nch) {
-                    float part[kResBatch];
-                    CRF_RES_BATCH(part, A, xb, c0);
+        for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
+            if (c0 < nch) {
+                float part[kResBatch];
+                CRF_RES_BATCH(part, A, xb, c0);
 #pragma unroll
-                    for (int ci = 0; ci < kResBatch; ++ci) {
-                        acc += part[ci];
-                        if (ends >> (c0 + ci) & 1u) {
-                            const float q = acc * sc;
-                            Qrow[rid] = q;
-                            const int4 mt = RM[rid - cu_row0];
-                            if (mt.x >= 0) {  // sole contributor: plain store (LDS float atomics are lane-serial)
-                                const float av = EPc[mt.y] * q;
-                                if (mt.z) Xn[mt.x] = av; else atomicAdd(&Xn[mt.x], av);
+                for (int ci = 0; ci < kResBatch; ++ci) {
+                    acc += part[ci];
+                    if (ends >> (c0 + ci) & 1u) {
+                        const float rv = acc * sc;   // q_t[row] (fwd) / (partial) b_t[state] (bwd)
+                        const int4 mt = RM[rid - cu_row0];
+                        if (DIR == 0) {
+                            Orow[rid] = rv;
+                            if (mt.x >= 0) {
+                                const float av = EPu[mt.y] * rv;
+                                if (mt.z) {  // sole contributor: final now (LDS float atomics are lane-serial)
+                                    Xn[mt.x] = av;
+                                    mymax = fmaxf(mymax, av);
+                                    if (xchg) res_publish(slot, mt.x, tag, av);
+                                } else {
+                                    atomicAdd(&Xn[mt.x], av);
+                                }
                             }
-                            acc = 0.f;
-                            rid += kWave;
+                        } else if (t == 0) {
+                            if (mt.x >= 0) zpart += R.brow_start[rid] * rv;
+                        } else {
+                            Orow[rid] = rv;
+                            if (mt.x == 1) {
+                                const float zv = EPu[mt.z & 0xffff] * rv;
+                                if (mt.z >> 16) {
+                                    Xn[mt.y] = zv;
+                                    mymax = fmaxf(mymax, zv);
+                                    if (xchg) res_publish(slot, mt.y, tag, zv);
+                                } else {
+                                    atomicAdd(&Xn[mt.y], zv);
+                                }
+                            } else if (mt.x > 1) {
+                                const bool ex = (mt.z >> 16) != 0;
+                                for (int q = 0; q < mt.x; ++q) {
+                                    const int2 zl = R.bcsr[mt.w + q];
+                                    const float zv = EPu[zl.y] * rv;
+                                    if (ex) { Xn[zl.x] = zv; mymax = fmaxf(mymax, zv); if (xchg) res_publish(slot, zl.x, tag, zv); }
+                                    else atomicAdd(&Xn[zl.x], zv);
+                                }
+                            }
                         }
+                        acc = 0.f;
+                        rid += kWave;
                     }
                 }
             }
-            if (t + 1 < lx) {
-                float *EPn = EP + ((t + 1) & 1) * Vp;
-#pragma unroll
-                for (int i = 0; i < kEpRegsR; ++i) { const int v = tid + i * kResThreads; if (v < V) EPn[v] = epn[i]; }
-            }
-            sync_lds();
-            if (K > 1) {
-                res_exchange(xch + (size_t)((t + 1) & 1) * G, Xn, G, own_lo, own_hi, (unsigned)(t + 1), p.err, tid);
-                sync_lds();
+        }
+        if (xchg) {  // exclusive entries of the peers (published from their epilogues)
+            for (int j = 1; j < K; ++j) {
+                const int pj = (k + j) % K, lo = L.own_off[pj];
+                mymax = fmaxf(mymax, res_fetch(slot, Xn, lo, lo + L.ex_cnt[pj], tag, p.err, tid));
             }
         }
+        mymax = wave_max(mymax);
+        float *wn = wm + ((i + 1) & 1) * 2 * kResWaves;
+        if (lane == 0) wn[wave] = mymax;
+        if (pre) {
+            float *EPw = EP + (DIR == 0 ? ((i + 1) & 1) : (i & 1)) * Vp;
+#pragma unroll
+            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; if (v < V) EPw[v] = epn[q]; }
+        }
+        sync_lds();
+        if (has_nx && produce) {  // entries summed by atomics: final only now
+            float mx2 = 0.f;
+            const int lo = L.own_off[k] + L.ex_cnt[k], hi = lo + L.ex_cnt[K + k];
+            for (int e = lo + tid; e < hi; e += kResThreads) {
+                const float v = Xn[e];
+                mx2 = fmaxf(mx2, v);
+                if (xchg) res_publish(slot, e, tag, v);
+            }
+            if (xchg)
+                for (int j = 1; j < K; ++j) {
+                    const int pj = (k + j) % K;
+                    const int plo = L.own_off[pj] + L.ex_cnt[pj];
+                    mx2 = fmaxf(mx2, res_fetch(slot, Xn, plo, plo + L.ex_cnt[K + pj], tag, p.err, tid));
+                }
+            mx2 = wave_max(mx2);
+            if (lane == 0) wn[kResWaves + wave] = mx2;
+            sync_lds();
+        }
+    }
+
+    if (DIR == 0) {
         if (k == 0) {
             const float *Xf = X + (lx % 3) * Gp;
             float part = 0.f;
@@ -863,94 +953,11 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
             if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); }
         }
     } else {
-        // ================= backward =================
-        int F = kScaleExp;
-        float zpart = 0.f;
-        for (int r = tid; r < 3 * Gp; r += kResThreads) X[r] = 0.f;
-        if (lx > 0) {
-            for (int v = tid; v < V; v += kResThreads) {
-                EP[v] = p.ep[(bt0 + lx - 1) * V + v];
-                if (lx > 1) EP[Vp + v] = p.ep[(bt0 + lx - 2) * V + v];
-            }
-            __syncthreads();
-            for (int z = tid; z < G; z += kResThreads) X[z] = EP[R.z_lab[z]] * (R.z_end[z] * pow2f(kScaleExp));
-            float *BProw = p.BP + (bt0 + lx - 1) * p.Rb;
-            for (int r = tid; r < cu_rows; r += kResThreads) BProw[cu_row0 + r] = R.brow_end[cu_row0 + r] * pow2f(kScaleExp);
-            if (tid == 0 && k == 0) p.EB[bt0 + lx - 1] = F;
-        } else {
-            for (int r = tid; r < cu_rows; r += kResThreads) zpart += R.brow_start[cu_row0 + r] * R.brow_end[cu_row0 + r] * pow2f(kScaleExp);
-        }
-        __syncthreads();
-        for (int i = 0; i < lx; ++i) {
-            const int t = lx - 1 - i;
-            const float *Zc = X + (i % 3) * Gp;
-            float *Zn = X + ((i + 1) % 3) * Gp, *Zz = X + ((i + 2) % 3) * Gp;
-            const float *EPn = EP + ((i + 1) & 1) * Vp;  // e'_{t-1}
-            float epn[kEpRegsR];
-            if (t >= 2) {
-                const float *er = p.ep + (bt0 + t - 2) * V;
-#pragma unroll
-                for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; epn[q] = v < V ? er[v] : 0.f; }
-            }
-            for (int z = tid; z < Gp; z += kResThreads) Zz[z] = 0.f;
-            float m = 0.f;
-            for (int z = tid; z < G; z += kResThreads) m = fmaxf(m, Zc[z]);
-            m = wave_max(m);
-            if (lane == 0) wm[(i & 1) * kResWaves + wave] = m;
-            sync_lds();
-            const int ksc = rescale_exp(res_frame_max(wm + (i & 1) * kResWaves));
-            const float sc = pow2f(ksc);
-            F += ksc + kEpExp;
-            if (t > 0 && tid == 0 && k == 0) p.EB[bt0 + t - 1] = F;
-            float *BProw = p.BP + (bt0 + (t > 0 ? t - 1 : 0)) * p.Rb;
-            const char *xb = (const char *)Zc;
-            float acc = 0.f;
-            int rid = row0 + lane;
-#pragma unroll
-            for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
-                if (c0 < nch) {
-                    float part[kResBatch];
-                    CRF_RES_BATCH(part, A, xb, c0);
-#pragma unroll
-                    for (int ci = 0; ci < kResBatch; ++ci) {
-                        acc += part[ci];
-                        if (ends >> (c0 + ci) & 1u) {
-                            const float bv = acc * sc;
-                            const int4 mt = RM[rid - cu_row0];
-                            if (t == 0) {
-                                if (mt.x >= 0) zpart += R.brow_start[rid] * bv;
-                            } else {
-                                BProw[rid] = bv;
-                                // a state's sub-rows add their partial b into z_{t-1} (LDS float atomics)
-                                if (mt.x == 1) {
-                                    const float zv = EPn[mt.z & 0xffff] * bv;
-                                    if (mt.z >> 16) Zn[mt.y] = zv; else atomicAdd(&Zn[mt.y], zv);
-                                } else if (mt.x > 1) {
-                                    for (int q = 0; q < mt.x; ++q) { const int2 zl = R.bcsr[mt.w + q]; atomicAdd(&Zn[zl.x], EPn[zl.y] * bv); }
-                                }
-                            }
-                            acc = 0.f;
-                            rid += kWave;
-                        }
-                    }
-                }
-            }
-            if (t >= 2) {
-                float *EPw = EP + (i & 1) * Vp;
-#pragma unroll
-                for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; if (v < V) EPw[v] = epn[q]; }
-            }
-            sync_lds();
-            if (K > 1 && t > 0) {
-                res_exchange(xch + (size_t)((i + 1) & 1) * G, Zn, G, own_lo, own_hi, (unsigned)(i + 1), p.err, tid);
-                sync_lds();
-            }
-        }
         const float zb = res_block_sum(zpart, (float *)red, tid);
         if (tid == 0) p.cb_part[(size_t)b * kResMaxK + k] = zb;
         if (k == 0) {
             const double mxs = res_mx_total(p, b, lx, red, tid);
-            if (tid == 0) { p.cb_F[b] = F; p.cb_mxs[b] = mxs; }
+            if (tid == 0) { p.cb_F[b] = E; p.cb_mxs[b] = mxs; }
         }
     }
 }
@@ -977,7 +984,8 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.y, V = p.V, Vp = rup64(V);
     const int lx = p.lx[b];
-    const bool do_den = p.c_den != 0.f, do_ctc = p.c_ctc != 0.f;
+    const bool do_den = p.c_den != 0.f && p.grad_phase != 2, do_ctc = p.c_ctc != 0.f && p.grad_phase != 1;
+    const bool accumulate = p.grad_phase == 2;
     const int Rq = do_den ? p.Rq : 0, Rb = do_den ? p.Rb : 0, NC = do_den ? p.gNC : 0;
     float *Qs = lds;               // [Rq] staged q_t row
     float *Bs = Qs + rup64(Rq);    // [Rb] staged b_{t+1} row
@@ -998,7 +1006,8 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
     for (int t = t0; t < t0 + kGradFrames && t < p.T; ++t) {
         float *row = p.grad + (bt0 + t) * V;
         if (t >= lx) {
-            for (int v = tid; v < V; v += kGradThreads) row[v] = 0.f;
+            if (!accumulate)
+                for (int v = tid; v < V; v += kGradThreads) row[v] = 0.f;
             continue;
         }
         if (do_den) {
@@ -1039,7 +1048,7 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
         }
         __syncthreads();
         for (int v = tid; v < V; v += kGradThreads) {
-            float o = 0.f;
+            float o = accumulate ? row[v] : 0.f;
             if (do_den) o = p.c_den * gd[v];
             if (do_ctc) o -= p.c_ctc * gc[v];
             row[v] = o;
@@ -1120,7 +1129,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
 
 static size_t res_lds_bytes(const HostGraph *h, int V, int dir, int rows_cu_max) {
     const int G = dir == 0 ? h->dev.res.f.G : h->dev.res.b.G;
-    return ((size_t)3 * rup64(G) + (size_t)rows_cu_max * 4 + 2 * (size_t)rup64(V) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
+    return ((size_t)3 * rup64(G) + (size_t)rows_cu_max * 4 + 2 * (size_t)rup64(V) + 4 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
 }
 
 static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role) {
@@ -1352,32 +1361,51 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if ((rc = launch_chain<0>(p, chain_lds_bytes(h, (int)V, Sc, 0), stream))) return rc;
         if ((rc = launch_chain<1>(p, chain_lds_bytes(h, (int)V, Sc, 1), side(0)))) return rc;
     }
-    if (ctc) {
-        // The resident den kernels with K > 1 own every CU (one workgroup per CU, peers spin on each
-        // other), so the numerator recursions are queued BEHIND them on the same two streams instead of
-        // competing for CUs; otherwise all four recursions run side by side.
-        static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
-        const bool ctc_after = ctc_after_env >= 0 ? ctc_after_env != 0 : (res && h->dev.res.K > 1);
-        if (ctc_after) {
-            if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), stream))) return rc;
-            if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(0)))) return rc;
-        } else {
+    // Resident den kernels with K > 1 own every CU (one workgroup per CU, peers spin on each other), so the
+    // numerator recursions cannot run beside them.  They run beside the DEN HALF of the grad pass instead
+    // (HBM-bound, small workgroups that share CUs happily); a second, cheap grad pass then subtracts
+    // the numerator posteriors.  Otherwise all four recursions run side by side and grad is one pass.
+    static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
+    const bool split = ctc && den && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && h->dev.res.K > 1)) && !serial;
+    auto join_all = [&]() -> int {
+        for (int i = 0; i < 3; ++i)
+            if (used[i]) {
+                if ((e = hipEventRecord(cx->join[i], cx->side[i])) != hipSuccess ||
+                    (e = hipStreamWaitEvent(stream, cx->join[i], 0)) != hipSuccess) {
+                    set_error(std::string("join: ") + hipGetErrorString(e));
+                    return CRF_ERR_HIP;
+                }
+                used[i] = false;
+            }
+        return CRF_OK;
+    };
+    const dim3 ggrid((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B);
+    if (!split) {
+        if (ctc) {
             if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream))) return rc;
             if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2)))) return rc;
         }
+        if ((rc = join_all())) return rc;
+        prof_mark(5, false, stream);
+        p.grad_phase = 0;
+        hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+        prof_mark(5, true, stream);
+        LAUNCH_CHECK("crf_grad_kernel");
+    } else {
+        if ((rc = join_all())) return rc;  // den complete
+        if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess) { set_error("hipEventRecord(fork2)"); return CRF_ERR_HIP; }
+        if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(1)))) return rc;
+        if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2)))) return rc;
+        prof_mark(5, false, stream);
+        p.grad_phase = 1;
+        hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+        LAUNCH_CHECK("crf_grad_kernel(den)");
+        if ((rc = join_all())) return rc;
+        p.grad_phase = 2;
+        hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+        prof_mark(5, true, stream);
+        LAUNCH_CHECK("crf_grad_kernel(ctc)");
     }
-    for (int i = 0; i < 3; ++i)
-        if (used[i]) {
-            if ((e = hipEventRecord(cx->join[i], cx->side[i])) != hipSuccess ||
-                (e = hipStreamWaitEvent(stream, cx->join[i], 0)) != hipSuccess) {
-                set_error(std::string("join: ") + hipGetErrorString(e));
-                return CRF_ERR_HIP;
-            }
-        }
-    prof_mark(5, false, stream);
-    hipLaunchKernelGGL(crf_grad_kernel, dim3((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B), dim3(kGradThreads), lds_grad, stream, p);
-    prof_mark(5, true, stream);
-    LAUNCH_CHECK("crf_grad_kernel");
     prof_mark(6, false, stream);
     hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
     prof_mark(6, true, stream);

@@ -30,14 +30,15 @@ struct DirOut {
 
 inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / kResW)); }
 
-// rows[r] = arcs (gather index already renumbered, weight); row_cu[r] = owning CU.
-bool layout_dir(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o) {
-    const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
+// Step 1: decide where every row lives (CU, wave, slice, lane) from the row LENGTHS only.
+struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; };
+bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices) {
     o->arcs.assign((size_t)K * kResWords * kResThreads, 0u);
     o->wave_info.assign((size_t)K * kResWaves, uint4{0u, 0u, 0u, 0u});
     o->rid_of_row.assign(rows.size(), -1);
     o->row_of.clear();
     o->cu_row_off.assign((size_t)K + 1, 0);
+    slices->clear();
     for (int k = 0; k < K; ++k) {
         std::vector<int> mine;
         for (size_t r = 0; r < rows.size(); ++r) if (row_cu[r] == k) mine.push_back((int)r);
@@ -72,63 +73,16 @@ bool layout_dir(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
             const int wave_row0 = rid;
             for (int j : lists[w]) {
                 ends |= 1u << (c0 + len[j] - 1);
-                // remaining arcs per lane
-                std::vector<std::vector<std::pair<int, float>>> rem(kWave);
+                SliceAt sl{k, w, c0, len[j], rid, {}};
                 for (int lane = 0; lane < kWave; ++lane) {
                     const size_t pos = (size_t)j * kWave + lane;
-                    int r = pos < mine.size() ? mine[pos] : -1;
+                    const int r = pos < mine.size() ? mine[pos] : -1;
+                    sl.rows.push_back(r);
                     o->row_of.push_back(r);
-                    if (r >= 0) { o->rid_of_row[r] = rid + lane; rem[lane] = rows[r]; }
+                    if (r >= 0) o->rid_of_row[r] = rid + lane;
                 }
+                slices->push_back(sl);
                 rid += kWave;
-                for (int ins = 0; ins < len[j] * kResW; ++ins) {
-                    const int c = c0 + ins / kResW, slot = ins % kResW;
-                    int off16[kWave];
-                    float wv[kWave];
-                    bool real[kWave];
-                    for (int half = 0; half < 2; ++half) {
-                        int used[32], occupant[32];
-                        for (int b = 0; b < 32; ++b) { used[b] = 0; occupant[b] = -1; }
-                        int lanes[32];
-                        for (int l = 0; l < 32; ++l) lanes[l] = half * 32 + l;
-                        std::stable_sort(lanes, lanes + 32, [&](int a, int b) { return rem[a].size() < rem[b].size(); });
-                        int first_real = -1;
-                        for (int li = 0; li < 32; ++li) {
-                            const int lane = lanes[li];
-                            auto &rv = rem[lane];
-                            real[lane] = false; off16[lane] = 0; wv[lane] = 0.f;
-                            if (rv.empty()) continue;
-                            size_t best = 0;
-                            int best_cost = 1 << 30;
-                            for (size_t q = 0; q < (arrange ? rv.size() : (size_t)1); ++q) {
-                                const int bank = rv[q].first & 31;
-                                const int cost = occupant[bank] == rv[q].first ? 0 : used[bank];
-                                if (cost < best_cost) { best_cost = cost; best = q; if (!cost) break; }
-                            }
-                            const auto arc = rv[best];
-                            rv.erase(rv.begin() + (long)best);
-                            const int bank = arc.first & 31;
-                            if (occupant[bank] != arc.first) { used[bank]++; if (occupant[bank] < 0) occupant[bank] = arc.first; }
-                            if (best_cost > 0) o->conflicts++;
-                            real[lane] = true; off16[lane] = arc.first * 4; wv[lane] = arc.second;
-                            if (first_real < 0) first_real = lane;
-                        }
-                        // padding gathers broadcast the address of a real lane of the same half
-                        for (int l = 0; l < 32; ++l) {
-                            const int lane = half * 32 + l;
-                            if (!real[lane]) off16[lane] = first_real >= 0 ? off16[first_real] : 0;
-                        }
-                    }
-                    for (int lane = 0; lane < kWave; ++lane) {
-                        const size_t t = (size_t)w * kWave + lane;
-                        unsigned &iw = o->arcs[((size_t)k * kResWords + (size_t)c * 6 + (slot >> 1)) * kResThreads + t];
-                        iw |= (unsigned)(off16[lane] & 0xffff) << ((slot & 1) * 16);
-                        unsigned wb;
-                        memcpy(&wb, &wv[lane], 4);
-                        o->arcs[((size_t)k * kResWords + (size_t)c * 6 + 2 + slot) * kResThreads + t] = wb;
-                    }
-                    o->slots += kWave;
-                }
                 c0 += len[j];
             }
             o->wave_info[(size_t)k * kResWaves + w] = uint4{ends, (unsigned)c0, (unsigned)wave_row0, 0u};
@@ -136,6 +90,66 @@ bool layout_dir(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         o->cu_row_off[(size_t)k + 1] = rid;
     }
     return true;
+}
+
+// Step 2: put the arcs (gather indices already renumbered) into the (chunk, slot) positions of their
+// slice.  One position = ONE ds_read_b32 gather per wave, serviced in two 32-lane halves over 32 banks
+// (bank = index mod 32): the order of a row's arcs is free, so each position is filled greedily -- lanes
+// with the fewest arcs left choose first, each takes the arc whose bank is least used in its half
+// (equal index = broadcast, free).  Padding gathers broadcast the address of a real lane.
+void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o) {
+    const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
+    for (const SliceAt &sl : slices) {
+        std::vector<std::vector<std::pair<int, float>>> rem(kWave);
+        for (int lane = 0; lane < kWave; ++lane) if (sl.rows[lane] >= 0) rem[lane] = rows[sl.rows[lane]];
+        for (int ins = 0; ins < sl.len * kResW; ++ins) {
+            const int c = sl.c0 + ins / kResW, slot = ins % kResW;
+            int off16[kWave];
+            float wv[kWave];
+            bool real[kWave];
+            for (int half = 0; half < 2; ++half) {
+                int used[32], occupant[32];
+                for (int b = 0; b < 32; ++b) { used[b] = 0; occupant[b] = -1; }
+                int lanes[32];
+                for (int l = 0; l < 32; ++l) lanes[l] = half * 32 + l;
+                std::stable_sort(lanes, lanes + 32, [&](int a, int b) { return rem[a].size() < rem[b].size(); });
+                int first_real = -1;
+                for (int li = 0; li < 32; ++li) {
+                    const int lane = lanes[li];
+                    auto &rv = rem[lane];
+                    real[lane] = false; off16[lane] = 0; wv[lane] = 0.f;
+                    if (rv.empty()) continue;
+                    size_t best = 0;
+                    int best_cost = 1 << 30;
+                    for (size_t q = 0; q < (arrange ? rv.size() : (size_t)1); ++q) {
+                        const int bank = rv[q].first & 31;
+                        const int cost = occupant[bank] == rv[q].first ? 0 : used[bank];
+                        if (cost < best_cost) { best_cost = cost; best = q; if (!cost) break; }
+                    }
+                    const auto arc = rv[best];
+                    rv.erase(rv.begin() + (long)best);
+                    const int bank = arc.first & 31;
+                    if (occupant[bank] != arc.first) { used[bank]++; if (occupant[bank] < 0) occupant[bank] = arc.first; }
+                    if (best_cost > 0) o->conflicts++;
+                    real[lane] = true; off16[lane] = arc.first * 4; wv[lane] = arc.second;
+                    if (first_real < 0) first_real = lane;
+                }
+                for (int l = 0; l < 32; ++l) {
+                    const int lane = half * 32 + l;
+                    if (!real[lane]) off16[lane] = first_real >= 0 ? off16[first_real] : 0;
+                }
+            }
+            for (int lane = 0; lane < kWave; ++lane) {
+                const size_t t = (size_t)sl.w * kWave + lane;
+                unsigned &iw = o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + (slot >> 1)) * kResThreads + t];
+                iw |= (unsigned)(off16[lane] & 0xffff) << ((slot & 1) * 16);
+                unsigned wb;
+                memcpy(&wb, &wv[lane], 4);
+                o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + 2 + slot) * kResThreads + t] = wb;
+            }
+            o->slots += kWave;
+        }
+    }
 }
 
 // balance states over K CUs by the chunk load of the rows keyed by each state
@@ -177,7 +191,6 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     ResDev &R = h->dev.res;
     R = ResDev{};
     if (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT"))) return CRF_OK;
-    if (S > 16383 || P > 16383) return CRF_OK;  // 16-bit LDS byte offsets
     // Rows may be SPLIT into sub-rows (pieces of <= thr arcs, thr a multiple of the chunk width).
     // Forward: a pair with many in-arcs becomes several sub-rows with the same (dst, label); everything
     // downstream is linear in q (a_{t+1}[dst] += e'*q, gamma = sum q*b), so sub-rows are simply separate
@@ -186,7 +199,13 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     // Splitting evens out row lengths: less slice padding and a tight fit into the per-wave register budget.
     const int max_lab = *std::max_element(pair_lab.begin(), pair_lab.end());
     static const int kSplit[] = {1 << 30, 96, 64, 48, 32, 16, 8};
-    struct Dir { DirOut o; std::vector<int> sub_of; std::vector<int> owner; bool ok = false; };
+    struct Dir {
+        DirOut o;
+        std::vector<int> sub_of, sub_j, owner, ex_cnt;  // sub-row -> input row / index among its key's sub-rows
+        std::vector<int> gbase, gmap;                   // gather entry g, copy i -> new index gmap[gbase[g] + i]
+        int G = 0, has_nx = 0;
+        bool ok = false;
+    };
     auto try_dir = [&](const Rows &rows, const std::vector<int> &key, int K, std::vector<int> *gmap_out,
                        const std::vector<int> &gkey, std::vector<int> *goff) -> Dir {
         // gkey[g] = state whose owner produces gather-vector entry g; gmap_out = renumbering of g
@@ -214,33 +233,75 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                     subkey.push_back(key[r]);
                 }
             }
+            // A key (state) with n > 1 sub-rows gets n VIRTUAL copies of every gather entry it produces:
+            // sub-row i writes copy i, and every arc that reads the entry is replicated to read all n copies.
+            // Each entry then has exactly one producing row -- no LDS atomics (they are lane-serial, ~2.5 clk
+            // per lane) and every value is final, publishable and usable for the frame maximum in its row's
+            // epilogue.  Splits are rare (long-tail rows), so the replicated arcs are few.
+            std::vector<int> nsub(S, 0);
+            d.sub_j.resize(sub.size());
+            for (size_t r = 0; r < sub.size(); ++r) d.sub_j[r] = nsub[subkey[r]]++;
+            d.gbase.assign(gkey.size() + 1, 0);
+            for (size_t g = 0; g < gkey.size(); ++g) d.gbase[g + 1] = d.gbase[g] + std::max(1, nsub[gkey[g]]);
+            d.G = d.gbase[gkey.size()];
+            if (d.G > 16383) continue;  // 16-bit LDS byte offsets
+            for (auto &row : sub) {
+                std::vector<std::pair<int, float>> ex;
+                for (auto &a : row)
+                    for (int i = d.gbase[a.first]; i < d.gbase[a.first + 1]; ++i) ex.push_back({i, a.second});
+                row.swap(ex);
+            }
             std::vector<int64_t> load(S, 0);
             for (size_t r = 0; r < sub.size(); ++r) load[subkey[r]] += chunks_of(sub[r].size());
             d.owner = assign_owner(S, K, load);
-            std::vector<int> gmap(gkey.size()), off(K + 1, 0);
-            for (int k = 0, n = 0; k < K; ++k) {
-                for (size_t g = 0; g < gkey.size(); ++g) if (d.owner[gkey[g]] == k) gmap[g] = n++;
-                off[k + 1] = n;
-            }
             std::vector<int> cu(sub.size());
-            for (size_t r = 0; r < sub.size(); ++r) {
-                cu[r] = d.owner[subkey[r]];
-                for (auto &a : sub[r]) a.first = gmap[a.first];
-            }
-            if (!layout_dir(sub, cu, K, &d.o)) {
-                if (attempt == 0) {  // mark the rows of each CU's ragged last slice for attempt 1
+            for (size_t r = 0; r < sub.size(); ++r) cu[r] = d.owner[subkey[r]];
+            std::vector<SliceAt> slices;
+            if (!place_rows(sub, cu, K, &d.o, &slices)) {
+                if (attempt == 0) {
+                    // For attempt 1: every CU has (rows mod 64) rows too many for full slices.  Split THOSE
+                    // finely so they fill leftover register space instead of claiming a slice of their own --
+                    // choosing the rows whose entries are read by the fewest arcs (ideally none, e.g. the
+                    // start state), because a split key's readers are replicated.
+                    std::vector<int64_t> refs(S, 0);
+                    for (const auto &row : rows)
+                        for (const auto &a : row) refs[gkey[a.first]]++;
                     for (int k = 0; k < K; ++k) {
                         std::vector<int> mine;
                         for (size_t r = 0; r < sub.size(); ++r) if (cu[r] == k) mine.push_back((int)r);
-                        std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return sub[a].size() > sub[b].size(); });
-                        for (size_t i = mine.size() / kWave * kWave; i < mine.size(); ++i) ragged[d.sub_of[mine[i]]] = 1;
+                        std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return refs[subkey[a]] < refs[subkey[b]]; });
+                        for (size_t i = 0; i < mine.size() % kWave; ++i) ragged[d.sub_of[mine[i]]] = 1;
                     }
                 }
                 continue;
             }
-            d.ok = true;
-            *gmap_out = gmap;
+            // Numbering of the (virtual) gather entries, CU by CU: first the produced entries IN THE ORDER
+            // OF THEIR PRODUCING ROW's id -- a slice's 64 epilogues then publish 64 consecutive granules (one
+            // coalesced 512-byte store) and write 64 consecutive LDS words; last the entries nobody produces
+            // (e.g. the start state: no in-arcs), which stay 0 after the first frame and are never exchanged.
+            std::vector<std::vector<int>> entries_of_key(S);
+            for (size_t g = 0; g < gkey.size(); ++g) entries_of_key[gkey[g]].push_back((int)g);
+            d.gmap.assign(d.G, -1);
+            std::vector<int> off(K + 1, 0);
+            d.ex_cnt.assign(2 * K, 0);  // [k] produced entries, [K + k] unused (no shared entries any more)
+            for (int k = 0, n = 0; k < K; ++k) {
+                const int before = n;
+                for (int rid = d.o.cu_row_off[k]; rid < d.o.cu_row_off[k + 1]; ++rid) {
+                    const int r = d.o.row_of[rid];
+                    if (r < 0) continue;
+                    for (int g : entries_of_key[subkey[r]]) d.gmap[d.gbase[g] + d.sub_j[r]] = n++;
+                }
+                d.ex_cnt[k] = n - before;
+                for (size_t g = 0; g < gkey.size(); ++g)
+                    if (d.owner[gkey[g]] == k && nsub[gkey[g]] == 0) d.gmap[d.gbase[g]] = n++;
+                off[k + 1] = n;
+            }
+            for (auto &row : sub)
+                for (auto &a : row) a.first = d.gmap[a.first];
+            pack_arcs(sub, slices, &d.o);
             *goff = off;
+            d.ok = true;
+            (void)gmap_out;
             return d;
         }
         return best;
@@ -266,12 +327,13 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         // ---- row metadata and side tables
         const int Rf = fo.cu_row_off[K], Rb = bo.cu_row_off[K];
         std::vector<int4> fmeta(Rf, int4{-1, 0, 0, 0}), bmeta(Rb, int4{-1, 0, 0, 0});
-        std::vector<int> contrib(S, 0);  // forward (sub-)rows per destination state
-        for (int r = 0; r < NRf; ++r) contrib[pair_dst[pair_of_sub(r)]]++;
+        auto xof = [&](int s, int j) { return F.gmap[F.gbase[s] + j]; };   // forward x entry of (state, copy)
+        auto zof = [&](int p, int j) { return Bk.gmap[Bk.gbase[p] + j]; };  // backward z entry of (pair, copy)
+        const int Gf = F.G, Gb = Bk.G;
         for (int r = 0; r < Rf; ++r)
-            if (fo.row_of[r] >= 0) {  // .z = 1: sole contributor to its destination -> plain LDS store
-                const int p = pair_of_sub(fo.row_of[r]);
-                fmeta[r] = int4{xid[pair_dst[p]], pair_lab[p], contrib[pair_dst[p]] == 1 ? 1 : 0, 0};
+            if (fo.row_of[r] >= 0) {  // every (virtual) entry has exactly one producing row: .z = 1, plain store
+                const int sr = fo.row_of[r], p = pair_of_sub(sr);
+                fmeta[r] = int4{xof(pair_dst[p], F.sub_j[sr]), pair_lab[p], 1, 0};
             }
         std::vector<std::vector<int>> pairs_into(S), bsubs_of(S);
         for (int p = 0; p < P; ++p) pairs_into[pair_dst[p]].push_back(p);
@@ -281,20 +343,28 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         for (int r = 0; r < Rb; ++r) {
             const int sr = bo.row_of[r];
             if (sr < 0) continue;
-            const int s = Bk.sub_of[sr];
+            const int s = Bk.sub_of[sr], j = Bk.sub_j[sr];
             const auto &pl = pairs_into[s];
             int4 m{(int)pl.size(), 0, 0, (int)bcsr.size()};
-            // .z = label | (1 << 16) when this is the state's only sub-row (plain LDS store of z)
-            if (!pl.empty()) { m.y = zid[pl[0]]; m.z = pair_lab[pl[0]] | (bsubs_of[s].size() == 1 ? 1 << 16 : 0); }
-            if (pl.size() > 1) for (int p : pl) bcsr.push_back(int2{zid[p], pair_lab[p]});
+            // .z = label | (1 << 16): sub-row j writes copy j of every pair into the state (plain LDS store)
+            if (!pl.empty()) { m.y = zof(pl[0], j); m.z = pair_lab[pl[0]] | (1 << 16); }
+            if (pl.size() > 1) for (int p : pl) bcsr.push_back(int2{zof(p, j), pair_lab[p]});
             bmeta[r] = m;
             brow_start[r] = start_lin[s];
-            brow_end[r] = (bsubs_of[s][0] == sr) ? end_lin[s] : 0.f;  // b_T[s] = end weight, counted once
+            brow_end[r] = j == 0 ? end_lin[s] : 0.f;  // b_T[s] = end weight, counted once
         }
-        std::vector<float> x_start(S), x_end(S), z_end(P);
-        std::vector<int> z_lab(P);
-        for (int s = 0; s < S; ++s) { x_start[xid[s]] = start_lin[s]; x_end[xid[s]] = end_lin[s]; }
-        for (int p = 0; p < P; ++p) { z_lab[zid[p]] = pair_lab[p]; z_end[zid[p]] = end_lin[pair_dst[p]]; }
+        std::vector<float> x_start(Gf, 0.f), x_end(Gf, 0.f), z_end(Gb, 0.f);
+        std::vector<int> z_lab(Gb, 0);
+        for (int s = 0; s < S; ++s)
+            for (int j = 0; j < F.gbase[s + 1] - F.gbase[s]; ++j) {  // x_0 = start weight once, end weight on every copy
+                x_start[xof(s, j)] = j == 0 ? start_lin[s] : 0.f;
+                x_end[xof(s, j)] = end_lin[s];
+            }
+        for (int p = 0; p < P; ++p)
+            for (int j = 0; j < Bk.gbase[p + 1] - Bk.gbase[p]; ++j) {
+                z_lab[zof(p, j)] = pair_lab[p];
+                z_end[zof(p, j)] = j == 0 ? end_lin[pair_dst[p]] : 0.f;
+            }
         // grad pass list: every (forward sub-row, backward sub-row of its dst state), label-sorted, cut into
         // chunks of <= kChunk entries within one label
         std::vector<int> gq, gb, glabel, gchunk{0}, glab((size_t)max_lab + 2, 0);
@@ -315,7 +385,8 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             glab[(size_t)max_lab + 1] = (int)gchunk.size() - 1;
         }
         R.K = K;
-        R.f.R = Rf; R.f.G = S; R.b.R = Rb; R.b.G = P;
+        R.f.R = Rf; R.f.G = Gf; R.b.R = Rb; R.b.G = Gb;
+        R.f.has_nx = 0; R.b.has_nx = 0;
         R.NC = (int)gchunk.size() - 1;
         for (int k = 0; k < K; ++k) {
             h->res_rows_cu_f = std::max(h->res_rows_cu_f, fo.cu_row_off[k + 1] - fo.cu_row_off[k]);
@@ -327,7 +398,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         int rc;
         if ((rc = up(h, fo.arcs, &R.f.arcs)) || (rc = up(h, fo.wave_info, &R.f.wave_info)) ||
             (rc = up(h, fmeta, &R.f.row_meta)) || (rc = up(h, fo.cu_row_off, &R.f.cu_row_off)) ||
-            (rc = up(h, xoff, &R.f.own_off)) || (rc = up(h, bo.arcs, &R.b.arcs)) ||
+            (rc = up(h, xoff, &R.f.own_off)) || (rc = up(h, F.ex_cnt, &R.f.ex_cnt)) || (rc = up(h, Bk.ex_cnt, &R.b.ex_cnt)) || (rc = up(h, bo.arcs, &R.b.arcs)) ||
             (rc = up(h, bo.wave_info, &R.b.wave_info)) || (rc = up(h, bmeta, &R.b.row_meta)) ||
             (rc = up(h, bo.cu_row_off, &R.b.cu_row_off)) || (rc = up(h, zoff, &R.b.own_off)) ||
             (rc = up(h, x_start, &R.x_start)) || (rc = up(h, x_end, &R.x_end)) || (rc = up(h, z_lab, &R.z_lab)) ||
