@@ -28,6 +28,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/ctc_crf_hip.h"
 #include "crf_internal.h"
@@ -62,6 +63,7 @@ struct LossParams {
     double *cb_mxs;               // [B]
     int *cb_F;                    // [B]
     int *err;                     // [1] set if an exchange timed out
+    float *Row0;                  // [B][Rb] spare rows (b_0 of the resident backward recursion)
     int *EQ, *EB;                 // [B*T] their binary exponents
     double *CA, *CB;              // [B*T*Sc] ctc forward (incl. emission) / backward (excl.)  (scaled, fp64)
     int *ECA, *ECB;
@@ -75,10 +77,20 @@ struct LossParams {
     int *out_invalid;
 };
 
+// Wave-wide max without touching the LDS crossbar (a __shfl_xor butterfly is six dependent
+// ds_bpermute round trips, ~0.25 us on the per-frame critical path): rotate-and-max inside each row
+// of 16 lanes with DPP (row_ror 8/4/2/1), then combine the four rows through readlane + scalar max.
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+#define CRF_DPP_MAX(ctrl) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
+    CRF_DPP_MAX(0x128);
+    CRF_DPP_MAX(0x124);
+    CRF_DPP_MAX(0x122);
+    CRF_DPP_MAX(0x121);
+#undef CRF_DPP_MAX
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -91,10 +103,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Wave-wide max of NON-NEGATIVE doubles, exact in the top 32 bits (sign, exponent, 20 mantissa bits) --
+// all the rescaling needs is the binary exponent.  Positive doubles order like their high words as
+// integers, so this is an integer DPP max (no LDS round trips).
 __device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    int hi = (int)((unsigned long long)__double_as_longlong(v) >> 32);
+#define CRF_DPP_IMAX(ctrl) hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false))
+    CRF_DPP_IMAX(0x128);
+    CRF_DPP_IMAX(0x124);
+    CRF_DPP_IMAX(0x122);
+    CRF_DPP_IMAX(0x121);
+#undef CRF_DPP_IMAX
+    const int m = max(max(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(hi, 16)),
+                      max(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(hi, 48)));
+    return __longlong_as_double((long long)(unsigned)m << 32);
 }
 // fp64 twin of rescale_exp / pow2f for the numerator chains
 __device__ __forceinline__ int rescale_exp_d(double m) {
@@ -534,19 +556,31 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         if (tid == 0) p.ECA[bt0] = E;
     }
     __syncthreads();
+    // emissions are fetched one frame ahead (an L2 round trip is ~1 us, longer than a whole frame)
+    float lraw[kCtcRegs], mraw = 0.f;
+    if (lx > 1) {
+        const float *lr = p.logp + (bt0 + 1) * V;
+        mraw = p.mx[bt0 + 1];
+#pragma unroll
+        for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kChainThreads < Sx) ? lr[mylab[i]] : 0.f;
+    }
     for (int t = 1; t < lx; ++t) {
         const double *Ac = A + ((t - 1) & 1) * Sxp;
         double *An = A + (t & 1) * Sxp;
-        const float *lr = p.logp + (bt0 + t) * V;
-        const float mt = p.mx[bt0 + t];
         double em[kCtcRegs];
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) em[i] = (tid + i * kChainThreads < Sx) ? exp_scaled_d(lr[mylab[i]] - mt) : 0.0;
+        for (int i = 0; i < kCtcRegs; ++i) em[i] = (tid + i * kChainThreads < Sx) ? exp_scaled_d(lraw[i] - mraw) : 0.0;
+        if (t + 1 < lx) {
+            const float *lr = p.logp + (bt0 + t + 1) * V;
+            mraw = p.mx[bt0 + t + 1];
+#pragma unroll
+            for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kChainThreads < Sx) ? lr[mylab[i]] : 0.f;
+        }
         double m = 0.0;
         for (int s = tid; s < Sx; s += kChainThreads) m = fmax(m, Ac[s]);
         m = wave_max_d(m);
         if (lane == 0) wm[(t & 1) * kChainWaves + wave] = m;
-        __syncthreads();
+        sync_lds();
         const int k = rescale_exp_d(frame_max_d(wm + (t & 1) * kChainWaves));
         const double sc = pow2d(k);
         E += k;
@@ -564,7 +598,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
             }
         }
         if (tid == 0) p.ECA[bt0 + t] = E;
-        __syncthreads();
+        sync_lds();
     }
     const double *Af = A + ((lx - 1) & 1) * Sxp;
     const double mxs = mx_total(p, b, lx, c.red, tid);
@@ -615,20 +649,31 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         if (tid == 0) p.ECB[bt0 + lx - 1] = F;
     }
     __syncthreads();
+    float lraw[kCtcRegs], mraw = 0.f;
+    if (lx > 1) {
+        const float *lr = p.logp + (bt0 + lx - 2) * V;
+        mraw = p.mx[bt0 + lx - 2];
+#pragma unroll
+        for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kChainThreads < Sx) ? lr[mylab[q]] : 0.f;
+    }
     for (int i = 1; i < lx; ++i) {
         const int t = lx - 1 - i;
         const double *Yc = Y + ((i - 1) & 1) * Sxp;
         double *Yn = Y + (i & 1) * Sxp;
-        const float *lr = p.logp + (bt0 + t) * V;
-        const float mt = p.mx[bt0 + t];
         double em[kCtcRegs];
 #pragma unroll
-        for (int q = 0; q < kCtcRegs; ++q) em[q] = (tid + q * kChainThreads < Sx) ? exp_scaled_d(lr[mylab[q]] - mt) : 0.0;
+        for (int q = 0; q < kCtcRegs; ++q) em[q] = (tid + q * kChainThreads < Sx) ? exp_scaled_d(lraw[q] - mraw) : 0.0;
+        if (t >= 1) {
+            const float *lr = p.logp + (bt0 + t - 1) * V;
+            mraw = p.mx[bt0 + t - 1];
+#pragma unroll
+            for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kChainThreads < Sx) ? lr[mylab[q]] : 0.f;
+        }
         double m = 0.0;
         for (int s = tid; s < Sx; s += kChainThreads) m = fmax(m, Yc[s]);
         m = wave_max_d(m);
         if (lane == 0) wm[(i & 1) * kChainWaves + wave] = m;
-        __syncthreads();
+        sync_lds();
         const int k = rescale_exp_d(frame_max_d(wm + (i & 1) * kChainWaves));
         const double sc = pow2d(k);
         F += k;
@@ -646,7 +691,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
             }
         }
         if (tid == 0) p.ECB[bt0 + t] = F;
-        __syncthreads();
+        sync_lds();
     }
 }
 
@@ -657,25 +702,26 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
 // barrier -> (K > 1) all-gather of the new state vector through tagged 8-byte granules in L2.
 // =============================================================================================
 constexpr int kEpRegsR = 2;   // emission-row prefetch registers (V <= 2*512 for the resident kernels)
-constexpr int kPoll = 8;      // granules polled concurrently per thread
+constexpr int kPoll = 4;      // granules polled concurrently per thread
 
 __device__ __forceinline__ float res_block_sum(float v, float *red, int tid) {
     v = wave_sum(v);
-    __syncthreads();
+    sync_lds();
     if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
+    sync_lds();
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kResWaves; ++i) s += red[i];
     return s;
 }
-__device__ __forceinline__ double res_mx_total(const LossParams &p, int b, int lx, double *red, int tid) {
+template <typename P>
+__device__ __forceinline__ double res_mx_total(const P &p, int b, int lx, double *red, int tid) {
     double part = 0.0;
     for (int t = tid; t < lx; t += kResThreads) part += (double)p.mx[(int64_t)b * p.T + t];
     part = wave_sum_d(part);
-    __syncthreads();
+    sync_lds();
     if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
+    sync_lds();
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < kResWaves; ++i) s += red[i];
@@ -745,12 +791,43 @@ static_assert(kResNCH % kResBatch == 0, "kResNCH must be a multiple of kResBatch
                    fmaf(g2, __uint_as_float(A[6 * c + 4]), g3 * __uint_as_float(A[6 * c + 5]));           \
     }
 
+// Kernel arguments of the resident kernels: only what ONE direction needs (the full LossParams is ~90
+// SGPRs of pointers, most of which the compiler would keep live or spill around the unrolled frame body).
+struct ResParams {
+    ResDirDev L;
+    int K, B, T, V, b0, rows_cu_max, Rout, Gf;
+    const int *lx;
+    const float *ep, *mx;
+    float *Out;                 // Q (fwd) or BP (bwd) rows
+    float *Row0;                // [B][Rout] spare rows: b_0 of the backward recursion
+    int *Eout;                  // EQ (fwd) or EB (bwd)
+    unsigned long long *xch;
+    int *err;
+    // forward side tables / results
+    const float *x_start, *x_end;
+    float *den_zs, *cost_alpha;
+    int *den_ez;
+    // backward side tables / results
+    const int *z_lab;
+    const float *z_end, *brow_start, *brow_end;
+    const int2 *bcsr;
+    float *cb_part;
+    double *cb_mxs;
+    int *cb_F;
+};
+
+// LDS map of the resident kernels: the two state-vector buffers sit at FIXED byte offsets 0 and
+// kResXB so that, with the frame loop unrolled by two, every gather is `ds_read_b32 v, off16
+// offset:<buffer base>` -- the 16-bit offset extracted from the packed arc word is the whole address
+// computation (one VALU per arc besides the FMA).
+constexpr int kResXB = 32768;                 // bytes per state-vector buffer  -> gather vector <= 8192 entries
+constexpr int kResGmax = kResXB / 4;
+
 template <int DIR>
-__global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p) {
+__global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const ResDev &R = p.g.res;
-    const ResDirDev &L = DIR == 0 ? R.f : R.b;
-    const int K = R.K;
+    const ResDirDev &L = p.L;
+    const int K = p.K;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Peers of one recursion are placed 8 block ids apart: the dispatcher is observed to put block x on
@@ -763,14 +840,14 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
         else { const int y = x - full; k = y % K; b = p.b0 + full / K + y / K; }
     }
     const int V = p.V, lx = p.lx[b], G = L.G;
-    const int Gp = rup64(G), Vp = rup64(V);
+    const int Vp = rup64(V);
     const int64_t bt0 = (int64_t)b * p.T;
-    const int rows_cu_max = DIR == 0 ? p.res_lds_rows_f : p.res_lds_rows_b;
-    float *X = lds;                                  // [3][Gp]: gather source / next vector / being zeroed
-    int4 *RM = (int4 *)(X + 3 * Gp);                 // [rows_cu_max] row metadata of this CU
-    float *EP = (float *)(RM + rows_cu_max);         // [2][Vp]
-    float *wm = EP + 2 * Vp;                         // [2][2][kResWaves] per-wave maxima (exclusive / shared entries)
-    double *red = (double *)(wm + 4 * kResWaves);    // [kResWaves]
+    const int rows_cu_max = p.rows_cu_max;
+    float *X = lds;                                          // [2][kResGmax]: ping-pong state vectors
+    int4 *RM = (int4 *)((char *)lds + 2 * kResXB);           // [rows_cu_max] row metadata of this CU
+    float *EP = (float *)(RM + rows_cu_max);                 // [2][Vp]
+    float *wm = EP + 2 * Vp;                                 // [2][kResWaves] per-wave maxima of the next vector
+    double *red = (double *)(wm + 2 * kResWaves);            // [kResWaves]
 
     // ---- one-time: arcs -> registers, row metadata -> LDS
     unsigned A[kResWords];
@@ -784,18 +861,16 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
     const int nch = __builtin_amdgcn_readfirstlane(wi.y);
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
     const int cu_row0 = L.cu_row_off[k], cu_rows = L.cu_row_off[k + 1] - cu_row0;
-    // entries of the gather vector produced by CU j: [own_off[j], own_off[j+1]); the first ex_cnt[j] of
-    // them have a single contributing row ("exclusive": final in that row's epilogue), the rest are
-    // summed by LDS atomics and are final only after the frame barrier
-    const bool has_nx = L.has_nx != 0;
     for (int r = tid; r < cu_rows; r += kResThreads) RM[r] = L.row_meta[cu_row0 + r];
-    // forward slots first ([B][2][S]), backward slots ([B][2][P]) after them
-    gu64 *xch = (gu64 *)(p.xch + (DIR == 0 ? 0 : (size_t)p.B * 2 * (size_t)R.f.G) + (size_t)b * 2 * (size_t)G);
+    // forward slots first ([B][2][Gf]), backward slots ([B][2][Gb]) after them
+    gu64 *xch = (gu64 *)(p.xch + (DIR == 0 ? 0 : (size_t)p.B * 2 * (size_t)p.Gf) + (size_t)b * 2 * (size_t)G);
     int E = kScaleExp;
     float zpart = 0.f;
 
-    // ---- initial vector (complete on every CU, no exchange needed)
-    for (int s = tid; s < 3 * Gp; s += kResThreads) X[s] = 0.f;
+    // ---- initial vector (complete on every CU, no exchange needed).  Entries nobody produces stay 0 in
+    // both buffers for ever; every other entry is rewritten by its one producing row in every frame, so
+    // the buffers never need clearing.
+    for (int s = tid; s < 2 * kResGmax; s += kResThreads) X[s] = 0.f;
     if (lx > 0)
         for (int v = tid; v < V; v += kResThreads) {
             EP[v] = p.ep[(bt0 + (DIR == 0 ? 0 : lx - 1)) * V + v];
@@ -805,26 +880,27 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
     {
         float m0 = 0.f;
         if (DIR == 0) {
-            for (int s = tid; s < G; s += kResThreads) { const float v = R.x_start[s] * pow2f(kScaleExp); X[s] = v; m0 = fmaxf(m0, v); }
+            for (int s = tid; s < G; s += kResThreads) { const float v = p.x_start[s] * pow2f(kScaleExp); X[s] = v; m0 = fmaxf(m0, v); }
         } else if (lx > 0) {
-            for (int z = tid; z < G; z += kResThreads) { const float v = EP[R.z_lab[z]] * (R.z_end[z] * pow2f(kScaleExp)); X[z] = v; m0 = fmaxf(m0, v); }
-            float *BProw = p.BP + (bt0 + lx - 1) * p.Rb;
-            for (int r = tid; r < cu_rows; r += kResThreads) BProw[cu_row0 + r] = R.brow_end[cu_row0 + r] * pow2f(kScaleExp);
-            if (tid == 0 && k == 0) p.EB[bt0 + lx - 1] = E;
+            for (int z = tid; z < G; z += kResThreads) { const float v = EP[p.z_lab[z]] * (p.z_end[z] * pow2f(kScaleExp)); X[z] = v; m0 = fmaxf(m0, v); }
+            float *BProw = p.Out + (bt0 + lx - 1) * p.Rout;
+            for (int r = tid; r < cu_rows; r += kResThreads) BProw[cu_row0 + r] = p.brow_end[cu_row0 + r] * pow2f(kScaleExp);
+            if (tid == 0 && k == 0) p.Eout[bt0 + lx - 1] = E;
         } else {
-            for (int r = tid; r < cu_rows; r += kResThreads) zpart += R.brow_start[cu_row0 + r] * R.brow_end[cu_row0 + r] * pow2f(kScaleExp);
+            for (int r = tid; r < cu_rows; r += kResThreads) zpart += p.brow_start[cu_row0 + r] * p.brow_end[cu_row0 + r] * pow2f(kScaleExp);
         }
         m0 = wave_max(m0);
-        if (lane == 0) { wm[wave] = m0; wm[kResWaves + wave] = 0.f; }
+        if (lane == 0) wm[wave] = m0;
     }
     __syncthreads();
 
-    for (int i = 0; i < lx; ++i) {
+    // one frame; PAR = parity of i = which buffer is the gather source (compile-time -> immediate offsets)
+    auto frame = [&](auto PAR, int i) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value;
         const int t = DIR == 0 ? i : lx - 1 - i;                     // frame whose emissions are consumed
         const bool produce = DIR == 0 || t > 0;                      // a next vector exists
-        const float *Xc = X + (i % 3) * Gp;
-        float *Xn = X + ((i + 1) % 3) * Gp, *Xz = X + ((i + 2) % 3) * Gp;
-        const float *EPu = EP + (DIR == 0 ? (i & 1) : ((i + 1) & 1)) * Vp;   // e'_t (fwd) / e'_{t-1} (bwd)
+        float *Xn = X + (1 - par) * kResGmax;
+        const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
         const int tpre = DIR == 0 ? t + 1 : t - 2;                   // emission row to prefetch
         const bool pre = DIR == 0 ? (t + 1 < lx) : (t >= 2);
         float epn[kEpRegsR];
@@ -833,27 +909,24 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
 #pragma unroll
             for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; epn[q] = v < V ? er[v] : 0.f; }
         }
-        const float *wc = wm + (i & 1) * 2 * kResWaves;
-        float m = res_frame_max(wc);
-        if (has_nx) m = fmaxf(m, res_frame_max(wc + kResWaves));
-        const int ksc = rescale_exp(m);
+        const int ksc = rescale_exp(res_frame_max(wm + par * kResWaves));
         const float sc = pow2f(ksc);
         float *Orow;
         if (DIR == 0) {
             E += ksc;                         // exponent of q_t
-            if (tid == 0 && k == 0) p.EQ[bt0 + t] = E;
+            if (tid == 0 && k == 0) p.Eout[bt0 + t] = E;
             E += kEpExp;                      // a_{t+1} = sum e'_t q_t carries the 2^kEpExp of e'_t
-            Orow = p.Q + (bt0 + t) * p.Rq;
+            Orow = p.Out + (bt0 + t) * p.Rout;
         } else {
             E += ksc + kEpExp;                // z_t = e'_t b_{t+1} carries the 2^kEpExp of e'_t
-            if (t > 0 && tid == 0 && k == 0) p.EB[bt0 + t - 1] = E;
-            Orow = p.BP + (bt0 + (t > 0 ? t - 1 : 0)) * p.Rb;
+            if (t > 0 && tid == 0 && k == 0) p.Eout[bt0 + t - 1] = E;
+            // b_t rows feed the grad pass as BP[t-1]; the last one (t = 0) only feeds logZ and goes to a spare row
+            Orow = t > 0 ? p.Out + (bt0 + t - 1) * p.Rout : p.Row0 + (int64_t)b * p.Rout;
         }
-        for (int s = tid; s < Gp; s += kResThreads) Xz[s] = 0.f;
-        gu64 *slot = xch + (size_t)((i + 1) & 1) * G;
+        gu64 *slot = xch + (size_t)(1 - par) * G;
         const unsigned tag = (unsigned)(i + 1);
         const bool xchg = K > 1 && produce;
-        const char *xb = (const char *)Xc;
+        const char *xb = (const char *)lds + par * kResXB;
         float acc = 0.f, mymax = 0.f;
         int rid = row0 + lane;
 #pragma unroll
@@ -865,41 +938,23 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
                 for (int ci = 0; ci < kResBatch; ++ci) {
                     acc += part[ci];
                     if (ends >> (c0 + ci) & 1u) {
-                        const float rv = acc * sc;   // q_t[row] (fwd) / (partial) b_t[state] (bwd)
+                        const float rv = acc * sc;   // q_t[row] (fwd) / b_t[state copy] (bwd)
                         const int4 mt = RM[rid - cu_row0];
                         if (DIR == 0) {
                             Orow[rid] = rv;
-                            if (mt.x >= 0) {
+                            if (mt.x >= 0) {  // the row is the only producer of its entry: final now
                                 const float av = EPu[mt.y] * rv;
-                                if (mt.z) {  // sole contributor: final now (LDS float atomics are lane-serial)
-                                    Xn[mt.x] = av;
-                                    mymax = fmaxf(mymax, av);
-                                    if (xchg) res_publish(slot, mt.x, tag, av);
-                                } else {
-                                    atomicAdd(&Xn[mt.x], av);
-                                }
+                                Xn[mt.x] = av;
+                                mymax = fmaxf(mymax, av);
+                                if (xchg) res_publish(slot, mt.x, tag, av);
                             }
-                        } else if (t == 0) {
-                            if (mt.x >= 0) zpart += R.brow_start[rid] * rv;
                         } else {
                             Orow[rid] = rv;
-                            if (mt.x == 1) {
+                            if (mt.x > 0) {  // every backward row produces exactly one z entry (or none)
                                 const float zv = EPu[mt.z & 0xffff] * rv;
-                                if (mt.z >> 16) {
-                                    Xn[mt.y] = zv;
-                                    mymax = fmaxf(mymax, zv);
-                                    if (xchg) res_publish(slot, mt.y, tag, zv);
-                                } else {
-                                    atomicAdd(&Xn[mt.y], zv);
-                                }
-                            } else if (mt.x > 1) {
-                                const bool ex = (mt.z >> 16) != 0;
-                                for (int q = 0; q < mt.x; ++q) {
-                                    const int2 zl = R.bcsr[mt.w + q];
-                                    const float zv = EPu[zl.y] * rv;
-                                    if (ex) { Xn[zl.x] = zv; mymax = fmaxf(mymax, zv); if (xchg) res_publish(slot, zl.x, tag, zv); }
-                                    else atomicAdd(&Xn[zl.x], zv);
-                                }
+                                Xn[mt.y] = zv;
+                                mymax = fmaxf(mymax, zv);
+                                if (xchg) res_publish(slot, mt.y, tag, zv);
                             }
                         }
                         acc = 0.f;
@@ -908,51 +963,41 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(LossParams p
                 }
             }
         }
-        if (xchg) {  // exclusive entries of the peers (published from their epilogues)
+        if (xchg) {  // the peers' entries (published from their row epilogues)
             for (int j = 1; j < K; ++j) {
                 const int pj = (k + j) % K, lo = L.own_off[pj];
                 mymax = fmaxf(mymax, res_fetch(slot, Xn, lo, lo + L.ex_cnt[pj], tag, p.err, tid));
             }
         }
         mymax = wave_max(mymax);
-        float *wn = wm + ((i + 1) & 1) * 2 * kResWaves;
-        if (lane == 0) wn[wave] = mymax;
+        if (lane == 0) wm[(1 - par) * kResWaves + wave] = mymax;
         if (pre) {
-            float *EPw = EP + (DIR == 0 ? ((i + 1) & 1) : (i & 1)) * Vp;
+            float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;
 #pragma unroll
             for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; if (v < V) EPw[v] = epn[q]; }
         }
         sync_lds();
-        if (has_nx && produce) {  // entries summed by atomics: final only now
-            float mx2 = 0.f;
-            const int lo = L.own_off[k] + L.ex_cnt[k], hi = lo + L.ex_cnt[K + k];
-            for (int e = lo + tid; e < hi; e += kResThreads) {
-                const float v = Xn[e];
-                mx2 = fmaxf(mx2, v);
-                if (xchg) res_publish(slot, e, tag, v);
-            }
-            if (xchg)
-                for (int j = 1; j < K; ++j) {
-                    const int pj = (k + j) % K;
-                    const int plo = L.own_off[pj] + L.ex_cnt[pj];
-                    mx2 = fmaxf(mx2, res_fetch(slot, Xn, plo, plo + L.ex_cnt[K + pj], tag, p.err, tid));
-                }
-            mx2 = wave_max(mx2);
-            if (lane == 0) wn[kResWaves + wave] = mx2;
-            sync_lds();
-        }
+    };
+    for (int i = 0; i < lx; i += 2) {
+        frame(std::integral_constant<int, 0>{}, i);
+        if (i + 1 < lx) frame(std::integral_constant<int, 1>{}, i + 1);
     }
 
     if (DIR == 0) {
         if (k == 0) {
-            const float *Xf = X + (lx % 3) * Gp;
+            const float *Xf = X + (lx & 1) * kResGmax;
             float part = 0.f;
-            for (int s = tid; s < G; s += kResThreads) part += Xf[s] * R.x_end[s];
+            for (int s = tid; s < G; s += kResThreads) part += Xf[s] * p.x_end[s];
             const float zs = res_block_sum(part, (float *)red, tid);
             const double mxs = res_mx_total(p, b, lx, red, tid);
             if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); }
         }
     } else {
+        if (lx > 0) {  // logZ from the backward side: sum_s start(s) b_0(s) over this CU's rows (written above)
+            __syncthreads();  // drains vmcnt: this workgroup's own stores to the spare row are visible to it
+            const float *r0 = p.Row0 + (int64_t)b * p.Rout;
+            for (int r = tid; r < cu_rows; r += kResThreads) zpart += p.brow_start[cu_row0 + r] * r0[cu_row0 + r];
+        }
         const float zb = res_block_sum(zpart, (float *)red, tid);
         if (tid == 0) p.cb_part[(size_t)b * kResMaxK + k] = zb;
         if (k == 0) {
@@ -1091,7 +1136,7 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
 // host side
 // ---------------------------------------------------------------------------------------------
 struct WsLayout {
-    int64_t off_ep, off_mx, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_xch, total;
+    int64_t off_ep, off_mx, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_xch, off_row0, total;
     int64_t xch_bytes;
     int64_t Rq, Rb;
     bool res;
@@ -1101,7 +1146,7 @@ static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
 // the register-resident kernels are used whenever the graph fits them (res.K > 0) and V fits their
 // emission-row prefetch; CRF_NO_RESIDENT=1 at graph creation forces the streaming kernels
 static bool use_resident(const HostGraph *h, int64_t V) {
-    return h && h->dev.res.K > 0 && V <= (int64_t)kEpRegsR * kResThreads;
+    return h && h->dev.res.K > 0 && V <= (int64_t)kEpRegsR * kResThreads && h->dev.res.f.G <= kResGmax && h->dev.res.b.G <= kResGmax;
 }
 
 static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, int64_t Sc) {
@@ -1123,13 +1168,15 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_pb = o; o = al(o + 32 * B * 8);
     w.xch_bytes = (w.res && h->dev.res.K > 1) ? al(B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) * 8) : 0;
     w.off_xch = o; o = al(o + w.xch_bytes + 256);
+    w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.total = o;
     return w;
 }
 
 static size_t res_lds_bytes(const HostGraph *h, int V, int dir, int rows_cu_max) {
     const int G = dir == 0 ? h->dev.res.f.G : h->dev.res.b.G;
-    return ((size_t)3 * rup64(G) + (size_t)rows_cu_max * 4 + 2 * (size_t)rup64(V) + 4 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
+    (void)G;
+    return (size_t)2 * kResXB + ((size_t)rows_cu_max * 4 + 2 * (size_t)rup64(V) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
 }
 
 static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role) {
@@ -1211,7 +1258,7 @@ static int launch_chain(const LossParams &p, size_t lds, hipStream_t st) {
 }
 
 template <int DIR>
-static int launch_res(LossParams p, size_t lds, int b0, int nb, hipStream_t st) {
+static int launch_res(const LossParams &lp, size_t lds, int b0, int nb, hipStream_t st) {
     static std::atomic<size_t> lds_set{0};
     hipError_t e;
     if (lds > lds_set.load()) {
@@ -1221,8 +1268,19 @@ static int launch_res(LossParams p, size_t lds, int b0, int nb, hipStream_t st) 
         }
         lds_set = lds;
     }
-    p.b0 = b0;
-    hipLaunchKernelGGL(crf_res_chain_kernel<DIR>, dim3((unsigned)(nb * p.g.res.K)), dim3(kResThreads), lds, st, p);
+    const ResDev &R = lp.g.res;
+    ResParams p{};
+    p.L = DIR == 0 ? R.f : R.b;
+    p.K = R.K; p.B = lp.B; p.T = lp.T; p.V = lp.V; p.b0 = b0;
+    p.rows_cu_max = DIR == 0 ? lp.res_lds_rows_f : lp.res_lds_rows_b;
+    p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.Gf = R.f.G;
+    p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
+    p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
+    p.xch = lp.xch; p.err = lp.err;
+    p.x_start = R.x_start; p.x_end = R.x_end; p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
+    p.z_lab = R.z_lab; p.z_end = R.z_end; p.brow_start = R.brow_start; p.brow_end = R.brow_end; p.bcsr = R.bcsr;
+    p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
+    hipLaunchKernelGGL(crf_res_chain_kernel<DIR>, dim3((unsigned)(nb * R.K)), dim3(kResThreads), lds, st, p);
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_res_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }
@@ -1295,6 +1353,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     p.cb_part = pb + 8 * B; p.cb_F = (int *)(pb + 8 * B + (int64_t)kResMaxK * B);
     p.xch = (unsigned long long *)(base + w.off_xch);
     p.err = (int *)(base + w.off_xch + w.xch_bytes);
+    p.Row0 = (float *)(base + w.off_row0);
     p.den_zs = pb; p.den_ez = (int *)(pb + B); p.ctc_ez = (int *)(pb + 2 * B);
     p.cost_alpha = pb + 3 * B; p.cost_beta = pb + 4 * B; p.cost_ctc = pb + 5 * B; p.invalid = (int *)(pb + 6 * B);
     p.grad = grad; p.loss = loss; p.out_den = costs_den; p.out_beta = costs_beta; p.out_ctc = costs_ctc;

@@ -206,9 +206,12 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         int G = 0, has_nx = 0;
         bool ok = false;
     };
-    auto try_dir = [&](const Rows &rows, const std::vector<int> &key, int K, std::vector<int> *gmap_out,
+    // rows[r]: arcs (gather entry, weight); key[r]: the state that owns the row (CU assignment); tgt[r]: the
+    // gather entry the row produces (-1: none).  Several rows may target the same entry (forward: pairs
+    // with different labels into one state; any row cut into sub-rows): they are partial sums, and each
+    // gets its own virtual copy of the entry.  gkey[g]: the state whose owner produces entry g.
+    auto try_dir = [&](const Rows &rows, const std::vector<int> &key, const std::vector<int> &tgt, int K,
                        const std::vector<int> &gkey, std::vector<int> *goff) -> Dir {
-        // gkey[g] = state whose owner produces gather-vector entry g; gmap_out = renumbering of g
         Dir best;
         // attempt 0: no splitting; attempt 1: split only the rows that would sit in a ragged last slice
         // (fewer than 64 rows) of their CU into 2-chunk pieces, so that they fill leftover register space
@@ -218,7 +221,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             const int thr = attempt <= 1 ? (1 << 30) : kSplit[attempt - 1];
             Dir d;
             Rows sub;
-            std::vector<int> subkey;
+            std::vector<int> subkey, subtgt;
             for (size_t r = 0; r < rows.size(); ++r) {
                 const auto &a = rows[r];
                 const int rthr = (attempt == 1 && ragged[r]) ? 2 * kResW : thr;
@@ -231,6 +234,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                     d.sub_of.push_back((int)r);
                     sub.emplace_back(a.begin() + (long)lo, a.begin() + (long)hi);
                     subkey.push_back(key[r]);
+                    subtgt.push_back(tgt[r]);
                 }
             }
             // A key (state) with n > 1 sub-rows gets n VIRTUAL copies of every gather entry it produces:
@@ -238,11 +242,11 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             // Each entry then has exactly one producing row -- no LDS atomics (they are lane-serial, ~2.5 clk
             // per lane) and every value is final, publishable and usable for the frame maximum in its row's
             // epilogue.  Splits are rare (long-tail rows), so the replicated arcs are few.
-            std::vector<int> nsub(S, 0);
-            d.sub_j.resize(sub.size());
-            for (size_t r = 0; r < sub.size(); ++r) d.sub_j[r] = nsub[subkey[r]]++;
+            std::vector<int> nparts(gkey.size(), 0);
+            d.sub_j.assign(sub.size(), 0);
+            for (size_t r = 0; r < sub.size(); ++r) if (subtgt[r] >= 0) d.sub_j[r] = nparts[subtgt[r]]++;
             d.gbase.assign(gkey.size() + 1, 0);
-            for (size_t g = 0; g < gkey.size(); ++g) d.gbase[g + 1] = d.gbase[g] + std::max(1, nsub[gkey[g]]);
+            for (size_t g = 0; g < gkey.size(); ++g) d.gbase[g + 1] = d.gbase[g] + std::max(1, nparts[g]);
             d.G = d.gbase[gkey.size()];
             if (d.G > 16383) continue;  // 16-bit LDS byte offsets
             for (auto &row : sub) {
@@ -279,8 +283,6 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             // OF THEIR PRODUCING ROW's id -- a slice's 64 epilogues then publish 64 consecutive granules (one
             // coalesced 512-byte store) and write 64 consecutive LDS words; last the entries nobody produces
             // (e.g. the start state: no in-arcs), which stay 0 after the first frame and are never exchanged.
-            std::vector<std::vector<int>> entries_of_key(S);
-            for (size_t g = 0; g < gkey.size(); ++g) entries_of_key[gkey[g]].push_back((int)g);
             d.gmap.assign(d.G, -1);
             std::vector<int> off(K + 1, 0);
             d.ex_cnt.assign(2 * K, 0);  // [k] produced entries, [K + k] unused (no shared entries any more)
@@ -289,11 +291,11 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                 for (int rid = d.o.cu_row_off[k]; rid < d.o.cu_row_off[k + 1]; ++rid) {
                     const int r = d.o.row_of[rid];
                     if (r < 0) continue;
-                    for (int g : entries_of_key[subkey[r]]) d.gmap[d.gbase[g] + d.sub_j[r]] = n++;
+                    if (subtgt[r] >= 0) d.gmap[d.gbase[subtgt[r]] + d.sub_j[r]] = n++;
                 }
                 d.ex_cnt[k] = n - before;
                 for (size_t g = 0; g < gkey.size(); ++g)
-                    if (d.owner[gkey[g]] == k && nsub[gkey[g]] == 0) d.gmap[d.gbase[g]] = n++;
+                    if (d.owner[gkey[g]] == k && nparts[g] == 0) d.gmap[d.gbase[g]] = n++;
                 off[k + 1] = n;
             }
             for (auto &row : sub)
@@ -301,7 +303,6 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             pack_arcs(sub, slices, &d.o);
             *goff = off;
             d.ok = true;
-            (void)gmap_out;
             return d;
         }
         return best;
@@ -311,18 +312,37 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     std::iota(state_id.begin(), state_id.end(), 0);
     gkey_f = state_id;
     for (int K = 1; K <= kResMaxK; K *= 2) {
-        std::vector<int> xid, xoff, zid, zoff;
-        // forward rows are taken in label-sorted pair order so that sub-rows come out label-sorted
+        std::vector<int> xoff, zoff;
+        // forward rows = pairs, taken in label-sorted order so that sub-rows come out label-sorted; each
+        // produces (a partial sum of) x[dst]
         Rows fin(P);
-        std::vector<int> fin_key(P);
-        for (int j = 0; j < P; ++j) { fin[j] = in_arcs_of_pair[label_sorted_pairs[j]]; fin_key[j] = pair_dst[label_sorted_pairs[j]]; }
-        Dir F = try_dir(fin, fin_key, K, &xid, gkey_f, &xoff);
+        std::vector<int> fin_key(P), fin_tgt(P);
+        for (int j = 0; j < P; ++j) {
+            const int p = label_sorted_pairs[j];
+            fin[j] = in_arcs_of_pair[p]; fin_key[j] = pair_dst[p]; fin_tgt[j] = pair_dst[p];
+        }
+        Dir F = try_dir(fin, fin_key, fin_tgt, K, gkey_f, &xoff);
         if (!F.ok) continue;
-        Dir Bk = try_dir(out_arcs_of_state, state_id, K, &zid, gkey_b, &zoff);
+        // backward rows = states; a state entered with n > 1 labels is listed n times (same arcs), once per
+        // pair it produces z for, so that every row writes exactly one entry (only the first copy feeds the
+        // grad pass and logZ); a state nobody enters (e.g. the start state) produces nothing
+        std::vector<std::vector<int>> pairs_into(S);
+        for (int p = 0; p < P; ++p) pairs_into[pair_dst[p]].push_back(p);
+        Rows bin;
+        std::vector<int> bin_key, bin_tgt, bin_dup;
+        for (int s = 0; s < S; ++s)
+            for (int dd = 0; dd < std::max<int>(1, (int)pairs_into[s].size()); ++dd) {
+                bin.push_back(out_arcs_of_state[s]);
+                bin_key.push_back(s);
+                bin_tgt.push_back(pairs_into[s].empty() ? -1 : pairs_into[s][dd]);
+                bin_dup.push_back(dd);
+            }
+        Dir Bk = try_dir(bin, bin_key, bin_tgt, K, gkey_b, &zoff);
         if (!Bk.ok) continue;
         const DirOut &fo = F.o, &bo = Bk.o;
         const int NRf = (int)F.sub_of.size(), NRb = (int)Bk.sub_of.size();
         auto pair_of_sub = [&](int r) { return label_sorted_pairs[F.sub_of[r]]; };
+        (void)NRf;
 
         // ---- row metadata and side tables
         const int Rf = fo.cu_row_off[K], Rb = bo.cu_row_off[K];
@@ -335,24 +355,21 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                 const int sr = fo.row_of[r], p = pair_of_sub(sr);
                 fmeta[r] = int4{xof(pair_dst[p], F.sub_j[sr]), pair_lab[p], 1, 0};
             }
-        std::vector<std::vector<int>> pairs_into(S), bsubs_of(S);
-        for (int p = 0; p < P; ++p) pairs_into[pair_dst[p]].push_back(p);
-        for (int r = 0; r < NRb; ++r) bsubs_of[Bk.sub_of[r]].push_back(r);
-        std::vector<int2> bcsr;
+        std::vector<std::vector<int>> bsubs_of(S);  // backward sub-rows of the FIRST copy of each state
+        for (int r = 0; r < NRb; ++r) if (bin_dup[Bk.sub_of[r]] == 0) bsubs_of[bin_key[Bk.sub_of[r]]].push_back(r);
         std::vector<float> brow_start(Rb, 0.f), brow_end(Rb, 0.f);
         for (int r = 0; r < Rb; ++r) {
             const int sr = bo.row_of[r];
             if (sr < 0) continue;
-            const int s = Bk.sub_of[sr], j = Bk.sub_j[sr];
-            const auto &pl = pairs_into[s];
-            int4 m{(int)pl.size(), 0, 0, (int)bcsr.size()};
-            // .z = label | (1 << 16): sub-row j writes copy j of every pair into the state (plain LDS store)
-            if (!pl.empty()) { m.y = zof(pl[0], j); m.z = pair_lab[pl[0]] | (1 << 16); }
-            if (pl.size() > 1) for (int p : pl) bcsr.push_back(int2{zof(p, j), pair_lab[p]});
-            bmeta[r] = m;
-            brow_start[r] = start_lin[s];
-            brow_end[r] = j == 0 ? end_lin[s] : 0.f;  // b_T[s] = end weight, counted once
+            const int in = Bk.sub_of[sr], s = bin_key[in], p = bin_tgt[in], j = Bk.sub_j[sr];
+            // {1 | -1 (produces nothing), z entry, label | 1 << 16, 0}
+            bmeta[r] = p >= 0 ? int4{1, zof(p, j), pair_lab[p] | (1 << 16), 0} : int4{-1, 0, 0, 0};
+            if (bin_dup[in] == 0) {  // logZ and the end weight are taken from the first copy only
+                brow_start[r] = start_lin[s];
+                brow_end[r] = j == 0 ? end_lin[s] : 0.f;
+            }
         }
+        std::vector<int2> bcsr;
         std::vector<float> x_start(Gf, 0.f), x_end(Gf, 0.f), z_end(Gb, 0.f);
         std::vector<int> z_lab(Gb, 0);
         for (int s = 0; s < S; ++s)
