@@ -740,8 +740,18 @@ __device__ __forceinline__ float res_frame_max(const float *wm) {
 // ahead, so two slots suffice.  Values are published from the row epilogues as soon as they are
 // final, so most of the hand-off latency overlaps the rest of the frame's gathers.
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-__device__ __forceinline__ void res_publish(gu64 *slot, int i, unsigned tag, float v) {
-    __hip_atomic_store(slot + i, ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// `same_l2`: every peer of this recursion was found (at run time, from HW_REG_XCC_ID) on this CU's XCD.
+// Then a PLAIN 8-byte store is enough: it is written through to the shared L2 and stays there, and the
+// peers' loads bypass their L1 (sc1), so the hand-off is an L2 round trip.  Otherwise the store is
+// write-through to memory (sc1): correct under any placement, ~1 us slower per frame (an sc1 store drops
+// the line from L2, MI355X_MICROARCH.md "stores of each flavour").
+__device__ __forceinline__ void res_publish(gu64 *slot, int i, unsigned tag, float v, bool same_l2) {
+    const unsigned long long g = ((unsigned long long)tag << 32) | __float_as_uint(v);
+    if (same_l2) {
+        asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(slot + i), "v"(g) : "memory");
+    } else {
+        __hip_atomic_store(slot + i, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // Fetch entries [lo,hi) published by a peer into LDS `v`; returns the largest value seen.
 __device__ __forceinline__ float res_fetch(gu64 *slot, float *v, int lo, int hi, unsigned tag, int *err, int tid) {
@@ -781,21 +791,26 @@ __device__ __forceinline__ float res_fetch(gu64 *slot, float *v, int lo, int hi,
 // branches sit between batches.  Unused chunks hold zero weights.
 constexpr int kResBatch = 5;
 static_assert(kResNCH % kResBatch == 0, "kResNCH must be a multiple of kResBatch");
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Packed math: the four products of a chunk are two v_pk_fma_f32 lanes (PMC showed the frame loop is
+// as much VALU-issue-bound as LDS-bound: ~530 VALU instructions per wave and frame before packing).
 #define CRF_RES_BATCH(part, A, xb, c0)                                                                    \
     _Pragma("unroll") for (int ci = 0; ci < kResBatch; ++ci) {                                            \
         const int c = (c0) + ci;                                                                          \
         const unsigned i01 = A[6 * c], i23 = A[6 * c + 1];                                                \
-        const float g0 = *(const float *)(xb + (i01 & 0xffffu)), g1 = *(const float *)(xb + (i01 >> 16)); \
-        const float g2 = *(const float *)(xb + (i23 & 0xffffu)), g3 = *(const float *)(xb + (i23 >> 16)); \
-        part[ci] = fmaf(g0, __uint_as_float(A[6 * c + 2]), g1 * __uint_as_float(A[6 * c + 3])) +          \
-                   fmaf(g2, __uint_as_float(A[6 * c + 4]), g3 * __uint_as_float(A[6 * c + 5]));           \
+        f32x2 g01, g23, w01, w23;                                                                         \
+        g01.x = *(const float *)(xb + (i01 & 0xffffu)); g01.y = *(const float *)(xb + (i01 >> 16));       \
+        g23.x = *(const float *)(xb + (i23 & 0xffffu)); g23.y = *(const float *)(xb + (i23 >> 16));       \
+        w01.x = __uint_as_float(A[6 * c + 2]); w01.y = __uint_as_float(A[6 * c + 3]);                     \
+        w23.x = __uint_as_float(A[6 * c + 4]); w23.y = __uint_as_float(A[6 * c + 5]);                     \
+        part[ci] = __builtin_elementwise_fma(g23, w23, g01 * w01);                                        \
     }
 
 // Kernel arguments of the resident kernels: only what ONE direction needs (the full LossParams is ~90
 // SGPRs of pointers, most of which the compiler would keep live or spill around the unrolled frame body).
 struct ResParams {
     ResDirDev L;
-    int K, B, T, V, b0, rows_cu_max, Rout, Gf;
+    int K, B, T, V, b0, rows_cu_max, Rout, Gf, Gb;
     const int *lx;
     const float *ep, *mx;
     float *Out;                 // Q (fwd) or BP (bwd) rows
@@ -894,6 +909,29 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
     }
     __syncthreads();
 
+    // ---- where are my peers?  Every CU publishes the id of its XCD (write-through, placement-independent)
+    // and reads its peers'; all peers on one XCD => the cheap same-L2 hand-off is used.  Both sides take the
+    // decision from the same K ids, so they always agree.
+    bool same_l2 = false;
+    if (K > 1) {
+        gu64 *hs = (gu64 *)(p.xch + (size_t)p.B * 2 * ((size_t)p.Gf + (size_t)p.Gb)) + ((size_t)DIR * p.B + b) * kResMaxK;
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+        if (tid == 0) __hip_atomic_store(hs + k, (1ull << 32) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int same = 1;
+        if (tid < K && tid != k) {
+            unsigned long long g = 0;
+            for (unsigned spins = 0; (g >> 32) != 1ull; ++spins) {
+                g = __hip_atomic_load(hs + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (spins > (1u << 22)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            same = ((unsigned)g & 0xf) == my_xcc && (g >> 32) == 1ull;
+        }
+        same_l2 = __syncthreads_and(same) != 0;
+        static_assert(kResMaxK <= kWave, "peer ids are read by the first K threads");
+    }
+
     // one frame; PAR = parity of i = which buffer is the gather source (compile-time -> immediate offsets)
     auto frame = [&](auto PAR, int i) __attribute__((always_inline)) {
         constexpr int par = decltype(PAR)::value;
@@ -927,18 +965,25 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
         const unsigned tag = (unsigned)(i + 1);
         const bool xchg = K > 1 && produce;
         const char *xb = (const char *)lds + par * kResXB;
-        float acc = 0.f, mymax = 0.f;
+        // keep the slice-end mask opaque per frame: otherwise hipcc hoists all 30 loop-invariant
+        // "bit c set?" conditions out of the time loop as 64-bit lane masks (60 SGPRs), spills them
+        // to VGPR lanes and pays two v_readlane per chunk to get them back
+        unsigned ends_f = ends;
+        int nch_f = nch;
+        asm volatile("" : "+s"(ends_f), "+s"(nch_f));
+        f32x2 acc = {0.f, 0.f};
+        float mymax = 0.f;
         int rid = row0 + lane;
 #pragma unroll
         for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
-            if (c0 < nch) {
-                float part[kResBatch];
+            if (c0 < nch_f) {
+                f32x2 part[kResBatch];
                 CRF_RES_BATCH(part, A, xb, c0);
 #pragma unroll
                 for (int ci = 0; ci < kResBatch; ++ci) {
                     acc += part[ci];
-                    if (ends >> (c0 + ci) & 1u) {
-                        const float rv = acc * sc;   // q_t[row] (fwd) / b_t[state copy] (bwd)
+                    if (ends_f >> (c0 + ci) & 1u) {
+                        const float rv = (acc.x + acc.y) * sc;   // q_t[row] (fwd) / b_t[state copy] (bwd)
                         const int4 mt = RM[rid - cu_row0];
                         if (DIR == 0) {
                             Orow[rid] = rv;
@@ -946,7 +991,7 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
                                 const float av = EPu[mt.y] * rv;
                                 Xn[mt.x] = av;
                                 mymax = fmaxf(mymax, av);
-                                if (xchg) res_publish(slot, mt.x, tag, av);
+                                if (xchg) res_publish(slot, mt.x, tag, av, same_l2);
                             }
                         } else {
                             Orow[rid] = rv;
@@ -954,10 +999,10 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
                                 const float zv = EPu[mt.z & 0xffff] * rv;
                                 Xn[mt.y] = zv;
                                 mymax = fmaxf(mymax, zv);
-                                if (xchg) res_publish(slot, mt.y, tag, zv);
+                                if (xchg) res_publish(slot, mt.y, tag, zv, same_l2);
                             }
                         }
-                        acc = 0.f;
+                        acc = f32x2{0.f, 0.f};
                         rid += kWave;
                     }
                 }
@@ -1166,7 +1211,8 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_ECA = o; o = al(o + B * T * 4);
     w.off_ECB = o; o = al(o + B * T * 4);
     w.off_pb = o; o = al(o + 32 * B * 8);
-    w.xch_bytes = (w.res && h->dev.res.K > 1) ? al(B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) * 8) : 0;
+    // tagged granules [2 slots] of both directions, then one XCD-id word per CU of every recursion
+    w.xch_bytes = (w.res && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8) : 0;
     w.off_xch = o; o = al(o + w.xch_bytes + 256);
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.total = o;
@@ -1273,7 +1319,7 @@ static int launch_res(const LossParams &lp, size_t lds, int b0, int nb, hipStrea
     p.L = DIR == 0 ? R.f : R.b;
     p.K = R.K; p.B = lp.B; p.T = lp.T; p.V = lp.V; p.b0 = b0;
     p.rows_cu_max = DIR == 0 ? lp.res_lds_rows_f : lp.res_lds_rows_b;
-    p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.Gf = R.f.G;
+    p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.Gf = R.f.G; p.Gb = R.b.G;
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
     p.xch = lp.xch; p.err = lp.err;

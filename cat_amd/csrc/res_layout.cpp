@@ -311,7 +311,9 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     for (int p = 0; p < P; ++p) { fkey[p] = pair_dst[p]; gkey_b[p] = pair_dst[p]; }
     std::iota(state_id.begin(), state_id.end(), 0);
     gkey_f = state_id;
+    const int min_k = getenv("CRF_RES_MINK") ? std::max(1, atoi(getenv("CRF_RES_MINK"))) : 1;  // experiments
     for (int K = 1; K <= kResMaxK; K *= 2) {
+        if (K < min_k) continue;
         std::vector<int> xoff, zoff;
         // forward rows = pairs, taken in label-sorted order so that sub-rows come out label-sorted; each
         // produces (a partial sum of) x[dst]
