@@ -539,10 +539,13 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         skip[i] = s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2];
     }
     int E = kScaleExpD;
+    // The frame maximum used for the (exact, power-of-two) rescale is taken from the values as they are
+    // WRITTEN: one barrier per frame instead of a separate reduction pass plus barrier.
     {   // t = 0 (gpu_ctc_kernels.h:146-152)
         const float *lr = p.logp + bt0 * V;
         const float m0 = p.mx[bt0];
         double *CArow = p.CA + bt0 * p.Sc;
+        double vmax = 0.0;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
             const int s = tid + i * kChainThreads;
@@ -551,9 +554,12 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
                 A[s] = v;
                 A[Sxp + s] = 0.0;
                 if (s < Sx) CArow[s] = v;
+                vmax = fmax(vmax, v);
             }
         }
         if (tid == 0) p.ECA[bt0] = E;
+        vmax = wave_max_d(vmax);
+        if (lane == 0) wm[kChainWaves + wave] = vmax;  // wm[t & 1] is read by frame t: slot 1 for t = 1
     }
     __syncthreads();
     // emissions are fetched one frame ahead (an L2 round trip is ~1 us, longer than a whole frame)
@@ -576,15 +582,11 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
 #pragma unroll
             for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kChainThreads < Sx) ? lr[mylab[i]] : 0.f;
         }
-        double m = 0.0;
-        for (int s = tid; s < Sx; s += kChainThreads) m = fmax(m, Ac[s]);
-        m = wave_max_d(m);
-        if (lane == 0) wm[(t & 1) * kChainWaves + wave] = m;
-        sync_lds();
         const int k = rescale_exp_d(frame_max_d(wm + (t & 1) * kChainWaves));
         const double sc = pow2d(k);
         E += k;
         double *CArow = p.CA + (bt0 + t) * p.Sc;
+        double vmax = 0.0;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
             const int s = tid + i * kChainThreads;
@@ -595,9 +597,12 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
                 const double v = sc * em[i] * a;
                 An[s] = v;
                 CArow[s] = v;
+                vmax = fmax(vmax, v);
             }
         }
         if (tid == 0) p.ECA[bt0 + t] = E;
+        vmax = wave_max_d(vmax);
+        if (lane == 0) wm[((t + 1) & 1) * kChainWaves + wave] = vmax;
         sync_lds();
     }
     const double *Af = A + ((lx - 1) & 1) * Sxp;
@@ -636,17 +641,22 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         const float *lr = p.logp + (bt0 + lx - 1) * V;
         const float ml = p.mx[bt0 + lx - 1];
         double *CBrow = p.CB + (bt0 + lx - 1) * p.Sc;
+        double vmax = 0.0;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
             const int s = tid + i * kChainThreads;
             if (s < Sxp) {
                 const double bx = (s < Sx && s >= Sx - 2) ? pow2d(kScaleExpD) : 0.0;
-                Y[s] = s < Sx ? exp_scaled_d(lr[mylab[i]] - ml) * bx : 0.0;
+                const double y = s < Sx ? exp_scaled_d(lr[mylab[i]] - ml) * bx : 0.0;
+                Y[s] = y;
                 Y[Sxp + s] = 0.0;
                 if (s < Sx) CBrow[s] = bx;
+                vmax = fmax(vmax, y);
             }
         }
         if (tid == 0) p.ECB[bt0 + lx - 1] = F;
+        vmax = wave_max_d(vmax);
+        if (lane == 0) wm[kChainWaves + wave] = vmax;  // read by iteration i = 1
     }
     __syncthreads();
     float lraw[kCtcRegs], mraw = 0.f;
@@ -669,15 +679,11 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
 #pragma unroll
             for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kChainThreads < Sx) ? lr[mylab[q]] : 0.f;
         }
-        double m = 0.0;
-        for (int s = tid; s < Sx; s += kChainThreads) m = fmax(m, Yc[s]);
-        m = wave_max_d(m);
-        if (lane == 0) wm[(i & 1) * kChainWaves + wave] = m;
-        sync_lds();
         const int k = rescale_exp_d(frame_max_d(wm + (i & 1) * kChainWaves));
         const double sc = pow2d(k);
         F += k;
         double *CBrow = p.CB + (bt0 + t) * p.Sc;
+        double vmax = 0.0;
 #pragma unroll
         for (int q = 0; q < kCtcRegs; ++q) {
             const int s = tid + q * kChainThreads;
@@ -686,11 +692,15 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
                 if (s + 1 < Sx) a += Yc[s + 1];
                 if (skip[q]) a += Yc[s + 2];
                 const double bx = sc * a;
+                const double y = em[q] * bx;
                 CBrow[s] = bx;
-                Yn[s] = em[q] * bx;
+                Yn[s] = y;
+                vmax = fmax(vmax, y);
             }
         }
         if (tid == 0) p.ECB[bt0 + t] = F;
+        vmax = wave_max_d(vmax);
+        if (lane == 0) wm[((i + 1) & 1) * kChainWaves + wave] = vmax;
         sync_lds();
     }
 }
@@ -1147,6 +1157,88 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// grad, denominator half, streaming form: gamma_den[t][v] = e'_t[v] * sum_{j in label v} Q_t[gq_j] * BP_t[gb_j] / Z.
+// One workgroup walks kGDFrames consecutive frames of one utterance.  The (gq, gb) index pairs of a
+// thread's chunk(s) are loaded ONCE into registers (packed 16+16 bit) -- in the generic kernel they were
+// re-read from L2 for every frame and doubled its traffic; the rows of frame t+1 are prefetched into
+// registers while frame t is reduced out of LDS.  HBM-bound: two coalesced rows per frame.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGDThreads = 256, kGDFrames = 16, kGDRowRegs = 5;   // rows of up to 5*256 float4 = 5120 floats
+template <int NCPT>
+__global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const GraphDev &g = p.g;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, V = p.V;
+    const int lx = p.lx[b], Rq = p.Rq, Rb = p.Rb, NC = p.gNC;
+    float *Qs = lds, *Bs = Qs + rup64(Rq + 1), *csum = Bs + rup64(Rb + 1);  // Qs[Rq] = 0: target of padding index pairs
+    const int64_t bt0 = (int64_t)b * p.T;
+    const float zs = p.den_zs[b];
+    const int ez = p.den_ez[b];
+    const float inv = zs > 0.f ? 1.f / zs : 0.f;
+    const int t0 = blockIdx.x * kGDFrames, t1 = min(t0 + kGDFrames, p.T), tl = min(t1, lx);
+
+    unsigned idx[NCPT][kChunk];
+    int clen[NCPT];
+#pragma unroll
+    for (int i = 0; i < NCPT; ++i) {
+        const int c = tid + i * kGDThreads;
+        const int j0 = c < NC ? p.gchunk[c] : 0;
+        clen[i] = c < NC ? p.gchunk[c + 1] - j0 : 0;
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) idx[i][j] = j < clen[i] ? ((unsigned)p.gq[j0 + j] | (unsigned)p.gb[j0 + j] << 16) : (unsigned)Rq;
+    }
+    if (tid == 0) Qs[Rq] = 0.f;
+    // rows are multiples of 64 floats and 256-byte aligned: 16-byte loads, prefetched one frame ahead
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 qr[kGDRowRegs], br[kGDRowRegs];
+#define CRF_GD_FETCH(t)                                                                                  \
+    {                                                                                                    \
+        const f32x4 *Qr = (const f32x4 *)(p.Q + (bt0 + (t)) * Rq), *Br = (const f32x4 *)(p.BP + (bt0 + (t)) * Rb); \
+        _Pragma("unroll") for (int i = 0; i < kGDRowRegs; ++i) {                                         \
+            const int r = tid + i * kGDThreads;                                                          \
+            qr[i] = 4 * r < Rq ? Qr[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
+            br[i] = 4 * r < Rb ? Br[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
+        }                                                                                                \
+    }
+    if (t0 < tl) CRF_GD_FETCH(t0);
+    for (int t = t0; t < tl; ++t) {
+#pragma unroll
+        for (int i = 0; i < kGDRowRegs; ++i) {
+            const int r = tid + i * kGDThreads;
+            if (4 * r < Rq) ((f32x4 *)Qs)[r] = qr[i];
+            if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];
+        }
+        __syncthreads();
+        if (t + 1 < tl) CRF_GD_FETCH(t + 1);
+#pragma unroll
+        for (int i = 0; i < NCPT; ++i) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < kChunk; j += 2) {  // padding pairs read Qs[Rq] = 0 (times Bs[0])
+                s0 = fmaf(Qs[idx[i][j] & 0xffffu], Bs[idx[i][j] >> 16], s0);
+                s1 = fmaf(Qs[idx[i][j + 1] & 0xffffu], Bs[idx[i][j + 1] >> 16], s1);
+            }
+            if (tid + i * kGDThreads < NC) csum[tid + i * kGDThreads] = s0 + s1;
+        }
+        __syncthreads();
+        const int e = ez - p.EQ[bt0 + t] - p.EB[bt0 + t] - kEpExp;  // er[] carries 2^kEpExp
+        const float *er = p.ep + (bt0 + t) * V;
+        float *row = p.grad + (bt0 + t) * V;
+        for (int v = tid; v < V; v += kGDThreads) {
+            float s = 0.f;
+            if (v <= g.max_label)
+                for (int c = p.glab[v]; c < p.glab[v + 1]; ++c) s += csum[c];
+            row[v] = p.c_den * (er[v] * (ldexpf(s, e) * inv));
+        }
+    }
+    for (int t = max(t0, tl); t < t1; ++t) {  // frames past the utterance's length: zero rows
+        float *row = p.grad + (bt0 + t) * V;
+        for (int v = tid; v < V; v += kGDThreads) row[v] = 0.f;
+    }
+}
+
 // loss = sum_b(c_den*logZ_b - c_ctc*logp_b); copies the per-utterance costs out (one workgroup)
 __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
     __shared__ double red[4];
@@ -1485,6 +1577,25 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         return CRF_OK;
     };
     const dim3 ggrid((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B);
+    // The denominator half of the grad pass has a streaming kernel (index pairs in registers, rows
+    // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
+    const int gnc = den ? (res ? h->dev.res.NC : h->dev.NC) : 0;
+    const bool fast_den = den && w.Rq <= 4 * kGDRowRegs * kGDThreads && w.Rb <= 4 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
+                          gnc <= 2 * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
+    auto launch_grad_den = [&]() -> int {
+        const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + rup64(gnc)) * sizeof(float);
+        const dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
+        static std::atomic<size_t> set1{0}, set2{0};
+        if (gnc <= kGDThreads) {
+            if (l > set1.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set1 = l; }
+            hipLaunchKernelGGL(crf_grad_den_kernel<1>, gg, dim3(kGDThreads), l, stream, p);
+        } else {
+            if (l > set2.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set2 = l; }
+            hipLaunchKernelGGL(crf_grad_den_kernel<2>, gg, dim3(kGDThreads), l, stream, p);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad_den_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+        return CRF_OK;
+    };
     if (!split) {
         if (ctc) {
             if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream))) return rc;
@@ -1492,19 +1603,39 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         }
         if ((rc = join_all())) return rc;
         prof_mark(5, false, stream);
-        p.grad_phase = 0;
-        hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+        if (fast_den) {
+            if ((rc = launch_grad_den())) return rc;
+            if (ctc) {
+                p.grad_phase = 2;
+                hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+            }
+        } else {
+            p.grad_phase = 0;
+            hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+        }
         prof_mark(5, true, stream);
         LAUNCH_CHECK("crf_grad_kernel");
     } else {
-        if ((rc = join_all())) return rc;  // den complete
-        if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess) { set_error("hipEventRecord(fork2)"); return CRF_ERR_HIP; }
+        // the numerator recursions start as soon as ONE of the two den kernels (the backward one, on side
+        // stream 0) has drained and freed its half of the CUs; the den half of the grad pass follows the
+        // forward den kernel on the caller's stream
+        if ((e = hipEventRecord(cx->fork, cx->side[0])) != hipSuccess) { set_error("hipEventRecord(fork2)"); return CRF_ERR_HIP; }
         if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(1)))) return rc;
         if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2)))) return rc;
+        {   // join side 0 (den backward) only; sides 1, 2 are joined after the den grad pass
+            if ((e = hipEventRecord(cx->join[0], cx->side[0])) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->join[0], 0)) != hipSuccess) {
+                set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+            }
+            used[0] = false;
+        }
         prof_mark(5, false, stream);
-        p.grad_phase = 1;
-        hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
-        LAUNCH_CHECK("crf_grad_kernel(den)");
+        if (fast_den) {
+            if ((rc = launch_grad_den())) return rc;
+        } else {
+            p.grad_phase = 1;
+            hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+            LAUNCH_CHECK("crf_grad_kernel(den)");
+        }
         if ((rc = join_all())) return rc;
         p.grad_phase = 2;
         hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
