@@ -36,7 +36,8 @@
 namespace crf {
 
 constexpr int kEpRegs = 8;    // ep row prefetch registers per thread  -> V  <= 8 * 1024
-constexpr int kCtcRegs = 4;   // ctc states per thread                  -> 2L+1 <= 4 * 1024
+constexpr int kCtcThreads = 512, kCtcWaves = kCtcThreads / 64;  // numerator chains: 8 waves (S' = 2L+1 is a few hundred)
+constexpr int kCtcRegs = 8;   // ctc states per thread                  -> 2L+1 <= 8 * 512
 constexpr int kGradThreads = 256;
 constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
 
@@ -475,6 +476,29 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
     if (tid == 0) p.cost_beta[b] = to_log(zb, F, mxs);
 }
 
+__device__ __forceinline__ float ctc_block_sum(float v, float *red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCtcWaves; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ double ctc_mx_total(const LossParams &p, int b, int lx, double *red, int tid) {
+    double part = 0.0;
+    for (int t = tid; t < lx; t += kCtcThreads) part += (double)p.mx[(int64_t)b * p.T + t];
+    part = wave_sum_d(part);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < kCtcWaves; ++i) s += red[i];
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // CTC numerator chains, in fp64: a forced alignment may have to pass through frames where the
 // label is e^-100 below the row max, so the numerator gets the e^+-700 range of doubles (it is
@@ -490,24 +514,24 @@ __device__ __forceinline__ CtcLds ctc_carve(float *lds, int Sxp) {
     CtcLds c;
     c.A = (double *)lds;
     c.wm = c.A + 2 * Sxp;
-    c.red = c.wm + 2 * kChainWaves;
-    c.lab = (int *)(c.red + kChainWaves);
+    c.red = c.wm + 2 * kCtcWaves;
+    c.lab = (int *)(c.red + kCtcWaves);
     return c;
 }
 __device__ __forceinline__ bool ctc_setup(const LossParams &p, int b, const CtcLds &c, int L, int lx, int tid) {
     const int *ul = p.labels + p.lab_off[b];
     const int Sx = 2 * L + 1;
     float rep = 0.f;
-    for (int s = tid; s < Sx; s += kChainThreads) c.lab[s] = (s & 1) ? ul[s >> 1] : 0;
-    for (int i = tid + 1; i < L; i += kChainThreads) rep += (ul[i] == ul[i - 1]) ? 1.f : 0.f;
-    const int repeats = (int)(block_sum(rep, (float *)c.red, tid) + 0.5f);  // also orders the lab[] writes
+    for (int s = tid; s < Sx; s += kCtcThreads) c.lab[s] = (s & 1) ? ul[s >> 1] : 0;
+    for (int i = tid + 1; i < L; i += kCtcThreads) rep += (ul[i] == ul[i - 1]) ? 1.f : 0.f;
+    const int repeats = (int)(ctc_block_sum(rep, (float *)c.red, tid) + 0.5f);  // also orders the lab[] writes
     __syncthreads();
     return lx > 0 && L + repeats <= lx;
 }
 __device__ __forceinline__ double frame_max_d(const double *wm) {
     double m = wm[0];
 #pragma unroll
-    for (int i = 1; i < kChainWaves; ++i) m = fmax(m, wm[i]);
+    for (int i = 1; i < kCtcWaves; ++i) m = fmax(m, wm[i]);
     return m;
 }
 __device__ __forceinline__ float to_log_d(double zs, int e, double mxs) {
@@ -534,7 +558,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
     bool skip[kCtcRegs];
 #pragma unroll
     for (int i = 0; i < kCtcRegs; ++i) {
-        const int s = tid + i * kChainThreads;
+        const int s = tid + i * kCtcThreads;
         mylab[i] = s < Sx ? lab[s] : 0;
         skip[i] = s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2];
     }
@@ -548,7 +572,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         double vmax = 0.0;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
-            const int s = tid + i * kChainThreads;
+            const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
                 const double v = (s < 2 && s < Sx) ? exp_scaled_d(lr[mylab[i]] - m0) * pow2d(kScaleExpD) : 0.0;
                 A[s] = v;
@@ -559,7 +583,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         }
         if (tid == 0) p.ECA[bt0] = E;
         vmax = wave_max_d(vmax);
-        if (lane == 0) wm[kChainWaves + wave] = vmax;  // wm[t & 1] is read by frame t: slot 1 for t = 1
+        if (lane == 0) wm[kCtcWaves + wave] = vmax;  // wm[t & 1] is read by frame t: slot 1 for t = 1
     }
     __syncthreads();
     // emissions are fetched one frame ahead (an L2 round trip is ~1 us, longer than a whole frame)
@@ -568,28 +592,28 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         const float *lr = p.logp + (bt0 + 1) * V;
         mraw = p.mx[bt0 + 1];
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kChainThreads < Sx) ? lr[mylab[i]] : 0.f;
+        for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kCtcThreads < Sx) ? lr[mylab[i]] : 0.f;
     }
     for (int t = 1; t < lx; ++t) {
         const double *Ac = A + ((t - 1) & 1) * Sxp;
         double *An = A + (t & 1) * Sxp;
         double em[kCtcRegs];
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) em[i] = (tid + i * kChainThreads < Sx) ? exp_scaled_d(lraw[i] - mraw) : 0.0;
+        for (int i = 0; i < kCtcRegs; ++i) em[i] = (tid + i * kCtcThreads < Sx) ? exp_scaled_d(lraw[i] - mraw) : 0.0;
         if (t + 1 < lx) {
             const float *lr = p.logp + (bt0 + t + 1) * V;
             mraw = p.mx[bt0 + t + 1];
 #pragma unroll
-            for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kChainThreads < Sx) ? lr[mylab[i]] : 0.f;
+            for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kCtcThreads < Sx) ? lr[mylab[i]] : 0.f;
         }
-        const int k = rescale_exp_d(frame_max_d(wm + (t & 1) * kChainWaves));
+        const int k = rescale_exp_d(frame_max_d(wm + (t & 1) * kCtcWaves));
         const double sc = pow2d(k);
         E += k;
         double *CArow = p.CA + (bt0 + t) * p.Sc;
         double vmax = 0.0;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
-            const int s = tid + i * kChainThreads;
+            const int s = tid + i * kCtcThreads;
             if (s < Sx) {
                 double a = Ac[s];
                 if (s >= 1) a += Ac[s - 1];
@@ -602,11 +626,11 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         }
         if (tid == 0) p.ECA[bt0 + t] = E;
         vmax = wave_max_d(vmax);
-        if (lane == 0) wm[((t + 1) & 1) * kChainWaves + wave] = vmax;
+        if (lane == 0) wm[((t + 1) & 1) * kCtcWaves + wave] = vmax;
         sync_lds();
     }
     const double *Af = A + ((lx - 1) & 1) * Sxp;
-    const double mxs = mx_total(p, b, lx, c.red, tid);
+    const double mxs = ctc_mx_total(p, b, lx, c.red, tid);
     if (tid == 0) {
         const double zc = Af[Sx - 1] + (Sx > 1 ? Af[Sx - 2] : 0.0);
         const bool ok = zc > 0.0;
@@ -632,7 +656,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     bool skip[kCtcRegs];
 #pragma unroll
     for (int i = 0; i < kCtcRegs; ++i) {
-        const int s = tid + i * kChainThreads;
+        const int s = tid + i * kCtcThreads;
         mylab[i] = s < Sx ? lab[s] : 0;
         skip[i] = (s + 2 < Sx) && lab[s + 2] != 0 && lab[s + 2] != mylab[i];
     }
@@ -644,7 +668,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         double vmax = 0.0;
 #pragma unroll
         for (int i = 0; i < kCtcRegs; ++i) {
-            const int s = tid + i * kChainThreads;
+            const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
                 const double bx = (s < Sx && s >= Sx - 2) ? pow2d(kScaleExpD) : 0.0;
                 const double y = s < Sx ? exp_scaled_d(lr[mylab[i]] - ml) * bx : 0.0;
@@ -656,7 +680,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         }
         if (tid == 0) p.ECB[bt0 + lx - 1] = F;
         vmax = wave_max_d(vmax);
-        if (lane == 0) wm[kChainWaves + wave] = vmax;  // read by iteration i = 1
+        if (lane == 0) wm[kCtcWaves + wave] = vmax;  // read by iteration i = 1
     }
     __syncthreads();
     float lraw[kCtcRegs], mraw = 0.f;
@@ -664,7 +688,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         const float *lr = p.logp + (bt0 + lx - 2) * V;
         mraw = p.mx[bt0 + lx - 2];
 #pragma unroll
-        for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kChainThreads < Sx) ? lr[mylab[q]] : 0.f;
+        for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kCtcThreads < Sx) ? lr[mylab[q]] : 0.f;
     }
     for (int i = 1; i < lx; ++i) {
         const int t = lx - 1 - i;
@@ -672,21 +696,21 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         double *Yn = Y + (i & 1) * Sxp;
         double em[kCtcRegs];
 #pragma unroll
-        for (int q = 0; q < kCtcRegs; ++q) em[q] = (tid + q * kChainThreads < Sx) ? exp_scaled_d(lraw[q] - mraw) : 0.0;
+        for (int q = 0; q < kCtcRegs; ++q) em[q] = (tid + q * kCtcThreads < Sx) ? exp_scaled_d(lraw[q] - mraw) : 0.0;
         if (t >= 1) {
             const float *lr = p.logp + (bt0 + t - 1) * V;
             mraw = p.mx[bt0 + t - 1];
 #pragma unroll
-            for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kChainThreads < Sx) ? lr[mylab[q]] : 0.f;
+            for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kCtcThreads < Sx) ? lr[mylab[q]] : 0.f;
         }
-        const int k = rescale_exp_d(frame_max_d(wm + (i & 1) * kChainWaves));
+        const int k = rescale_exp_d(frame_max_d(wm + (i & 1) * kCtcWaves));
         const double sc = pow2d(k);
         F += k;
         double *CBrow = p.CB + (bt0 + t) * p.Sc;
         double vmax = 0.0;
 #pragma unroll
         for (int q = 0; q < kCtcRegs; ++q) {
-            const int s = tid + q * kChainThreads;
+            const int s = tid + q * kCtcThreads;
             if (s < Sx) {
                 double a = Yc[s];
                 if (s + 1 < Sx) a += Yc[s + 1];
@@ -700,7 +724,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         }
         if (tid == 0) p.ECB[bt0 + t] = F;
         vmax = wave_max_d(vmax);
-        if (lane == 0) wm[((i + 1) & 1) * kChainWaves + wave] = vmax;
+        if (lane == 0) wm[((i + 1) & 1) * kCtcWaves + wave] = vmax;
         sync_lds();
     }
 }
@@ -1389,7 +1413,7 @@ static int launch_chain(const LossParams &p, size_t lds, hipStream_t st) {
         lds_set = lds;
     }
     prof_mark(1 + ROLE, false, st);
-    hipLaunchKernelGGL(crf_chain_kernel<ROLE>, dim3((unsigned)p.B), dim3(kChainThreads), lds, st, p);
+    hipLaunchKernelGGL(crf_chain_kernel<ROLE>, dim3((unsigned)p.B), dim3(ROLE >= 2 ? kCtcThreads : kChainThreads), lds, st, p);
     prof_mark(1 + ROLE, true, st);
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
@@ -1453,7 +1477,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     }
     if (V > kEpRegs * kChainThreads) { set_error("V > 8192 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
     const int Sc = rup64((int)(2 * (ctc ? max_label_len : 0) + 1));
-    if (ctc && 2 * max_label_len + 1 > kCtcRegs * kChainThreads) { set_error("label length > 2047 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
+    if (ctc && 2 * max_label_len + 1 > kCtcRegs * kCtcThreads) { set_error("label length > 2047 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
     const WsLayout w = ws_layout(h, B, T, V, Sc);
     if (ws_bytes < w.total) { set_error("workspace too small: need " + std::to_string(w.total)); return CRF_ERR_WORKSPACE; }
     const bool res = den && w.res;

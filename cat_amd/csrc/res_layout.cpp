@@ -94,58 +94,93 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
 
 // Step 2: put the arcs (gather indices already renumbered) into the (chunk, slot) positions of their
 // slice.  One position = ONE ds_read_b32 gather per wave, serviced in two 32-lane halves over 32 banks
-// (bank = index mod 32): the order of a row's arcs is free, so each position is filled greedily -- lanes
-// with the fewest arcs left choose first, each takes the arc whose bank is least used in its half
-// (equal index = broadcast, free).  Padding gathers broadcast the address of a real lane.
+// (bank = index mod 32, MI355X_MICROARCH.md LDS table): the order of a row's arcs is free.
+//   pass 1 (greedy): position by position, lanes with the fewest arcs left choose first, each takes the
+//           arc whose bank is least used in its half (equal index = broadcast, free);
+//   pass 2 (local search): swap two arcs of one lane between two positions whenever that lowers the
+//           number of extra bank cycles of the two positions.
+// Padding gathers (weight 0) broadcast the address of a real lane of their half.
 void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o) {
     const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
     for (const SliceAt &sl : slices) {
+        const int NI = sl.len * kResW;
         std::vector<std::vector<std::pair<int, float>>> rem(kWave);
         for (int lane = 0; lane < kWave; ++lane) if (sl.rows[lane] >= 0) rem[lane] = rows[sl.rows[lane]];
-        for (int ins = 0; ins < sl.len * kResW; ++ins) {
-            const int c = sl.c0 + ins / kResW, slot = ins % kResW;
-            int off16[kWave];
-            float wv[kWave];
-            bool real[kWave];
+        // place[ins][lane] = arc (index, weight) or index -1
+        std::vector<std::vector<std::pair<int, float>>> place(NI, std::vector<std::pair<int, float>>(kWave, {-1, 0.f}));
+        std::vector<std::vector<int>> cnt(NI, std::vector<int>(2 * 32, 0));  // lanes per (half, bank)
+        for (int ins = 0; ins < NI; ++ins)
             for (int half = 0; half < 2; ++half) {
-                int used[32], occupant[32];
-                for (int b = 0; b < 32; ++b) { used[b] = 0; occupant[b] = -1; }
+                int occupant[32];
+                for (int b = 0; b < 32; ++b) occupant[b] = -1;
                 int lanes[32];
                 for (int l = 0; l < 32; ++l) lanes[l] = half * 32 + l;
                 std::stable_sort(lanes, lanes + 32, [&](int a, int b) { return rem[a].size() < rem[b].size(); });
-                int first_real = -1;
                 for (int li = 0; li < 32; ++li) {
                     const int lane = lanes[li];
                     auto &rv = rem[lane];
-                    real[lane] = false; off16[lane] = 0; wv[lane] = 0.f;
                     if (rv.empty()) continue;
                     size_t best = 0;
                     int best_cost = 1 << 30;
                     for (size_t q = 0; q < (arrange ? rv.size() : (size_t)1); ++q) {
                         const int bank = rv[q].first & 31;
-                        const int cost = occupant[bank] == rv[q].first ? 0 : used[bank];
+                        const int cost = occupant[bank] == rv[q].first ? 0 : cnt[ins][half * 32 + bank];
                         if (cost < best_cost) { best_cost = cost; best = q; if (!cost) break; }
                     }
-                    const auto arc = rv[best];
+                    place[ins][lane] = rv[best];
+                    const int bank = rv[best].first & 31;
+                    if (occupant[bank] != rv[best].first) cnt[ins][half * 32 + bank]++;
+                    if (occupant[bank] < 0) occupant[bank] = rv[best].first;
                     rv.erase(rv.begin() + (long)best);
-                    const int bank = arc.first & 31;
-                    if (occupant[bank] != arc.first) { used[bank]++; if (occupant[bank] < 0) occupant[bank] = arc.first; }
-                    if (best_cost > 0) o->conflicts++;
-                    real[lane] = true; off16[lane] = arc.first * 4; wv[lane] = arc.second;
-                    if (first_real < 0) first_real = lane;
-                }
-                for (int l = 0; l < 32; ++l) {
-                    const int lane = half * 32 + l;
-                    if (!real[lane]) off16[lane] = first_real >= 0 ? off16[first_real] : 0;
                 }
             }
-            for (int lane = 0; lane < kWave; ++lane) {
-                const size_t t = (size_t)sl.w * kWave + lane;
-                unsigned &iw = o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + (slot >> 1)) * kResThreads + t];
-                iw |= (unsigned)(off16[lane] & 0xffff) << ((slot & 1) * 16);
-                unsigned wb;
-                memcpy(&wb, &wv[lane], 4);
-                o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + 2 + slot) * kResThreads + t] = wb;
+        if (arrange) {
+            for (int pass = 0; pass < 3; ++pass) {
+                bool any = false;
+                for (int lane = 0; lane < kWave; ++lane) {
+                    const int h = (lane >> 5) * 32;
+                    for (int i1 = 0; i1 < NI; ++i1) {
+                        if (place[i1][lane].first < 0) continue;
+                        const int b1 = place[i1][lane].first & 31;
+                        if (cnt[i1][h + b1] <= 1) continue;  // not in conflict here
+                        for (int i2 = 0; i2 < NI; ++i2) {
+                            if (i2 == i1 || place[i2][lane].first < 0) continue;
+                            const int b2 = place[i2][lane].first & 31;
+                            if (b1 == b2) continue;
+                            // extra cycles before/after the swap on the four affected (position, bank) cells
+                            auto x = [](int c) { return c > 1 ? c - 1 : 0; };
+                            const int before = x(cnt[i1][h + b1]) + x(cnt[i1][h + b2]) + x(cnt[i2][h + b1]) + x(cnt[i2][h + b2]);
+                            const int after = x(cnt[i1][h + b1] - 1) + x(cnt[i1][h + b2] + 1) + x(cnt[i2][h + b1] + 1) + x(cnt[i2][h + b2] - 1);
+                            if (after < before) {
+                                cnt[i1][h + b1]--; cnt[i1][h + b2]++; cnt[i2][h + b1]++; cnt[i2][h + b2]--;
+                                std::swap(place[i1][lane], place[i2][lane]);
+                                any = true;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (!any) break;
+            }
+        }
+        for (int ins = 0; ins < NI; ++ins) {
+            const int c = sl.c0 + ins / kResW, slot = ins % kResW;
+            for (int half = 0; half < 2; ++half) {
+                int first_real = -1;
+                for (int l = 0; l < 32; ++l) if (place[ins][half * 32 + l].first >= 0) { first_real = half * 32 + l; break; }
+                for (int b = 0; b < 32; ++b) if (cnt[ins][half * 32 + b] > 1) o->conflicts += cnt[ins][half * 32 + b] - 1;
+                for (int l = 0; l < 32; ++l) {
+                    const int lane = half * 32 + l;
+                    const bool real = place[ins][lane].first >= 0;
+                    const int off16 = real ? place[ins][lane].first * 4 : (first_real >= 0 ? place[ins][first_real].first * 4 : 0);
+                    const float wv = real ? place[ins][lane].second : 0.f;
+                    const size_t t = (size_t)sl.w * kWave + lane;
+                    unsigned &iw = o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + (slot >> 1)) * kResThreads + t];
+                    iw |= (unsigned)(off16 & 0xffff) << ((slot & 1) * 16);
+                    unsigned wb;
+                    memcpy(&wb, &wv, 4);
+                    o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + 2 + slot) * kResThreads + t] = wb;
+                }
             }
             o->slots += kWave;
         }
