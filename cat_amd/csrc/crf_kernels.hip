@@ -65,6 +65,8 @@ struct LossParams {
     int *cb_F;                    // [B]
     int *err;                     // [1] set if an exchange timed out
     float *Row0;                  // [B][Rb] spare rows (b_0 of the resident backward recursion)
+    float *gvec;                  // streaming kernels, graphs too large for LDS: [B][3*Sp + 4*Pr] state vectors in global memory
+    int grad_stage;               // crf_grad_kernel: 1 = stage the Q / BP rows in LDS, 0 = gather them from global memory
     int *EQ, *EB;                 // [B*T] their binary exponents
     double *CA, *CB;              // [B*T*Sc] ctc forward (incl. emission) / backward (excl.)  (scaled, fp64)
     int *ECA, *ECB;
@@ -291,14 +293,21 @@ __host__ __device__ inline int rup64(int x) { return (x + 63) & ~63; }
 // ---------------------------------------------------------------------------------------------
 // denominator forward.  LDS: X[3][Sp] | EP[2][Vp] | wmax[2][16] | red (16 doubles)
 // ---------------------------------------------------------------------------------------------
+// GV = true: the state vectors live in global memory (L2) instead of LDS -- the fallback for graphs whose
+// vectors exceed the 160 KiB of a CU.  Same code; gathers become L2 hits, the frame barrier also drains vmcnt.
+template <bool GV>
+__device__ __forceinline__ void chain_sync() {
+    if (GV) __syncthreads(); else sync_lds();
+}
+template <bool GV>
 __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *lds) {
     const GraphDev &g = p.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = g.S, V = p.V, Pr = g.Pr, lx = p.lx[b];
     const int Sp = rup64(S), Vp = rup64(V);
-    float *X = lds;
-    float *EP = X + 3 * Sp;
+    float *X = GV ? p.gvec + (size_t)b * (3 * (size_t)Sp + 4 * (size_t)Pr) : lds;
+    float *EP = GV ? lds : X + 3 * Sp;
     float *wm = EP + 2 * Vp;
     double *red = (double *)(wm + 2 * kChainWaves);
     const int64_t bt0 = (int64_t)b * p.T;
@@ -327,7 +336,7 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
         for (int s = tid; s < S; s += kChainThreads) m = fmaxf(m, Xc[s]);
         m = wave_max(m);
         if (lane == 0) wm[(t & 1) * kChainWaves + wave] = m;
-        sync_lds();
+        chain_sync<GV>();
         const int k = rescale_exp(frame_max(wm + (t & 1) * kChainWaves));
         const float sc = pow2f(k);
         E += k;                       // exponent of q_t
@@ -356,7 +365,7 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
                 if (v < V) EPn[v] = epn[i];
             }
         }
-        sync_lds();
+        chain_sync<GV>();
     }
     const float *Xf = X + (lx % 3) * Sp;
     float part = 0.f;
@@ -374,15 +383,16 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
 // denominator backward.  LDS: Z[2][Pr] | BPst[2][Pr] | EP[2][Vp] | wmax[2][16] | red
 // iteration i handles frame t = lx-1-i:  b_t[s] = sc * sum_k w_k * Z[cur][pair_k]
 // ---------------------------------------------------------------------------------------------
+template <bool GV>
 __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *lds) {
     const GraphDev &g = p.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = g.S, V = p.V, Pr = g.Pr, lx = p.lx[b];
     const int Vp = rup64(V);
-    float *Z = lds;
+    float *Z = GV ? p.gvec + (size_t)b * (3 * (size_t)rup64(S) + 4 * (size_t)Pr) + 3 * (size_t)rup64(S) : lds;
     float *BPst = Z + 2 * Pr;
-    float *EP = BPst + 2 * Pr;
+    float *EP = GV ? lds : BPst + 2 * Pr;
     float *wm = EP + 2 * Vp;
     double *red = (double *)(wm + 2 * kChainWaves);
     const int64_t bt0 = (int64_t)b * p.T;
@@ -435,7 +445,7 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
             for (int r = tid; r < Pr; r += kChainThreads) BProw[r] = BPp[r];
             if (tid == 0) p.EB[bt0 + t] = F;
         }
-        sync_lds();
+        chain_sync<GV>();
         const int k = rescale_exp(frame_max(wm + (i & 1) * kChainWaves));
         const float sc = pow2f(k);
         F += k + kEpExp;              // Z_t = e'_t b_{t+1} carries the 2^kEpExp of e'_t
@@ -469,7 +479,7 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
                 if (v < V) EPw[v] = epn[q];
             }
         }
-        sync_lds();
+        chain_sync<GV>();
     }
     const float zb = block_sum(zpart, (float *)red, tid);
     const double mxs = mx_total(p, b, lx, red, tid);
@@ -1088,12 +1098,12 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
 
 // One kernel per recursion so each keeps its own (small) set of live kernel arguments in SGPRs; the
 // four launches are issued on forked HIP streams and run concurrently (crf_loss_fwd_bwd).
-template <int ROLE>
+template <int ROLE, bool GV = false>
 __global__ __launch_bounds__(kChainThreads) void crf_chain_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = (int)blockIdx.x;
-    if (ROLE == 0) den_forward(p, b, lds);
-    else if (ROLE == 1) den_backward(p, b, lds);
+    if (ROLE == 0) den_forward<GV>(p, b, lds);
+    else if (ROLE == 1) den_backward<GV>(p, b, lds);
     else if (ROLE == 2) ctc_forward(p, b, lds);
     else ctc_backward(p, b, lds);
 }
@@ -1111,9 +1121,10 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
     const bool do_den = p.c_den != 0.f && p.grad_phase != 2, do_ctc = p.c_ctc != 0.f && p.grad_phase != 1;
     const bool accumulate = p.grad_phase == 2;
     const int Rq = do_den ? p.Rq : 0, Rb = do_den ? p.Rb : 0, NC = do_den ? p.gNC : 0;
-    float *Qs = lds;               // [Rq] staged q_t row
-    float *Bs = Qs + rup64(Rq);    // [Rb] staged b_{t+1} row
-    float *csum = Bs + rup64(Rb);
+    const bool stage = p.grad_stage != 0;
+    float *Qs = lds;                              // [Rq] staged q_t row       (when the rows fit in LDS)
+    float *Bs = Qs + (stage ? rup64(Rq) : 0);     // [Rb] staged b_{t+1} row
+    float *csum = Bs + (stage ? rup64(Rb) : 0);
     float *gd = csum + rup64(NC);
     float *gc = gd + Vp;
     const int64_t bt0 = (int64_t)b * p.T;
@@ -1136,12 +1147,15 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
         }
         if (do_den) {
             const float *Qr = p.Q + (bt0 + t) * Rq, *Br = p.BP + (bt0 + t) * Rb;
-            for (int r = tid; r < Rq; r += kGradThreads) Qs[r] = Qr[r];
-            for (int r = tid; r < Rb; r += kGradThreads) Bs[r] = Br[r];
-            __syncthreads();
+            if (stage) {
+                for (int r = tid; r < Rq; r += kGradThreads) Qs[r] = Qr[r];
+                for (int r = tid; r < Rb; r += kGradThreads) Bs[r] = Br[r];
+                __syncthreads();
+            }
+            const float *Qg = stage ? Qs : Qr, *Bg = stage ? Bs : Br;
             for (int c = tid; c < NC; c += kGradThreads) {
                 float s = 0.f;
-                for (int j = p.gchunk[c]; j < p.gchunk[c + 1]; ++j) s += Qs[p.gq[j]] * Bs[p.gb[j]];
+                for (int j = p.gchunk[c]; j < p.gchunk[c + 1]; ++j) s += Qg[p.gq[j]] * Bg[p.gb[j]];
                 csum[c] = s;
             }
             __syncthreads();
@@ -1300,7 +1314,8 @@ struct WsLayout {
     int64_t off_ep, off_mx, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_xch, off_row0, total;
     int64_t xch_bytes;
     int64_t Rq, Rb;
-    bool res;
+    bool res, gv;
+    int64_t off_gvec;
 };
 static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -1331,6 +1346,8 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.xch_bytes = (w.res && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8) : 0;
     w.off_xch = o; o = al(o + w.xch_bytes + 256);
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
+    w.gv = h && !w.res && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
+    w.off_gvec = o; o = al(o + (w.gv ? B * (3 * (int64_t)rup64(h->dev.S) + 4 * (int64_t)h->dev.Pr) * 4 : 0));
     w.total = o;
     return w;
 }
@@ -1341,11 +1358,11 @@ static size_t res_lds_bytes(const HostGraph *h, int V, int dir, int rows_cu_max)
     return (size_t)2 * kResXB + ((size_t)rows_cu_max * 4 + 2 * (size_t)rup64(V) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
 }
 
-static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role) {
+static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role, bool gv = false) {
     const size_t tail = 2 * kChainWaves + 2 * kChainWaves + 16;  // wmax + 16 doubles + slack
     size_t fl;
-    if (role == 0) fl = (size_t)3 * rup64(h->dev.S) + 2 * rup64(V) + tail;
-    else if (role == 1) fl = (size_t)4 * h->dev.Pr + 2 * rup64(V) + tail;
+    if (role == 0) fl = (gv ? 0 : (size_t)3 * rup64(h->dev.S)) + 2 * rup64(V) + tail;
+    else if (role == 1) fl = (gv ? 0 : (size_t)4 * h->dev.Pr) + 2 * rup64(V) + tail;
     else fl = (size_t)2 * (2 * Sc + 3 * kChainWaves) + Sc + 16;  // doubles counted as 2 floats
     return fl * sizeof(float);
 }
@@ -1401,19 +1418,19 @@ static void prof_mark(int slot, bool stop, hipStream_t st) {
     g_prof.used[slot] = true;
 }
 
-template <int ROLE>
+template <int ROLE, bool GV = false>
 static int launch_chain(const LossParams &p, size_t lds, hipStream_t st) {
     static std::atomic<size_t> lds_set{0};  // dynamic LDS above 64 KiB must be opted into; only raised
     hipError_t e;
     if (lds > lds_set.load()) {
-        if ((e = hipFuncSetAttribute((const void *)crf_chain_kernel<ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
+        if ((e = hipFuncSetAttribute((const void *)crf_chain_kernel<ROLE, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
             set_error(std::string("hipFuncSetAttribute(chain): ") + hipGetErrorString(e));
             return CRF_ERR_HIP;
         }
         lds_set = lds;
     }
     prof_mark(1 + ROLE, false, st);
-    hipLaunchKernelGGL(crf_chain_kernel<ROLE>, dim3((unsigned)p.B), dim3(ROLE >= 2 ? kCtcThreads : kChainThreads), lds, st, p);
+    hipLaunchKernelGGL((crf_chain_kernel<ROLE, GV>), dim3((unsigned)p.B), dim3(ROLE >= 2 ? kCtcThreads : kChainThreads), lds, st, p);
     prof_mark(1 + ROLE, true, st);
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
@@ -1480,14 +1497,17 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     if (ctc && 2 * max_label_len + 1 > kCtcRegs * kCtcThreads) { set_error("label length > 2047 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
     const WsLayout w = ws_layout(h, B, T, V, Sc);
     if (ws_bytes < w.total) { set_error("workspace too small: need " + std::to_string(w.total)); return CRF_ERR_WORKSPACE; }
-    const bool res = den && w.res;
+    const bool res = den && w.res, gv = den && w.gv;
     size_t lds_chain = 0;
-    if (den && !res) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0), chain_lds_bytes(h, (int)V, Sc, 1));
+    if (den && !res) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0, gv), chain_lds_bytes(h, (int)V, Sc, 1, gv));
     if (res) lds_chain = std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b));
     if (ctc) lds_chain = std::max(lds_chain, chain_lds_bytes(h, (int)V, Sc, 2));
-    const size_t lds_grad = ((den ? (size_t)rup64((int)w.Rq) + rup64((int)w.Rb) + rup64(std::max(h->dev.NC, h->dev.res.NC)) : 0) + 2 * (size_t)rup64((int)V)) * sizeof(float);
+    const int gnc_all = den ? std::max(h->dev.NC, h->dev.res.NC) : 0;
+    // the generic grad kernel stages the two rows of a frame in LDS when they fit, else gathers them from L2
+    const bool grad_stage = !den || ((size_t)rup64((int)w.Rq) + rup64((int)w.Rb) + rup64(gnc_all) + 2 * (size_t)rup64((int)V)) * 4 <= 150 * 1024;
+    const size_t lds_grad = ((den && grad_stage ? (size_t)rup64((int)w.Rq) + rup64((int)w.Rb) : 0) + rup64(gnc_all) + 2 * (size_t)rup64((int)V)) * sizeof(float);
     if (lds_chain > 160 * 1024 || lds_grad > 160 * 1024) {
-        set_error("graph too large for the LDS-resident kernels of this build (states=" + std::to_string(h ? h->S : 0) + ")");
+        set_error("graph too large for this build (states=" + std::to_string(h ? h->S : 0) + ")");
         return CRF_ERR_UNSUPPORTED;
     }
 
@@ -1499,7 +1519,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     char *base = (char *)ws;
     p.ep = (float *)(base + w.off_ep); p.mx = (float *)(base + w.off_mx);
     p.Q = (float *)(base + w.off_Q); p.BP = (float *)(base + w.off_BP);
-    p.Rq = (int)w.Rq; p.Rb = (int)w.Rb; p.res = res ? 1 : 0;
+    p.Rq = (int)w.Rq; p.Rb = (int)w.Rb; p.res = res ? 1 : 0; p.grad_stage = grad_stage ? 1 : 0;
     if (den) {
         p.gq = res ? h->dev.res.gq : h->dev.perm; p.gb = res ? h->dev.res.gb : h->dev.perm;
         p.gchunk = res ? h->dev.res.chunk_off : h->dev.chunk_off; p.glab = res ? h->dev.res.lab_chunk_off : h->dev.lab_chunk_off;
@@ -1516,6 +1536,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     p.xch = (unsigned long long *)(base + w.off_xch);
     p.err = (int *)(base + w.off_xch + w.xch_bytes);
     p.Row0 = (float *)(base + w.off_row0);
+    p.gvec = (float *)(base + w.off_gvec);
     p.den_zs = pb; p.den_ez = (int *)(pb + B); p.ctc_ez = (int *)(pb + 2 * B);
     p.cost_alpha = pb + 3 * B; p.cost_beta = pb + 4 * B; p.cost_ctc = pb + 5 * B; p.invalid = (int *)(pb + 6 * B);
     p.grad = grad; p.loss = loss; p.out_den = costs_den; p.out_beta = costs_beta; p.out_ctc = costs_ctc;
@@ -1578,6 +1599,9 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         }
         prof_mark(1, true, stream);
         prof_mark(2, true, sb);
+    } else if (den && gv) {
+        if ((rc = launch_chain<0, true>(p, chain_lds_bytes(h, (int)V, Sc, 0, true), stream))) return rc;
+        if ((rc = launch_chain<1, true>(p, chain_lds_bytes(h, (int)V, Sc, 1, true), side(0)))) return rc;
     } else if (den) {
         if ((rc = launch_chain<0>(p, chain_lds_bytes(h, (int)V, Sc, 0), stream))) return rc;
         if ((rc = launch_chain<1>(p, chain_lds_bytes(h, (int)V, Sc, 1), side(0)))) return rc;

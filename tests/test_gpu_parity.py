@@ -274,6 +274,21 @@ def test_full_size_invariants(crf, default_graph):
     del ctx
 
 
+def test_large_graph_global_vectors(crf, tmp_path):
+    """A den_lm whose state vectors exceed a CU's LDS (S = 20 001 states, ~200 k arcs): neither the
+    register-resident nor the LDS streaming kernels apply, the recursions keep their vectors in L2."""
+    from cat_amd.den_lm import synth_den_lm
+    p = os.path.join(str(tmp_path), "big.fst")
+    g = synth_den_lm(72, 10000, 8, seed=3, path=p)
+    logits, labels, lx, ly = make_batch(g, 2, 40, 72, seed=9, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
+    st = crf._C.compile_graph_host_only(p)
+    assert crf._C.graph_stats(st)["S"] == 20001
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
 def _ref_den(p, logits, lx):
     """The reference's own kernels (den_calculate.cu, compiled for gfx950 into oracle/_ref)."""
     so = os.path.join(os.path.dirname(oracle.__file__), "_ref", "libden_ref.so")
