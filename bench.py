@@ -161,6 +161,16 @@ def main():
                         "frac_of_peak": round((bytes_den + bytes_num) / (kern_ms.get("call", 1e9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
     }
 
+    # secondary ceilings: arc evaluations and the 2T-step dependency chain bind before HBM does
+    arc_evals = 2 * int(np.asarray(lx, dtype=np.int64).sum()) * dims["A"]
+    roofline["ceilings"] = {
+        "arc_evals_per_step": arc_evals,
+        "arc_evals_per_s": round(arc_evals / (max(kern_ms.get("den_fwd_chain", 0), kern_ms.get("den_bwd_chain", 0)) * 1e-3)),
+        "dependent_frames": 2 * int(max(lx)),
+        "us_per_frame_den_fwd": round(kern_ms.get("den_fwd_chain", 0) * 1e3 / max(1, int(max(lx))), 3),
+        "arc_stream_bytes_reference_style": 2 * B * int(max(lx)) * dims["A"] * 12,
+    }
+
     # --- optional: the same step behind a DDP stand-in acoustic head (N > 1 only) -------------
     ddp_info = None
     if world > 1:

@@ -821,9 +821,10 @@ __device__ __forceinline__ float res_fetch(gu64 *slot, float *v, int lo, int hi,
             if (!pending) break;
             // a peer died or was never scheduled: give up loudly (error word -> NaN loss), never hang;
             // once the word is set nobody waits again
-            if (spins > (1u << 20)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (spins > (1u << 24)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // ~tens of seconds
             if ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            if (spins > 2) __builtin_amdgcn_s_sleep(1);
+            if (spins > 64) __builtin_amdgcn_s_sleep(8);  // back off when the peer is clearly not there yet
+            else if (spins > 2) __builtin_amdgcn_s_sleep(1);
         }
     }
     return mx;
