@@ -50,13 +50,13 @@ constexpr int kResMaxK = 4;
 struct ResDirDev {
     const unsigned *arcs;    // [K][kResWords][kResThreads]
     const uint4 *wave_info;  // [K][kResWaves] {slice-end mask, chunks used, first row id, unused}
-    const int4 *row_meta;    // [R] fwd {x index of dst state | -1 pad, label, 0, 0}
-                             //     bwd {#pairs into the state | -1 pad, first z index, its label, csr begin}
+    const int *row_lab;      // [R] label whose emission scales the row's result (fwd: the pair's label; bwd: the
+                             //     label of the pair the row produces z for); V (= "emission 0") for rows that
+                             //     produce nothing.  The gather entry a row produces is IMPLICIT:
+                             //     own_off[k] + (row id - cu_row_off[k]) -- every row, padding included, owns one.
     const int *cu_row_off;   // [K+1] row-id range of each CU
     const int *own_off;      // [K+1] range of gather-vector indices PRODUCED by each CU
-    const int *ex_cnt;       // [2K] per CU: [k] entries with a single contributing row (numbered first),
-                             //       [K+k] entries summed from several rows (next); the rest have no producer
-    int has_nx;              // some entry is summed from several (sub-)rows (LDS atomics, published after the barrier)
+    const int *ex_cnt;       // [2K] per CU: [k] produced (= exchanged) entries = its rows; [K+k] unused
     int R;                   // rows incl. padding = row stride of the per-frame HBM store
     int G;                   // gather-vector length (fwd: states, bwd: pairs)
 };

@@ -38,6 +38,7 @@ namespace crf {
 constexpr int kEpRegs = 8;    // ep row prefetch registers per thread  -> V  <= 8 * 1024
 constexpr int kCtcThreads = 512, kCtcWaves = kCtcThreads / 64;  // numerator chains: 8 waves (S' = 2L+1 is a few hundred)
 constexpr int kCtcRegs = 8;   // ctc states per thread                  -> 2L+1 <= 8 * 512
+constexpr int kCtcPF = 4;     // frames per emission prefetch batch (ctc_forward)
 constexpr int kGradThreads = 256;
 constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
 
@@ -150,6 +151,16 @@ __device__ __forceinline__ double exp_scaled_d(float d) {
 __device__ __forceinline__ void sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+// In-kernel phase timing for diagnosis (build with CRF_BUILD_DEFS=-DCRF_TIMING; tools/timing_probe.py):
+// one chosen workgroup stamps s_memtime (shader cycles) at phase boundaries into g_tm, read back with
+// crf_timing_read().  Compiled out of the product build.
+#ifdef CRF_TIMING
+__device__ unsigned long long g_tm[16384];
+#define CRF_TM(on, idx) do { if (on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) g_tm[(idx)] = t_; } } while (0)
+#else
+#define CRF_TM(on, idx) do { } while (0)
+#endif
 
 // exact power-of-two rescale that brings m into [2^kScaleExp, 2^(kScaleExp+1))
 __device__ __forceinline__ int rescale_exp(float m) {
@@ -548,6 +559,10 @@ __device__ __forceinline__ float to_log_d(double zs, int e, double mxs) {
     return zs > 0.0 ? (float)(log(zs) - (double)e * 0.6931471805599453 + mxs) : -INFINITY;
 }
 
+// NR = ctc states per thread actually needed (ceil((2L+1)/512) rounded up to 1, 2, 4, 8): a frame is ONE
+// in-order instruction stream per wave (~5 cycles per instruction, dependent or not), so the predicated-off
+// register iterations of a fixed NR = 8 were most of a frame's ~440 instructions for ordinary label lengths.
+template <int NR>
 __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -564,10 +579,10 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         }
         return;
     }
-    int mylab[kCtcRegs];
-    bool skip[kCtcRegs];
+    int mylab[NR];
+    bool skip[NR];
 #pragma unroll
-    for (int i = 0; i < kCtcRegs; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int s = tid + i * kCtcThreads;
         mylab[i] = s < Sx ? lab[s] : 0;
         skip[i] = s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2];
@@ -581,7 +596,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         double *CArow = p.CA + bt0 * p.Sc;
         double vmax = 0.0;
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
                 const double v = (s < 2 && s < Sx) ? exp_scaled_d(lr[mylab[i]] - m0) * pow2d(kScaleExpD) : 0.0;
@@ -596,33 +611,56 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         if (lane == 0) wm[kCtcWaves + wave] = vmax;  // wm[t & 1] is read by frame t: slot 1 for t = 1
     }
     __syncthreads();
-    // emissions are fetched one frame ahead (an L2 round trip is ~1 us, longer than a whole frame)
-    float lraw[kCtcRegs], mraw = 0.f;
-    if (lx > 1) {
-        const float *lr = p.logp + (bt0 + 1) * V;
-        mraw = p.mx[bt0 + 1];
+    // Emissions are fetched in BATCHES of kCtcPF frames into two alternating register sets.  A gather from
+    // L2/HBM takes ~1 us, a frame ~0.5 us, and vmcnt counts in order: with branches around the (Sx-
+    // dependent) loads and stores the compiler cannot count what is younger than a prefetch and waits
+    // vmcnt(0) -- i.e. for everything issued up to the previous frame, which ties the frame time to the
+    // memory latency.  Batching leaves ONE such wait per kCtcPF frames, for loads issued kCtcPF frames ago.
+    // The row maximum is read through a per-lane (VGPR) address: as a scalar load it would be counted by
+    // lgkmcnt and the per-frame LDS barrier would wait for it.
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    float lr[2][kCtcPF][NR], mr[2][kCtcPF];
+    auto fetch1 = [&](auto SET, auto F, int t) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value, f = decltype(F)::value;
+        if (t < lx) {
+            const float *row = p.logp + (bt0 + t) * V;
+            mr[st][f] = p.mx[bt0 + t + vz];
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kCtcThreads < Sx) ? lr[mylab[i]] : 0.f;
-    }
-    for (int t = 1; t < lx; ++t) {
+            for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? row[mylab[i]] : 0.f;
+        }
+    };
+    auto fetch4 = [&](auto SET, int t) __attribute__((always_inline)) {
+        fetch1(SET, std::integral_constant<int, 0>{}, t);
+        fetch1(SET, std::integral_constant<int, 1>{}, t + 1);
+        fetch1(SET, std::integral_constant<int, 2>{}, t + 2);
+        fetch1(SET, std::integral_constant<int, 3>{}, t + 3);
+    };
+    static_assert(kCtcPF == 4, "fetch4 / the frame loop are written for batches of four");
+    auto step = [&](auto SET, auto F, int t) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value, f = decltype(F)::value;
         const double *Ac = A + ((t - 1) & 1) * Sxp;
         double *An = A + (t & 1) * Sxp;
-        double em[kCtcRegs];
+        double em[NR];
+        const bool tm_on = b == 3 && t >= 100 && t < 228 && wave == 0;
+        const int tm_i = 14336 + (t - 100) * 8;
+        CRF_TM(tm_on, tm_i + 0);
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) em[i] = (tid + i * kCtcThreads < Sx) ? exp_scaled_d(lraw[i] - mraw) : 0.0;
-        if (t + 1 < lx) {
-            const float *lr = p.logp + (bt0 + t + 1) * V;
-            mraw = p.mx[bt0 + t + 1];
-#pragma unroll
-            for (int i = 0; i < kCtcRegs; ++i) lraw[i] = (tid + i * kCtcThreads < Sx) ? lr[mylab[i]] : 0.f;
+        for (int i = 0; i < NR; ++i) {
+            float x = lr[st][f][i] - mr[st][f];
+            asm volatile("" : "+v"(x));  // keeps the fp64 exp of LATER frames of the batch from being hoisted up here (VGPRs)
+            em[i] = (tid + i * kCtcThreads < Sx) ? exp_scaled_d(x) : 0.0;
         }
+        CRF_TM(tm_on, tm_i + 1);
+        if (f == 0) fetch4(std::integral_constant<int, 1 - st>{}, t + kCtcPF);  // after this batch has landed
+        CRF_TM(tm_on, tm_i + 2);
         const int k = rescale_exp_d(frame_max_d(wm + (t & 1) * kCtcWaves));
         const double sc = pow2d(k);
         E += k;
         double *CArow = p.CA + (bt0 + t) * p.Sc;
         double vmax = 0.0;
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int s = tid + i * kCtcThreads;
             if (s < Sx) {
                 double a = Ac[s];
@@ -634,10 +672,28 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
                 vmax = fmax(vmax, v);
             }
         }
+        CRF_TM(tm_on, tm_i + 3);
         if (tid == 0) p.ECA[bt0 + t] = E;
         vmax = wave_max_d(vmax);
         if (lane == 0) wm[((t + 1) & 1) * kCtcWaves + wave] = vmax;
+        CRF_TM(tm_on, tm_i + 4);
         sync_lds();
+        CRF_TM(tm_on, tm_i + 5);
+    };
+    {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        fetch4(I0{}, 1);
+        for (int t = 1; t < lx; t += 2 * kCtcPF) {
+            step(I0{}, I0{}, t);
+            if (t + 1 < lx) step(I0{}, I1{}, t + 1);
+            if (t + 2 < lx) step(I0{}, I2{}, t + 2);
+            if (t + 3 < lx) step(I0{}, I3{}, t + 3);
+            if (t + 4 < lx) step(I1{}, I0{}, t + 4);
+            if (t + 5 < lx) step(I1{}, I1{}, t + 5);
+            if (t + 6 < lx) step(I1{}, I2{}, t + 6);
+            if (t + 7 < lx) step(I1{}, I3{}, t + 7);
+        }
     }
     const double *Af = A + ((lx - 1) & 1) * Sxp;
     const double mxs = ctc_mx_total(p, b, lx, c.red, tid);
@@ -653,6 +709,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
 
 // backward, EXCLUDING the emission at t:  Bx_t[s] = sum_{s' in {s,s+1,s+2*}} e_{t+1}[l'_s'] Bx_{t+1}[s']
 // LDS holds Y_t[s] = e_t[l'_s] * Bx_t[s]; Bx_t itself only goes to HBM (CB).
+template <int NR>
 __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -662,22 +719,22 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     const int *lab = c.lab;
     const int64_t bt0 = (int64_t)b * p.T;
     if (!ctc_setup(p, b, c, L, lx, tid)) return;
-    int mylab[kCtcRegs];
-    bool skip[kCtcRegs];
+    int mylab[NR];
+    bool skip[NR];
 #pragma unroll
-    for (int i = 0; i < kCtcRegs; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int s = tid + i * kCtcThreads;
         mylab[i] = s < Sx ? lab[s] : 0;
         skip[i] = (s + 2 < Sx) && lab[s + 2] != 0 && lab[s + 2] != mylab[i];
     }
-    int F = kScaleExpD;
+    int F_ = kScaleExpD;
     {   // t = lx-1
         const float *lr = p.logp + (bt0 + lx - 1) * V;
         const float ml = p.mx[bt0 + lx - 1];
         double *CBrow = p.CB + (bt0 + lx - 1) * p.Sc;
         double vmax = 0.0;
 #pragma unroll
-        for (int i = 0; i < kCtcRegs; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
                 const double bx = (s < Sx && s >= Sx - 2) ? pow2d(kScaleExpD) : 0.0;
@@ -688,38 +745,51 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
                 vmax = fmax(vmax, y);
             }
         }
-        if (tid == 0) p.ECB[bt0 + lx - 1] = F;
+        if (tid == 0) p.ECB[bt0 + lx - 1] = F_;
         vmax = wave_max_d(vmax);
         if (lane == 0) wm[kCtcWaves + wave] = vmax;  // read by iteration i = 1
     }
     __syncthreads();
-    float lraw[kCtcRegs], mraw = 0.f;
-    if (lx > 1) {
-        const float *lr = p.logp + (bt0 + lx - 2) * V;
-        mraw = p.mx[bt0 + lx - 2];
+    // emissions in batches of kCtcPF frames, as in ctc_forward
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    float lr[2][kCtcPF][NR], mr[2][kCtcPF];
+    auto fetch1 = [&](auto SET, auto F, int t) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value, f = decltype(F)::value;
+        if (t >= 0) {
+            const float *row = p.logp + (bt0 + t) * V;
+            mr[st][f] = p.mx[bt0 + t + vz];
 #pragma unroll
-        for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kCtcThreads < Sx) ? lr[mylab[q]] : 0.f;
-    }
-    for (int i = 1; i < lx; ++i) {
+            for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? row[mylab[q]] : 0.f;
+        }
+    };
+    auto fetch4 = [&](auto SET, int t) __attribute__((always_inline)) {  // frames t, t-1, t-2, t-3
+        fetch1(SET, std::integral_constant<int, 0>{}, t);
+        fetch1(SET, std::integral_constant<int, 1>{}, t - 1);
+        fetch1(SET, std::integral_constant<int, 2>{}, t - 2);
+        fetch1(SET, std::integral_constant<int, 3>{}, t - 3);
+    };
+    // iteration i handles frame t = lx-1-i with the emissions of frame t
+    auto step = [&](auto SET, auto F, int i) __attribute__((always_inline)) {
+        constexpr int st = decltype(SET)::value, f = decltype(F)::value;
         const int t = lx - 1 - i;
         const double *Yc = Y + ((i - 1) & 1) * Sxp;
         double *Yn = Y + (i & 1) * Sxp;
-        double em[kCtcRegs];
+        double em[NR];
 #pragma unroll
-        for (int q = 0; q < kCtcRegs; ++q) em[q] = (tid + q * kCtcThreads < Sx) ? exp_scaled_d(lraw[q] - mraw) : 0.0;
-        if (t >= 1) {
-            const float *lr = p.logp + (bt0 + t - 1) * V;
-            mraw = p.mx[bt0 + t - 1];
-#pragma unroll
-            for (int q = 0; q < kCtcRegs; ++q) lraw[q] = (tid + q * kCtcThreads < Sx) ? lr[mylab[q]] : 0.f;
+        for (int q = 0; q < NR; ++q) {
+            float x = lr[st][f][q] - mr[st][f];
+            asm volatile("" : "+v"(x));
+            em[q] = (tid + q * kCtcThreads < Sx) ? exp_scaled_d(x) : 0.0;
         }
+        if (f == 0) fetch4(std::integral_constant<int, 1 - st>{}, t - kCtcPF);
         const int k = rescale_exp_d(frame_max_d(wm + (i & 1) * kCtcWaves));
         const double sc = pow2d(k);
-        F += k;
+        F_ += k;
         double *CBrow = p.CB + (bt0 + t) * p.Sc;
         double vmax = 0.0;
 #pragma unroll
-        for (int q = 0; q < kCtcRegs; ++q) {
+        for (int q = 0; q < NR; ++q) {
             const int s = tid + q * kCtcThreads;
             if (s < Sx) {
                 double a = Yc[s];
@@ -732,10 +802,25 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
                 vmax = fmax(vmax, y);
             }
         }
-        if (tid == 0) p.ECB[bt0 + t] = F;
+        if (tid == 0) p.ECB[bt0 + t] = F_;
         vmax = wave_max_d(vmax);
         if (lane == 0) wm[((i + 1) & 1) * kCtcWaves + wave] = vmax;
         sync_lds();
+    };
+    {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        fetch4(I0{}, lx - 2);
+        for (int i = 1; i < lx; i += 2 * kCtcPF) {
+            step(I0{}, I0{}, i);
+            if (i + 1 < lx) step(I0{}, I1{}, i + 1);
+            if (i + 2 < lx) step(I0{}, I2{}, i + 2);
+            if (i + 3 < lx) step(I0{}, I3{}, i + 3);
+            if (i + 4 < lx) step(I1{}, I0{}, i + 4);
+            if (i + 5 < lx) step(I1{}, I1{}, i + 5);
+            if (i + 6 < lx) step(I1{}, I2{}, i + 6);
+            if (i + 7 < lx) step(I1{}, I3{}, i + 7);
+        }
     }
 }
 
@@ -876,10 +961,9 @@ struct ResParams {
     int *cb_F;
 };
 
-// LDS map of the resident kernels: the two state-vector buffers sit at FIXED byte offsets 0 and
-// kResXB so that, with the frame loop unrolled by two, every gather is `ds_read_b32 v, off16
-// offset:<buffer base>` -- the 16-bit offset extracted from the packed arc word is the whole address
-// computation (one VALU per arc besides the FMA).
+// LDS map of the resident kernels: the two state-vector buffers sit at byte offsets 0 and kResXB; a gather
+// is `ds_read_b32 v, (buffer base SGPR + 16-bit offset from the packed arc word)` -- one VALU (an SDWA add)
+// per arc besides the FMA.
 constexpr int kResXB = 32768;                 // bytes per state-vector buffer  -> gather vector <= 8192 entries
 constexpr int kResGmax = kResXB / 4;
 
@@ -900,14 +984,15 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
         else { const int y = x - full; k = y % K; b = p.b0 + full / K + y / K; }
     }
     const int V = p.V, lx = p.lx[b], G = L.G;
-    const int Vp = rup64(V);
+    const int Vp = rup64(V + 1);                             // emissions + a zero at [V] for rows that produce nothing
     const int64_t bt0 = (int64_t)b * p.T;
     const int rows_cu_max = p.rows_cu_max;
     float *X = lds;                                          // [2][kResGmax]: ping-pong state vectors
-    int4 *RM = (int4 *)((char *)lds + 2 * kResXB);           // [rows_cu_max] row metadata of this CU
-    float *EP = (float *)(RM + rows_cu_max);                 // [2][Vp]
+    int *RL = (int *)((char *)lds + 2 * kResXB);             // [rows_cu_max] emission index (label) of this CU's rows
+    float *EP = (float *)(RL + rows_cu_max);                 // [2][Vp]
     float *wm = EP + 2 * Vp;                                 // [2][kResWaves] per-wave maxima of the next vector
     double *red = (double *)(wm + 2 * kResWaves);            // [kResWaves]
+    int *PL = (int *)(red + kResWaves);                      // [2 * (kResMaxK - 1)] entry ranges of the peers
 
     // ---- one-time: arcs -> registers, row metadata -> LDS
     unsigned A[kResWords];
@@ -921,7 +1006,9 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
     const int nch = __builtin_amdgcn_readfirstlane(wi.y);
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
     const int cu_row0 = L.cu_row_off[k], cu_rows = L.cu_row_off[k + 1] - cu_row0;
-    for (int r = tid; r < cu_rows; r += kResThreads) RM[r] = L.row_meta[cu_row0 + r];
+    const int own0 = __builtin_amdgcn_readfirstlane(L.own_off[k]);  // first gather entry produced by this CU
+    for (int r = tid; r < cu_rows; r += kResThreads) { const int l = L.row_lab[cu_row0 + r]; RL[r] = l < 0 ? V : l; }
+    if (tid < 2) EP[tid * Vp + V] = 0.f;
     // forward slots first ([B][2][Gf]), backward slots ([B][2][Gb]) after them
     gu64 *xch = (gu64 *)(p.xch + (DIR == 0 ? 0 : (size_t)p.B * 2 * (size_t)p.Gf) + (size_t)b * 2 * (size_t)G);
     int E = kScaleExp;
@@ -977,11 +1064,33 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
         static_assert(kResMaxK <= kWave, "peer ids are read by the first K threads");
     }
 
-    // one frame; PAR = parity of i = which buffer is the gather source (compile-time -> immediate offsets)
-    auto frame = [&](auto PAR, int i) __attribute__((always_inline)) {
-        constexpr int par = decltype(PAR)::value;
+    // Ranges of the gather vector produced by each peer: loop-invariant, but read through a pointer, so
+    // inside the frame loop (whose barriers and publishes clobber memory) the compiler re-loaded them from
+    // global memory in every frame and waited vmcnt(0) twice.  They live in LDS (a few words; keeping them
+    // in registers unrolls the peer loop three times, and this kernel's code has to stay small: the 64 KiB
+    // instruction cache is shared by two CUs that usually run the forward and the backward kernel).
+    if (tid < kResMaxK - 1) {
+        int lo = 0, n = 0;
+        if (tid + 1 < K) { const int pj = (k + tid + 1) % K; lo = L.own_off[pj]; n = L.ex_cnt[pj]; }
+        PL[2 * tid] = lo;
+        PL[2 * tid + 1] = lo + n;
+    }
+    __syncthreads();
+    // Everything loaded so far (the arc registers above all) has landed: tell the compiler, whose
+    // wait-count bookkeeping otherwise carries "arc registers may still be in flight" into the loop and
+    // answers it with vmcnt(0) right after the emission prefetch is issued (vmcnt(0), expcnt/lgkmcnt free).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    // one frame; par = parity of i = which buffer is the gather source
+    auto frame = [&](const int par, int i) __attribute__((always_inline)) {
         const int t = DIR == 0 ? i : lx - 1 - i;                     // frame whose emissions are consumed
         const bool produce = DIR == 0 || t > 0;                      // a next vector exists
+        const bool tm_on = b == p.b0 + 3 && i >= 100 && i < 228 && wave == 0;
+        const int tm_i = (DIR * 4 + k) * 1024 + (i - 100) * 8;
+        CRF_TM(tm_on, tm_i + 0);
+#ifdef CRF_TIMING
+        if (b == p.b0 + 3 && i >= 150 && i < 158 && wave == 0) CRF_TM(true, 12288 + 1024 + (DIR * 4 + k) * 8 + (i - 150));  // frame start
+#endif
         float *Xn = X + (1 - par) * kResGmax;
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
         const int tpre = DIR == 0 ? t + 1 : t - 2;                   // emission row to prefetch
@@ -1019,46 +1128,53 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
         f32x2 acc = {0.f, 0.f};
         float mymax = 0.f;
         int rid = row0 + lane;
+        // Entry produced by row `rid` (implicit numbering, res_layout.cpp): rid + eoff; its LDS word and its
+        // exchange granule follow from that, so a row epilogue needs ONE table value, the row's emission.
+        const int eoff = own0 - cu_row0;
+        float *Xe = Xn + eoff;
+        gu64 *slot_e = slot + eoff;
 #pragma unroll
         for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
             if (c0 < nch_f) {
+                // Row epilogues: the entry a row produces is implicit (rid + eoff), so the only table value
+                // needed is the row's emission e'[label(row)] -- two dependent LDS reads.  (Tried and measured
+                // slower: prefetching label and e' for ALL row ends of a batch ahead of the gathers -- the
+                // second code path per batch cost more, in moves, branches and instruction-cache misses,
+                // than the waves with many short slices gained.)
                 f32x2 part[kResBatch];
                 CRF_RES_BATCH(part, A, xb, c0);
 #pragma unroll
                 for (int ci = 0; ci < kResBatch; ++ci) {
                     acc += part[ci];
                     if (ends_f >> (c0 + ci) & 1u) {
-                        const float rv = (acc.x + acc.y) * sc;   // q_t[row] (fwd) / b_t[state copy] (bwd)
-                        const int4 mt = RM[rid - cu_row0];
-                        if (DIR == 0) {
-                            Orow[rid] = rv;
-                            if (mt.x >= 0) {  // the row is the only producer of its entry: final now
-                                const float av = EPu[mt.y] * rv;
-                                Xn[mt.x] = av;
-                                mymax = fmaxf(mymax, av);
-                                if (xchg) res_publish(slot, mt.x, tag, av, same_l2);
-                            }
-                        } else {
-                            Orow[rid] = rv;
-                            if (mt.x > 0) {  // every backward row produces exactly one z entry (or none)
-                                const float zv = EPu[mt.z & 0xffff] * rv;
-                                Xn[mt.y] = zv;
-                                mymax = fmaxf(mymax, zv);
-                                if (xchg) res_publish(slot, mt.y, tag, zv, same_l2);
-                            }
-                        }
+                        const float rv = (acc.x + acc.y) * sc;       // q_t[row] (fwd) / b_t[state copy] (bwd)
+                        Orow[rid] = rv;
+                        const float av = EPu[RL[rid - cu_row0]] * rv;  // a_{t+1}[dst] (fwd) / z_{t-1}[pair] (bwd): final, one producer per entry
+                        Xe[rid] = av;
+                        mymax = fmaxf(mymax, av);
+                        if (xchg) res_publish(slot_e, rid, tag, av, same_l2);
                         acc = f32x2{0.f, 0.f};
                         rid += kWave;
                     }
                 }
             }
         }
+        CRF_TM(tm_on, tm_i + 1);
+#ifdef CRF_TIMING
+        if (b == p.b0 + 3 && i >= 150 && i < 158) {  // per-wave compute end (8 frames), chunks and slices of the wave
+            const int o = 12288 + ((DIR * 4 + k) * 8 + wave) * 16;
+            CRF_TM(true, o + (i - 150));
+            if (lane == 0 && i == 150) { g_tm[o + 8] = (unsigned long long)nch; g_tm[o + 9] = (unsigned long long)__builtin_popcount(ends); }
+        }
+#endif
         if (xchg) {  // the peers' entries (published from their row epilogues)
-            for (int j = 1; j < K; ++j) {
-                const int pj = (k + j) % K, lo = L.own_off[pj];
-                mymax = fmaxf(mymax, res_fetch(slot, Xn, lo, lo + L.ex_cnt[pj], tag, p.err, tid));
+#pragma clang loop unroll(disable)
+            for (int j = 0; j < K - 1; ++j) {
+                const int lo = __builtin_amdgcn_readfirstlane(PL[2 * j]), hi = __builtin_amdgcn_readfirstlane(PL[2 * j + 1]);
+                mymax = fmaxf(mymax, res_fetch(slot, Xn, lo, hi, tag, p.err, tid));
             }
         }
+        CRF_TM(tm_on, tm_i + 2);
         mymax = wave_max(mymax);
         if (lane == 0) wm[(1 - par) * kResWaves + wave] = mymax;
         if (pre) {
@@ -1066,12 +1182,14 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
 #pragma unroll
             for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; if (v < V) EPw[v] = epn[q]; }
         }
+        CRF_TM(tm_on, tm_i + 3);
         sync_lds();
+        CRF_TM(tm_on, tm_i + 4);
     };
-    for (int i = 0; i < lx; i += 2) {
-        frame(std::integral_constant<int, 0>{}, i);
-        if (i + 1 < lx) frame(std::integral_constant<int, 1>{}, i + 1);
-    }
+    // NOT unrolled by two for compile-time buffer offsets: the gathers add an SGPR base either way, and the
+    // doubled loop body (2 x 30 KiB) did not fit the instruction cache next to the other direction's kernel
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < lx; ++i) frame(i & 1, i);
 
     if (DIR == 0) {
         if (k == 0) {
@@ -1099,14 +1217,15 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
 
 // One kernel per recursion so each keeps its own (small) set of live kernel arguments in SGPRs; the
 // four launches are issued on forked HIP streams and run concurrently (crf_loss_fwd_bwd).
-template <int ROLE, bool GV = false>
-__global__ __launch_bounds__(kChainThreads) void crf_chain_kernel(LossParams p) {
+// NR (numerator roles only): ctc states per thread, chosen by the host from the batch's longest label sequence.
+template <int ROLE, bool GV = false, int NR = kCtcRegs>
+__global__ __launch_bounds__(ROLE >= 2 ? kCtcThreads : kChainThreads) void crf_chain_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = (int)blockIdx.x;
     if (ROLE == 0) den_forward<GV>(p, b, lds);
     else if (ROLE == 1) den_backward<GV>(p, b, lds);
-    else if (ROLE == 2) ctc_forward(p, b, lds);
-    else ctc_backward(p, b, lds);
+    else if (ROLE == 2) ctc_forward<NR>(p, b, lds);
+    else ctc_backward<NR>(p, b, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1204,6 +1323,11 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
 // registers while frame t is reduced out of LDS.  HBM-bound: two coalesced rows per frame.
 // ---------------------------------------------------------------------------------------------
 constexpr int kGDThreads = 256, kGDFrames = 16, kGDRowRegs = 5;   // rows of up to 5*256 float4 = 5120 floats
+constexpr int kGDEpRegs = 4;                                      // V <= 4*256
+// Nothing in the frame loop may wait on global memory except for data requested a whole frame earlier:
+// the rows AND the emission row of frame t+1 are requested while frame t is reduced, the per-frame
+// exponents are read once per workgroup, and the barriers are LDS-only (sync_lds) -- __syncthreads()
+// would drain vmcnt, i.e. wait for the prefetch it has just issued (that alone was ~2/3 of this kernel).
 template <int NCPT>
 __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1211,7 +1335,10 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
     const int tid = threadIdx.x;
     const int b = blockIdx.y, V = p.V;
     const int lx = p.lx[b], Rq = p.Rq, Rb = p.Rb, NC = p.gNC;
-    float *Qs = lds, *Bs = Qs + rup64(Rq + 1), *csum = Bs + rup64(Rb + 1);  // Qs[Rq] = 0: target of padding index pairs
+    const int Vp = rup64(V);
+    float *Qs = lds, *Bs = Qs + rup64(Rq + 1), *gd = Bs + rup64(Rb + 1);    // Qs[Rq] = 0: target of padding index pairs
+    int *eoff = (int *)(gd + 4 * Vp);                                       // [kGDFrames]; gd: [4][Vp] label sums in rotation
+    int *clab_s = eoff + kGDFrames;                                         // [NC] label of each chunk (prologue only)
     const int64_t bt0 = (int64_t)b * p.T;
     const float zs = p.den_zs[b];
     const int ez = p.den_ez[b];
@@ -1219,19 +1346,59 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
     const int t0 = blockIdx.x * kGDFrames, t1 = min(t0 + kGDFrames, p.T), tl = min(t1, lx);
 
     unsigned idx[NCPT][kChunk];
-    int clen[NCPT];
+    {
+        // unconditional (clamped) loads, selected afterwards: predicated loads were issued one at a time,
+        // 32 L2 round trips in a row before the first frame
+        const int nlist = p.gchunk[NC];
+#pragma unroll
+        for (int i = 0; i < NCPT; ++i) {
+            const int c = tid + i * kGDThreads;
+            const int j0 = c < NC ? p.gchunk[c] : 0;
+            const int clen = c < NC ? p.gchunk[c + 1] - j0 : 0;
+            unsigned short gqv[kChunk], gbv[kChunk];
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) {
+                const int jj = min(j0 + j, nlist - 1);
+                gqv[j] = (unsigned short)p.gq[jj];
+                gbv[j] = (unsigned short)p.gb[jj];
+            }
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j) idx[i][j] = j < clen ? ((unsigned)gqv[j] | (unsigned)gbv[j] << 16) : (unsigned)Rq;
+        }
+    }
+    // label of each chunk: the per-label chunk ranges, inverted once per workgroup.  The chunk sums of a
+    // label are combined with LDS float adds -- a per-label loop over its chunks made one thread (the blank
+    // label owns a third of all pairs) walk 64 chunks in every frame, half the time of this kernel.
+    for (int v = tid; v <= g.max_label && v < V; v += kGDThreads)
+        for (int c = p.glab[v]; c < p.glab[v + 1]; ++c) clab_s[c] = v;
+    for (int v = tid; v < 4 * Vp; v += kGDThreads) gd[v] = 0.f;
+    if (tid == 0) Qs[Rq] = 0.f;
+    __syncthreads();
+    // Chunks are label-sorted, so the lanes of a wave that share a label are neighbours: a segmented
+    // shuffle reduction (the "same label d lanes up" tests are static, bit j of segm) leaves one LDS add per
+    // (wave, label) -- 64 lanes adding to ONE address (the blank label) took ~50 cycles per lane.
+    int clab[NCPT];
+    unsigned segm[NCPT];
+    const int lane = tid & 63;
 #pragma unroll
     for (int i = 0; i < NCPT; ++i) {
         const int c = tid + i * kGDThreads;
-        const int j0 = c < NC ? p.gchunk[c] : 0;
-        clen[i] = c < NC ? p.gchunk[c + 1] - j0 : 0;
+        clab[i] = c < NC ? clab_s[c] : -1;
+        segm[i] = 0;
 #pragma unroll
-        for (int j = 0; j < kChunk; ++j) idx[i][j] = j < clen[i] ? ((unsigned)p.gq[j0 + j] | (unsigned)p.gb[j0 + j] << 16) : (unsigned)Rq;
+        for (int j = 0; j < 6; ++j) {
+            const int d = 1 << j;
+            const int other = (lane + d < 64 && c + d < NC) ? clab_s[c + d] : -2;
+            if (other == clab[i]) segm[i] |= 1u << j;
+        }
+        const bool head = lane == 0 || c >= NC || clab_s[c - 1] != clab[i];
+        if (!head || c >= NC) segm[i] |= 1u << 31;   // bit 31: not the lane that adds the segment's sum
     }
-    if (tid == 0) Qs[Rq] = 0.f;
+    if (tid < kGDFrames) eoff[tid] = t0 + tid < tl ? ez - p.EQ[bt0 + t0 + tid] - p.EB[bt0 + t0 + tid] - kEpExp : 0;  // er[] carries 2^kEpExp
     // rows are multiples of 64 floats and 256-byte aligned: 16-byte loads, prefetched one frame ahead
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 qr[kGDRowRegs], br[kGDRowRegs];
+    float ern[kGDEpRegs];
 #define CRF_GD_FETCH(t)                                                                                  \
     {                                                                                                    \
         const f32x4 *Qr = (const f32x4 *)(p.Q + (bt0 + (t)) * Rq), *Br = (const f32x4 *)(p.BP + (bt0 + (t)) * Rb); \
@@ -1240,17 +1407,32 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
             qr[i] = 4 * r < Rq ? Qr[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
             br[i] = 4 * r < Rb ? Br[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
         }                                                                                                \
+        const float *er_ = p.ep + (bt0 + (t)) * V;                                                       \
+        _Pragma("unroll") for (int q = 0; q < kGDEpRegs; ++q) {                                          \
+            const int v = tid + q * kGDThreads;                                                          \
+            ern[q] = v < V ? er_[v] : 0.f;                                                               \
+        }                                                                                                \
     }
-    if (t0 < tl) CRF_GD_FETCH(t0);
-    for (int t = t0; t < tl; ++t) {
+#define CRF_GD_STAGE()                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < kGDRowRegs; ++i) {                                             \
+        const int r = tid + i * kGDThreads;                                                              \
+        if (4 * r < Rq) ((f32x4 *)Qs)[r] = qr[i];                                                        \
+        if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];                                                        \
+    }
+    float erc[kGDEpRegs];
+    if (t0 < tl) {
+        CRF_GD_FETCH(t0);
+        CRF_GD_STAGE();
 #pragma unroll
-        for (int i = 0; i < kGDRowRegs; ++i) {
-            const int r = tid + i * kGDThreads;
-            if (4 * r < Rq) ((f32x4 *)Qs)[r] = qr[i];
-            if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];
-        }
-        __syncthreads();
-        if (t + 1 < tl) CRF_GD_FETCH(t + 1);
+        for (int q = 0; q < kGDEpRegs; ++q) erc[q] = ern[q];
+    }
+    sync_lds();
+    const bool tm_on = blockIdx.x == 40 && blockIdx.y == 3 && tid < 64;
+    for (int t = t0; t < tl; ++t) {
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
+        float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
+        if (t + 1 < tl) CRF_GD_FETCH(t + 1);   // lands while frame t is reduced
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 1);
 #pragma unroll
         for (int i = 0; i < NCPT; ++i) {
             float s0 = 0.f, s1 = 0.f;
@@ -1259,23 +1441,159 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
                 s0 = fmaf(Qs[idx[i][j] & 0xffffu], Bs[idx[i][j] >> 16], s0);
                 s1 = fmaf(Qs[idx[i][j + 1] & 0xffffu], Bs[idx[i][j + 1] >> 16], s1);
             }
-            if (tid + i * kGDThreads < NC) csum[tid + i * kGDThreads] = s0 + s1;
+            float sv = s0 + s1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {   // suffix sums within the label segment: lane gets sum over [lane, segment end]
+                const float o = __shfl_down(sv, 1 << j, 64);
+                if (segm[i] >> j & 1u) sv += o;
+            }
+            if (!(segm[i] >> 31)) atomicAdd(&gsum[clab[i]], sv);
         }
-        __syncthreads();
-        const int e = ez - p.EQ[bt0 + t] - p.EB[bt0 + t] - kEpExp;  // er[] carries 2^kEpExp
-        const float *er = p.ep + (bt0 + t) * V;
+#pragma unroll
+        for (int q = 0; q < kGDEpRegs; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
+            const int v = tid + q * kGDThreads;
+            if (v < V) gzero[v] = 0.f;
+        }
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 2);
+        sync_lds();                             // every gather of frame t is done: the row buffers are free
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 3);
+        // Stage frame t+1 BEFORE this frame's stores are issued: the vmcnt wait in front of the LDS writes
+        // then covers loads only (vmcnt counts in order; behind the stores it would also wait for their
+        // acknowledgement).
+        if (t + 1 < tl) CRF_GD_STAGE();
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 4);
+        const int e = eoff[t - t0];
         float *row = p.grad + (bt0 + t) * V;
-        for (int v = tid; v < V; v += kGDThreads) {
-            float s = 0.f;
-            if (v <= g.max_label)
-                for (int c = p.glab[v]; c < p.glab[v + 1]; ++c) s += csum[c];
-            row[v] = p.c_den * (er[v] * (ldexpf(s, e) * inv));
+#pragma unroll
+        for (int q = 0; q < kGDEpRegs; ++q) {
+            const int v = tid + q * kGDThreads;
+            if (v < V) row[v] = p.c_den * (erc[q] * (ldexpf(gsum[v], e) * inv));
+            erc[q] = ern[q];
         }
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
+        sync_lds();                             // rows of frame t+1 visible
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 6);
     }
+#undef CRF_GD_STAGE
+#undef CRF_GD_FETCH
     for (int t = max(t0, tl); t < t1; ++t) {  // frames past the utterance's length: zero rows
         float *row = p.grad + (bt0 + t) * V;
         for (int v = tid; v < V; v += kGDThreads) row[v] = 0.f;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grad, numerator half, streaming form: grad[b][t][v] (-)= c_ctc * gamma_ctc[b][t][v],
+// gamma_ctc[t][v] = sum_{s: l'_s = v} A_t[s] * Bx_t[s] / Z  (gpu_ctc_kernels.h:377-458 computes the same
+// posterior per unique label after an in-kernel sort; here labels are scattered with LDS float adds).
+// Same rules as crf_grad_den_kernel: everything a frame needs from global memory (the two fp64 rows,
+// the grad row it accumulates into) is requested one frame ahead, the per-frame factors are read once
+// per workgroup, barriers are LDS-only.  grad_phase 2 = subtract from the row the den half wrote,
+// otherwise write -c_ctc * gamma (plain CTC).  blockDim is even, so a thread's s-values all have the
+// parity of its tid: odd threads own label positions, even threads blanks.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGCThreads = 256, kGCFrames = 16, kGCRegs = 16, kGCVRegs = 4;  // 2L+1 <= 4096, V <= 1024
+__global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.y, V = p.V, Vp = rup64(V);
+    const int lx = p.lx[b];
+    const bool accumulate = p.grad_phase == 2;
+    float *gc = lds;                          // [4][Vp] in rotation
+    double *fcs = (double *)(gc + 4 * Vp);    // [kGCFrames]
+    const int64_t bt0 = (int64_t)b * p.T;
+    const double zc = p.ctc_zc[b];
+    const int ezc = p.ctc_ez[b], Sx = 2 * p.ly[b] + 1;
+    const int *ul = p.labels + p.lab_off[b];
+    const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
+    const int t0 = blockIdx.x * kGCFrames, t1 = min(t0 + kGCFrames, p.T), tl = min(t1, lx);
+    int mylab[kGCRegs];
+#pragma unroll
+    for (int i = 0; i < kGCRegs; ++i) {
+        const int s = tid + i * kGCThreads;
+        mylab[i] = (s < Sx && (s & 1)) ? ul[s >> 1] : 0;
+    }
+    if (tid < kGCFrames)
+        fcs[tid] = (t0 + tid < tl && zc > 0.0) ? ldexp(invc, ezc - p.ECA[bt0 + t0 + tid] - p.ECB[bt0 + t0 + tid]) : 0.0;
+    double an[kGCRegs], bn[kGCRegs];
+    float rown[kGCVRegs];
+#define CRF_GC_FETCH(t)                                                                          \
+    {                                                                                            \
+        const double *Ar = p.CA + (bt0 + (t)) * p.Sc, *Br = p.CB + (bt0 + (t)) * p.Sc;           \
+        _Pragma("unroll") for (int i = 0; i < kGCRegs; ++i) {                                    \
+            const int s = tid + i * kGCThreads;                                                  \
+            if (s < Sx) { an[i] = Ar[s]; bn[i] = Br[s]; }                                        \
+        }                                                                                        \
+        if (accumulate) {                                                                        \
+            const float *row_ = p.grad + (bt0 + (t)) * V;                                        \
+            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) {                               \
+                const int v = tid + q * kGCThreads;                                              \
+                rown[q] = v < V ? row_[v] : 0.f;                                                 \
+            }                                                                                    \
+        }                                                                                        \
+    }
+#define CRF_GC_CONSUME()                                                                         \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < kGCRegs; ++i) prod[i] = (tid + i * kGCThreads < Sx) ? an[i] * bn[i] : 0.0; \
+        _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) rowc[q] = rown[q];                  \
+    }
+    double prod[kGCRegs];
+    float rowc[kGCVRegs];
+#pragma unroll
+    for (int q = 0; q < kGCVRegs; ++q) rown[q] = 0.f;
+    for (int v = tid; v < 4 * Vp; v += kGCThreads) gc[v] = 0.f;
+    if (t0 < tl) {
+        CRF_GC_FETCH(t0);
+        CRF_GC_CONSUME();
+    }
+    sync_lds();
+    // Four label-sum buffers in rotation: frame t adds into buffer t&3 and clears buffer (t+2)&3, whose last
+    // readers (the stores of frame t-2) are behind the barrier of frame t-1 -- ONE barrier per frame.
+    for (int t = t0; t < tl; ++t) {
+        float *g = gc + (t & 3) * Vp, *gz = gc + ((t + 2) & 3) * Vp;
+        if (t + 1 < tl) CRF_GC_FETCH(t + 1);
+        const double fc = fcs[t - t0];
+        if (zc > 0.0) {
+            float blank = 0.f;
+#pragma unroll
+            for (int i = 0; i < kGCRegs; ++i)
+                if (tid + i * kGCThreads < Sx) {
+                    const float pr = (float)(prod[i] * fc);  // a posterior, in [0,1]
+                    if (tid & 1) atomicAdd(&g[mylab[i]], pr);
+                    else blank += pr;
+                }
+            blank = wave_sum(blank);
+            if (lane == 0) atomicAdd(&g[0], blank);
+        }
+#pragma unroll
+        for (int q = 0; q < kGCVRegs; ++q) {
+            const int v = tid + q * kGCThreads;
+            if (v < V) gz[v] = 0.f;
+        }
+        sync_lds();
+        float out[kGCVRegs];
+#pragma unroll
+        for (int q = 0; q < kGCVRegs; ++q) {
+            const int v = tid + q * kGCThreads;
+            out[q] = v < V ? rowc[q] - p.c_ctc * g[v] : 0.f;
+        }
+        // take the next frame's loads out of their registers BEFORE this frame's stores are issued (a
+        // vmcnt wait behind the stores would also wait for their acknowledgement)
+        if (t + 1 < tl) CRF_GC_CONSUME();
+        float *row = p.grad + (bt0 + t) * V;
+#pragma unroll
+        for (int q = 0; q < kGCVRegs; ++q) {
+            const int v = tid + q * kGCThreads;
+            if (v < V) row[v] = out[q];
+        }
+    }
+#undef CRF_GC_CONSUME
+#undef CRF_GC_FETCH
+    if (!accumulate)
+        for (int t = max(t0, tl); t < t1; ++t) {
+            float *row = p.grad + (bt0 + t) * V;
+            for (int v = tid; v < V; v += kGCThreads) row[v] = 0.f;
+        }
 }
 
 // loss = sum_b(c_den*logZ_b - c_ctc*logp_b); copies the per-utterance costs out (one workgroup)
@@ -1356,7 +1674,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
 static size_t res_lds_bytes(const HostGraph *h, int V, int dir, int rows_cu_max) {
     const int G = dir == 0 ? h->dev.res.f.G : h->dev.res.b.G;
     (void)G;
-    return (size_t)2 * kResXB + ((size_t)rows_cu_max * 4 + 2 * (size_t)rup64(V) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
+    return (size_t)2 * kResXB + ((size_t)rows_cu_max + 2 * (size_t)rup64(V + 1) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
 }
 
 static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role, bool gv = false) {
@@ -1419,22 +1737,31 @@ static void prof_mark(int slot, bool stop, hipStream_t st) {
     g_prof.used[slot] = true;
 }
 
-template <int ROLE, bool GV = false>
+template <int ROLE, bool GV = false, int NR = kCtcRegs>
 static int launch_chain(const LossParams &p, size_t lds, hipStream_t st) {
     static std::atomic<size_t> lds_set{0};  // dynamic LDS above 64 KiB must be opted into; only raised
     hipError_t e;
     if (lds > lds_set.load()) {
-        if ((e = hipFuncSetAttribute((const void *)crf_chain_kernel<ROLE, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
+        if ((e = hipFuncSetAttribute((const void *)crf_chain_kernel<ROLE, GV, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
             set_error(std::string("hipFuncSetAttribute(chain): ") + hipGetErrorString(e));
             return CRF_ERR_HIP;
         }
         lds_set = lds;
     }
     prof_mark(1 + ROLE, false, st);
-    hipLaunchKernelGGL((crf_chain_kernel<ROLE, GV>), dim3((unsigned)p.B), dim3(ROLE >= 2 ? kCtcThreads : kChainThreads), lds, st, p);
+    hipLaunchKernelGGL((crf_chain_kernel<ROLE, GV, NR>), dim3((unsigned)p.B), dim3(ROLE >= 2 ? kCtcThreads : kChainThreads), lds, st, p);
     prof_mark(1 + ROLE, true, st);
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
+}
+// numerator chains: states per thread from the longest label sequence of the batch
+template <int ROLE>
+static int launch_ctc(const LossParams &p, size_t lds, hipStream_t st, int64_t max_label_len) {
+    const int64_t ni = (2 * max_label_len + 1 + kCtcThreads - 1) / kCtcThreads;
+    if (ni <= 1) return launch_chain<ROLE, false, 1>(p, lds, st);
+    if (ni <= 2) return launch_chain<ROLE, false, 2>(p, lds, st);
+    if (ni <= 4) return launch_chain<ROLE, false, 4>(p, lds, st);
+    return launch_chain<ROLE, false, kCtcRegs>(p, lds, st);
 }
 
 template <int DIR>
@@ -1630,9 +1957,9 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
     const int gnc = den ? (res ? h->dev.res.NC : h->dev.NC) : 0;
     const bool fast_den = den && w.Rq <= 4 * kGDRowRegs * kGDThreads && w.Rb <= 4 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
-                          gnc <= 2 * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
+                          gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
     auto launch_grad_den = [&]() -> int {
-        const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + rup64(gnc)) * sizeof(float);
+        const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + 4 * rup64((int)V) + kGDFrames + rup64(gnc)) * sizeof(float);
         const dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
         static std::atomic<size_t> set1{0}, set2{0};
         if (gnc <= kGDThreads) {
@@ -1645,19 +1972,33 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad_den_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
     };
+    // numerator half of the grad pass: streaming kernel when the vocabulary fits its registers
+    const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
+                          !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
+    auto launch_grad_ctc = [&](int phase) -> int {  // phase 2: subtract from the den half; 0: plain CTC (writes)
+        p.grad_phase = phase;
+        if (fast_ctc) {
+            const size_t l = (size_t)4 * rup64((int)V) * sizeof(float) + kGCFrames * sizeof(double);
+            const dim3 gg((unsigned)((T + kGCFrames - 1) / kGCFrames), (unsigned)B);
+            hipLaunchKernelGGL(crf_grad_ctc_kernel, gg, dim3(kGCThreads), l, stream, p);
+        } else {
+            hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad(ctc): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+        return CRF_OK;
+    };
     if (!split) {
         if (ctc) {
-            if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream))) return rc;
-            if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2)))) return rc;
+            if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream, max_label_len))) return rc;
+            if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2), max_label_len))) return rc;
         }
         if ((rc = join_all())) return rc;
         prof_mark(5, false, stream);
         if (fast_den) {
             if ((rc = launch_grad_den())) return rc;
-            if (ctc) {
-                p.grad_phase = 2;
-                hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
-            }
+            if (ctc && (rc = launch_grad_ctc(2))) return rc;
+        } else if (!den && fast_ctc) {
+            if ((rc = launch_grad_ctc(0))) return rc;
         } else {
             p.grad_phase = 0;
             hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
@@ -1669,8 +2010,8 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         // stream 0) has drained and freed its half of the CUs; the den half of the grad pass follows the
         // forward den kernel on the caller's stream
         if ((e = hipEventRecord(cx->fork, cx->side[0])) != hipSuccess) { set_error("hipEventRecord(fork2)"); return CRF_ERR_HIP; }
-        if ((rc = launch_chain<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(1)))) return rc;
-        if ((rc = launch_chain<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2)))) return rc;
+        if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(1), max_label_len))) return rc;
+        if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2), max_label_len))) return rc;
         {   // join side 0 (den backward) only; sides 1, 2 are joined after the den grad pass
             if ((e = hipEventRecord(cx->join[0], cx->side[0])) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->join[0], 0)) != hipSuccess) {
                 set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
@@ -1686,10 +2027,8 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
             LAUNCH_CHECK("crf_grad_kernel(den)");
         }
         if ((rc = join_all())) return rc;
-        p.grad_phase = 2;
-        hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+        if ((rc = launch_grad_ctc(2))) return rc;
         prof_mark(5, true, stream);
-        LAUNCH_CHECK("crf_grad_kernel(ctc)");
     }
     prof_mark(6, false, stream);
     hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
@@ -1699,6 +2038,18 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     LAUNCH_CHECK("crf_finalize_kernel");
 #undef LAUNCH_CHECK
     return CRF_OK;
+}
+
+int crf_timing_read(unsigned long long *out, int n) {
+#ifdef CRF_TIMING
+    if (!out || n <= 0) return 0;
+    if (n > 16384) n = 16384;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tm), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return 0;
+    return n;
+#else
+    (void)out; (void)n;
+    return 0;  // not a timing build
+#endif
 }
 
 void crf_profile_enable(int on) { g_prof.on = on != 0; if (!on) g_prof.have = false; }

@@ -7,6 +7,8 @@
 // No reference counterpart: the reference keeps one flat arc array per direction in global memory and
 // re-reads it in every one of its T kernel launches (den_calculate.cu:309-355, 75-103, 189-227).
 #include <algorithm>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -26,6 +28,7 @@ struct DirOut {
     std::vector<int> rid_of_row;  // input row -> rid
     std::vector<int> cu_row_off;  // [K+1]
     int64_t slots = 0, conflicts = 0;
+    int est_cost = 0;             // max over CUs and waves of (chunks + kEpiCost * slices): the frame-time estimate
 };
 
 inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / kResW)); }
@@ -38,6 +41,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
     o->rid_of_row.assign(rows.size(), -1);
     o->row_of.clear();
     o->cu_row_off.assign((size_t)K + 1, 0);
+    o->est_cost = 0;
     slices->clear();
     for (int k = 0; k < K; ++k) {
         std::vector<int> mine;
@@ -46,26 +50,77 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         const int nsl = (int)((mine.size() + kWave - 1) / kWave);
         std::vector<int> len(nsl);
         for (int j = 0; j < nsl; ++j) len[j] = chunks_of(rows[mine[(size_t)j * kWave]].size());
-        // slices (sorted by length) -> waves with the register capacity as bin size: balanced
-        // longest-processing-time first; if that does not fit, best-fit-decreasing (tighter, less balanced)
+        // slices (sorted by length) -> waves with the register capacity as bin size.  What is balanced is
+        // the TIME of a wave, measured on the MI355X (tools/timing_probe.py) as roughly linear in its chunks
+        // plus a fixed price per slice end (row epilogue: emission lookup, stores, publish) worth several
+        // chunks -- a wave with nine 1-chunk slices ran 1.5x longer than one with two 15-chunk slices, and the
+        // frame waits for the slowest wave.  Step 1: best-fit-decreasing finds a feasible packing (the
+        // registers are ~97% full for the benchmark graph, so balance-first heuristics do not even fit).
+        // Step 2: a deterministic annealing over single moves and pair swaps lowers the maximum wave cost.
+        const int kEpiCost = getenv("CRF_RES_EPI") ? atoi(getenv("CRF_RES_EPI")) : 4;  // slice end, in chunks
+        std::vector<int> wave_of(nsl, -1), load(kResWaves, 0), cnt(kResWaves, 0);
+        bool packed = true;
+        for (int j = 0; j < nsl && packed; ++j) {
+            int best = -1;
+            for (int w = 0; w < kResWaves; ++w) {
+                if (load[w] + len[j] > kResNCH) continue;
+                if (best < 0 || load[w] > load[best]) best = w;
+            }
+            if (best < 0) { packed = false; break; }
+            wave_of[j] = best; load[best] += len[j]; cnt[best]++;
+        }
         std::vector<std::vector<int>> lists(kResWaves);
-        bool packed = false;
-        for (int mode = 0; mode < 2 && !packed; ++mode) {
-            std::vector<int> load(kResWaves, 0);
-            for (auto &l : lists) l.clear();
-            packed = true;
-            for (int j = 0; j < nsl && packed; ++j) {
-                int best = -1;
-                for (int w = 0; w < kResWaves; ++w) {
-                    if (load[w] + len[j] > kResNCH) continue;
-                    if (best < 0 || (mode == 0 ? load[w] < load[best] : load[w] > load[best])) best = w;
+        std::vector<int> cost(kResWaves, 0);
+        if (packed) {
+            auto wcost = [&](int w) { return load[w] + kEpiCost * cnt[w]; };
+            // objective: (max cost, sum of squares) lexicographically, folded into one number
+            auto objective = [&]() {
+                int64_t mx = 0, sq = 0;
+                for (int w = 0; w < kResWaves; ++w) { const int64_t c = wcost(w); mx = std::max(mx, c); sq += c * c; }
+                return mx * 1000000 + sq;
+            };
+            uint64_t rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)nsl << 32) ^ (uint64_t)k;
+            auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+            int64_t cur = objective(), best_obj = cur;
+            std::vector<int> best_assign = wave_of;
+            const int iters = nsl > 1 ? 60000 : 0;
+            for (int it = 0; it < iters; ++it) {
+                const double temp = 4.0e6 * (1.0 - (double)it / iters);  // in objective units: a few chunks of max cost at the start
+                const int ja = (int)(rnd() % (uint64_t)nsl), a_ = wave_of[ja];
+                if (rnd() & 1) {  // move
+                    const int b_ = (int)(rnd() % kResWaves);
+                    if (b_ == a_ || load[b_] + len[ja] > kResNCH) continue;
+                    load[a_] -= len[ja]; cnt[a_]--; load[b_] += len[ja]; cnt[b_]++; wave_of[ja] = b_;
+                    const int64_t nw = objective();
+                    if (nw <= cur || (double)(rnd() % 1000000) / 1e6 < std::exp(-(double)(nw - cur) / std::max(temp, 1.0))) cur = nw;
+                    else { load[b_] -= len[ja]; cnt[b_]--; load[a_] += len[ja]; cnt[a_]++; wave_of[ja] = a_; }
+                } else {          // swap
+                    const int jb = (int)(rnd() % (uint64_t)nsl), b_ = wave_of[jb];
+                    if (b_ == a_ || len[ja] == len[jb]) continue;
+                    const int d = len[ja] - len[jb];
+                    if (load[b_] + d > kResNCH || load[a_] - d > kResNCH) continue;
+                    load[a_] -= d; load[b_] += d; wave_of[ja] = b_; wave_of[jb] = a_;
+                    const int64_t nw = objective();
+                    if (nw <= cur || (double)(rnd() % 1000000) / 1e6 < std::exp(-(double)(nw - cur) / std::max(temp, 1.0))) cur = nw;
+                    else { load[a_] += d; load[b_] -= d; wave_of[ja] = a_; wave_of[jb] = b_; }
                 }
-                if (best < 0) { packed = false; break; }
-                lists[best].push_back(j);
-                load[best] += len[j];
+                if (cur < best_obj) { best_obj = cur; best_assign = wave_of; }
+            }
+            wave_of = best_assign;
+            std::fill(load.begin(), load.end(), 0);
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int j = 0; j < nsl; ++j) { lists[wave_of[j]].push_back(j); load[wave_of[j]] += len[j]; cnt[wave_of[j]]++; }
+            for (int w = 0; w < kResWaves; ++w) cost[w] = wcost(w);
+            if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"))) {
+                fprintf(stderr, "[res_layout] lens:");
+                for (int j = 0; j < nsl; ++j) fprintf(stderr, " %d", len[j]);
+                fprintf(stderr, "\n[res_layout] K=%d cu=%d:", K, k);
+                for (int w = 0; w < kResWaves; ++w) fprintf(stderr, " w%d(%dch,%zusl)", w, load[w], lists[w].size());
+                fprintf(stderr, "\n");
             }
         }
         if (!packed) return false;  // does not fit with this K
+        o->est_cost = std::max(o->est_cost, *std::max_element(cost.begin(), cost.end()));
         int rid = o->cu_row_off[k];
         for (int w = 0; w < kResWaves; ++w) {
             unsigned ends = 0;
@@ -248,12 +303,17 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     auto try_dir = [&](const Rows &rows, const std::vector<int> &key, const std::vector<int> &tgt, int K,
                        const std::vector<int> &gkey, std::vector<int> *goff) -> Dir {
         Dir best;
+        Rows best_sub;
+        std::vector<int> best_subtgt, best_nparts;
+        std::vector<SliceAt> best_slices;
+        bool have = false, any_ragged = false;
         // attempt 0: no splitting; attempt 1: split only the rows that would sit in a ragged last slice
         // (fewer than 64 rows) of their CU into 2-chunk pieces, so that they fill leftover register space
         // instead of claiming a whole slice; attempts 2..: global thresholds
         std::vector<char> ragged(rows.size(), 0);
         for (int attempt = 0; attempt < 1 + (int)(sizeof(kSplit) / sizeof(kSplit[0])); ++attempt) {
             const int thr = attempt <= 1 ? (1 << 30) : kSplit[attempt - 1];
+            if (attempt == 1 && !any_ragged) continue;  // attempt 0 placed everything: nothing is ragged
             Dir d;
             Rows sub;
             std::vector<int> subkey, subtgt;
@@ -309,11 +369,26 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                         std::vector<int> mine;
                         for (size_t r = 0; r < sub.size(); ++r) if (cu[r] == k) mine.push_back((int)r);
                         std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return refs[subkey[a]] < refs[subkey[b]]; });
-                        for (size_t i = 0; i < mine.size() % kWave; ++i) ragged[d.sub_of[mine[i]]] = 1;
+                        for (size_t i = 0; i < mine.size() % kWave; ++i) { ragged[d.sub_of[mine[i]]] = 1; any_ragged = true; }
                     }
                 }
                 continue;
             }
+            // keep the attempt with the lowest frame-time estimate (splitting long rows removes slice padding
+            // and lets the waves balance, at the price of more slice ends and replicated arcs); ties and
+            // near-ties go to the earlier attempt = fewer splits
+            if (!have || d.o.est_cost + 1 < best.o.est_cost) {
+                best = std::move(d);
+                best_sub = std::move(sub); best_subtgt = std::move(subtgt); best_slices = std::move(slices); best_nparts = std::move(nparts);
+                have = true;
+            }
+        }
+        if (!have) return best;
+        {
+            Dir &d = best;
+            Rows &sub = best_sub;
+            std::vector<int> &subtgt = best_subtgt, &nparts = best_nparts;
+            std::vector<SliceAt> &slices = best_slices;
             // Numbering of the (virtual) gather entries, CU by CU: first the produced entries IN THE ORDER
             // OF THEIR PRODUCING ROW's id -- a slice's 64 epilogues then publish 64 consecutive granules (one
             // coalesced 512-byte store) and write 64 consecutive LDS words; last the entries nobody produces
@@ -323,22 +398,25 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             d.ex_cnt.assign(2 * K, 0);  // [k] produced entries, [K + k] unused (no shared entries any more)
             for (int k = 0, n = 0; k < K; ++k) {
                 const int before = n;
-                for (int rid = d.o.cu_row_off[k]; rid < d.o.cu_row_off[k + 1]; ++rid) {
+                // EVERY row id owns the entry own_off[k] + (rid - cu_row_off[k]) -- also padding rows and rows that
+                // produce nothing (they publish zeros into entries nobody reads).  The kernel then needs no
+                // per-row "which entry" lookup in the row epilogue, only the row's label.
+                for (int rid = d.o.cu_row_off[k]; rid < d.o.cu_row_off[k + 1]; ++rid, ++n) {
                     const int r = d.o.row_of[rid];
-                    if (r < 0) continue;
-                    if (subtgt[r] >= 0) d.gmap[d.gbase[subtgt[r]] + d.sub_j[r]] = n++;
+                    if (r >= 0 && subtgt[r] >= 0) d.gmap[d.gbase[subtgt[r]] + d.sub_j[r]] = n;
                 }
                 d.ex_cnt[k] = n - before;
                 for (size_t g = 0; g < gkey.size(); ++g)
                     if (d.owner[gkey[g]] == k && nparts[g] == 0) d.gmap[d.gbase[g]] = n++;
                 off[k + 1] = n;
+                if (k == K - 1) d.G = n;  // virtual entries + the rows that own an unused one
             }
+            if (d.G > 16383) { d.ok = false; return d; }
             for (auto &row : sub)
                 for (auto &a : row) a.first = d.gmap[a.first];
             pack_arcs(sub, slices, &d.o);
             *goff = off;
             d.ok = true;
-            return d;
         }
         return best;
     };
@@ -383,15 +461,13 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 
         // ---- row metadata and side tables
         const int Rf = fo.cu_row_off[K], Rb = bo.cu_row_off[K];
-        std::vector<int4> fmeta(Rf, int4{-1, 0, 0, 0}), bmeta(Rb, int4{-1, 0, 0, 0});
+        const int kNoLab = -1;  // padding rows / rows that produce nothing: the kernels scale them by 0
+        std::vector<int> flab(Rf, kNoLab), blab(Rb, kNoLab);
         auto xof = [&](int s, int j) { return F.gmap[F.gbase[s] + j]; };   // forward x entry of (state, copy)
         auto zof = [&](int p, int j) { return Bk.gmap[Bk.gbase[p] + j]; };  // backward z entry of (pair, copy)
         const int Gf = F.G, Gb = Bk.G;
         for (int r = 0; r < Rf; ++r)
-            if (fo.row_of[r] >= 0) {  // every (virtual) entry has exactly one producing row: .z = 1, plain store
-                const int sr = fo.row_of[r], p = pair_of_sub(sr);
-                fmeta[r] = int4{xof(pair_dst[p], F.sub_j[sr]), pair_lab[p], 1, 0};
-            }
+            if (fo.row_of[r] >= 0) flab[r] = pair_lab[pair_of_sub(fo.row_of[r])];
         std::vector<std::vector<int>> bsubs_of(S);  // backward sub-rows of the FIRST copy of each state
         for (int r = 0; r < NRb; ++r) if (bin_dup[Bk.sub_of[r]] == 0) bsubs_of[bin_key[Bk.sub_of[r]]].push_back(r);
         std::vector<float> brow_start(Rb, 0.f), brow_end(Rb, 0.f);
@@ -399,8 +475,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             const int sr = bo.row_of[r];
             if (sr < 0) continue;
             const int in = Bk.sub_of[sr], s = bin_key[in], p = bin_tgt[in], j = Bk.sub_j[sr];
-            // {1 | -1 (produces nothing), z entry, label | 1 << 16, 0}
-            bmeta[r] = p >= 0 ? int4{1, zof(p, j), pair_lab[p] | (1 << 16), 0} : int4{-1, 0, 0, 0};
+            if (p >= 0) blab[r] = pair_lab[p];
             if (bin_dup[in] == 0) {  // logZ and the end weight are taken from the first copy only
                 brow_start[r] = start_lin[s];
                 brow_end[r] = j == 0 ? end_lin[s] : 0.f;
@@ -440,7 +515,6 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         }
         R.K = K;
         R.f.R = Rf; R.f.G = Gf; R.b.R = Rb; R.b.G = Gb;
-        R.f.has_nx = 0; R.b.has_nx = 0;
         R.NC = (int)gchunk.size() - 1;
         for (int k = 0; k < K; ++k) {
             h->res_rows_cu_f = std::max(h->res_rows_cu_f, fo.cu_row_off[k + 1] - fo.cu_row_off[k]);
@@ -451,9 +525,9 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         h->res_stats.conflicts_f = fo.conflicts; h->res_stats.conflicts_b = bo.conflicts;
         int rc;
         if ((rc = up(h, fo.arcs, &R.f.arcs)) || (rc = up(h, fo.wave_info, &R.f.wave_info)) ||
-            (rc = up(h, fmeta, &R.f.row_meta)) || (rc = up(h, fo.cu_row_off, &R.f.cu_row_off)) ||
+            (rc = up(h, flab, &R.f.row_lab)) || (rc = up(h, fo.cu_row_off, &R.f.cu_row_off)) ||
             (rc = up(h, xoff, &R.f.own_off)) || (rc = up(h, F.ex_cnt, &R.f.ex_cnt)) || (rc = up(h, Bk.ex_cnt, &R.b.ex_cnt)) || (rc = up(h, bo.arcs, &R.b.arcs)) ||
-            (rc = up(h, bo.wave_info, &R.b.wave_info)) || (rc = up(h, bmeta, &R.b.row_meta)) ||
+            (rc = up(h, bo.wave_info, &R.b.wave_info)) || (rc = up(h, blab, &R.b.row_lab)) ||
             (rc = up(h, bo.cu_row_off, &R.b.cu_row_off)) || (rc = up(h, zoff, &R.b.own_off)) ||
             (rc = up(h, x_start, &R.x_start)) || (rc = up(h, x_end, &R.x_end)) || (rc = up(h, z_lab, &R.z_lab)) ||
             (rc = up(h, z_end, &R.z_end)) || (rc = up(h, brow_start, &R.brow_start)) ||

@@ -11,7 +11,7 @@ from typing import Dict, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libctc_crf_hip.so")
+LIB_PATH = os.environ.get("CRF_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libctc_crf_hip.so")  # CRF_LIB: A/B builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -41,12 +41,14 @@ _lib.crf_profile_enable.argtypes = [ctypes.c_int]
 _lib.crf_profile_enable.restype = None
 _lib.crf_profile_read.argtypes = [ctypes.POINTER(_f32), ctypes.c_int]
 _lib.crf_profile_read.restype = ctypes.c_int
+_lib.crf_timing_read.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+_lib.crf_timing_read.restype = ctypes.c_int
 _lib.crf_last_error.restype = ctypes.c_char_p
 _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
-    "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_profile_enable", "crf_profile_read",
+    "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_profile_enable", "crf_profile_read", "crf_timing_read",
     "crf_last_error", "crf_version",
 )
 
@@ -94,6 +96,13 @@ def graph_stats(handle: int):
     d["max_in_deg"], d["max_out_deg"] = d["deg"] // 100000, d.pop("deg") % 100000
     d["res_fwd_rows"], d["res_bwd_rows"] = d["res_rows"] // 100000, d.pop("res_rows") % 100000
     return d
+
+
+def timing_read(n: int = 16384):
+    """In-kernel phase stamps of the last call (timing builds only; [] in a product build)."""
+    buf = (ctypes.c_uint64 * n)()
+    k = _lib.crf_timing_read(buf, n)
+    return [int(buf[i]) for i in range(k)]
 
 
 def compile_graph_host_only(fst_name: str) -> int:

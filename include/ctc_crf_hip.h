@@ -111,6 +111,11 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *log_probs_dev, const int32
 void crf_profile_enable(int on);
 int crf_profile_read(float *ms_out, int n);
 
+/* Diagnostics, timing builds only (CRF_BUILD_DEFS=-DCRF_TIMING python -m cat_amd.build --force): copies
+ * the in-kernel phase stamps (shader cycles, s_memtime) of the last call into `out`; returns the number of
+ * values, 0 in a product build.  tools/timing_probe.py decodes them.  No reference counterpart. */
+int crf_timing_read(unsigned long long *out, int n);
+
 /* Message for the last non-zero status returned on this thread. */
 const char *crf_last_error(void);
 

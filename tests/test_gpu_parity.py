@@ -205,6 +205,28 @@ def test_warp_ctc_loss_vs_torch(crf):
     assert rel_err(-xg.grad.cpu().numpy(), gamma_ref.numpy()) <= 5e-4
 
 
+@pytest.mark.parametrize("L,T", [(200, 500), (300, 700), (700, 1500), (1400, 3000), (2047, 4200)])
+def test_ctc_label_length_variants(crf, L, T):
+    """The numerator kernels are specialised on ctc states per thread (1, 2, 4, 8 <- ceil((2L+1)/512)):
+    every variant against torch's CPU ctc_loss, with one short utterance riding along in the same batch."""
+    rng = np.random.default_rng(L)
+    V = 37
+    x = torch.tensor(rng.normal(size=(2, T, V)) * 1.5, dtype=torch.float32).log_softmax(-1)
+    ly = torch.tensor([L, 7], dtype=torch.int32)
+    lx = torch.tensor([T, T // 3], dtype=torch.int32)
+    labels = torch.tensor(rng.integers(1, V, size=int(ly.sum())), dtype=torch.int32)
+    xg = x.cuda().requires_grad_(True)
+    loss = crf.WARP_CTC_LOSS(size_average=False)(xg, labels, lx, ly)
+    loss.backward()
+    xr = x.clone().double().requires_grad_(True)
+    ref = torch.nn.functional.ctc_loss(xr.transpose(0, 1), labels.long(), lx.long(), ly.long(), blank=0, reduction="sum")
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= TOL * abs(ref.item())
+    mask = (torch.arange(T)[None, :] < lx[:, None]).double()[..., None]
+    gamma_ref = (x.double().exp() * mask - xr.grad)
+    assert rel_err(-xg.grad.cpu().numpy(), gamma_ref.numpy()) <= 5e-4
+
+
 def _default_graph(tmp_path_factory):
     d = tmp_path_factory.mktemp("denlm")
     p = os.path.join(str(d), "den_lm_v72.fst")
