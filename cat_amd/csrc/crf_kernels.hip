@@ -916,24 +916,30 @@ __device__ __forceinline__ float res_fetch(gu64 *slot, float *v, int lo, int hi,
 }
 
 // Chunk sums in batches of kResBatch chunks: the 4*kResBatch gathers of a batch are one straight-line
-// block (no branch between them), so every wave keeps ~20 independent ds_read_b32 in flight -- with
+// block (no branch between them), so every wave keeps 24 independent ds_read_b32 in flight -- with
 // only 2 waves per SIMD that, not occupancy, is what hides the LDS latency.  The (uniform) slice-end
 // branches sit between batches.  Unused chunks hold zero weights.
-constexpr int kResBatch = 5;
+constexpr int kResBatch = 6;   // measured: 5 -> 6 = -2% (fewer, longer straight-line blocks); 10 spills
 static_assert(kResNCH % kResBatch == 0, "kResNCH must be a multiple of kResBatch");
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Packed math: the four products of a chunk are two v_pk_fma_f32 lanes (PMC showed the frame loop is
 // as much VALU-issue-bound as LDS-bound: ~530 VALU instructions per wave and frame before packing).
-#define CRF_RES_BATCH(part, A, xb, c0)                                                                    \
+// The 4*kResBatch gathers of a batch; the products are chained FMAs into the row accumulator (measured:
+// the frame loop is bound by instruction issue as much as by LDS -- one packed instruction less per
+// chunk than "multiply, FMA, add" was worth 3%).
+#define CRF_RES_GATHER(g01, g23, A, xb, c0)                                                               \
     _Pragma("unroll") for (int ci = 0; ci < kResBatch; ++ci) {                                            \
         const int c = (c0) + ci;                                                                          \
         const unsigned i01 = A[6 * c], i23 = A[6 * c + 1];                                                \
-        f32x2 g01, g23, w01, w23;                                                                         \
-        g01.x = *(const float *)(xb + (i01 & 0xffffu)); g01.y = *(const float *)(xb + (i01 >> 16));       \
-        g23.x = *(const float *)(xb + (i23 & 0xffffu)); g23.y = *(const float *)(xb + (i23 >> 16));       \
-        w01.x = __uint_as_float(A[6 * c + 2]); w01.y = __uint_as_float(A[6 * c + 3]);                     \
-        w23.x = __uint_as_float(A[6 * c + 4]); w23.y = __uint_as_float(A[6 * c + 5]);                     \
-        part[ci] = __builtin_elementwise_fma(g23, w23, g01 * w01);                                        \
+        g01[ci].x = *(const float *)(xb + (i01 & 0xffffu)); g01[ci].y = *(const float *)(xb + (i01 >> 16)); \
+        g23[ci].x = *(const float *)(xb + (i23 & 0xffffu)); g23[ci].y = *(const float *)(xb + (i23 >> 16)); \
+    }
+#define CRF_RES_CHUNK_ACC(accv, g01, g23, A, c, ci)                                                       \
+    {                                                                                                     \
+        f32x2 w01, w23;                                                                                   \
+        w01.x = __uint_as_float(A[6 * (c) + 2]); w01.y = __uint_as_float(A[6 * (c) + 3]);                 \
+        w23.x = __uint_as_float(A[6 * (c) + 4]); w23.y = __uint_as_float(A[6 * (c) + 5]);                 \
+        accv = __builtin_elementwise_fma(g23[ci], w23, __builtin_elementwise_fma(g01[ci], w01, accv));    \
     }
 
 // Kernel arguments of the resident kernels: only what ONE direction needs (the full LossParams is ~90
@@ -1138,14 +1144,15 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
             if (c0 < nch_f) {
                 // Row epilogues: the entry a row produces is implicit (rid + eoff), so the only table value
                 // needed is the row's emission e'[label(row)] -- two dependent LDS reads.  (Tried and measured
-                // slower: prefetching label and e' for ALL row ends of a batch ahead of the gathers -- the
-                // second code path per batch cost more, in moves, branches and instruction-cache misses,
-                // than the waves with many short slices gained.)
-                f32x2 part[kResBatch];
-                CRF_RES_BATCH(part, A, xb, c0);
+                // slower, both of them: prefetching label and e' for ALL row ends of a batch ahead of the
+                // gathers -- the second code path per batch cost more, in moves, branches and instruction-cache
+                // misses, than the waves with many short slices gained; and a rolling prefetch, label when
+                // the previous row ends and e' at every batch top: +4% on both kernels.)
+                f32x2 g01[kResBatch], g23[kResBatch];
+                CRF_RES_GATHER(g01, g23, A, xb, c0);
 #pragma unroll
                 for (int ci = 0; ci < kResBatch; ++ci) {
-                    acc += part[ci];
+                    CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
                     if (ends_f >> (c0 + ci) & 1u) {
                         const float rv = (acc.x + acc.y) * sc;       // q_t[row] (fwd) / b_t[state copy] (bwd)
                         Orow[rid] = rv;

@@ -152,8 +152,8 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
 // (bank = index mod 32, MI355X_MICROARCH.md LDS table): the order of a row's arcs is free.
 //   pass 1 (greedy): position by position, lanes with the fewest arcs left choose first, each takes the
 //           arc whose bank is least used in its half (equal index = broadcast, free);
-//   pass 2 (local search): swap two arcs of one lane between two positions whenever that lowers the
-//           number of extra bank cycles of the two positions.
+//   pass 2 (local search): swap two arcs of one lane between two positions whenever that lowers the LDS
+//           cycles (busiest bank) of the two gathers.
 // Padding gathers (weight 0) broadcast the address of a real lane of their half.
 void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o) {
     const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
@@ -189,41 +189,91 @@ void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o) 
                     rv.erase(rv.begin() + (long)best);
                 }
             }
+        // pass 2: local search on the TRUE cost.  A half-wave gather takes as many LDS cycles as its busiest
+        // bank has distinct addresses, so what counts is sum over (position, half) of that maximum -- not the
+        // number of colliding lanes (ten 2-way collisions in one gather cost one extra cycle, the same ten
+        // spread over ten gathers cost ten).  Move: swap two arcs of one lane between two positions; accepted
+        // if the two positions together get cheaper, or stay equal while the collisions shrink (plateau moves
+        // that later allow a maximum to drop).  Deterministic order, bounded passes.
         if (arrange) {
-            for (int pass = 0; pass < 3; ++pass) {
+            auto half_cost = [&](int ins, int h, int *coll) {  // cycles of one half-wave gather, #colliding lanes
+                int n[32] = {0}, first[32], mx = 1, c = 0;
+                for (int l = 0; l < 32; ++l) {
+                    const int idx = place[ins][h + l].first;
+                    if (idx < 0) continue;
+                    const int bk = idx & 31;
+                    if (n[bk] == 0) { first[bk] = idx; n[bk] = 1; continue; }
+                    // distinct addresses per bank: count exactly (rows are short lists, 32 lanes)
+                    bool seen = false;
+                    for (int l2 = 0; l2 < l && !seen; ++l2) seen = place[ins][h + l2].first == idx;
+                    if (!seen) { ++n[bk]; ++c; mx = std::max(mx, n[bk]); }
+                    (void)first;
+                }
+                if (coll) *coll = c;
+                return mx;
+            };
+            std::vector<int> hc(2 * NI), hcoll(2 * NI);
+            for (int ins = 0; ins < NI; ++ins)
+                for (int hh = 0; hh < 2; ++hh) hc[2 * ins + hh] = half_cost(ins, hh * 32, &hcoll[2 * ins + hh]);
+            for (int pass = 0; pass < 6; ++pass) {
                 bool any = false;
-                for (int lane = 0; lane < kWave; ++lane) {
-                    const int h = (lane >> 5) * 32;
-                    for (int i1 = 0; i1 < NI; ++i1) {
-                        if (place[i1][lane].first < 0) continue;
-                        const int b1 = place[i1][lane].first & 31;
-                        if (cnt[i1][h + b1] <= 1) continue;  // not in conflict here
-                        for (int i2 = 0; i2 < NI; ++i2) {
-                            if (i2 == i1 || place[i2][lane].first < 0) continue;
-                            const int b2 = place[i2][lane].first & 31;
-                            if (b1 == b2) continue;
-                            // extra cycles before/after the swap on the four affected (position, bank) cells
-                            auto x = [](int c) { return c > 1 ? c - 1 : 0; };
-                            const int before = x(cnt[i1][h + b1]) + x(cnt[i1][h + b2]) + x(cnt[i2][h + b1]) + x(cnt[i2][h + b2]);
-                            const int after = x(cnt[i1][h + b1] - 1) + x(cnt[i1][h + b2] + 1) + x(cnt[i2][h + b1] + 1) + x(cnt[i2][h + b2] - 1);
-                            if (after < before) {
-                                cnt[i1][h + b1]--; cnt[i1][h + b2]++; cnt[i2][h + b1]++; cnt[i2][h + b2]--;
-                                std::swap(place[i1][lane], place[i2][lane]);
-                                any = true;
-                                break;
+                for (int i1 = 0; i1 < NI; ++i1)
+                    for (int hh = 0; hh < 2; ++hh) {
+                        if (hc[2 * i1 + hh] <= 1) continue;  // conflict-free gather
+                        const int h = hh * 32;
+                        for (int l = 0; l < 32; ++l) {
+                            const int lane = h + l;
+                            if (place[i1][lane].first < 0) continue;
+                            const int b1 = place[i1][lane].first & 31;
+                            // only lanes that sit in a contended bank of this gather are worth moving
+                            int same = 0;
+                            for (int l2 = 0; l2 < 32; ++l2) {
+                                const int idx2 = place[i1][h + l2].first;
+                                if (idx2 >= 0 && (idx2 & 31) == b1 && idx2 != place[i1][lane].first) ++same;
                             }
+                            if (!same) continue;
+                            for (int i2 = 0; i2 < NI; ++i2) {
+                                if (i2 == i1 || place[i2][lane].first < 0) continue;
+                                if (((place[i2][lane].first ^ place[i1][lane].first) & 31) == 0) continue;
+                                const int before = hc[2 * i1 + hh] + hc[2 * i2 + hh], cb = hcoll[2 * i1 + hh] + hcoll[2 * i2 + hh];
+                                std::swap(place[i1][lane], place[i2][lane]);
+                                int c1, c2;
+                                const int n1 = half_cost(i1, h, &c1), n2 = half_cost(i2, h, &c2);
+                                if (n1 + n2 < before || (n1 + n2 == before && c1 + c2 < cb)) {
+                                    hc[2 * i1 + hh] = n1; hc[2 * i2 + hh] = n2; hcoll[2 * i1 + hh] = c1; hcoll[2 * i2 + hh] = c2;
+                                    any = true;
+                                    break;
+                                }
+                                std::swap(place[i1][lane], place[i2][lane]);
+                            }
+                            if (hc[2 * i1 + hh] <= 1) break;
                         }
                     }
-                }
                 if (!any) break;
             }
+            // cnt[][] is used below for the statistics: rebuild it as distinct addresses per bank
+            for (int ins = 0; ins < NI; ++ins)
+                for (int hb = 0; hb < 64; ++hb) cnt[ins][hb] = 0;
+            for (int ins = 0; ins < NI; ++ins)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int l = 0; l < 32; ++l) {
+                        const int idx = place[ins][hh * 32 + l].first;
+                        if (idx < 0) continue;
+                        bool seen = false;
+                        for (int l2 = 0; l2 < l && !seen; ++l2) seen = place[ins][hh * 32 + l2].first == idx;
+                        if (!seen) cnt[ins][hh * 32 + (idx & 31)]++;
+                    }
         }
         for (int ins = 0; ins < NI; ++ins) {
             const int c = sl.c0 + ins / kResW, slot = ins % kResW;
             for (int half = 0; half < 2; ++half) {
                 int first_real = -1;
                 for (int l = 0; l < 32; ++l) if (place[ins][half * 32 + l].first >= 0) { first_real = half * 32 + l; break; }
-                for (int b = 0; b < 32; ++b) if (cnt[ins][half * 32 + b] > 1) o->conflicts += cnt[ins][half * 32 + b] - 1;
+                {   // extra LDS cycles of this half-wave gather: the busiest bank serves one address per cycle
+                    int mx = 1;
+                    for (int b = 0; b < 32; ++b) mx = std::max(mx, cnt[ins][half * 32 + b]);
+                    o->conflicts += mx - 1;
+                }
                 for (int l = 0; l < 32; ++l) {
                     const int lane = half * 32 + l;
                     const bool real = place[ins][lane].first >= 0;
