@@ -1088,7 +1088,10 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
     __builtin_amdgcn_s_waitcnt(0x0F70);
 
     // one frame; par = parity of i = which buffer is the gather source
-    auto frame = [&](const int par, int i) __attribute__((always_inline)) {
+    // MODE (compile-time, one copy of the loop per value; a workgroup runs exactly one): how a row result
+    // reaches the peers -- 0: not at all (K = 1), 1: plain store into the shared L2, 2: write-through store.
+    auto frame = [&](auto MODE, const int par, int i) __attribute__((always_inline)) {
+        constexpr int mode = decltype(MODE)::value;
         const int t = DIR == 0 ? i : lx - 1 - i;                     // frame whose emissions are consumed
         const bool produce = DIR == 0 || t > 0;                      // a next vector exists
         const bool tm_on = b == p.b0 + 3 && i >= 100 && i < 228 && wave == 0;
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
         }
         gu64 *slot = xch + (size_t)(1 - par) * G;
         const unsigned tag = (unsigned)(i + 1);
-        const bool xchg = K > 1 && produce;
+        const bool xchg = mode != 0 && produce;
         const char *xb = (const char *)lds + par * kResXB;
         // keep the slice-end mask opaque per frame: otherwise hipcc hoists all 30 loop-invariant
         // "bit c set?" conditions out of the time loop as 64-bit lane masks (60 SGPRs), spills them
@@ -1133,17 +1136,20 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
         asm volatile("" : "+s"(ends_f), "+s"(nch_f));
         f32x2 acc = {0.f, 0.f};
         float mymax = 0.f;
-        int rid = row0 + lane;
-        // Entry produced by row `rid` (implicit numbering, res_layout.cpp): rid + eoff; its LDS word and its
-        // exchange granule follow from that, so a row epilogue needs ONE table value, the row's emission.
+        // Row `rid` of the wave's current slice, kept as the byte offset r4 = 4*rid: the row's slot in the
+        // per-frame HBM row, its label (RL), its LDS word and (times two) its exchange granule are all "uniform
+        // base + r4" -- SGPR-base addressing, no per-epilogue 64-bit address arithmetic.  The entry produced by
+        // row rid is implicit: rid + eoff (res_layout.cpp), so an epilogue needs ONE table value, the emission.
+        unsigned r4 = (unsigned)(row0 + lane) * 4u;
         const int eoff = own0 - cu_row0;
-        float *Xe = Xn + eoff;
-        gu64 *slot_e = slot + eoff;
+        const char *RLb = (const char *)RL - (size_t)cu_row0 * 4;
+        char *Xeb = (char *)(Xn + eoff);
+        char *Ob = (char *)Orow;
+        char *Sb = (char *)(slot + eoff);
 #pragma unroll
         for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
             if (c0 < nch_f) {
-                // Row epilogues: the entry a row produces is implicit (rid + eoff), so the only table value
-                // needed is the row's emission e'[label(row)] -- two dependent LDS reads.  (Tried and measured
+                // Row epilogues: two dependent LDS reads (label, then e'[label]).  (Tried and measured
                 // slower, both of them: prefetching label and e' for ALL row ends of a batch ahead of the
                 // gathers -- the second code path per batch cost more, in moves, branches and instruction-cache
                 // misses, than the waves with many short slices gained; and a rolling prefetch, label when
@@ -1155,13 +1161,18 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
                     if (ends_f >> (c0 + ci) & 1u) {
                         const float rv = (acc.x + acc.y) * sc;       // q_t[row] (fwd) / b_t[state copy] (bwd)
-                        Orow[rid] = rv;
-                        const float av = EPu[RL[rid - cu_row0]] * rv;  // a_{t+1}[dst] (fwd) / z_{t-1}[pair] (bwd): final, one producer per entry
-                        Xe[rid] = av;
+                        *(float *)(Ob + r4) = rv;
+                        const float av = EPu[*(const int *)(RLb + r4)] * rv;  // a_{t+1}[dst] (fwd) / z_{t-1}[pair] (bwd): final, one producer per entry
+                        *(float *)(Xeb + r4) = av;
                         mymax = fmaxf(mymax, av);
-                        if (xchg) res_publish(slot_e, rid, tag, av, same_l2);
+                        if (mode != 0 && (DIR == 0 || produce)) {
+                            const unsigned long long g = ((unsigned long long)tag << 32) | __float_as_uint(av);
+                            gu64 *dst = (gu64 *)(Sb + 2u * r4);
+                            if (mode == 1) asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(dst), "v"(g) : "memory");
+                            else __hip_atomic_store(dst, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         acc = f32x2{0.f, 0.f};
-                        rid += kWave;
+                        r4 += kWave * 4u;
                     }
                 }
             }
@@ -1195,8 +1206,16 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
     };
     // NOT unrolled by two for compile-time buffer offsets: the gathers add an SGPR base either way, and the
     // doubled loop body (2 x 30 KiB) did not fit the instruction cache next to the other direction's kernel
+    if (K == 1) {
 #pragma clang loop unroll(disable)
-    for (int i = 0; i < lx; ++i) frame(i & 1, i);
+        for (int i = 0; i < lx; ++i) frame(std::integral_constant<int, 0>{}, i & 1, i);
+    } else if (same_l2) {
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < lx; ++i) frame(std::integral_constant<int, 1>{}, i & 1, i);
+    } else {
+#pragma clang loop unroll(disable)
+        for (int i = 0; i < lx; ++i) frame(std::integral_constant<int, 2>{}, i & 1, i);
+    }
 
     if (DIR == 0) {
         if (k == 0) {
