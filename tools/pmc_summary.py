@@ -1,0 +1,85 @@
+"""tools/pmc_summary.py TAG -- condense the rocprofv3 outputs of tools/gpu_round.sh + tools/gpu_prof.sh
+(gpurun_out/) into the small summaries kept under profiles/:
+
+    profiles/round1_<TAG>_bench.json          the bench line (with cpu_baseline)
+    profiles/round1_<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary
+    profiles/round1_<TAG>_pmc.json            per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch) and SQ counters
+    profiles/pmc_traffic.json                 HBM bytes per launch of the two den chain kernels (read by bench.py)
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+PROF = os.path.join(ROOT, "profiles")
+
+
+def counters(tag, what):
+    f = glob.glob(os.path.join(OUT, f"pmc_{what}_{tag}", "**", "*counter_collection.csv"), recursive=True)
+    acc = defaultdict(lambda: defaultdict(list))
+    if not f:
+        return acc
+    per_dispatch = defaultdict(lambda: defaultdict(float))
+    names = {}
+    for r in csv.DictReader(open(f[0])):
+        key = r["Dispatch_Id"]
+        names[key] = r["Kernel_Name"]
+        per_dispatch[key][r["Counter_Name"]] += float(r["Counter_Value"])
+    for key, cs in per_dispatch.items():
+        for c, v in cs.items():
+            acc[names[key]][c].append(v)
+    return acc
+
+
+def main():
+    tag = sys.argv[1]
+    os.makedirs(PROF, exist_ok=True)
+    shutil.copy(os.path.join(OUT, f"bench_{tag}.json"), os.path.join(PROF, f"round1_{tag}_bench.json"))
+    ks = glob.glob(os.path.join(OUT, f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(PROF, f"round1_{tag}_kernel_stats.csv"))
+    traffic, sq = {}, {}
+    fe, wr, s = counters(tag, "fetch"), counters(tag, "write"), counters(tag, "sq")
+    for k in sorted(set(fe) | set(wr)):
+        if "crf" not in k:
+            continue
+        traffic[k] = {}
+        if "FETCH_SIZE" in fe.get(k, {}):
+            v = fe[k]["FETCH_SIZE"]
+            traffic[k]["FETCH_SIZE_KB_avg_per_launch"] = round(sum(v) / len(v), 1)
+        if "WRITE_SIZE" in wr.get(k, {}):
+            v = wr[k]["WRITE_SIZE"]
+            traffic[k]["WRITE_SIZE_KB_avg_per_launch"] = round(sum(v) / len(v), 1)
+    for k in sorted(s):
+        if "crf" in k:
+            sq[k] = {c: int(sum(v) / len(v)) for c, v in sorted(s[k].items())}
+    doc = {
+        "command": "rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline "
+                   "(tools/gpu_prof.sh; FETCH_SIZE, WRITE_SIZE and the SQ counters in three separate passes)",
+        "note": "FETCH_SIZE/WRITE_SIZE in KB per launch. On gfx950 FETCH_SIZE reports 1/2 of a wide (16 B/lane) coalesced "
+                "stream (MI355X_MICROARCH.md HBM section): the grad kernels' row reads are such streams.",
+        "traffic": traffic, "sq": sq,
+    }
+    json.dump(doc, open(os.path.join(PROF, f"round1_{tag}_pmc.json"), "w"), indent=1)
+    tr = {}
+    for k, v in traffic.items():
+        if "crf_res_chain_kernel<0>" in k:
+            tr["den_fwd_chain"] = int((v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024)
+        if "crf_res_chain_kernel<1>" in k:
+            tr["den_bwd_chain"] = int((v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024)
+    if tr:
+        tr["source"] = (f"profiles/round1_{tag}_pmc.json: (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; the chain kernels' "
+                        "reads are small and not 16-byte streams, so FETCH_SIZE is not doubled")
+        json.dump(tr, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(tr, indent=1))
+    for k, v in traffic.items():
+        print(k[:60], v)
+
+
+if __name__ == "__main__":
+    main()
