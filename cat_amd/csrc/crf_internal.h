@@ -76,6 +76,44 @@ struct ResDev {
     int NC;
 };
 
+// ---------------------------------------------------------------------------------------------
+// FACTORED register-resident layout: ONE compute unit per recursion (no exchange at all), made possible
+// by two structural facts of a CTC-topology o LM graph (den_lm = T o LM: every LM state g appears as the
+// states (g, blank) and (g, last token)), found by the graph compiler without being told:
+//  * forward: the two states of such a pair feed the same rows with the same weights, so with their
+//    gather entries ADJACENT one `ds_read_b64` + one weight serve two arcs (w * (x0 + x1));
+//  * backward: the two states have the same out-arcs but (at most) one each, so ONE row computes the
+//    common sum and its epilogue adds each state's extra arc: two outputs per row.
+// Both halve the arc registers: the 104 k-arc benchmark graph fits 512 threads x 180 words per direction.
+// Graphs without that structure (or with states entered by several labels) keep the generic layout.
+// ---------------------------------------------------------------------------------------------
+struct FacDirDev {
+    const unsigned *arcs;    // [kResWords][kResThreads]
+    const uint4 *wave_info;  // [kResWaves] {slice-end mask, chunks used, first row id, unused}
+    int R;                   // rows incl. padding (multiple of 64)
+    int G;                   // gather-vector entries (floats) incl. the sink pair at [G-2, G-1]
+};
+struct FacDev {
+    int ok;                    // 0 = not available for this graph
+    FacDirDev f, b;
+    // forward: rows = pairs.  Gathers are 8-byte (entry pair) reads with one weight.
+    const int2 *frow_meta;     // [Rf] {byte offset of the produced entry | label << 16, byte offset of its solo copy (or sink)}
+    const int4 *ftail;         // [NT*512] rows with a single gather, one per thread and j:
+                               //   {gather byte offset | label << 16, weight bits, entry offset | copy offset << 16, 0}
+    int NT;
+    const float *x_start, *x_end;   // [Gf]
+    // backward: rows = one or two states with common out-arcs; z entry of output o of row r = 2r + o.
+    const int4 *brow_meta;     // [Rb] {extra-arc z byte offset 0 | offset 1 << 16, weight 0 bits, weight 1 bits, label 0 | label 1 << 16}
+    const int *z_lab;          // [Gb] label of each z entry (V = none)
+    const float *z_end;        // [Gb] exp(end weight) of the entry's state
+    const float *brow_start, *brow_end;  // [2*Rb] per output
+    // grad pass
+    const int *gq, *gb, *chunk_off, *lab_chunk_off;
+    int NC;
+    int Rq;                    // Q row stride = Rf + NT*512
+    int Rbp;                   // BP row stride = 2*Rb
+};
+
 // The denominator graph as the kernels see it (all pointers device memory).
 // A "pair" is a distinct (destination state, label); pairs are numbered in forward-ELL row order.
 struct GraphDev {
@@ -98,9 +136,11 @@ struct GraphDev {
     const int *lab_chunk_off;// [max_label+2] chunk range of each label
     int NC;
     ResDev res;
+    FacDev fac;
 };
 
 struct ResBuildStats { int K = 0; int64_t slots_f = 0, slots_b = 0, conflicts_f = 0, conflicts_b = 0; };
+struct FacBuildStats { int ok = 0; int64_t matched = 0, solo = 0, tail = 0, slots_f = 0, slots_b = 0, fused = 0, Gf = 0, Gb = 0; };
 
 struct HostGraph {
     int device = 0;
@@ -111,6 +151,7 @@ struct HostGraph {
     int64_t fwd_padded_arcs = 0, bwd_padded_arcs = 0, fwd_conflicts = 0, bwd_conflicts = 0;
     int max_in_deg = 0, max_out_deg = 0;
     ResBuildStats res_stats;
+    FacBuildStats fac_stats;
     int res_rows_cu_f = 0, res_rows_cu_b = 0;  // max rows of one CU (LDS carve of the resident kernels)
 };
 
@@ -126,6 +167,11 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                    const std::vector<std::vector<std::pair<int, float>>> &out_arcs_of_state,
                    const std::vector<float> &start_lin, const std::vector<float> &end_lin,
                    const std::vector<int> &label_sorted_pairs);
+// Builds the factored layout into h->dev.fac (fac.ok = 0 when the graph has no such structure or does not fit).
+int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
+                   const std::vector<std::vector<std::pair<int, float>>> &in_arcs_of_pair,
+                   const std::vector<std::vector<std::pair<int, float>>> &out_arcs_of_state,
+                   const std::vector<float> &start_lin, const std::vector<float> &end_lin);
 int read_fst_file(const char *path, int64_t *S, std::vector<int32_t> *src, std::vector<int32_t> *dst,
                   std::vector<int32_t> *lab, std::vector<float> *w, std::vector<float> *start_w,
                   std::vector<float> *end_w);

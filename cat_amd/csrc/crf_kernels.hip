@@ -58,6 +58,7 @@ struct LossParams {
     const int *gchunk, *glab;     // its chunks (<= kChunk entries of one label) and per-label chunk ranges
     int gNC;
     int res;                      // 1: register-resident den kernels (g.res), 0: streaming kernels
+    int grad_den_acc;             // crf_grad_den_kernel: add to the row (the numerator half has written it) instead of writing
     int grad_phase;               // crf_grad_kernel: 0 = den and ctc in one pass, 1 = den part only (writes), 2 = ctc part only (subtracts)
     int b0;                       // first utterance of this launch (resident kernels with K > 1 run in groups)
     unsigned long long *xch;      // [2][B][2][G] tagged granules for the K-way exchange of the state vector
@@ -1241,6 +1242,289 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
     }
 }
 
+// =============================================================================================
+// FACTORED resident recursions (crf_internal.h: FacDev, res_layout.cpp: build_factored): one compute unit
+// per recursion and utterance, no exchange.  Same arithmetic and scaling as crf_res_chain_kernel.
+//   forward : a gather is an 8-byte read of two adjacent entries with ONE weight (w * (x0 + x1) -- the two
+//             states of a T o LM pair, or a state and the permanent zero next to its solo copy); rows with
+//             a single gather sit in a per-thread list ("tail rows") outside the slice machinery; a row
+//             epilogue writes the produced entry and, if the state is also read alone, its solo copy.
+//   backward: a row is the common out-arc sum of one or two states; the epilogue adds each state's one
+//             extra arc and produces two outputs (BP positions / z entries 2*rid, 2*rid + 1).
+// LDS: V0 | V1 (two state vectors of Gp floats) | row metadata | (fwd) tail-row metadata | EP[2][Vp] | wm | red
+// =============================================================================================
+struct FacParams {
+    FacDirDev L;
+    int B, T, V, Rout, NT, Rf;
+    const int *lx;
+    const float *ep, *mx;
+    float *Out;                 // Q (fwd) or BP (bwd) rows
+    float *Row0;                // [B][Rout] spare rows: b_0 of the backward recursion
+    int *Eout;                  // EQ (fwd) or EB (bwd)
+    int *started;               // workgroups of the den kernels that have started (gate for the numerator chains)
+    const int2 *frow_meta;
+    const int4 *ftail;
+    const float *x_start, *x_end;
+    float *den_zs, *cost_alpha;
+    int *den_ez;
+    const int4 *brow_meta;
+    const int *z_lab;
+    const float *z_end, *brow_start, *brow_end;
+    float *cb_part;
+    double *cb_mxs;
+    int *cb_F;
+};
+
+constexpr int kFacBatchF = 3;   // forward gathers return 8 bytes: 12 of them are the registers of 24 ordinary ones
+static_assert(kResNCH % kFacBatchF == 0, "kResNCH must be a multiple of kFacBatchF");
+#define CRF_FAC_GATHER(g, A, xb, c0)                                                                      \
+    _Pragma("unroll") for (int ci = 0; ci < kFacBatchF; ++ci) {                                            \
+        const int c = (c0) + ci;                                                                          \
+        const unsigned i01 = A[6 * c], i23 = A[6 * c + 1];                                                \
+        g[ci][0] = *(const f32x2 *)(xb + (i01 & 0xffffu)); g[ci][1] = *(const f32x2 *)(xb + (i01 >> 16)); \
+        g[ci][2] = *(const f32x2 *)(xb + (i23 & 0xffffu)); g[ci][3] = *(const f32x2 *)(xb + (i23 >> 16)); \
+    }
+// acc += g * (w, w): the weight is ONE half of a register pair, selected with op_sel -- written as (w, w)
+// in C++ the compiler materialises the splat pairs, hoists all 120 of them out of the time loop and spills.
+#define CRF_FAC_FMA_LO(accv, gv, wp) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(accv) : "v"(gv), "v"(wp))
+#define CRF_FAC_FMA_HI(accv, gv, wp) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(accv) : "v"(gv), "v"(wp))
+#define CRF_FAC_CHUNK_ACC(accv, g, A, c, ci)                                                              \
+    {                                                                                                     \
+        f32x2 w01_, w23_;                                                                                 \
+        w01_.x = __uint_as_float(A[6 * (c) + 2]); w01_.y = __uint_as_float(A[6 * (c) + 3]);               \
+        w23_.x = __uint_as_float(A[6 * (c) + 4]); w23_.y = __uint_as_float(A[6 * (c) + 5]);               \
+        CRF_FAC_FMA_LO(accv, g[ci][0], w01_); CRF_FAC_FMA_HI(accv, g[ci][1], w01_);                       \
+        CRF_FAC_FMA_LO(accv, g[ci][2], w23_); CRF_FAC_FMA_HI(accv, g[ci][3], w23_);                       \
+    }
+
+template <int DIR>
+__global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FacDirDev &L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.x;
+    const int V = p.V, lx = p.lx[b], G = L.G, R = L.R;
+    const int Vp = rup64(V + 1), Gp = rup64(G);
+    const int XB = Gp * 4;                                   // bytes per state vector
+    const int64_t bt0 = (int64_t)b * p.T;
+    float *X = lds;                                          // [2][Gp]
+    char *RMc = (char *)(X + 2 * Gp);                        // fwd: int2[R]   bwd: int4[R]
+    char *TMc = RMc + (size_t)R * (DIR == 0 ? 8 : 16);       // fwd: int4[NT*512]
+    float *EP = (float *)(TMc + (DIR == 0 ? (size_t)p.NT * kResThreads * 16 : 0));   // [2][Vp]
+    float *wm = EP + 2 * Vp;                                 // [2][kResWaves]
+    double *red = (double *)(wm + 2 * kResWaves);            // [kResWaves]
+    if (tid == 0 && p.started) atomicAdd(p.started, 1);      // this workgroup holds its CU: see crf_gate_kernel
+
+    unsigned A[kResWords];
+    {
+        const unsigned *src = L.arcs + tid;
+#pragma unroll
+        for (int i = 0; i < kResWords; ++i) A[i] = src[(size_t)i * kResThreads];
+    }
+    const uint4 wi = L.wave_info[wave];
+    const unsigned ends = __builtin_amdgcn_readfirstlane(wi.x);
+    const int nch = __builtin_amdgcn_readfirstlane(wi.y);
+    const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
+    if (DIR == 0) {
+        int2 *RM = (int2 *)RMc;
+        for (int r = tid; r < R; r += kResThreads) { int2 m = p.frow_meta[r]; RM[r] = m; }
+        int4 *TM = (int4 *)TMc;
+        for (int r = tid; r < p.NT * kResThreads; r += kResThreads) TM[r] = p.ftail[r];
+    } else {
+        int4 *RM = (int4 *)RMc;
+        for (int r = tid; r < R; r += kResThreads) {
+            int4 m = p.brow_meta[r];
+            const int l0 = (short)(m.w & 0xffff), l1 = m.w >> 16;       // -1 = no label: emission 0 at EP[V]
+            m.w = ((l0 < 0 ? V : l0) & 0xffff) | ((l1 < 0 ? V : l1) << 16);
+            RM[r] = m;
+        }
+    }
+    int E = kScaleExp;
+    float zpart = 0.f;
+    for (int s = tid; s < 2 * Gp; s += kResThreads) X[s] = 0.f;
+    if (tid < 2) EP[tid * Vp + V] = 0.f;
+    if (lx > 0)
+        for (int v = tid; v < V; v += kResThreads) {
+            EP[v] = p.ep[(bt0 + (DIR == 0 ? 0 : lx - 1)) * V + v];
+            if (DIR == 1 && lx > 1) EP[Vp + v] = p.ep[(bt0 + lx - 2) * V + v];
+        }
+    __syncthreads();
+    {
+        float m0 = 0.f;
+        if (DIR == 0) {
+            for (int s = tid; s < G; s += kResThreads) { const float v = p.x_start[s] * pow2f(kScaleExp); X[s] = v; m0 = fmaxf(m0, v); }
+        } else if (lx > 0) {
+            for (int z = tid; z < G; z += kResThreads) {
+                const int l = p.z_lab[z];
+                const float v = EP[l < 0 ? V : l] * (p.z_end[z] * pow2f(kScaleExp));
+                X[z] = v; m0 = fmaxf(m0, v);
+            }
+            float *BProw = p.Out + (bt0 + lx - 1) * p.Rout;
+            for (int r = tid; r < 2 * R; r += kResThreads) BProw[r] = p.brow_end[r] * pow2f(kScaleExp);
+            if (tid == 0) p.Eout[bt0 + lx - 1] = E;
+        } else {
+            for (int r = tid; r < 2 * R; r += kResThreads) zpart += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
+        }
+        m0 = wave_max(m0);
+        if (lane == 0) wm[wave] = m0;
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // arcs and tables have landed (see crf_res_chain_kernel)
+
+    auto frame = [&](const int par, int i) __attribute__((always_inline)) {
+        const int t = DIR == 0 ? i : lx - 1 - i;
+        const bool tm_on = b == 3 && i >= 100 && i < 228 && wave == 0;
+        const int tm_i = (DIR * 4) * 1024 + (i - 100) * 8;
+        CRF_TM(tm_on, tm_i + 0);
+#ifdef CRF_TIMING
+        if (b == 3 && i >= 150 && i < 158 && wave == 0) CRF_TM(true, 12288 + 1024 + (DIR * 4) * 8 + (i - 150));  // frame start
+#endif
+        const char *xb = (const char *)lds + par * XB;
+        char *xnb = (char *)lds + (1 - par) * XB;
+        const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
+        const int tpre = DIR == 0 ? t + 1 : t - 2;
+        const bool pre = DIR == 0 ? (t + 1 < lx) : (t >= 2);
+        float epn[kEpRegsR];
+        if (pre) {
+            const float *er = p.ep + (bt0 + tpre) * V;
+#pragma unroll
+            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; epn[q] = v < V ? er[v] : 0.f; }
+        }
+        const int ksc = rescale_exp(res_frame_max(wm + par * kResWaves));
+        const float sc = pow2f(ksc);
+        float *Orow;
+        if (DIR == 0) {
+            E += ksc;
+            if (tid == 0) p.Eout[bt0 + t] = E;
+            E += kEpExp;
+            Orow = p.Out + (bt0 + t) * p.Rout;
+        } else {
+            E += ksc + kEpExp;
+            if (t > 0 && tid == 0) p.Eout[bt0 + t - 1] = E;
+            Orow = t > 0 ? p.Out + (bt0 + t - 1) * p.Rout : p.Row0 + (int64_t)b * p.Rout;
+        }
+        unsigned ends_f = ends;
+        int nch_f = nch;
+        asm volatile("" : "+s"(ends_f), "+s"(nch_f));
+        f32x2 acc = {0.f, 0.f};
+        float mymax = 0.f;
+        if (DIR == 0) {   // rows with a single gather: one per thread and j, no slice machinery
+            const int4 *TM = (const int4 *)TMc;
+            float *Ot = Orow + p.Rf;
+            for (int j = 0; j < p.NT; ++j) {
+                const int4 m = TM[j * kResThreads + tid];
+                const f32x2 g = *(const f32x2 *)(xb + (m.x & 0xffff));
+                const float qv = (g.x + g.y) * __int_as_float(m.y) * sc;
+                Ot[j * kResThreads + tid] = qv;
+                const float av = EPu[(unsigned)m.x >> 16] * qv;
+                *(float *)(xnb + (m.z & 0xffff)) = av;
+                *(float *)(xnb + ((unsigned)m.z >> 16)) = av;
+                mymax = fmaxf(mymax, av);
+            }
+        }
+        CRF_TM(tm_on, tm_i + 1);
+        unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
+        constexpr int kB = DIR == 0 ? kFacBatchF : kResBatch;
+#pragma unroll
+        for (int c0 = 0; c0 < kResNCH; c0 += kB) {
+            if (c0 < nch_f) {
+                if (DIR == 0) {
+                    f32x2 g[kFacBatchF][4];
+                    CRF_FAC_GATHER(g, A, xb, c0);
+#pragma unroll
+                    for (int ci = 0; ci < kFacBatchF; ++ci) {
+                        CRF_FAC_CHUNK_ACC(acc, g, A, c0 + ci, ci);
+                        if (ends_f >> (c0 + ci) & 1u) {
+                            const float rv = (acc.x + acc.y) * sc;                      // q_t[pair]
+                            *(float *)((char *)Orow + r4) = rv;
+                            const int2 m = *(const int2 *)(RMc + 2u * r4);
+                            const float av = EPu[(unsigned)m.x >> 16] * rv;               // a_{t+1}[dst]
+                            *(float *)(xnb + (m.x & 0xffff)) = av;
+                            *(float *)(xnb + m.y) = av;                                 // solo copy (or the sink)
+                            mymax = fmaxf(mymax, av);
+                            acc = f32x2{0.f, 0.f};
+                            r4 += kWave * 4u;
+                        }
+                    }
+                } else {
+                    f32x2 g01[kResBatch], g23[kResBatch];
+                    CRF_RES_GATHER(g01, g23, A, xb, c0);
+#pragma unroll
+                    for (int ci = 0; ci < kResBatch; ++ci) {
+                        CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
+                        if (ends_f >> (c0 + ci) & 1u) {
+                            const int4 m = *(const int4 *)(RMc + 4u * r4);
+                            const float craw = acc.x + acc.y;                           // common out-arcs of the row's states
+                            const float z0 = *(const float *)(xb + (m.x & 0xffff)), z1 = *(const float *)(xb + ((unsigned)m.x >> 16));
+                            f32x2 bv;                                                    // b_t of the two states
+                            bv.x = fmaf(__int_as_float(m.y), z0, craw) * sc;
+                            bv.y = fmaf(__int_as_float(m.z), z1, craw) * sc;
+                            *(f32x2 *)((char *)Orow + 2u * r4) = bv;
+                            f32x2 zv;                                                    // z_{t-1} of the pairs entering them
+                            zv.x = EPu[m.w & 0xffff] * bv.x;
+                            zv.y = EPu[(unsigned)m.w >> 16] * bv.y;
+                            *(f32x2 *)(xnb + 2u * r4) = zv;
+                            mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
+                            acc = f32x2{0.f, 0.f};
+                            r4 += kWave * 4u;
+                        }
+                    }
+                }
+            }
+        }
+        CRF_TM(tm_on, tm_i + 2);
+#ifdef CRF_TIMING
+        if (b == 3 && i >= 150 && i < 158) {
+            const int o = 12288 + ((DIR * 4) * 8 + wave) * 16;
+            CRF_TM(true, o + (i - 150));
+            if (lane == 0 && i == 150) { g_tm[o + 8] = (unsigned long long)nch; g_tm[o + 9] = (unsigned long long)__builtin_popcount(ends); }
+        }
+#endif
+        mymax = wave_max(mymax);
+        if (lane == 0) wm[(1 - par) * kResWaves + wave] = mymax;
+        if (pre) {
+            float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;
+#pragma unroll
+            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; if (v < V) EPw[v] = epn[q]; }
+        }
+        CRF_TM(tm_on, tm_i + 3);
+        sync_lds();
+        CRF_TM(tm_on, tm_i + 4);
+    };
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < lx; ++i) frame(i & 1, i);
+
+    if (DIR == 0) {
+        const float *Xf = X + (lx & 1) * Gp;
+        float part = 0.f;
+        for (int s = tid; s < G; s += kResThreads) part += Xf[s] * p.x_end[s];
+        const float zs = res_block_sum(part, (float *)red, tid);
+        const double mxs = res_mx_total(p, b, lx, red, tid);
+        if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); }
+    } else {
+        if (lx > 0) {
+            __syncthreads();  // drains vmcnt: this workgroup's own stores to the spare row are visible to it
+            const float *r0 = p.Row0 + (int64_t)b * p.Rout;
+            for (int r = tid; r < 2 * R; r += kResThreads) zpart += p.brow_start[r] * r0[r];
+        }
+        const float zb = res_block_sum(zpart, (float *)red, tid);
+        const double mxs = res_mx_total(p, b, lx, red, tid);
+        if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E; p.cb_mxs[b] = mxs; }
+    }
+}
+
+// Holds a (side) stream until `target` workgroups of the den kernels have started, i.e. own their compute
+// units: the numerator chains launched behind it then land on the remaining CUs instead of scattering over
+// all of them and keeping den workgroups (which need a whole CU's registers) waiting.  Bounded: after ~2 ms
+// it lets go regardless (a speed matter only).
+__global__ void crf_gate_kernel(const int *started, int target) {
+    for (int spins = 0; spins < 20000; ++spins) {
+        if (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 // One kernel per recursion so each keeps its own (small) set of live kernel arguments in SGPRs; the
 // four launches are issued on forked HIP streams and run concurrently (crf_loss_fwd_bwd).
 // NR (numerator roles only): ctc states per thread, chosen by the host from the batch's longest label sequence.
@@ -1493,7 +1777,10 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
 #pragma unroll
         for (int q = 0; q < kGDEpRegs; ++q) {
             const int v = tid + q * kGDThreads;
-            if (v < V) row[v] = p.c_den * (erc[q] * (ldexpf(gsum[v], e) * inv));
+            if (v < V) {
+                const float gv = p.c_den * (erc[q] * (ldexpf(gsum[v], e) * inv));
+                row[v] = p.grad_den_acc ? row[v] + gv : gv;
+            }
             erc[q] = ern[q];
         }
         CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
@@ -1502,10 +1789,11 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
     }
 #undef CRF_GD_STAGE
 #undef CRF_GD_FETCH
-    for (int t = max(t0, tl); t < t1; ++t) {  // frames past the utterance's length: zero rows
-        float *row = p.grad + (bt0 + t) * V;
-        for (int v = tid; v < V; v += kGDThreads) row[v] = 0.f;
-    }
+    if (!p.grad_den_acc)
+        for (int t = max(t0, tl); t < t1; ++t) {  // frames past the utterance's length: zero rows
+            float *row = p.grad + (bt0 + t) * V;
+            for (int v = tid; v < V; v += kGDThreads) row[v] = 0.f;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1632,7 +1920,8 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
         if (p.c_den != 0.f) {
             if (p.res) {  // backward partition sum = sum of the K per-CU partials
                 float zb = 0.f;
-                for (int k = 0; k < p.g.res.K; ++k) zb += p.cb_part[(size_t)b * kResMaxK + k];
+                const int nk = p.res == 2 ? 1 : p.g.res.K;
+                for (int k = 0; k < nk; ++k) zb += p.cb_part[(size_t)b * kResMaxK + k];
                 p.cost_beta[b] = to_log(zb, p.cb_F[b], p.cb_mxs[b]);
             }
             c += (double)p.c_den * (double)p.cost_alpha[b];
@@ -1659,7 +1948,7 @@ struct WsLayout {
     int64_t off_ep, off_mx, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_xch, off_row0, total;
     int64_t xch_bytes;
     int64_t Rq, Rb;
-    bool res, gv;
+    bool res, gv, fac;
     int64_t off_gvec;
 };
 static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -1670,12 +1959,19 @@ static bool use_resident(const HostGraph *h, int64_t V) {
     return h && h->dev.res.K > 0 && V <= (int64_t)kEpRegsR * kResThreads && h->dev.res.f.G <= kResGmax && h->dev.res.b.G <= kResGmax;
 }
 
+// the factored layout (one CU per recursion) is preferred whenever the graph has it; CRF_NO_FACTORED=1 at
+// graph creation keeps the generic resident kernels
+static bool use_factored(const HostGraph *h, int64_t V) {
+    return h && h->dev.fac.ok && V <= (int64_t)kEpRegsR * kResThreads;
+}
+
 static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, int64_t Sc) {
     WsLayout w{};
     int64_t o = 0;
-    w.res = use_resident(h, V);
-    w.Rq = h ? (w.res ? h->dev.res.f.R : h->dev.Pr) : 0;
-    w.Rb = h ? (w.res ? h->dev.res.b.R : h->dev.Pr) : 0;
+    w.fac = use_factored(h, V);
+    w.res = w.fac || use_resident(h, V);   // "res": register-resident kernels of either layout
+    w.Rq = h ? (w.fac ? h->dev.fac.Rq : w.res ? h->dev.res.f.R : h->dev.Pr) : 0;
+    w.Rb = h ? (w.fac ? h->dev.fac.Rbp : w.res ? h->dev.res.b.R : h->dev.Pr) : 0;
     w.off_ep = o; o = al(o + B * T * V * 4);
     w.off_mx = o; o = al(o + B * T * 4);
     w.off_Q = o; o = al(o + B * T * w.Rq * 4);
@@ -1688,7 +1984,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_ECB = o; o = al(o + B * T * 4);
     w.off_pb = o; o = al(o + 32 * B * 8);
     // tagged granules [2 slots] of both directions, then one XCD-id word per CU of every recursion
-    w.xch_bytes = (w.res && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8) : 0;
+    w.xch_bytes = (w.res && !w.fac && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8) : 0;
     w.off_xch = o; o = al(o + w.xch_bytes + 256);
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.gv = h && !w.res && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
@@ -1818,6 +2114,39 @@ static int launch_res(const LossParams &lp, size_t lds, int b0, int nb, hipStrea
     return CRF_OK;
 }
 
+static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
+    const FacDev &F = h->dev.fac;
+    const FacDirDev &L = dir == 0 ? F.f : F.b;
+    return (size_t)2 * rup64(L.G) * 4 + (size_t)L.R * (dir == 0 ? 8 : 16) + (dir == 0 ? (size_t)F.NT * kResThreads * 16 : 0) +
+           ((size_t)2 * rup64(V + 1) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
+}
+template <int DIR>
+static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started) {
+    static std::atomic<size_t> lds_set{0};
+    hipError_t e;
+    if (lds > lds_set.load()) {
+        if ((e = hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
+            set_error(std::string("hipFuncSetAttribute(fac chain): ") + hipGetErrorString(e));
+            return CRF_ERR_HIP;
+        }
+        lds_set = lds;
+    }
+    const FacDev &F = lp.g.fac;
+    FacParams p{};
+    p.L = DIR == 0 ? F.f : F.b;
+    p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
+    p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
+    p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
+    p.started = started;
+    p.frow_meta = F.frow_meta; p.ftail = F.ftail; p.x_start = F.x_start; p.x_end = F.x_end;
+    p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
+    p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
+    p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
+    hipLaunchKernelGGL(crf_fac_chain_kernel<DIR>, dim3((unsigned)lp.B), dim3(kResThreads), lds, st, p);
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return CRF_OK;
+}
+
 }  // namespace crf
 
 using namespace crf;
@@ -1851,12 +2180,13 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     if (ctc && 2 * max_label_len + 1 > kCtcRegs * kCtcThreads) { set_error("label length > 2047 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
     const WsLayout w = ws_layout(h, B, T, V, Sc);
     if (ws_bytes < w.total) { set_error("workspace too small: need " + std::to_string(w.total)); return CRF_ERR_WORKSPACE; }
-    const bool res = den && w.res, gv = den && w.gv;
+    const bool res = den && w.res, gv = den && w.gv, fac = den && w.fac;
     size_t lds_chain = 0;
     if (den && !res) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0, gv), chain_lds_bytes(h, (int)V, Sc, 1, gv));
-    if (res) lds_chain = std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b));
+    if (res && !fac) lds_chain = std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b));
+    if (fac) lds_chain = std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1));
     if (ctc) lds_chain = std::max(lds_chain, chain_lds_bytes(h, (int)V, Sc, 2));
-    const int gnc_all = den ? std::max(h->dev.NC, h->dev.res.NC) : 0;
+    const int gnc_all = den ? std::max(std::max(h->dev.NC, h->dev.res.NC), h->dev.fac.ok ? h->dev.fac.NC : 0) : 0;
     // the generic grad kernel stages the two rows of a frame in LDS when they fit, else gathers them from L2
     const bool grad_stage = !den || ((size_t)rup64((int)w.Rq) + rup64((int)w.Rb) + rup64(gnc_all) + 2 * (size_t)rup64((int)V)) * 4 <= 150 * 1024;
     const size_t lds_grad = ((den && grad_stage ? (size_t)rup64((int)w.Rq) + rup64((int)w.Rb) : 0) + rup64(gnc_all) + 2 * (size_t)rup64((int)V)) * sizeof(float);
@@ -1873,13 +2203,16 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     char *base = (char *)ws;
     p.ep = (float *)(base + w.off_ep); p.mx = (float *)(base + w.off_mx);
     p.Q = (float *)(base + w.off_Q); p.BP = (float *)(base + w.off_BP);
-    p.Rq = (int)w.Rq; p.Rb = (int)w.Rb; p.res = res ? 1 : 0; p.grad_stage = grad_stage ? 1 : 0;
-    if (den) {
+    p.Rq = (int)w.Rq; p.Rb = (int)w.Rb; p.res = fac ? 2 : res ? 1 : 0; p.grad_stage = grad_stage ? 1 : 0;
+    if (fac) {
+        const FacDev &F = h->dev.fac;
+        p.gq = F.gq; p.gb = F.gb; p.gchunk = F.chunk_off; p.glab = F.lab_chunk_off; p.gNC = F.NC;
+    } else if (den) {
         p.gq = res ? h->dev.res.gq : h->dev.perm; p.gb = res ? h->dev.res.gb : h->dev.perm;
         p.gchunk = res ? h->dev.res.chunk_off : h->dev.chunk_off; p.glab = res ? h->dev.res.lab_chunk_off : h->dev.lab_chunk_off;
         p.gNC = res ? h->dev.res.NC : h->dev.NC;
     }
-    if (res) { p.res_lds_rows_f = h->res_rows_cu_f; p.res_lds_rows_b = h->res_rows_cu_b; }
+    if (res && !fac) { p.res_lds_rows_f = h->res_rows_cu_f; p.res_lds_rows_b = h->res_rows_cu_b; }
     p.EQ = (int *)(base + w.off_EQ); p.EB = (int *)(base + w.off_EB);
     p.CA = (double *)(base + w.off_CA); p.CB = (double *)(base + w.off_CB);
     p.ECA = (int *)(base + w.off_ECA); p.ECB = (int *)(base + w.off_ECB);
@@ -1934,7 +2267,17 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         (void)hipStreamWaitEvent(cx->side[i], cx->fork, 0);
         return cx->side[i];
     };
-    if (res) {
+    int *started = p.err + 1;   // workgroups of the den kernels that hold a CU (cleared with the error word)
+    if (fac) {
+        // factored resident recursions: one CU per utterance and direction, nothing to exchange
+        hipStream_t sb = side(0);
+        prof_mark(1, false, stream);
+        if ((rc = launch_fac<0>(p, fac_lds_bytes(h, (int)V, 0), stream, started))) return rc;
+        prof_mark(1, true, stream);
+        prof_mark(2, false, sb);
+        if ((rc = launch_fac<1>(p, fac_lds_bytes(h, (int)V, 1), sb, started))) return rc;
+        prof_mark(2, true, sb);
+    } else if (res) {
         // register-resident recursions: K CUs per utterance and direction, exchanging the state vector
         // through L2 every frame.  With K > 1 every workgroup of a launch must be resident at once
         // (its peers spin on it), so the batch goes in groups of at most CUs/(2K) utterances.
@@ -1965,7 +2308,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // (HBM-bound, small workgroups that share CUs happily); a second, cheap grad pass then subtracts
     // the numerator posteriors.  Otherwise all four recursions run side by side and grad is one pass.
     static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
-    const bool split = ctc && den && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && h->dev.res.K > 1)) && !serial;
+    const bool split = ctc && den && !fac && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && h->dev.res.K > 1)) && !serial;
     auto join_all = [&]() -> int {
         for (int i = 0; i < 3; ++i)
             if (used[i]) {
@@ -1981,7 +2324,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     const dim3 ggrid((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B);
     // The denominator half of the grad pass has a streaming kernel (index pairs in registers, rows
     // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
-    const int gnc = den ? (res ? h->dev.res.NC : h->dev.NC) : 0;
+    const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
     const bool fast_den = den && w.Rq <= 4 * kGDRowRegs * kGDThreads && w.Rb <= 4 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
                           gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
     auto launch_grad_den = [&]() -> int {
@@ -2001,19 +2344,40 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // numerator half of the grad pass: streaming kernel when the vocabulary fits its registers
     const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
                           !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
-    auto launch_grad_ctc = [&](int phase) -> int {  // phase 2: subtract from the den half; 0: plain CTC (writes)
+    auto launch_grad_ctc = [&](int phase, hipStream_t st = nullptr) -> int {  // phase 2: subtract from the den half; 0: plain CTC (writes)
+        if (!st) st = stream;
         p.grad_phase = phase;
         if (fast_ctc) {
             const size_t l = (size_t)4 * rup64((int)V) * sizeof(float) + kGCFrames * sizeof(double);
             const dim3 gg((unsigned)((T + kGCFrames - 1) / kGCFrames), (unsigned)B);
-            hipLaunchKernelGGL(crf_grad_ctc_kernel, gg, dim3(kGCThreads), l, stream, p);
+            hipLaunchKernelGGL(crf_grad_ctc_kernel, gg, dim3(kGCThreads), l, st, p);
         } else {
-            hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+            hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, st, p);
         }
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad(ctc): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
     };
-    if (!split) {
+    if (fac && ctc && fast_den && fast_ctc && !serial) {
+        // Factored den kernels use one CU per recursion: half the chip.  The numerator chains AND the numerator
+        // half of the grad pass run beside them on the other half, behind a gate that waits until every den
+        // workgroup holds its CU; the den half of the grad pass then ADDS to what the numerator half wrote.
+        hipStream_t s1 = side(1), s2 = side(2);
+        const int target = 2 * (int)B;
+        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s1, started, target);
+        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s2, started, target);
+        if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), s1, max_label_len))) return rc;
+        if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), s2, max_label_len))) return rc;
+        if ((e = hipEventRecord(cx->join[2], s2)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->join[2], 0)) != hipSuccess) {
+            set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+        }
+        used[2] = false;
+        prof_mark(5, false, s1);
+        if ((rc = launch_grad_ctc(0, s1))) return rc;
+        if ((rc = join_all())) return rc;
+        p.grad_den_acc = 1;
+        if ((rc = launch_grad_den())) return rc;
+        prof_mark(5, true, stream);
+    } else if (!split) {
         if (ctc) {
             if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream, max_label_len))) return rc;
             if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2), max_label_len))) return rc;

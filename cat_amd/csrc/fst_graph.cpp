@@ -347,6 +347,7 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     if (device < 0) {  // host-only compile (diagnostics / CPU tests): tables are built, nothing is uploaded
         h->device = -1;
         int rcr = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon);
+        if (!rcr) rcr = build_factored(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin);
         if (rcr) { delete h; return rcr; }
         *out = h;
         return CRF_OK;
@@ -375,6 +376,7 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
         if ((rc = upload(h, chunk_off, &d.chunk_off))) break;
         if ((rc = upload(h, lab_chunk_off, &d.lab_chunk_off))) break;
         if ((rc = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon))) break;
+        if ((rc = build_factored(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin))) break;
     } while (0);
     (void)hipSetDevice(prev);
     if (rc) {
@@ -436,11 +438,14 @@ int crf_graph_dims(const crf_graph *g, int64_t *S, int64_t *A, int64_t *P, int64
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
     if (!g || !g->h || !out) { crf::set_error("null argument"); return CRF_ERR_ARG; }
     const crf::HostGraph *h = g->h;
-    const int64_t v[16] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
+    const int64_t v[24] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
                            h->fwd_conflicts, h->bwd_conflicts, (int64_t)h->max_in_deg * 100000 + h->max_out_deg,
                            h->res_stats.K, h->res_stats.slots_f, h->res_stats.slots_b, h->res_stats.conflicts_f,
-                           h->res_stats.conflicts_b, (int64_t)h->dev.res.f.R * 100000 + h->dev.res.b.R};
-    for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
+                           h->res_stats.conflicts_b, (int64_t)h->dev.res.f.R * 100000 + h->dev.res.b.R,
+                           h->fac_stats.ok, h->fac_stats.matched, h->fac_stats.solo, h->fac_stats.tail,
+                           h->fac_stats.slots_f, h->fac_stats.slots_b, h->fac_stats.fused,
+                           h->fac_stats.Gf * 100000 + h->fac_stats.Gb};
+    for (int i = 0; i < n && i < 24; ++i) out[i] = v[i];
     return CRF_OK;
 }
 

@@ -155,7 +155,9 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
 //   pass 2 (local search): swap two arcs of one lane between two positions whenever that lowers the LDS
 //           cycles (busiest bank) of the two gathers.
 // Padding gathers (weight 0) broadcast the address of a real lane of their half.
-void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o) {
+// `stride`: bytes per gather index (4: one float per gather; 8: an entry PAIR per gather, ds_read_b64, whose
+// bank class is again index mod 32 -- 64 banks, two per lane).
+void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, int stride = 4) {
     const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
     for (const SliceAt &sl : slices) {
         const int NI = sl.len * kResW;
@@ -277,7 +279,7 @@ void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o) 
                 for (int l = 0; l < 32; ++l) {
                     const int lane = half * 32 + l;
                     const bool real = place[ins][lane].first >= 0;
-                    const int off16 = real ? place[ins][lane].first * 4 : (first_real >= 0 ? place[ins][first_real].first * 4 : 0);
+                    const int off16 = real ? place[ins][lane].first * stride : (first_real >= 0 ? place[ins][first_real].first * stride : 0);
                     const float wv = real ? place[ins][lane].second : 0.f;
                     const size_t t = (size_t)sl.w * kWave + lane;
                     unsigned &iw = o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + (slot >> 1)) * kResThreads + t];
@@ -587,6 +589,242 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         return CRF_OK;
     }
     return CRF_OK;  // K stays 0: not resident
+}
+
+// =================================================================================================
+// Factored layout (crf_internal.h: FacDev).
+// =================================================================================================
+int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
+                   const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
+                   const std::vector<float> &end_lin) {
+    FacDev &F = h->dev.fac;
+    F = FacDev{};
+    if ((getenv("CRF_NO_FACTORED") && atoi(getenv("CRF_NO_FACTORED"))) || (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT")))) return CRF_OK;
+    const bool verbose = getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"));
+    auto give_up = [&](const char *why) { if (verbose) fprintf(stderr, "[fac_layout] not used: %s\n", why); return CRF_OK; };
+    // ---- precondition: every state is entered with at most one label (true for T o LM: a state of the
+    // composition remembers the last token), so "pair" and "destination state" are the same thing
+    std::vector<int> pair_of(S, -1);
+    for (int p = 0; p < P; ++p) {
+        if (pair_of[pair_dst[p]] >= 0) return give_up("a state is entered with several labels");
+        pair_of[pair_dst[p]] = p;
+    }
+    auto wbits = [](float w) { unsigned b; memcpy(&b, &w, 4); return b; };
+
+    // ---- 1. match states that feed the same rows with the same weights
+    std::vector<int> mate(S, -1);
+    {
+        std::vector<std::pair<uint64_t, int>> cand;  // (s1 << 32 | s2) -> count, via sort
+        std::vector<uint64_t> keys;
+        for (int p = 0; p < P; ++p) {
+            std::vector<std::pair<unsigned, int>> a;
+            for (auto &x : in_arcs_of_pair[p]) a.push_back({wbits(x.second), x.first});
+            std::sort(a.begin(), a.end());
+            for (size_t i = 0; i < a.size();) {
+                size_t j = i;
+                while (j < a.size() && a[j].first == a[i].first) ++j;
+                if (j - i >= 2 && j - i <= 64)
+                    for (size_t u = i; u < j; ++u)
+                        for (size_t v = u + 1; v < j; ++v)
+                            if (a[u].second != a[v].second)
+                                keys.push_back((uint64_t)std::min(a[u].second, a[v].second) << 32 | (unsigned)std::max(a[u].second, a[v].second));
+                i = j;
+            }
+        }
+        std::sort(keys.begin(), keys.end());
+        for (size_t i = 0; i < keys.size();) {
+            size_t j = i;
+            while (j < keys.size() && keys[j] == keys[i]) ++j;
+            cand.push_back({keys[i], (int)(j - i)});
+            i = j;
+        }
+        std::stable_sort(cand.begin(), cand.end(), [](const std::pair<uint64_t, int> &x, const std::pair<uint64_t, int> &y) { return x.second > y.second; });
+        for (auto &c : cand) {
+            const int s1 = (int)(c.first >> 32), s2 = (int)(c.first & 0xffffffffu);
+            if (c.second < 2) break;
+            if (mate[s1] < 0 && mate[s2] < 0) { mate[s1] = s2; mate[s2] = s1; }
+        }
+    }
+    int64_t nmatched = 0;
+    for (int s = 0; s < S; ++s) if (mate[s] > s) ++nmatched;
+    if (nmatched * 4 < S) return give_up("fewer than half of the states pair up");
+
+    // ---- 2. forward rows as gathers of entry PAIRS.  A gather reads two adjacent entries and applies one
+    // weight to both.  Matched states (s1 < s2) live at entries (2j, 2j+1); a state that some row needs
+    // WITHOUT its mate (self-loops; rows that only one of the two feeds) additionally gets a solo slot
+    // (x, 0) written by the same producer; unmatched states live in a solo slot only.
+    std::vector<int> loc(S, -1), solo(S, -1);
+    int nent = 0;
+    for (int s = 0; s < S; ++s) if (mate[s] > s) { loc[s] = nent; loc[mate[s]] = nent + 1; nent += 2; }
+    struct Gather { int ent; float w; };   // even entry index
+    std::vector<std::vector<Gather>> frow(P);
+    std::vector<char> need_solo(S, 0);
+    for (int s = 0; s < S; ++s) if (mate[s] < 0) need_solo[s] = 1;
+    std::vector<std::vector<std::pair<int, float>>> solo_reads(P);  // filled in a first pass (entries not final yet)
+    for (int p = 0; p < P; ++p) {
+        std::vector<std::pair<int, float>> a = in_arcs_of_pair[p];
+        std::vector<char> used(a.size(), 0);
+        for (size_t i = 0; i < a.size(); ++i) {
+            if (used[i]) continue;
+            const int s = a[i].first, m = mate[s];
+            size_t j = a.size();
+            if (m >= 0)
+                for (size_t q = i + 1; q < a.size(); ++q)
+                    if (!used[q] && a[q].first == m && wbits(a[q].second) == wbits(a[i].second)) { j = q; break; }
+            if (j < a.size()) { used[i] = used[j] = 1; frow[p].push_back({std::min(loc[s], loc[m]), a[i].second}); }
+            else { used[i] = 1; need_solo[s] = 1; solo_reads[p].push_back({s, a[i].second}); }
+        }
+    }
+    int64_t nsolo = 0;
+    for (int s = 0; s < S; ++s) if (need_solo[s]) { solo[s] = nent; nent += 2; ++nsolo; if (loc[s] < 0) loc[s] = solo[s]; }
+    for (int p = 0; p < P; ++p)
+        for (auto &r : solo_reads[p]) frow[p].push_back({solo[r.first], r.second});
+    const int sink = nent;   // (sink, sink+1): target of unused second writes, never read with a non-zero weight
+    const int Gf = nent + 2;
+    if ((size_t)Gf * 4 > 65536) return give_up("forward gather vector > 64 KiB");
+
+    // ---- 3. forward rows: single-gather rows go to the per-thread tail list, the rest to slices
+    constexpr int kMaxNT = 4;
+    std::vector<int> tail_rows, main_rows;
+    for (int p = 0; p < P; ++p) (frow[p].size() == 1 && (int)tail_rows.size() < kMaxNT * kResThreads ? tail_rows : main_rows).push_back(p);
+    const int NT = (int)((tail_rows.size() + kResThreads - 1) / kResThreads);
+    Rows fsub(main_rows.size());
+    for (size_t i = 0; i < main_rows.size(); ++i)
+        for (auto &gth : frow[main_rows[i]]) fsub[i].push_back({gth.ent / 2, gth.w});
+    DirOut fo;
+    std::vector<SliceAt> fslices;
+    if (!place_rows(fsub, std::vector<int>(fsub.size(), 0), 1, &fo, &fslices)) return give_up("forward rows do not fit one CU");
+    pack_arcs(fsub, fslices, &fo, 8);
+    const int Rf = fo.cu_row_off[1];
+    std::vector<int> fpos(P, -1);   // position of pair p in the Q row
+    std::vector<int2> frow_meta(Rf, int2{sink * 4, sink * 4});   // padding rows: emission index 0 (their sum is 0), sink
+    for (int rid = 0; rid < Rf; ++rid) {
+        const int r = fo.row_of[rid];
+        if (r < 0) continue;
+        const int p = main_rows[r], s = pair_dst[p];
+        fpos[p] = rid;
+        frow_meta[rid] = int2{(loc[s] * 4) | (pair_lab[p] << 16), (solo[s] >= 0 && solo[s] != loc[s] ? solo[s] : sink) * 4};
+    }
+    std::vector<int4> ftail((size_t)std::max(NT, 1) * kResThreads, int4{sink * 4, 0, (sink * 4) | ((sink * 4) << 16), 0});
+    for (size_t i = 0; i < tail_rows.size(); ++i) {
+        const int p = tail_rows[i], s = pair_dst[p];
+        fpos[p] = Rf + (int)i;
+        const int dup = (solo[s] >= 0 && solo[s] != loc[s]) ? solo[s] : sink;
+        ftail[i] = int4{(frow[p][0].ent * 4) | (pair_lab[p] << 16), (int)wbits(frow[p][0].w), (loc[s] * 4) | ((dup * 4) << 16), 0};
+    }
+    const int Rq = Rf + NT * kResThreads;
+    std::vector<float> x_start(Gf, 0.f), x_end(Gf, 0.f);
+    for (int s = 0; s < S; ++s) {
+        x_start[loc[s]] = start_lin[s];
+        x_end[loc[s]] = end_lin[s];
+        if (solo[s] >= 0 && solo[s] != loc[s]) x_start[solo[s]] = start_lin[s];   // the copy starts equal; counted once in logZ
+    }
+
+    // ---- 4. backward rows: matched states with common out-arcs and at most one extra arc each share a row
+    struct BRow { int s0, s1; std::vector<std::pair<int, float>> arcs; int e0 = -1, e1 = -1; float w0 = 0.f, w1 = 0.f; };  // arcs: (pair, w)
+    std::vector<BRow> brow;
+    int64_t nfused = 0;
+    {
+        std::vector<char> done(S, 0);
+        for (int s = 0; s < S; ++s) {
+            if (done[s]) continue;
+            const int m = mate[s];
+            bool fused = false;
+            if (m > s) {
+                std::vector<std::pair<int, unsigned>> a, b;
+                for (auto &x : out_arcs_of_state[s]) a.push_back({x.first, wbits(x.second)});
+                for (auto &x : out_arcs_of_state[m]) b.push_back({x.first, wbits(x.second)});
+                std::sort(a.begin(), a.end());
+                std::sort(b.begin(), b.end());
+                std::vector<std::pair<int, unsigned>> common, ea, eb;
+                std::set_intersection(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(common));
+                std::set_difference(a.begin(), a.end(), common.begin(), common.end(), std::back_inserter(ea));
+                std::set_difference(b.begin(), b.end(), common.begin(), common.end(), std::back_inserter(eb));
+                if (ea.size() <= 1 && eb.size() <= 1 && !common.empty()) {
+                    BRow r{s, m, {}, -1, -1, 0.f, 0.f};
+                    for (auto &c : common) { float w; memcpy(&w, &c.second, 4); r.arcs.push_back({c.first, w}); }
+                    if (!ea.empty()) { r.e0 = ea[0].first; memcpy(&r.w0, &ea[0].second, 4); }
+                    if (!eb.empty()) { r.e1 = eb[0].first; memcpy(&r.w1, &eb[0].second, 4); }
+                    brow.push_back(r);
+                    done[s] = done[m] = 1;
+                    fused = true;
+                    ++nfused;
+                }
+            }
+            if (!fused) { brow.push_back(BRow{s, -1, out_arcs_of_state[s], -1, -1, 0.f, 0.f}); done[s] = 1; }
+        }
+    }
+    Rows bsub(brow.size());
+    for (size_t i = 0; i < brow.size(); ++i) bsub[i] = brow[i].arcs;   // pair ids for now; lengths are all placement needs
+    DirOut bo;
+    std::vector<SliceAt> bslices;
+    if (!place_rows(bsub, std::vector<int>(bsub.size(), 0), 1, &bo, &bslices)) return give_up("backward rows do not fit one CU");
+    const int Rb = bo.cu_row_off[1], Gb = 2 * Rb + 2, zsink = 2 * Rb;
+    if ((size_t)Gb * 4 > 65536) return give_up("backward gather vector > 64 KiB");
+    std::vector<int> zpos(S, -1);   // BP / z position of state s: 2*rid + output
+    for (int rid = 0; rid < Rb; ++rid) {
+        const int r = bo.row_of[rid];
+        if (r < 0) continue;
+        zpos[brow[r].s0] = 2 * rid;
+        if (brow[r].s1 >= 0) zpos[brow[r].s1] = 2 * rid + 1;
+    }
+    auto zof_pair = [&](int p) { return zpos[pair_dst[p]]; };
+    for (auto &row : bsub)
+        for (auto &a : row) a.first = zof_pair(a.first);
+    pack_arcs(bsub, bslices, &bo, 4);
+    const int noLab = -1;
+    std::vector<int4> brow_meta(Rb, int4{(zsink * 4) | ((zsink * 4) << 16), 0, 0, (noLab & 0xffff) | (noLab << 16)});
+    std::vector<float> brow_start((size_t)2 * Rb, 0.f), brow_end((size_t)2 * Rb, 0.f), z_end(Gb, 0.f);
+    std::vector<int> z_lab(Gb, -1);
+    for (int rid = 0; rid < Rb; ++rid) {
+        const int r = bo.row_of[rid];
+        if (r < 0) continue;
+        const BRow &br = brow[r];
+        const int o0 = br.e0 >= 0 ? zof_pair(br.e0) : zsink, o1 = br.e1 >= 0 ? zof_pair(br.e1) : zsink;
+        const int l0 = pair_of[br.s0] >= 0 ? pair_lab[pair_of[br.s0]] : noLab;
+        const int l1 = (br.s1 >= 0 && pair_of[br.s1] >= 0) ? pair_lab[pair_of[br.s1]] : noLab;
+        brow_meta[rid] = int4{(o0 * 4) | ((o1 * 4) << 16), (int)wbits(br.w0), (int)wbits(br.w1), (l0 & 0xffff) | (l1 << 16)};
+        brow_start[2 * rid] = start_lin[br.s0]; brow_end[2 * rid] = end_lin[br.s0];
+        z_lab[2 * rid] = l0; z_end[2 * rid] = end_lin[br.s0];
+        if (br.s1 >= 0) {
+            brow_start[2 * rid + 1] = start_lin[br.s1]; brow_end[2 * rid + 1] = end_lin[br.s1];
+            z_lab[2 * rid + 1] = l1; z_end[2 * rid + 1] = end_lin[br.s1];
+        }
+    }
+
+    // ---- 5. grad pass list: one (Q position, BP position) per pair, label-sorted (pairs already are), chunked
+    const int max_lab = *std::max_element(pair_lab.begin(), pair_lab.end());
+    std::vector<int> gq, gb, gchunk{0}, glab((size_t)max_lab + 2, 0);
+    for (int p = 0; p < P; ++p) { gq.push_back(fpos[p]); gb.push_back(zpos[pair_dst[p]]); }
+    {
+        int r = 0;
+        for (int v = 0; v <= max_lab; ++v) {
+            glab[v] = (int)gchunk.size() - 1;
+            int e = r;
+            while (e < P && pair_lab[e] == v) ++e;
+            for (int c = r; c < e; c += kChunk) gchunk.push_back(std::min(e, c + kChunk));
+            r = e;
+        }
+        glab[(size_t)max_lab + 1] = (int)gchunk.size() - 1;
+    }
+    for (int p = 1; p < P; ++p) if (pair_lab[p] < pair_lab[p - 1]) return give_up("pairs are not label-sorted");
+
+    h->fac_stats = FacBuildStats{1, nmatched, nsolo, (int64_t)tail_rows.size(), fo.slots, bo.slots, nfused, Gf, Gb};
+    if (verbose)
+        fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld, bwd rows %d (fused %lld) slots %lld, Gf=%d Gb=%d\n",
+                (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, Rb, (long long)nfused, (long long)bo.slots, Gf, Gb);
+    F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb;
+    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1;
+    int rc;
+    if ((rc = up(h, fo.arcs, &F.f.arcs)) || (rc = up(h, fo.wave_info, &F.f.wave_info)) || (rc = up(h, bo.arcs, &F.b.arcs)) ||
+        (rc = up(h, bo.wave_info, &F.b.wave_info)) || (rc = up(h, frow_meta, &F.frow_meta)) || (rc = up(h, ftail, &F.ftail)) ||
+        (rc = up(h, x_start, &F.x_start)) || (rc = up(h, x_end, &F.x_end)) || (rc = up(h, brow_meta, &F.brow_meta)) ||
+        (rc = up(h, z_lab, &F.z_lab)) || (rc = up(h, z_end, &F.z_end)) || (rc = up(h, brow_start, &F.brow_start)) ||
+        (rc = up(h, brow_end, &F.brow_end)) || (rc = up(h, gq, &F.gq)) || (rc = up(h, gb, &F.gb)) ||
+        (rc = up(h, gchunk, &F.chunk_off)) || (rc = up(h, glab, &F.lab_chunk_off)))
+        return rc;
+    F.ok = 1;
+    return CRF_OK;
 }
 
 }  // namespace crf

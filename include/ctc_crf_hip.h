@@ -66,7 +66,10 @@ int crf_graph_dims(const crf_graph *g, int64_t *num_states, int64_t *num_arcs, i
  * gathers that share a bank with an earlier lane of their half-wave (extra LDS cycles per frame),
  * max_in_degree*100000 + max_out_degree; out[10..15] = register-resident layout: CUs per recursion K
  * (0 = graph too large, streaming kernels are used), forward / backward arc slots incl. padding,
- * forward / backward bank-sharing gathers, forward_rows*100000 + backward_rows.  A graph created with device < 0 is compiled on the host
+ * forward / backward extra LDS cycles (busiest bank per half-wave gather), forward_rows*100000 + backward_rows;
+ * out[16..23] = factored layout (one CU per recursion, T o LM structure): available (0/1), matched state pairs,
+ * solo slots, single-gather (tail) rows, forward / backward arc slots, fused backward rows, Gf*100000 + Gb.
+ * A graph created with device < 0 is compiled on the host
  * only (no GPU needed) and can be used with crf_graph_dims / crf_graph_stats / crf_graph_destroy. */
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n);
 

@@ -27,33 +27,38 @@ def crf():
     return ctc_crf
 
 
-MODES = ["resident", "streaming"]
+MODES = ["factored", "resident", "streaming"]
 
 
 class _mode:
-    """The denominator has two kernel families: register-resident (default whenever the graph fits) and
-    streaming (fallback).  CRF_NO_RESIDENT is read when a graph is created."""
+    """The denominator has three kernel families: factored register-resident (one CU per recursion; needs the
+    T o LM structure, else it falls back to the next), generic register-resident, and streaming (fallback for
+    graphs that do not fit registers).  CRF_NO_FACTORED / CRF_NO_RESIDENT are read when a graph is created."""
 
     def __init__(self, mode):
         self.mode = mode
 
     def __enter__(self):
-        self.old = os.environ.get("CRF_NO_RESIDENT")
+        self.old = {k: os.environ.get(k) for k in ("CRF_NO_RESIDENT", "CRF_NO_FACTORED")}
         os.environ["CRF_NO_RESIDENT"] = "1" if self.mode == "streaming" else "0"
+        os.environ["CRF_NO_FACTORED"] = "0" if self.mode == "factored" else "1"
 
     def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("CRF_NO_RESIDENT", None)
-        else:
-            os.environ["CRF_NO_RESIDENT"] = self.old
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
-def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mode="resident"):
+def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mode="factored"):
     with _mode(mode):
         ctx = crf.CRFContext(den_lm, 0)
-    want = 0 if mode == "streaming" else None
-    k = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))["res_K"]
-    assert (k == 0) if want == 0 else True
+    st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+    if mode == "streaming":
+        assert st["res_K"] == 0 and st["fac"] == 0
+    if mode == "resident":
+        assert st["fac"] == 0
     x = torch.tensor(logits, device="cuda:0", requires_grad=True)
     crit = crf.CTC_CRF_LOSS(lamb=lamb, size_average=size_average)
     loss = crit(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32),

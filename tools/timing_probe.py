@@ -39,7 +39,9 @@ def main():
     if not tm:
         print("not a timing build")
         return
-    names = ["compute(gathers+epilogues)", "fetch peers", "wave max + emission stage", "barrier"]
+    fac = bool(_C.graph_stats(_C.graph_for(dev))["fac"])
+    names = ["frame top + tail rows", "main rows (gathers+epilogues)", "wave max + emission stage", "barrier"] if fac else \
+        ["compute(gathers+epilogues)", "fetch peers", "wave max + emission stage", "barrier"]
     for d, dn in enumerate(("fwd", "bwd")):
         for k in range(2):
             base = (d * 4 + k) * 1024
