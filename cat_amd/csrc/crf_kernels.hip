@@ -1275,7 +1275,11 @@ struct FacParams {
     int *cb_F;
 };
 
-constexpr int kFacBatchF = 3;   // forward gathers return 8 bytes: 12 of them are the registers of 24 ordinary ones
+constexpr int kFacMaxNT = 4;    // single-gather rows per thread (res_layout.cpp: kMaxNT)
+#ifndef CRF_V_FB
+#define CRF_V_FB 2
+#endif
+constexpr int kFacBatchF = CRF_V_FB;   // measured 2..6: no difference beyond noise, 2 is the smallest code   // forward gathers return 8 bytes: 12 of them are the registers of 24 ordinary ones
 static_assert(kResNCH % kFacBatchF == 0, "kResNCH must be a multiple of kFacBatchF");
 #define CRF_FAC_GATHER(g, A, xb, c0)                                                                      \
     _Pragma("unroll") for (int ci = 0; ci < kFacBatchF; ++ci) {                                            \
@@ -1412,17 +1416,28 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         if (DIR == 0) {   // rows with a single gather: one per thread and j, no slice machinery
             const int4 *TM = (const int4 *)TMc;
             float *Ot = Orow + p.Rf;
-            for (int j = 0; j < p.NT; ++j) {
-                const int4 m = TM[j * kResThreads + tid];
-                const f32x2 g = *(const f32x2 *)(xb + (m.x & 0xffff));
-                const float qv = (g.x + g.y) * __int_as_float(m.y) * sc;
-                Ot[j * kResThreads + tid] = qv;
-                const float av = EPu[(unsigned)m.x >> 16] * qv;
-                *(float *)(xnb + (m.z & 0xffff)) = av;
-                *(float *)(xnb + ((unsigned)m.z >> 16)) = av;
-                mymax = fmaxf(mymax, av);
-            }
+            // all (up to kFacMaxNT) rows of the thread in flight together: three dependent LDS round trips for
+            // the lot (metadata -> entry pair, emission -> two writes), not per row
+            int4 m[kFacMaxNT];
+            f32x2 g[kFacMaxNT];
+            float ev[kFacMaxNT];
+#pragma unroll
+            for (int j = 0; j < kFacMaxNT; ++j) if (j < p.NT) m[j] = TM[j * kResThreads + tid];
+#pragma unroll
+            for (int j = 0; j < kFacMaxNT; ++j)
+                if (j < p.NT) { g[j] = *(const f32x2 *)(xb + (m[j].x & 0xffff)); ev[j] = EPu[(unsigned)m[j].x >> 16]; }
+#pragma unroll
+            for (int j = 0; j < kFacMaxNT; ++j)
+                if (j < p.NT) {
+                    const float qv = (g[j].x + g[j].y) * __int_as_float(m[j].y) * sc;
+                    Ot[j * kResThreads + tid] = qv;
+                    const float av = ev[j] * qv;
+                    *(float *)(xnb + (m[j].z & 0xffff)) = av;
+                    *(float *)(xnb + ((unsigned)m[j].z >> 16)) = av;
+                    mymax = fmaxf(mymax, av);
+                }
         }
+        CRF_TM(tm_on, tm_i + 1);
         CRF_TM(tm_on, tm_i + 1);
         unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
         constexpr int kB = DIR == 0 ? kFacBatchF : kResBatch;

@@ -684,7 +684,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     if ((size_t)Gf * 4 > 65536) return give_up("forward gather vector > 64 KiB");
 
     // ---- 3. forward rows: single-gather rows go to the per-thread tail list, the rest to slices
-    constexpr int kMaxNT = 4;
+    constexpr int kMaxNT = 4;   // = kFacMaxNT of the kernel
     std::vector<int> tail_rows, main_rows;
     for (int p = 0; p < P; ++p) (frow[p].size() == 1 && (int)tail_rows.size() < kMaxNT * kResThreads ? tail_rows : main_rows).push_back(p);
     const int NT = (int)((tail_rows.size() + kResThreads - 1) / kResThreads);
@@ -745,6 +745,10 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                     for (auto &c : common) { float w; memcpy(&w, &c.second, 4); r.arcs.push_back({c.first, w}); }
                     if (!ea.empty()) { r.e0 = ea[0].first; memcpy(&r.w0, &ea[0].second, 4); }
                     if (!eb.empty()) { r.e1 = eb[0].first; memcpy(&r.w1, &eb[0].second, 4); }
+                    // which of the two states is output 0 alternates: the z entries 2*rid + output are what the
+                    // rows gather, and in a T o LM graph nearly all arcs enter the "token" state of a pair -- with
+                    // a fixed order every gather would hit an odd entry, i.e. half of the LDS banks
+                    if (brow.size() & 1) { std::swap(r.s0, r.s1); std::swap(r.e0, r.e1); std::swap(r.w0, r.w1); }
                     brow.push_back(r);
                     done[s] = done[m] = 1;
                     fused = true;
@@ -811,8 +815,8 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 
     h->fac_stats = FacBuildStats{1, nmatched, nsolo, (int64_t)tail_rows.size(), fo.slots, bo.slots, nfused, Gf, Gb};
     if (verbose)
-        fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld, bwd rows %d (fused %lld) slots %lld, Gf=%d Gb=%d\n",
-                (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, Rb, (long long)nfused, (long long)bo.slots, Gf, Gb);
+        fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
+                (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb;
     F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1;
     int rc;
