@@ -80,8 +80,9 @@ struct ResDev {
 // FACTORED register-resident layout: ONE compute unit per recursion (no exchange at all), made possible
 // by two structural facts of a CTC-topology o LM graph (den_lm = T o LM: every LM state g appears as the
 // states (g, blank) and (g, last token)), found by the graph compiler without being told:
-//  * forward: the two states of such a pair feed the same rows with the same weights, so with their
-//    gather entries ADJACENT one `ds_read_b64` + one weight serve two arcs (w * (x0 + x1));
+//  * forward: the two states of such a pair feed the same rows with the same weights, and the row of
+//    (g, blank) is just w * (sum of the pair): the recursion carries the pair SUM as an entry of its own, so
+//    one gather and one weight serve two arcs, and that row is folded into the epilogue of its mate's row;
 //  * backward: the two states have the same out-arcs but (at most) one each, so ONE row computes the
 //    common sum and its epilogue adds each state's extra arc: two outputs per row.
 // Both halve the arc registers: the 104 k-arc benchmark graph fits 512 threads x 180 words per direction.
@@ -96,11 +97,10 @@ struct FacDirDev {
 struct FacDev {
     int ok;                    // 0 = not available for this graph
     FacDirDev f, b;
-    // forward: rows = pairs.  Gathers are 8-byte (entry pair) reads with one weight.
-    const int2 *frow_meta;     // [Rf] {byte offset of the produced entry | label << 16, byte offset of its solo copy (or sink)}
-    const int4 *ftail;         // [NT*512] rows with a single gather, one per thread and j:
-                               //   {gather byte offset | label << 16, weight bits, entry offset | copy offset << 16, 0}
-    int NT;
+    // forward: rows = pairs except "tail" rows; a (tail, main) state pair keeps three entries U = sum, L, A.
+    const int4 *frow_meta;     // [Rf] {U byte offset | main label << 16, L offset | A offset << 16, tail weight bits, tail label}
+                               //      plain rows: U = A = sink, tail weight 0
+    int NT;                    // unused (0)
     const float *x_start, *x_end;   // [Gf]
     // backward: rows = one or two states with common out-arcs; z entry of output o of row r = 2r + o.
     const int4 *brow_meta;     // [Rb] {extra-arc z byte offset 0 | offset 1 << 16, weight 0 bits, weight 1 bits, label 0 | label 1 << 16}
@@ -110,7 +110,7 @@ struct FacDev {
     // grad pass
     const int *gq, *gb, *chunk_off, *lab_chunk_off;
     int NC;
-    int Rq;                    // Q row stride = Rf + NT*512
+    int Rq;                    // Q row stride = 2*Rf: main rows, then the tail row of each main row
     int Rbp;                   // BP row stride = 2*Rb
 };
 

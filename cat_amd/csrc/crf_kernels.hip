@@ -1244,14 +1244,14 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
 
 // =============================================================================================
 // FACTORED resident recursions (crf_internal.h: FacDev, res_layout.cpp: build_factored): one compute unit
-// per recursion and utterance, no exchange.  Same arithmetic and scaling as crf_res_chain_kernel.
-//   forward : a gather is an 8-byte read of two adjacent entries with ONE weight (w * (x0 + x1) -- the two
-//             states of a T o LM pair, or a state and the permanent zero next to its solo copy); rows with
-//             a single gather sit in a per-thread list ("tail rows") outside the slice machinery; a row
-//             epilogue writes the produced entry and, if the state is also read alone, its solo copy.
+// per recursion and utterance, no exchange.  Same arithmetic and scaling as crf_res_chain_kernel, same arc
+// format (4 gathers of one float + 4 weights per chunk); what differs is the row epilogue, which has TWO outputs:
+//   forward : a row belongs to the main state s2 of a pair (s1, s2).  L' = e'[l2] * rowsum is a[s2];
+//             A' = e'[l1] * w * U is a[s1] (its own row is exactly w * (a[s1] + a[s2]) = w * U); U' = A' + L'
+//             is the entry every other row gathers for the pair.  Q row: [rowsum of each row | w*U of each row].
 //   backward: a row is the common out-arc sum of one or two states; the epilogue adds each state's one
-//             extra arc and produces two outputs (BP positions / z entries 2*rid, 2*rid + 1).
-// LDS: V0 | V1 (two state vectors of Gp floats) | row metadata | (fwd) tail-row metadata | EP[2][Vp] | wm | red
+//             extra arc (BP positions / z entries 2*rid, 2*rid + 1).
+// LDS: V0 | V1 (two state vectors of Gp floats) | row metadata int4[R] | EP[2][Vp] | wm | red
 // =============================================================================================
 struct FacParams {
     FacDirDev L;
@@ -1262,8 +1262,7 @@ struct FacParams {
     float *Row0;                // [B][Rout] spare rows: b_0 of the backward recursion
     int *Eout;                  // EQ (fwd) or EB (bwd)
     int *started;               // workgroups of the den kernels that have started (gate for the numerator chains)
-    const int2 *frow_meta;
-    const int4 *ftail;
+    const int4 *frow_meta;
     const float *x_start, *x_end;
     float *den_zs, *cost_alpha;
     int *den_ez;
@@ -1274,32 +1273,6 @@ struct FacParams {
     double *cb_mxs;
     int *cb_F;
 };
-
-constexpr int kFacMaxNT = 4;    // single-gather rows per thread (res_layout.cpp: kMaxNT)
-#ifndef CRF_V_FB
-#define CRF_V_FB 2
-#endif
-constexpr int kFacBatchF = CRF_V_FB;   // measured 2..6: no difference beyond noise, 2 is the smallest code   // forward gathers return 8 bytes: 12 of them are the registers of 24 ordinary ones
-static_assert(kResNCH % kFacBatchF == 0, "kResNCH must be a multiple of kFacBatchF");
-#define CRF_FAC_GATHER(g, A, xb, c0)                                                                      \
-    _Pragma("unroll") for (int ci = 0; ci < kFacBatchF; ++ci) {                                            \
-        const int c = (c0) + ci;                                                                          \
-        const unsigned i01 = A[6 * c], i23 = A[6 * c + 1];                                                \
-        g[ci][0] = *(const f32x2 *)(xb + (i01 & 0xffffu)); g[ci][1] = *(const f32x2 *)(xb + (i01 >> 16)); \
-        g[ci][2] = *(const f32x2 *)(xb + (i23 & 0xffffu)); g[ci][3] = *(const f32x2 *)(xb + (i23 >> 16)); \
-    }
-// acc += g * (w, w): the weight is ONE half of a register pair, selected with op_sel -- written as (w, w)
-// in C++ the compiler materialises the splat pairs, hoists all 120 of them out of the time loop and spills.
-#define CRF_FAC_FMA_LO(accv, gv, wp) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(accv) : "v"(gv), "v"(wp))
-#define CRF_FAC_FMA_HI(accv, gv, wp) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(accv) : "v"(gv), "v"(wp))
-#define CRF_FAC_CHUNK_ACC(accv, g, A, c, ci)                                                              \
-    {                                                                                                     \
-        f32x2 w01_, w23_;                                                                                 \
-        w01_.x = __uint_as_float(A[6 * (c) + 2]); w01_.y = __uint_as_float(A[6 * (c) + 3]);               \
-        w23_.x = __uint_as_float(A[6 * (c) + 4]); w23_.y = __uint_as_float(A[6 * (c) + 5]);               \
-        CRF_FAC_FMA_LO(accv, g[ci][0], w01_); CRF_FAC_FMA_HI(accv, g[ci][1], w01_);                       \
-        CRF_FAC_FMA_LO(accv, g[ci][2], w23_); CRF_FAC_FMA_HI(accv, g[ci][3], w23_);                       \
-    }
 
 template <int DIR>
 __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p) {
@@ -1313,9 +1286,8 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     const int XB = Gp * 4;                                   // bytes per state vector
     const int64_t bt0 = (int64_t)b * p.T;
     float *X = lds;                                          // [2][Gp]
-    char *RMc = (char *)(X + 2 * Gp);                        // fwd: int2[R]   bwd: int4[R]
-    char *TMc = RMc + (size_t)R * (DIR == 0 ? 8 : 16);       // fwd: int4[NT*512]
-    float *EP = (float *)(TMc + (DIR == 0 ? (size_t)p.NT * kResThreads * 16 : 0));   // [2][Vp]
+    char *RMc = (char *)(X + 2 * Gp);                        // int4[R]
+    float *EP = (float *)(RMc + (size_t)R * 16);             // [2][Vp]
     float *wm = EP + 2 * Vp;                                 // [2][kResWaves]
     double *red = (double *)(wm + 2 * kResWaves);            // [kResWaves]
     if (tid == 0 && p.started) atomicAdd(p.started, 1);      // this workgroup holds its CU: see crf_gate_kernel
@@ -1330,17 +1302,14 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     const unsigned ends = __builtin_amdgcn_readfirstlane(wi.x);
     const int nch = __builtin_amdgcn_readfirstlane(wi.y);
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
-    if (DIR == 0) {
-        int2 *RM = (int2 *)RMc;
-        for (int r = tid; r < R; r += kResThreads) { int2 m = p.frow_meta[r]; RM[r] = m; }
-        int4 *TM = (int4 *)TMc;
-        for (int r = tid; r < p.NT * kResThreads; r += kResThreads) TM[r] = p.ftail[r];
-    } else {
+    {
         int4 *RM = (int4 *)RMc;
         for (int r = tid; r < R; r += kResThreads) {
-            int4 m = p.brow_meta[r];
-            const int l0 = (short)(m.w & 0xffff), l1 = m.w >> 16;       // -1 = no label: emission 0 at EP[V]
-            m.w = ((l0 < 0 ? V : l0) & 0xffff) | ((l1 < 0 ? V : l1) << 16);
+            int4 m = DIR == 0 ? p.frow_meta[r] : p.brow_meta[r];
+            if (DIR == 1) {
+                const int l0 = (short)(m.w & 0xffff), l1 = m.w >> 16;       // -1 = no label: emission 0 at EP[V]
+                m.w = ((l0 < 0 ? V : l0) & 0xffff) | ((l1 < 0 ? V : l1) << 16);
+            }
             RM[r] = m;
         }
     }
@@ -1413,63 +1382,31 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         asm volatile("" : "+s"(ends_f), "+s"(nch_f));
         f32x2 acc = {0.f, 0.f};
         float mymax = 0.f;
-        if (DIR == 0) {   // rows with a single gather: one per thread and j, no slice machinery
-            const int4 *TM = (const int4 *)TMc;
-            float *Ot = Orow + p.Rf;
-            // all (up to kFacMaxNT) rows of the thread in flight together: three dependent LDS round trips for
-            // the lot (metadata -> entry pair, emission -> two writes), not per row
-            int4 m[kFacMaxNT];
-            f32x2 g[kFacMaxNT];
-            float ev[kFacMaxNT];
-#pragma unroll
-            for (int j = 0; j < kFacMaxNT; ++j) if (j < p.NT) m[j] = TM[j * kResThreads + tid];
-#pragma unroll
-            for (int j = 0; j < kFacMaxNT; ++j)
-                if (j < p.NT) { g[j] = *(const f32x2 *)(xb + (m[j].x & 0xffff)); ev[j] = EPu[(unsigned)m[j].x >> 16]; }
-#pragma unroll
-            for (int j = 0; j < kFacMaxNT; ++j)
-                if (j < p.NT) {
-                    const float qv = (g[j].x + g[j].y) * __int_as_float(m[j].y) * sc;
-                    Ot[j * kResThreads + tid] = qv;
-                    const float av = ev[j] * qv;
-                    *(float *)(xnb + (m[j].z & 0xffff)) = av;
-                    *(float *)(xnb + ((unsigned)m[j].z >> 16)) = av;
-                    mymax = fmaxf(mymax, av);
-                }
-        }
-        CRF_TM(tm_on, tm_i + 1);
-        CRF_TM(tm_on, tm_i + 1);
         unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
-        constexpr int kB = DIR == 0 ? kFacBatchF : kResBatch;
 #pragma unroll
-        for (int c0 = 0; c0 < kResNCH; c0 += kB) {
+        for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
             if (c0 < nch_f) {
-                if (DIR == 0) {
-                    f32x2 g[kFacBatchF][4];
-                    CRF_FAC_GATHER(g, A, xb, c0);
+                f32x2 g01[kResBatch], g23[kResBatch];
+                CRF_RES_GATHER(g01, g23, A, xb, c0);
 #pragma unroll
-                    for (int ci = 0; ci < kFacBatchF; ++ci) {
-                        CRF_FAC_CHUNK_ACC(acc, g, A, c0 + ci, ci);
-                        if (ends_f >> (c0 + ci) & 1u) {
-                            const float rv = (acc.x + acc.y) * sc;                      // q_t[pair]
+                for (int ci = 0; ci < kResBatch; ++ci) {
+                    CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
+                    if (ends_f >> (c0 + ci) & 1u) {
+                        const int4 m = *(const int4 *)(RMc + 4u * r4);
+                        if (DIR == 0) {
+                            const float rv = (acc.x + acc.y) * sc;                      // q_t[pair of the main state]
+                            const float uold = *(const float *)(xb + (m.x & 0xffff));   // U_t of the row's pair
+                            const float qt = __int_as_float(m.z) * uold * sc;           // q_t[pair of the tail state]
                             *(float *)((char *)Orow + r4) = rv;
-                            const int2 m = *(const int2 *)(RMc + 2u * r4);
-                            const float av = EPu[(unsigned)m.x >> 16] * rv;               // a_{t+1}[dst]
-                            *(float *)(xnb + (m.x & 0xffff)) = av;
-                            *(float *)(xnb + m.y) = av;                                 // solo copy (or the sink)
-                            mymax = fmaxf(mymax, av);
-                            acc = f32x2{0.f, 0.f};
-                            r4 += kWave * 4u;
-                        }
-                    }
-                } else {
-                    f32x2 g01[kResBatch], g23[kResBatch];
-                    CRF_RES_GATHER(g01, g23, A, xb, c0);
-#pragma unroll
-                    for (int ci = 0; ci < kResBatch; ++ci) {
-                        CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
-                        if (ends_f >> (c0 + ci) & 1u) {
-                            const int4 m = *(const int4 *)(RMc + 4u * r4);
+                            *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
+                            const float Lp = EPu[(unsigned)m.x >> 16] * rv;              // a_{t+1}[main]
+                            const float Ap = EPu[m.w] * qt;                             // a_{t+1}[tail]
+                            const float Up = Ap + Lp;
+                            *(float *)(xnb + (m.x & 0xffff)) = Up;
+                            *(float *)(xnb + (m.y & 0xffff)) = Lp;
+                            *(float *)(xnb + ((unsigned)m.y >> 16)) = Ap;
+                            mymax = fmaxf(mymax, Up);
+                        } else {
                             const float craw = acc.x + acc.y;                           // common out-arcs of the row's states
                             const float z0 = *(const float *)(xb + (m.x & 0xffff)), z1 = *(const float *)(xb + ((unsigned)m.x >> 16));
                             f32x2 bv;                                                    // b_t of the two states
@@ -1481,21 +1418,13 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
                             zv.y = EPu[(unsigned)m.w >> 16] * bv.y;
                             *(f32x2 *)(xnb + 2u * r4) = zv;
                             mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
-                            acc = f32x2{0.f, 0.f};
-                            r4 += kWave * 4u;
                         }
+                        acc = f32x2{0.f, 0.f};
+                        r4 += kWave * 4u;
                     }
                 }
             }
         }
-        CRF_TM(tm_on, tm_i + 2);
-#ifdef CRF_TIMING
-        if (b == 3 && i >= 150 && i < 158) {
-            const int o = 12288 + ((DIR * 4) * 8 + wave) * 16;
-            CRF_TM(true, o + (i - 150));
-            if (lane == 0 && i == 150) { g_tm[o + 8] = (unsigned long long)nch; g_tm[o + 9] = (unsigned long long)__builtin_popcount(ends); }
-        }
-#endif
         mymax = wave_max(mymax);
         if (lane == 0) wm[(1 - par) * kResWaves + wave] = mymax;
         if (pre) {
@@ -2132,7 +2061,7 @@ static int launch_res(const LossParams &lp, size_t lds, int b0, int nb, hipStrea
 static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     const FacDev &F = h->dev.fac;
     const FacDirDev &L = dir == 0 ? F.f : F.b;
-    return (size_t)2 * rup64(L.G) * 4 + (size_t)L.R * (dir == 0 ? 8 : 16) + (dir == 0 ? (size_t)F.NT * kResThreads * 16 : 0) +
+    return (size_t)2 * rup64(L.G) * 4 + (size_t)L.R * 16 +
            ((size_t)2 * rup64(V + 1) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
 }
 template <int DIR>
@@ -2153,7 +2082,7 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
     p.started = started;
-    p.frow_meta = F.frow_meta; p.ftail = F.ftail; p.x_start = F.x_start; p.x_end = F.x_end;
+    p.frow_meta = F.frow_meta; p.x_start = F.x_start; p.x_end = F.x_end;
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;

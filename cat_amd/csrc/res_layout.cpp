@@ -649,76 +649,102 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     for (int s = 0; s < S; ++s) if (mate[s] > s) ++nmatched;
     if (nmatched * 4 < S) return give_up("fewer than half of the states pair up");
 
-    // ---- 2. forward rows as gathers of entry PAIRS.  A gather reads two adjacent entries and applies one
-    // weight to both.  Matched states (s1 < s2) live at entries (2j, 2j+1); a state that some row needs
-    // WITHOUT its mate (self-loops; rows that only one of the two feeds) additionally gets a solo slot
-    // (x, 0) written by the same producer; unmatched states live in a solo slot only.
-    std::vector<int> loc(S, -1), solo(S, -1);
+    // ---- 2. forward: pair SUMS.  In T o LM the row of (g, blank) has exactly two in-arcs, from (g, blank) and
+    // (g, token), with one weight w: a_{t+1}[(g,blank)] = e'[blank] * w * (a_t[(g,blank)] + a_t[(g,token)]).
+    // So the recursion keeps, per matched pair (tail state s1 with such a row, main state s2), three entries:
+    //     U = a[s1] + a[s2]   (what every other row reads of the pair: ONE gather, ONE weight for two arcs)
+    //     L = a[s2], A = a[s1] (read by the few arcs that need one of them alone; logZ at the end)
+    // and the row of s2 updates all three in its epilogue: L' = e'[l2] * rowsum, A' = e'[l1] * w * U, U' = A' + L'
+    // (no subtraction anywhere) -- the row of s1 disappears.  A matched pair without that structure is
+    // un-matched again (generic graphs: everything below still works, there is just nothing to save).
+    std::vector<int> tail_of(S, -1);   // main state -> its tail state
+    std::vector<float> tail_w(S, 0.f);
+    for (int s = 0; s < S; ++s) {
+        const int m = mate[s];
+        if (m < 0 || m < s) continue;
+        auto self_pair = [&](int t, int o, float *w) {   // is the row of t exactly {t: w, o: w}?
+            const int p = pair_of[t];
+            if (p < 0 || in_arcs_of_pair[p].size() != 2) return false;
+            const auto &a = in_arcs_of_pair[p];
+            if (wbits(a[0].second) != wbits(a[1].second)) return false;
+            if (!((a[0].first == t && a[1].first == o) || (a[0].first == o && a[1].first == t))) return false;
+            *w = a[0].second;
+            return true;
+        };
+        float w = 0.f;
+        if (pair_of[m] >= 0 && self_pair(s, m, &w)) { tail_of[m] = s; tail_w[m] = w; }
+        else if (pair_of[s] >= 0 && self_pair(m, s, &w)) { tail_of[s] = m; tail_w[s] = w; }
+        else { mate[s] = mate[m] = -1; }
+    }
+    nmatched = 0;
+    for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) ++nmatched;
+    if (nmatched * 4 < S) return give_up("fewer than half of the states form (tail, main) pairs");
+    std::vector<char> is_tail(S, 0);
+    for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) is_tail[tail_of[s]] = 1;
+    // entries: [U of every pair][L of every pair][A of every pair][plain states][sink]
+    std::vector<int> entU(S, -1), ent(S, -1);   // entU: by main state; ent: a[s] itself (L, A or plain)
     int nent = 0;
-    for (int s = 0; s < S; ++s) if (mate[s] > s) { loc[s] = nent; loc[mate[s]] = nent + 1; nent += 2; }
-    struct Gather { int ent; float w; };   // even entry index
-    std::vector<std::vector<Gather>> frow(P);
-    std::vector<char> need_solo(S, 0);
-    for (int s = 0; s < S; ++s) if (mate[s] < 0) need_solo[s] = 1;
-    std::vector<std::vector<std::pair<int, float>>> solo_reads(P);  // filled in a first pass (entries not final yet)
-    for (int p = 0; p < P; ++p) {
-        std::vector<std::pair<int, float>> a = in_arcs_of_pair[p];
+    for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) entU[s] = nent++;
+    for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) ent[s] = nent++;
+    for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) ent[tail_of[s]] = nent++;
+    for (int s = 0; s < S; ++s) if (ent[s] < 0) ent[s] = nent++;
+    const int sink = nent;
+    const int Gf = nent + 1;
+    if ((size_t)Gf * 4 > 65536) return give_up("forward gather vector > 64 KiB");
+    const int64_t nsolo = 0;
+    // rows: every pair except the tail rows
+    std::vector<int> main_rows;
+    for (int p = 0; p < P; ++p) if (!is_tail[pair_dst[p]]) main_rows.push_back(p);
+    Rows fsub(main_rows.size());
+    for (size_t i = 0; i < main_rows.size(); ++i) {
+        std::vector<std::pair<int, float>> a = in_arcs_of_pair[main_rows[i]];
         std::vector<char> used(a.size(), 0);
-        for (size_t i = 0; i < a.size(); ++i) {
-            if (used[i]) continue;
-            const int s = a[i].first, m = mate[s];
-            size_t j = a.size();
-            if (m >= 0)
-                for (size_t q = i + 1; q < a.size(); ++q)
-                    if (!used[q] && a[q].first == m && wbits(a[q].second) == wbits(a[i].second)) { j = q; break; }
-            if (j < a.size()) { used[i] = used[j] = 1; frow[p].push_back({std::min(loc[s], loc[m]), a[i].second}); }
-            else { used[i] = 1; need_solo[s] = 1; solo_reads[p].push_back({s, a[i].second}); }
+        for (size_t u = 0; u < a.size(); ++u) {
+            if (used[u]) continue;
+            used[u] = 1;
+            const int s = a[u].first;
+            const int mn = tail_of[s] >= 0 ? s : (is_tail[s] ? mate[s] : -1);   // main state of s's pair, if any
+            size_t v = a.size();
+            if (mn >= 0) {
+                const int other = s == mn ? tail_of[mn] : mn;
+                for (size_t q = u + 1; q < a.size(); ++q)
+                    if (!used[q] && a[q].first == other && wbits(a[q].second) == wbits(a[u].second)) { v = q; break; }
+            }
+            if (v < a.size()) { used[v] = 1; fsub[i].push_back({entU[mn], a[u].second}); }
+            else fsub[i].push_back({ent[s], a[u].second});
         }
     }
-    int64_t nsolo = 0;
-    for (int s = 0; s < S; ++s) if (need_solo[s]) { solo[s] = nent; nent += 2; ++nsolo; if (loc[s] < 0) loc[s] = solo[s]; }
-    for (int p = 0; p < P; ++p)
-        for (auto &r : solo_reads[p]) frow[p].push_back({solo[r.first], r.second});
-    const int sink = nent;   // (sink, sink+1): target of unused second writes, never read with a non-zero weight
-    const int Gf = nent + 2;
-    if ((size_t)Gf * 4 > 65536) return give_up("forward gather vector > 64 KiB");
-
-    // ---- 3. forward rows: single-gather rows go to the per-thread tail list, the rest to slices
-    constexpr int kMaxNT = 4;   // = kFacMaxNT of the kernel
-    std::vector<int> tail_rows, main_rows;
-    for (int p = 0; p < P; ++p) (frow[p].size() == 1 && (int)tail_rows.size() < kMaxNT * kResThreads ? tail_rows : main_rows).push_back(p);
-    const int NT = (int)((tail_rows.size() + kResThreads - 1) / kResThreads);
-    Rows fsub(main_rows.size());
-    for (size_t i = 0; i < main_rows.size(); ++i)
-        for (auto &gth : frow[main_rows[i]]) fsub[i].push_back({gth.ent / 2, gth.w});
     DirOut fo;
     std::vector<SliceAt> fslices;
     if (!place_rows(fsub, std::vector<int>(fsub.size(), 0), 1, &fo, &fslices)) return give_up("forward rows do not fit one CU");
-    pack_arcs(fsub, fslices, &fo, 8);
+    pack_arcs(fsub, fslices, &fo, 4);
     const int Rf = fo.cu_row_off[1];
-    std::vector<int> fpos(P, -1);   // position of pair p in the Q row
-    std::vector<int2> frow_meta(Rf, int2{sink * 4, sink * 4});   // padding rows: emission index 0 (their sum is 0), sink
+    const int NT = 0;
+    std::vector<int> fpos(P, -1);   // position of pair p in the Q row: main rows [0, Rf), their tails [Rf, 2 Rf)
+    std::vector<int4> frow_meta(Rf, int4{sink * 4, (sink * 4) | ((sink * 4) << 16), 0, 0});   // padding rows: all to the sink
     for (int rid = 0; rid < Rf; ++rid) {
         const int r = fo.row_of[rid];
         if (r < 0) continue;
         const int p = main_rows[r], s = pair_dst[p];
         fpos[p] = rid;
-        frow_meta[rid] = int2{(loc[s] * 4) | (pair_lab[p] << 16), (solo[s] >= 0 && solo[s] != loc[s] ? solo[s] : sink) * 4};
+        if (tail_of[s] >= 0) {
+            const int t = tail_of[s], pt = pair_of[t];
+            fpos[pt] = Rf + rid;
+            frow_meta[rid] = int4{(entU[s] * 4) | (pair_lab[p] << 16), (ent[s] * 4) | ((ent[t] * 4) << 16), (int)wbits(tail_w[s]), pair_lab[pt]};
+        } else {
+            frow_meta[rid] = int4{(sink * 4) | (pair_lab[p] << 16), (ent[s] * 4) | ((sink * 4) << 16), 0, 0};
+        }
     }
-    std::vector<int4> ftail((size_t)std::max(NT, 1) * kResThreads, int4{sink * 4, 0, (sink * 4) | ((sink * 4) << 16), 0});
-    for (size_t i = 0; i < tail_rows.size(); ++i) {
-        const int p = tail_rows[i], s = pair_dst[p];
-        fpos[p] = Rf + (int)i;
-        const int dup = (solo[s] >= 0 && solo[s] != loc[s]) ? solo[s] : sink;
-        ftail[i] = int4{(frow[p][0].ent * 4) | (pair_lab[p] << 16), (int)wbits(frow[p][0].w), (loc[s] * 4) | ((dup * 4) << 16), 0};
-    }
-    const int Rq = Rf + NT * kResThreads;
+    const int Rq = 2 * Rf;
     std::vector<float> x_start(Gf, 0.f), x_end(Gf, 0.f);
     for (int s = 0; s < S; ++s) {
-        x_start[loc[s]] = start_lin[s];
-        x_end[loc[s]] = end_lin[s];
-        if (solo[s] >= 0 && solo[s] != loc[s]) x_start[solo[s]] = start_lin[s];   // the copy starts equal; counted once in logZ
+        x_start[ent[s]] = start_lin[s];
+        x_end[ent[s]] = end_lin[s];
+        if (tail_of[s] >= 0) x_start[entU[s]] = start_lin[s] + start_lin[tail_of[s]];
     }
+    std::vector<int4> ftail(1, int4{0, 0, 0, 0});
+    std::vector<int> tail_rows;   // (statistics only)
+    for (int s = 0; s < S; ++s) if (is_tail[s]) tail_rows.push_back(s);
 
     // ---- 4. backward rows: matched states with common out-arcs and at most one extra arc each share a row
     struct BRow { int s0, s1; std::vector<std::pair<int, float>> arcs; int e0 = -1, e1 = -1; float w0 = 0.f, w1 = 0.f; };  // arcs: (pair, w)
@@ -821,7 +847,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1;
     int rc;
     if ((rc = up(h, fo.arcs, &F.f.arcs)) || (rc = up(h, fo.wave_info, &F.f.wave_info)) || (rc = up(h, bo.arcs, &F.b.arcs)) ||
-        (rc = up(h, bo.wave_info, &F.b.wave_info)) || (rc = up(h, frow_meta, &F.frow_meta)) || (rc = up(h, ftail, &F.ftail)) ||
+        (rc = up(h, bo.wave_info, &F.b.wave_info)) || (rc = up(h, frow_meta, &F.frow_meta)) ||
         (rc = up(h, x_start, &F.x_start)) || (rc = up(h, x_end, &F.x_end)) || (rc = up(h, brow_meta, &F.brow_meta)) ||
         (rc = up(h, z_lab, &F.z_lab)) || (rc = up(h, z_end, &F.z_end)) || (rc = up(h, brow_start, &F.brow_start)) ||
         (rc = up(h, brow_end, &F.brow_end)) || (rc = up(h, gq, &F.gq)) || (rc = up(h, gb, &F.gb)) ||
