@@ -58,6 +58,7 @@ struct LossParams {
     const int *gchunk, *glab;     // its chunks (<= kChunk entries of one label) and per-label chunk ranges
     int gNC;
     int res;                      // 1: register-resident den kernels (g.res), 0: streaming kernels
+    const int *prog;              // crf_grad_den_kernel: [2][B] frames finished by the den forward / backward kernels (nullptr: all)
     int grad_den_acc;             // crf_grad_den_kernel: add to the row (the numerator half has written it) instead of writing
     int grad_phase;               // crf_grad_kernel: 0 = den and ctc in one pass, 1 = den part only (writes), 2 = ctc part only (subtracts)
     int b0;                       // first utterance of this launch (resident kernels with K > 1 run in groups)
@@ -1262,6 +1263,7 @@ struct FacParams {
     float *Row0;                // [B][Rout] spare rows: b_0 of the backward recursion
     int *Eout;                  // EQ (fwd) or EB (bwd)
     int *started;               // workgroups of the den kernels that have started (gate for the numerator chains)
+    int *prog;                  // [B] frames of this recursion whose rows are complete in memory (read by the grad pass)
     const int4 *frow_meta;
     const float *x_start, *x_end;
     float *den_zs, *cost_alpha;
@@ -1353,6 +1355,11 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
 #ifdef CRF_TIMING
         if (b == 3 && i >= 150 && i < 158 && wave == 0) CRF_TM(true, 12288 + 1024 + (DIR * 4) * 8 + (i - 150));  // frame start
 #endif
+        // Progress for the grad pass, which runs beside this kernel on other compute units: every 16 frames all
+        // waves wait for their row stores (vmcnt(0)); one frame and one barrier later every wave has done so, and
+        // `i - 1` frames (forward: Q rows 0..i-2; backward: BP rows lx-i..lx-1) are complete in memory.
+        if ((i & 15) == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+        if ((i & 15) == 1 && i > 1 && tid == 0) __hip_atomic_store(p.prog + b, DIR == 0 ? i - 1 : i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const char *xb = (const char *)lds + par * XB;
         char *xnb = (char *)lds + (1 - par) * XB;
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
@@ -1397,8 +1404,10 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
                             const float rv = (acc.x + acc.y) * sc;                      // q_t[pair of the main state]
                             const float uold = *(const float *)(xb + (m.x & 0xffff));   // U_t of the row's pair
                             const float qt = __int_as_float(m.z) * uold * sc;           // q_t[pair of the tail state]
-                            *(float *)((char *)Orow + r4) = rv;
-                            *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
+                            // rows are stored write-through (agent scope): the grad pass reads them from other
+                            // XCDs while this kernel is still running (progress counters below)
+                            __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store((unsigned *)((char *)Orow + r4 + 4u * (unsigned)R), __float_as_uint(qt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             const float Lp = EPu[(unsigned)m.x >> 16] * rv;              // a_{t+1}[main]
                             const float Ap = EPu[m.w] * qt;                             // a_{t+1}[tail]
                             const float Up = Ap + Lp;
@@ -1412,7 +1421,9 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
                             f32x2 bv;                                                    // b_t of the two states
                             bv.x = fmaf(__int_as_float(m.y), z0, craw) * sc;
                             bv.y = fmaf(__int_as_float(m.z), z1, craw) * sc;
-                            *(f32x2 *)((char *)Orow + 2u * r4) = bv;
+                            __hip_atomic_store((unsigned long long *)((char *)Orow + 2u * r4),
+                                               (unsigned long long)__float_as_uint(bv.x) | ((unsigned long long)__float_as_uint(bv.y) << 32),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             f32x2 zv;                                                    // z_{t-1} of the pairs entering them
                             zv.x = EPu[m.w & 0xffff] * bv.x;
                             zv.y = EPu[(unsigned)m.w >> 16] * bv.y;
@@ -1438,6 +1449,8 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     };
 #pragma clang loop unroll(disable)
     for (int i = 0; i < lx; ++i) frame(i & 1, i);
+    __syncthreads();   // fence + barrier: every wave's row stores are complete
+    if (tid == 0) __hip_atomic_store(p.prog + b, lx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     if (DIR == 0) {
         const float *Xf = X + (lx & 1) * Gp;
@@ -1587,17 +1600,29 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
     const int tid = threadIdx.x;
-    const int b = blockIdx.y, V = p.V;
+    // Progressive mode (p.prog): the launch is one-dimensional and ordered by readiness -- the forward den
+    // kernel works up from frame 0, the backward one down from the last, so a 16-frame block is complete once
+    // both have passed it: the middle blocks first, then outwards -- and every workgroup waits (bounded) for
+    // its block's rows.  Otherwise the grid is (frame blocks, utterances) and everything is ready.
+    int b, blk;
+    if (p.prog) {
+        const int nblk = (p.T + kGDFrames - 1) / kGDFrames, k = (int)blockIdx.x / p.B;
+        b = (int)blockIdx.x % p.B;
+        const int mid = nblk / 2;
+        blk = 0;
+        for (int j = 0, cnt = -1; j <= 2 * nblk; ++j) {        // k-th block of the order mid, mid+1, mid-1, mid+2, ... (in range)
+            const int c = (j & 1) ? mid + (j + 1) / 2 : mid - j / 2;
+            if (c >= 0 && c < nblk && ++cnt == k) { blk = c; break; }
+        }
+    } else { b = blockIdx.y; blk = blockIdx.x; }
+    const int V = p.V;
     const int lx = p.lx[b], Rq = p.Rq, Rb = p.Rb, NC = p.gNC;
     const int Vp = rup64(V);
     float *Qs = lds, *Bs = Qs + rup64(Rq + 1), *gd = Bs + rup64(Rb + 1);    // Qs[Rq] = 0: target of padding index pairs
-    int *eoff = (int *)(gd + 4 * Vp);                                       // [kGDFrames]; gd: [4][Vp] label sums in rotation
-    int *clab_s = eoff + kGDFrames;                                         // [NC] label of each chunk (prologue only)
+    float *nrm = gd + 4 * Vp;                                               // [4] per-frame normalisers; gd: [4][Vp] label sums, both in rotation
+    int *clab_s = (int *)(nrm + kGDFrames);                                 // [NC] label of each chunk (prologue only)
     const int64_t bt0 = (int64_t)b * p.T;
-    const float zs = p.den_zs[b];
-    const int ez = p.den_ez[b];
-    const float inv = zs > 0.f ? 1.f / zs : 0.f;
-    const int t0 = blockIdx.x * kGDFrames, t1 = min(t0 + kGDFrames, p.T), tl = min(t1, lx);
+    const int t0 = blk * kGDFrames, t1 = min(t0 + kGDFrames, p.T), tl = min(t1, lx);
 
     unsigned idx[NCPT][kChunk];
     {
@@ -1648,11 +1673,11 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
         const bool head = lane == 0 || c >= NC || clab_s[c - 1] != clab[i];
         if (!head || c >= NC) segm[i] |= 1u << 31;   // bit 31: not the lane that adds the segment's sum
     }
-    if (tid < kGDFrames) eoff[tid] = t0 + tid < tl ? ez - p.EQ[bt0 + t0 + tid] - p.EB[bt0 + t0 + tid] - kEpExp : 0;  // er[] carries 2^kEpExp
+    if (tid < 4) nrm[tid] = 0.f;
     // rows are multiples of 64 floats and 256-byte aligned: 16-byte loads, prefetched one frame ahead
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 qr[kGDRowRegs], br[kGDRowRegs];
-    float ern[kGDEpRegs];
+    float ern[kGDEpRegs], rwn[kGDEpRegs];   // next frame's emissions and (accumulate mode) grad row
 #define CRF_GD_FETCH(t)                                                                                  \
     {                                                                                                    \
         const f32x4 *Qr = (const f32x4 *)(p.Q + (bt0 + (t)) * Rq), *Br = (const f32x4 *)(p.BP + (bt0 + (t)) * Rb); \
@@ -1662,9 +1687,11 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
             br[i] = 4 * r < Rb ? Br[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
         }                                                                                                \
         const float *er_ = p.ep + (bt0 + (t)) * V;                                                       \
+        const float *gr_ = p.grad + (bt0 + (t)) * V;                                                     \
         _Pragma("unroll") for (int q = 0; q < kGDEpRegs; ++q) {                                          \
             const int v = tid + q * kGDThreads;                                                          \
             ern[q] = v < V ? er_[v] : 0.f;                                                               \
+            rwn[q] = (p.grad_den_acc && v < V) ? gr_[v] : 0.f;                                           \
         }                                                                                                \
     }
 #define CRF_GD_STAGE()                                                                                  \
@@ -1673,12 +1700,25 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
         if (4 * r < Rq) ((f32x4 *)Qs)[r] = qr[i];                                                        \
         if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];                                                        \
     }
-    float erc[kGDEpRegs];
+    float erc[kGDEpRegs], rwc[kGDEpRegs];
+    // (progressive mode) wait for this block's rows -- after the prologue above, which does not need them
+    if (p.prog && t0 < tl) {
+        if (tid == 0) {
+            const int need_f = tl, need_b = lx - t0;
+            for (unsigned spins = 0;; ++spins) {
+                if (__hip_atomic_load(p.prog + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need_f &&
+                    __hip_atomic_load(p.prog + p.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need_b) break;
+                if (spins > (1u << 22)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // never hang: NaN loss
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+    }
     if (t0 < tl) {
         CRF_GD_FETCH(t0);
         CRF_GD_STAGE();
 #pragma unroll
-        for (int q = 0; q < kGDEpRegs; ++q) erc[q] = ern[q];
+        for (int q = 0; q < kGDEpRegs; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
     }
     sync_lds();
     const bool tm_on = blockIdx.x == 40 && blockIdx.y == 3 && tid < 64;
@@ -1708,6 +1748,7 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
             const int v = tid + q * kGDThreads;
             if (v < V) gzero[v] = 0.f;
         }
+        if (tid == 0) nrm[(t + 2) & 3] = 0.f;
         CRF_TM(tm_on, 8192 + (t - t0) * 8 + 2);
         sync_lds();                             // every gather of frame t is done: the row buffers are free
         CRF_TM(tm_on, 8192 + (t - t0) * 8 + 3);
@@ -1716,20 +1757,33 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
         // acknowledgement).
         if (t + 1 < tl) CRF_GD_STAGE();
         CRF_TM(tm_on, 8192 + (t - t0) * 8 + 4);
-        const int e = eoff[t - t0];
+        // gamma[t][v] = u_v / sum_v u_v with u_v = e'_t[v] * (label sum): the posteriors of a frame sum to 1, so
+        // the frame normalises itself -- no logZ, no per-frame exponents, hence no dependence on the END of the
+        // recursions (the pass runs beside them).  e' is taken without its 2^kEpExp (range: label sums reach 2^50).
+        float u[kGDEpRegs], part = 0.f;
+#pragma unroll
+        for (int q = 0; q < kGDEpRegs; ++q) {
+            const int v = tid + q * kGDThreads;
+            u[q] = v < V ? (erc[q] * pow2f(-kEpExp)) * gsum[v] : 0.f;
+            part += u[q];
+            erc[q] = ern[q];
+        }
+        float rw[kGDEpRegs];
+#pragma unroll
+        for (int q = 0; q < kGDEpRegs; ++q) { rw[q] = rwc[q]; rwc[q] = rwn[q]; }
+        part = wave_sum(part);
+        if ((tid & 63) == 0 && part != 0.f) atomicAdd(&nrm[t & 3], part);
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
+        sync_lds();                             // rows of frame t+1 visible, normaliser complete
+        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 6);
+        const float nv = nrm[t & 3];
+        const float inv = nv > 0.f ? p.c_den / nv : 0.f;
         float *row = p.grad + (bt0 + t) * V;
 #pragma unroll
         for (int q = 0; q < kGDEpRegs; ++q) {
             const int v = tid + q * kGDThreads;
-            if (v < V) {
-                const float gv = p.c_den * (erc[q] * (ldexpf(gsum[v], e) * inv));
-                row[v] = p.grad_den_acc ? row[v] + gv : gv;
-            }
-            erc[q] = ern[q];
+            if (v < V) row[v] = rw[q] + u[q] * inv;   // rw = 0 unless accumulating onto the numerator half
         }
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
-        sync_lds();                             // rows of frame t+1 visible
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 6);
     }
 #undef CRF_GD_STAGE
 #undef CRF_GD_FETCH
@@ -1929,7 +1983,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_pb = o; o = al(o + 32 * B * 8);
     // tagged granules [2 slots] of both directions, then one XCD-id word per CU of every recursion
     w.xch_bytes = (w.res && !w.fac && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8) : 0;
-    w.off_xch = o; o = al(o + w.xch_bytes + 256);
+    w.off_xch = o; o = al(o + w.xch_bytes + 256 + 8 * B);   // granules | error word, start counter | per-utterance progress of the two den recursions
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.gv = h && !w.res && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
     w.off_gvec = o; o = al(o + (w.gv ? B * (3 * (int64_t)rup64(h->dev.S) + 4 * (int64_t)h->dev.Pr) * 4 : 0));
@@ -2081,7 +2135,7 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
-    p.started = started;
+    p.started = started; p.prog = started + 63 + (DIR == 0 ? 0 : lp.B);
     p.frow_meta = F.frow_meta; p.x_start = F.x_start; p.x_end = F.x_end;
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
@@ -2185,7 +2239,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     prof_mark(0, true, stream);
     LAUNCH_CHECK("crf_prep_kernel");
     if (res) {  // exchange granules (tags) and the error word start at zero in every call
-        if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
+        if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256 + 8 * (size_t)B, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
     }
 
     static std::atomic<size_t> lds_set_grad{0};
@@ -2271,16 +2325,19 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
     const bool fast_den = den && w.Rq <= 4 * kGDRowRegs * kGDThreads && w.Rb <= 4 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
                           gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
-    auto launch_grad_den = [&]() -> int {
+    auto launch_grad_den = [&](hipStream_t st = nullptr, const int *prog = nullptr) -> int {
+        if (!st) st = stream;
+        p.prog = prog;
         const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + 4 * rup64((int)V) + kGDFrames + rup64(gnc)) * sizeof(float);
-        const dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
+        const unsigned nblk = (unsigned)((T + kGDFrames - 1) / kGDFrames);
+        const dim3 gg = prog ? dim3(nblk * (unsigned)B) : dim3(nblk, (unsigned)B);
         static std::atomic<size_t> set1{0}, set2{0};
         if (gnc <= kGDThreads) {
             if (l > set1.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set1 = l; }
-            hipLaunchKernelGGL(crf_grad_den_kernel<1>, gg, dim3(kGDThreads), l, stream, p);
+            hipLaunchKernelGGL(crf_grad_den_kernel<1>, gg, dim3(kGDThreads), l, st, p);
         } else {
             if (l > set2.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set2 = l; }
-            hipLaunchKernelGGL(crf_grad_den_kernel<2>, gg, dim3(kGDThreads), l, stream, p);
+            hipLaunchKernelGGL(crf_grad_den_kernel<2>, gg, dim3(kGDThreads), l, st, p);
         }
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad_den_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
@@ -2317,10 +2374,12 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         used[2] = false;
         prof_mark(5, false, s1);
         if ((rc = launch_grad_ctc(0, s1))) return rc;
-        if ((rc = join_all())) return rc;
+        // ... and so does the den half: behind the numerator half on the same side stream, in readiness order,
+        // every workgroup waiting for the den kernels' progress counters to pass its 16 frames
         p.grad_den_acc = 1;
-        if ((rc = launch_grad_den())) return rc;
-        prof_mark(5, true, stream);
+        if ((rc = launch_grad_den(s1, started + 63))) return rc;
+        prof_mark(5, true, s1);
+        if ((rc = join_all())) return rc;
     } else if (!split) {
         if (ctc) {
             if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream, max_label_len))) return rc;
