@@ -1389,6 +1389,7 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         asm volatile("" : "+s"(ends_f), "+s"(nch_f));
         f32x2 acc = {0.f, 0.f};
         float mymax = 0.f;
+        CRF_TM(tm_on, tm_i + 1);
         unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
 #pragma unroll
         for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
@@ -1436,6 +1437,14 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
                 }
             }
         }
+        CRF_TM(tm_on, tm_i + 2);
+#ifdef CRF_TIMING
+        if (b == 3 && i >= 150 && i < 158) {
+            const int o = 12288 + ((DIR * 4) * 8 + wave) * 16;
+            CRF_TM(true, o + (i - 150));
+            if (lane == 0 && i == 150) { g_tm[o + 8] = (unsigned long long)nch; g_tm[o + 9] = (unsigned long long)__builtin_popcount(ends); }
+        }
+#endif
         mymax = wave_max(mymax);
         if (lane == 0) wm[(1 - par) * kResWaves + wave] = mymax;
         if (pre) {
