@@ -2275,6 +2275,11 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         return cx->side[i];
     };
     int *started = p.err + 1;   // workgroups of the den kernels that hold a CU (cleared with the error word)
+    int ncu_dev = 256;
+    {
+        int devid = 0;
+        if (hipGetDevice(&devid) == hipSuccess) (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, devid);
+    }
     if (fac) {
         // factored resident recursions: one CU per utterance and direction, nothing to exchange
         hipStream_t sb = side(0);
@@ -2315,7 +2320,11 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // (HBM-bound, small workgroups that share CUs happily); a second, cheap grad pass then subtracts
     // the numerator posteriors.  Otherwise all four recursions run side by side and grad is one pass.
     static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
-    const bool split = ctc && den && !fac && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && h->dev.res.K > 1)) && !serial;
+    // Factored den kernels: 2B workgroups, one CU each.  While they leave half of the chip free (2B <= CUs/2)
+    // everything else runs BESIDE them (below); otherwise the numerator follows the den kernels as for K > 1 --
+    // workgroups of the grad pass that wait for den progress must never keep a queued den workgroup off a CU.
+    const bool fac_overlap = fac && !serial && 2 * B <= ncu_dev / 2;
+    const bool split = ctc && den && !fac_overlap && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && (fac || h->dev.res.K > 1))) && !serial;
     auto join_all = [&]() -> int {
         for (int i = 0; i < 3; ++i)
             if (used[i]) {
@@ -2367,7 +2376,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad(ctc): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
     };
-    if (fac && ctc && fast_den && fast_ctc && !serial) {
+    if (fac_overlap && ctc && fast_den && fast_ctc) {
         // Factored den kernels use one CU per recursion: half the chip.  The numerator chains AND the numerator
         // half of the grad pass run beside them on the other half, behind a gate that waits until every den
         // workgroup holds its CU; the den half of the grad pass then ADDS to what the numerator half wrote.

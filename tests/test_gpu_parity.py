@@ -131,6 +131,30 @@ def test_synth_vs_oracle_ragged(crf, tmp_path, seed, B, T, vocab, hist, fan, mod
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
+def test_factored_schedules(crf, tmp_path):
+    """The factored den kernels run everything else BESIDE them while 2B workgroups leave half of the CUs free
+    (B = 3 here and in the tests above) and fall back to 'numerator after denominator' for larger batches
+    (B = 160 > CUs/4 on any current part); den-only calls (gpu_den) take a third path."""
+    g, p = small_synth(tmp_path, 12, 40, 6, 7)
+    B, T, V = 160, 24, 12
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=11, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode="factored")
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+    with _mode("factored"):
+        ctx = crf.CRFContext(p, 0)
+    assert crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))["fac"] == 1
+    lg = torch.tensor(logits[:5], device="cuda:0")
+    gd, ca, cb = torch.zeros_like(lg), torch.zeros(5, device="cuda:0"), torch.zeros(5, device="cuda:0")
+    crf._C.gpu_den(lg, gd, torch.tensor(lx[:5]).cuda(), ca, cb)
+    den = oracle.den(fst_io.read_fst(p), logits[:5], lx[:5])
+    assert np.allclose(ca.cpu().numpy(), np.asarray(den[1]).ravel(), rtol=TOL, atol=0)
+    assert np.allclose(cb.cpu().numpy(), np.asarray(den[2]).ravel(), rtol=TOL, atol=0)
+    assert post_err(gd.cpu().numpy(), np.asarray(den[0])) <= TOL
+    del ctx
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_edge_cases(crf, tmp_path, mode):
     """repeats, L = 0, L + repeats == T (no slack), lx < T, and an invalid utterance (L + repeats > T)."""
