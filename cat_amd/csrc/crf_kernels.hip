@@ -58,6 +58,7 @@ struct LossParams {
     const int *gchunk, *glab;     // its chunks (<= kChunk entries of one label) and per-label chunk ranges
     int gNC;
     int res;                      // 1: register-resident den kernels (g.res), 0: streaming kernels
+    int dbg_step;                 // (timing builds) host call counter
     const int *prog;              // crf_grad_den_kernel: [2][B] frames finished by the den forward / backward kernels (nullptr: all)
     int grad_den_acc;             // crf_grad_den_kernel: add to the row (the numerator half has written it) instead of writing
     int grad_phase;               // crf_grad_kernel: 0 = den and ctc in one pass, 1 = den part only (writes), 2 = ctc part only (subtracts)
@@ -1264,6 +1265,7 @@ struct FacParams {
     int *Eout;                  // EQ (fwd) or EB (bwd)
     int *started;               // workgroups of the den kernels that have started (gate for the numerator chains)
     int *prog;                  // [B] frames of this recursion whose rows are complete in memory (read by the grad pass)
+    int dbg_step;
     const int4 *frow_meta;
     const float *x_start, *x_end;
     float *den_zs, *cost_alpha;
@@ -1293,6 +1295,9 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     float *wm = EP + 2 * Vp;                                 // [2][kResWaves]
     double *red = (double *)(wm + 2 * kResWaves);            // [kResWaves]
     if (tid == 0 && p.started) atomicAdd(p.started, 1);      // this workgroup holds its CU: see crf_gate_kernel
+#ifdef CRF_TIMING
+    if (tid == 0) g_tm[15000 + DIR * 128 + b] = (unsigned long long)p.dbg_step;
+#endif
 
     unsigned A[kResWords];
     {
@@ -1460,6 +1465,9 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     for (int i = 0; i < lx; ++i) frame(i & 1, i);
     __syncthreads();   // fence + barrier: every wave's row stores are complete
     if (tid == 0) __hip_atomic_store(p.prog + b, lx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CRF_TIMING
+    if (tid == 0) g_tm[15500 + DIR * 128 + b] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     if (DIR == 0) {
         const float *Xf = X + (lx & 1) * Gp;
@@ -1482,13 +1490,16 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
 
 // Holds a (side) stream until `target` workgroups of the den kernels have started, i.e. own their compute
 // units: the numerator chains launched behind it then land on the remaining CUs instead of scattering over
-// all of them and keeping den workgroups (which need a whole CU's registers) waiting.  Bounded: after ~2 ms
-// it lets go regardless (a speed matter only).
+// all of them and keeping den workgroups (which need a whole CU's registers) waiting.  Bounded: after ~0.2 ms
+// it lets go regardless (a speed matter only; the den kernels do not depend on this kernel).
 __global__ void crf_gate_kernel(const int *started, int target) {
-    for (int spins = 0; spins < 20000; ++spins) {
-        if (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+    for (int spins = 0; spins < 120; ++spins) {   // ~0.2 ms at most
+        if (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
         __builtin_amdgcn_s_sleep(64);
     }
+#ifdef CRF_TIMING
+    atomicAdd(&g_tm[16000], 1ull);
+#endif
 }
 
 // One kernel per recursion so each keeps its own (small) set of live kernel arguments in SGPRs; the
@@ -1717,7 +1728,22 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
             for (unsigned spins = 0;; ++spins) {
                 if (__hip_atomic_load(p.prog + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need_f &&
                     __hip_atomic_load(p.prog + p.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need_b) break;
-                if (spins > (1u << 22)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }  // never hang: NaN loss
+                if (spins > (1u << 22)) {  // never hang: NaN loss
+                    __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CRF_TIMING
+                    {
+                        const unsigned long long n = atomicAdd(&g_tm[16001], 1ull);
+                        if (n < 40) {
+                            g_tm[16010 + n * 6 + 0] = b; g_tm[16010 + n * 6 + 1] = blk;
+                            g_tm[16010 + n * 6 + 2] = __hip_atomic_load(p.prog + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            g_tm[16010 + n * 6 + 3] = __hip_atomic_load(p.prog + p.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            g_tm[16010 + n * 6 + 4] = need_f;
+                            g_tm[16010 + n * 6 + 5] = __builtin_amdgcn_s_memrealtime();   // vs the chains' end stamps
+                        }
+                    }
+#endif
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(32);
             }
         }
@@ -2021,7 +2047,9 @@ struct DevCtx {
     bool init = false;
     hipStream_t side[3]{};
     hipEvent_t fork{}, join[3]{};
+    int *flags = nullptr;   // fine-grained (uncached, cross-XCD coherent) words: error, start counter, den progress
 };
+constexpr int kFlagInts = 16384;
 static DevCtx g_ctx[64];
 static std::mutex g_ctx_mu;
 
@@ -2043,6 +2071,13 @@ static int get_ctx(DevCtx **out) {
             set_error(std::string("event create: ") + hipGetErrorString(e));
             return CRF_ERR_HIP;
         }
+        // Words that one kernel polls while another, on a different XCD, updates them must not be cached in
+        // the poller's L2 (the per-XCD L2s are not coherent with each other; an `sc1` load bypasses only L1, so
+        // a poller kept re-reading its own stale line -- seen as multi-second stalls of the grad pass):
+        // fine-grained device memory is uncached in L2.
+        void *fl = nullptr;
+        if (hipExtMallocWithFlags(&fl, kFlagInts * sizeof(int), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); fl = nullptr; }
+        c.flags = (int *)fl;
         c.init = true;
     }
     *out = &c;
@@ -2144,7 +2179,7 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
-    p.started = started; p.prog = started + 63 + (DIR == 0 ? 0 : lp.B);
+    p.started = started; p.prog = started + 63 + (DIR == 0 ? 0 : lp.B); p.dbg_step = lp.dbg_step;
     p.frow_meta = F.frow_meta; p.x_start = F.x_start; p.x_end = F.x_end;
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
@@ -2236,6 +2271,8 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     p.grad = grad; p.loss = loss; p.out_den = costs_den; p.out_beta = costs_beta; p.out_ctc = costs_ctc;
     p.out_invalid = invalid;
 
+    static std::atomic<int> call_no{0};
+    p.dbg_step = ++call_no;
     hipError_t e;
 #define LAUNCH_CHECK(what)                                                                         \
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string(what) + ": " + hipGetErrorString(e)); return CRF_ERR_HIP; }
@@ -2274,6 +2311,13 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         (void)hipStreamWaitEvent(cx->side[i], cx->fork, 0);
         return cx->side[i];
     };
+    // factored path: error word, start counter and progress counters live in fine-grained memory (get_ctx)
+    const bool have_flags = fac && cx && cx->flags && 64 + 2 * B <= kFlagInts;
+    if (have_flags) {
+        p.err = cx->flags;
+        if ((e = hipMemsetAsync(cx->flags, 0, (size_t)(64 + 2 * B) * sizeof(int), stream)) != hipSuccess) { set_error("hipMemsetAsync(flags)"); return CRF_ERR_HIP; }
+        if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess) { set_error("hipEventRecord(fork)"); return CRF_ERR_HIP; }  // side streams start after the clear
+    }
     int *started = p.err + 1;   // workgroups of the den kernels that hold a CU (cleared with the error word)
     int ncu_dev = 256;
     {
@@ -2323,7 +2367,13 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // Factored den kernels: 2B workgroups, one CU each.  While they leave half of the chip free (2B <= CUs/2)
     // everything else runs BESIDE them (below); otherwise the numerator follows the den kernels as for K > 1 --
     // workgroups of the grad pass that wait for den progress must never keep a queued den workgroup off a CU.
-    const bool fac_overlap = fac && !serial && 2 * B <= ncu_dev / 2;
+    static const bool no_overlap = getenv("CRF_NO_OVERLAP") && atoi(getenv("CRF_NO_OVERLAP")) != 0;          // diagnostics
+    // A grad pass whose workgroups SPIN on the den kernels' progress (CRF_PROGRESSIVE=1, experiments only) is
+    // faster on a quiet device but not safe: with many launches queued ahead, running den kernels were observed
+    // to stop for seconds (queue oversubscription -> the scheduler swaps queues out) while the waiting
+    // workgroups kept their queue busy; only the time-out ended it.  One kernel must never wait for another.
+    static const bool no_progressive = !(getenv("CRF_PROGRESSIVE") && atoi(getenv("CRF_PROGRESSIVE")) != 0);
+    const bool fac_overlap = fac && !serial && !no_overlap && have_flags && 2 * B <= ncu_dev / 2;
     const bool split = ctc && den && !fac_overlap && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && (fac || h->dev.res.K > 1))) && !serial;
     auto join_all = [&]() -> int {
         for (int i = 0; i < 3; ++i)
@@ -2395,9 +2445,15 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         // ... and so does the den half: behind the numerator half on the same side stream, in readiness order,
         // every workgroup waiting for the den kernels' progress counters to pass its 16 frames
         p.grad_den_acc = 1;
-        if ((rc = launch_grad_den(s1, started + 63))) return rc;
-        prof_mark(5, true, s1);
-        if ((rc = join_all())) return rc;
+        if (!no_progressive) {
+            if ((rc = launch_grad_den(s1, started + 63))) return rc;
+            prof_mark(5, true, s1);
+            if ((rc = join_all())) return rc;
+        } else {
+            if ((rc = join_all())) return rc;
+            if ((rc = launch_grad_den())) return rc;
+            prof_mark(5, true, stream);
+        }
     } else if (!split) {
         if (ctc) {
             if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream, max_label_len))) return rc;
