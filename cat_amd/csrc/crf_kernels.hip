@@ -58,8 +58,8 @@ struct LossParams {
     const int *gchunk, *glab;     // its chunks (<= kChunk entries of one label) and per-label chunk ranges
     int gNC;
     int res;                      // 1: register-resident den kernels (g.res), 0: streaming kernels
-    int dbg_step;                 // (timing builds) host call counter
-    const int *prog;              // crf_grad_den_kernel: [2][B] frames finished by the den forward / backward kernels (nullptr: all)
+    int gd_stage, gd_nb;          // crf_grad_den_kernel: process only the 16-frame blocks completed by den segment `gd_stage` (0 = all)
+    int gd_bound[16];             //   segment k (1-based) runs the recursion iterations [gd_bound[k-1], gd_bound[k])
     int grad_den_acc;             // crf_grad_den_kernel: add to the row (the numerator half has written it) instead of writing
     int grad_phase;               // crf_grad_kernel: 0 = den and ctc in one pass, 1 = den part only (writes), 2 = ctc part only (subtracts)
     int b0;                       // first utterance of this launch (resident kernels with K > 1 run in groups)
@@ -1264,8 +1264,8 @@ struct FacParams {
     float *Row0;                // [B][Rout] spare rows: b_0 of the backward recursion
     int *Eout;                  // EQ (fwd) or EB (bwd)
     int *started;               // workgroups of the den kernels that have started (gate for the numerator chains)
-    int *prog;                  // [B] frames of this recursion whose rows are complete in memory (read by the grad pass)
-    int dbg_step;
+    int i0, i1;                 // iterations of this launch (segment)
+    float *state;               // [B][rup64(G) + 64] parked state vector and exponent between segments
     const int4 *frow_meta;
     const float *x_start, *x_end;
     float *den_zs, *cost_alpha;
@@ -1294,10 +1294,7 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     float *EP = (float *)(RMc + (size_t)R * 16);             // [2][Vp]
     float *wm = EP + 2 * Vp;                                 // [2][kResWaves]
     double *red = (double *)(wm + 2 * kResWaves);            // [kResWaves]
-    if (tid == 0 && p.started) atomicAdd(p.started, 1);      // this workgroup holds its CU: see crf_gate_kernel
-#ifdef CRF_TIMING
-    if (tid == 0) g_tm[15000 + DIR * 128 + b] = (unsigned long long)p.dbg_step;
-#endif
+    if (tid == 0 && p.started && p.i0 == 0) atomicAdd(p.started, 1);   // this workgroup holds its CU: see crf_gate_kernel
 
     unsigned A[kResWords];
     {
@@ -1320,19 +1317,35 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
             RM[r] = m;
         }
     }
+    // One launch runs the iterations [i0, i1) of the recursion ("segment"): the host cuts a long recursion into
+    // a few launches so that the grad pass can be released stage by stage with stream events (a kernel that
+    // waits for another kernel's progress is not safe, see crf_loss_fwd_bwd).  Between launches the state --
+    // the current vector and its exponent -- rests in HBM (p.state: [B][Gp + 64] floats per direction).
+    const int i0 = p.i0, i1 = min(p.i1, lx);
+    if (i0 > 0 && i0 >= lx) return;                          // this utterance was finished by an earlier segment
+    float *state = p.state + (size_t)b * (Gp + 64);
+    const int par0 = i0 & 1;
     int E = kScaleExp;
     float zpart = 0.f;
     for (int s = tid; s < 2 * Gp; s += kResThreads) X[s] = 0.f;
     if (tid < 2) EP[tid * Vp + V] = 0.f;
     if (lx > 0)
         for (int v = tid; v < V; v += kResThreads) {
-            EP[v] = p.ep[(bt0 + (DIR == 0 ? 0 : lx - 1)) * V + v];
-            if (DIR == 1 && lx > 1) EP[Vp + v] = p.ep[(bt0 + lx - 2) * V + v];
+            if (DIR == 0) EP[par0 * Vp + v] = p.ep[(bt0 + i0) * V + v];                 // e'_t of the first frame
+            else {
+                const int t = lx - 1 - i0;                                             // first frame of this segment
+                if (i0 == 0) EP[v] = p.ep[(bt0 + lx - 1) * V + v];                     // for the initial z vector
+                if (t >= 1) EP[(1 - par0) * Vp + v] = p.ep[(bt0 + t - 1) * V + v];     // e'_{t-1}
+            }
         }
     __syncthreads();
     {
         float m0 = 0.f;
-        if (DIR == 0) {
+        if (i0 > 0) {                                        // resume
+            float *Xc = X + par0 * Gp;
+            for (int s = tid; s < G; s += kResThreads) { const float v = state[s]; Xc[s] = v; m0 = fmaxf(m0, v); }
+            E = __float_as_int(state[Gp]);
+        } else if (DIR == 0) {
             for (int s = tid; s < G; s += kResThreads) { const float v = p.x_start[s] * pow2f(kScaleExp); X[s] = v; m0 = fmaxf(m0, v); }
         } else if (lx > 0) {
             for (int z = tid; z < G; z += kResThreads) {
@@ -1347,7 +1360,7 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
             for (int r = tid; r < 2 * R; r += kResThreads) zpart += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
         }
         m0 = wave_max(m0);
-        if (lane == 0) wm[wave] = m0;
+        if (lane == 0) wm[par0 * kResWaves + wave] = m0;
     }
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // arcs and tables have landed (see crf_res_chain_kernel)
@@ -1360,11 +1373,6 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
 #ifdef CRF_TIMING
         if (b == 3 && i >= 150 && i < 158 && wave == 0) CRF_TM(true, 12288 + 1024 + (DIR * 4) * 8 + (i - 150));  // frame start
 #endif
-        // Progress for the grad pass, which runs beside this kernel on other compute units: every 16 frames all
-        // waves wait for their row stores (vmcnt(0)); one frame and one barrier later every wave has done so, and
-        // `i - 1` frames (forward: Q rows 0..i-2; backward: BP rows lx-i..lx-1) are complete in memory.
-        if ((i & 15) == 0) __builtin_amdgcn_s_waitcnt(0x0F70);
-        if ((i & 15) == 1 && i > 1 && tid == 0) __hip_atomic_store(p.prog + b, DIR == 0 ? i - 1 : i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const char *xb = (const char *)lds + par * XB;
         char *xnb = (char *)lds + (1 - par) * XB;
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
@@ -1410,10 +1418,8 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
                             const float rv = (acc.x + acc.y) * sc;                      // q_t[pair of the main state]
                             const float uold = *(const float *)(xb + (m.x & 0xffff));   // U_t of the row's pair
                             const float qt = __int_as_float(m.z) * uold * sc;           // q_t[pair of the tail state]
-                            // rows are stored write-through (agent scope): the grad pass reads them from other
-                            // XCDs while this kernel is still running (progress counters below)
-                            __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store((unsigned *)((char *)Orow + r4 + 4u * (unsigned)R), __float_as_uint(qt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *(float *)((char *)Orow + r4) = rv;
+                            *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
                             const float Lp = EPu[(unsigned)m.x >> 16] * rv;              // a_{t+1}[main]
                             const float Ap = EPu[m.w] * qt;                             // a_{t+1}[tail]
                             const float Up = Ap + Lp;
@@ -1427,9 +1433,7 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
                             f32x2 bv;                                                    // b_t of the two states
                             bv.x = fmaf(__int_as_float(m.y), z0, craw) * sc;
                             bv.y = fmaf(__int_as_float(m.z), z1, craw) * sc;
-                            __hip_atomic_store((unsigned long long *)((char *)Orow + 2u * r4),
-                                               (unsigned long long)__float_as_uint(bv.x) | ((unsigned long long)__float_as_uint(bv.y) << 32),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *(f32x2 *)((char *)Orow + 2u * r4) = bv;
                             f32x2 zv;                                                    // z_{t-1} of the pairs entering them
                             zv.x = EPu[m.w & 0xffff] * bv.x;
                             zv.y = EPu[(unsigned)m.w >> 16] * bv.y;
@@ -1462,13 +1466,13 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         CRF_TM(tm_on, tm_i + 4);
     };
 #pragma clang loop unroll(disable)
-    for (int i = 0; i < lx; ++i) frame(i & 1, i);
-    __syncthreads();   // fence + barrier: every wave's row stores are complete
-    if (tid == 0) __hip_atomic_store(p.prog + b, lx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef CRF_TIMING
-    if (tid == 0) g_tm[15500 + DIR * 128 + b] = __builtin_amdgcn_s_memrealtime();
-#endif
-
+    for (int i = i0; i < i1; ++i) frame(i & 1, i);
+    if (i1 < lx) {                                           // not the last segment of this utterance: park the state
+        const float *Xc = X + (i1 & 1) * Gp;
+        for (int s = tid; s < G; s += kResThreads) state[s] = Xc[s];
+        if (tid == 0) state[Gp] = __int_as_float(E);
+        return;
+    }
     if (DIR == 0) {
         const float *Xf = X + (lx & 1) * Gp;
         float part = 0.f;
@@ -1620,21 +1624,7 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
     const int tid = threadIdx.x;
-    // Progressive mode (p.prog): the launch is one-dimensional and ordered by readiness -- the forward den
-    // kernel works up from frame 0, the backward one down from the last, so a 16-frame block is complete once
-    // both have passed it: the middle blocks first, then outwards -- and every workgroup waits (bounded) for
-    // its block's rows.  Otherwise the grid is (frame blocks, utterances) and everything is ready.
-    int b, blk;
-    if (p.prog) {
-        const int nblk = (p.T + kGDFrames - 1) / kGDFrames, k = (int)blockIdx.x / p.B;
-        b = (int)blockIdx.x % p.B;
-        const int mid = nblk / 2;
-        blk = 0;
-        for (int j = 0, cnt = -1; j <= 2 * nblk; ++j) {        // k-th block of the order mid, mid+1, mid-1, mid+2, ... (in range)
-            const int c = (j & 1) ? mid + (j + 1) / 2 : mid - j / 2;
-            if (c >= 0 && c < nblk && ++cnt == k) { blk = c; break; }
-        }
-    } else { b = blockIdx.y; blk = blockIdx.x; }
+    const int b = blockIdx.y, blk = blockIdx.x;
     const int V = p.V;
     const int lx = p.lx[b], Rq = p.Rq, Rb = p.Rb, NC = p.gNC;
     const int Vp = rup64(V);
@@ -1643,6 +1633,19 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
     int *clab_s = (int *)(nrm + kGDFrames);                                 // [NC] label of each chunk (prologue only)
     const int64_t bt0 = (int64_t)b * p.T;
     const int t0 = blk * kGDFrames, t1 = min(t0 + kGDFrames, p.T), tl = min(t1, lx);
+    if (p.gd_stage > 0) {
+        // Staged mode: the den recursions run in segments (iteration bounds gd_bound[]), and after segment k an event
+        // releases the launch with gd_stage = k.  A block belongs to the FIRST stage at which both its Q rows
+        // (forward has passed frame tl) and its BP rows (backward has come down to frame t0) exist; the other
+        // stages' launches skip it.  (No waiting inside kernels: see crf_loss_fwd_bwd.)
+        int sf = 1, sb = 1;                                        // first segment that has run `tl` / `lx-1-t0` iterations
+        for (int k = 1; k < p.gd_nb; ++k) {                        // (BP[t0] is stored by iteration lx-2-t0; BP[lx-1] by the set-up)
+            if (p.gd_bound[k] < tl) sf = k + 1;
+            if (p.gd_bound[k] < lx - 1 - t0) sb = k + 1;
+        }
+        const int mine = t0 < tl ? max(sf, sb) : 1;                // blocks past the utterance: first stage
+        if (mine != p.gd_stage) return;
+    }
 
     unsigned idx[NCPT][kChunk];
     {
@@ -1721,34 +1724,6 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
         if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];                                                        \
     }
     float erc[kGDEpRegs], rwc[kGDEpRegs];
-    // (progressive mode) wait for this block's rows -- after the prologue above, which does not need them
-    if (p.prog && t0 < tl) {
-        if (tid == 0) {
-            const int need_f = tl, need_b = lx - t0;
-            for (unsigned spins = 0;; ++spins) {
-                if (__hip_atomic_load(p.prog + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need_f &&
-                    __hip_atomic_load(p.prog + p.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need_b) break;
-                if (spins > (1u << 22)) {  // never hang: NaN loss
-                    __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef CRF_TIMING
-                    {
-                        const unsigned long long n = atomicAdd(&g_tm[16001], 1ull);
-                        if (n < 40) {
-                            g_tm[16010 + n * 6 + 0] = b; g_tm[16010 + n * 6 + 1] = blk;
-                            g_tm[16010 + n * 6 + 2] = __hip_atomic_load(p.prog + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            g_tm[16010 + n * 6 + 3] = __hip_atomic_load(p.prog + p.B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            g_tm[16010 + n * 6 + 4] = need_f;
-                            g_tm[16010 + n * 6 + 5] = __builtin_amdgcn_s_memrealtime();   // vs the chains' end stamps
-                        }
-                    }
-#endif
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-        }
-        __syncthreads();
-    }
     if (t0 < tl) {
         CRF_GD_FETCH(t0);
         CRF_GD_STAGE();
@@ -1982,7 +1957,7 @@ struct WsLayout {
     int64_t xch_bytes;
     int64_t Rq, Rb;
     bool res, gv, fac;
-    int64_t off_gvec;
+    int64_t off_gvec, off_state, state_stride;
 };
 static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -2022,6 +1997,9 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.gv = h && !w.res && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
     w.off_gvec = o; o = al(o + (w.gv ? B * (3 * (int64_t)rup64(h->dev.S) + 4 * (int64_t)h->dev.Pr) * 4 : 0));
+    // factored recursions launched in segments park their state vector + exponent here: [2 dir][B][stride]
+    w.state_stride = w.fac ? rup64(std::max(h->dev.fac.f.G, h->dev.fac.b.G)) + 64 : 0;
+    w.off_state = o; o = al(o + 2 * B * w.state_stride * 4);
     w.total = o;
     return w;
 }
@@ -2043,11 +2021,18 @@ static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role, bool 
 
 // Side streams + events used to run the four recursions concurrently (fork/join around the
 // caller's stream).  One set per device, created on first use.
+constexpr int kMaxStages = 16;
 struct DevCtx {
     bool init = false;
     hipStream_t side[3]{};
     hipEvent_t fork{}, join[3]{};
-    int *flags = nullptr;   // fine-grained (uncached, cross-XCD coherent) words: error, start counter, den progress
+    int *flags = nullptr;   // fine-grained (uncached, cross-XCD coherent) words: error word, start counter
+    // Two disjoint halves of the chip (CU-masked streams): the factored den recursions -- one workgroup per CU,
+    // relaunched segment by segment -- keep half A to themselves; the numerator chains and both halves of the
+    // grad pass, thousands of short workgroups that would otherwise grab every CU a den segment frees, run on B.
+    hipStream_t mA[2]{}, mB[2]{};
+    bool masked = false;
+    hipEvent_t evf[kMaxStages]{}, evb[kMaxStages]{}, jm[4]{};
 };
 constexpr int kFlagInts = 16384;
 static DevCtx g_ctx[64];
@@ -2078,6 +2063,25 @@ static int get_ctx(DevCtx **out) {
         void *fl = nullptr;
         if (hipExtMallocWithFlags(&fl, kFlagInts * sizeof(int), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); fl = nullptr; }
         c.flags = (int *)fl;
+        int ncu = 0;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (getenv("CRF_CU_MASK") && atoi(getenv("CRF_CU_MASK")) != 0 && ncu >= 64 && ncu % 32 == 0 && ncu / 32 <= 32) {
+            // bit i of the mask = CU i in the driver's enumeration; 16 of every 32 gave 128 distinct CUs spread over
+            // all 8 XCDs on the MI355X (checked with HW_REG_HW_ID / XCC_ID); the complement gives the other 128
+            uint32_t ma[32], mb[32];
+            for (int i = 0; i < ncu / 32; ++i) { ma[i] = 0x0000ffffu; mb[i] = 0xffff0000u; }
+            bool ok = true;
+            for (int i = 0; i < 2 && ok; ++i)
+                ok = hipExtStreamCreateWithCUMask(&c.mA[i], (uint32_t)(ncu / 32), ma) == hipSuccess &&
+                     hipExtStreamCreateWithCUMask(&c.mB[i], (uint32_t)(ncu / 32), mb) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            c.masked = ok;
+        }
+        for (int i = 0; i < kMaxStages; ++i) {
+            (void)hipEventCreateWithFlags(&c.evf[i], hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&c.evb[i], hipEventDisableTiming);
+        }
+        for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&c.jm[i], hipEventDisableTiming);
         c.init = true;
     }
     *out = &c;
@@ -2163,7 +2167,7 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
            ((size_t)2 * rup64(V + 1) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
 }
 template <int DIR>
-static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started) {
+static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *state) {
     static std::atomic<size_t> lds_set{0};
     hipError_t e;
     if (lds > lds_set.load()) {
@@ -2179,7 +2183,7 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
-    p.started = started; p.prog = started + 63 + (DIR == 0 ? 0 : lp.B); p.dbg_step = lp.dbg_step;
+    p.started = started; p.i0 = i0; p.i1 = i1; p.state = state;
     p.frow_meta = F.frow_meta; p.x_start = F.x_start; p.x_end = F.x_end;
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
@@ -2271,8 +2275,6 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     p.grad = grad; p.loss = loss; p.out_den = costs_den; p.out_beta = costs_beta; p.out_ctc = costs_ctc;
     p.out_invalid = invalid;
 
-    static std::atomic<int> call_no{0};
-    p.dbg_step = ++call_no;
     hipError_t e;
 #define LAUNCH_CHECK(what)                                                                         \
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string(what) + ": " + hipGetErrorString(e)); return CRF_ERR_HIP; }
@@ -2324,14 +2326,75 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         int devid = 0;
         if (hipGetDevice(&devid) == hipSuccess) (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, devid);
     }
-    if (fac) {
+    // The denominator half of the grad pass has a streaming kernel (index pairs in registers, rows
+    // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
+    const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
+    const bool fast_den = den && w.Rq <= 4 * kGDRowRegs * kGDThreads && w.Rb <= 4 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
+                          gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
+    // numerator half of the grad pass: streaming kernel when the vocabulary fits its registers
+    const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
+                          !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
+    // Factored den kernels: 2B workgroups, one CU each.  While that is at most half of the chip, everything else
+    // runs BESIDE them: den recursions on the CU-masked half A, numerator chains and grad pass on half B.  The
+    // den half of the grad pass needs rows of BOTH recursions, which work towards each other; it is released
+    // in stages: the recursions are launched in `nstage` segments, an event after each, and the grad launch of
+    // stage k (ordered behind the events of segment k) takes the 16-frame blocks that segment completed.
+    // (A grad pass that SPINS on progress counters of the running den kernels is faster still on a quiet device,
+    // but with many launches queued ahead the den kernels were observed to stop for seconds while the waiting
+    // workgroups kept their queue busy -- one kernel must never wait for another.)
+    static const bool no_overlap = getenv("CRF_NO_OVERLAP") && atoi(getenv("CRF_NO_OVERLAP")) != 0;   // diagnostics
+    static const int stages_env = getenv("CRF_STAGES") ? atoi(getenv("CRF_STAGES")) : 4;
+    static const bool use_mask = getenv("CRF_CU_MASK") && atoi(getenv("CRF_CU_MASK")) != 0;
+    const bool staged = fac && ctc && fast_den && fast_ctc && !serial && !no_overlap && cx && cx->flags && (!use_mask || cx->masked) &&
+                        2 * B <= ncu_dev / 2;
+    // streams of the staged schedule: den forward / backward segments, and two for everything else
+    hipStream_t sA0 = stream, sA1 = stream, sB0 = stream, sB1 = stream;
+    if (staged) {
+        if (use_mask) { sA0 = cx->mA[0]; sA1 = cx->mA[1]; sB0 = cx->mB[0]; sB1 = cx->mB[1]; }
+        else { sA0 = stream; sA1 = cx->side[0]; sB0 = cx->side[1]; sB1 = cx->side[2]; }
+    }
+    // Segment bounds: nothing can be released before the two recursions have met, so the first segment is half of
+    // the frames; the second half is cut into `stages_env` pieces (each relaunch costs ~40 us; the last piece's
+    // blocks are the tail left after the recursions end).
+    int bound[kMaxStages + 1] = {0};
+    int nstage = 1;
+    bound[1] = (int)T;
+    if (staged && T >= 256) {
+        const int half = (int)((T / 2 + kGDFrames - 1) / kGDFrames * kGDFrames);
+        const int nshort = std::max(1, std::min(std::min(stages_env, kMaxStages - 1), (int)((T - half) / 32)));
+        int piece = (int)((T - half + nshort - 1) / nshort);
+        piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
+        nstage = 1;
+        bound[1] = half;
+        while (bound[nstage] < T && nstage < kMaxStages) { bound[nstage + 1] = std::min((int)T, bound[nstage] + piece); ++nstage; }
+        bound[nstage] = (int)T;
+    }
+    p.gd_nb = nstage + 1;
+    for (int k = 0; k <= nstage && k < 16; ++k) p.gd_bound[k] = bound[k];
+    float *fstate = (float *)(base + w.off_state), *bstate = fstate + B * w.state_stride;
+    if (staged) {
+        // den segments on the masked A streams; nothing of this call runs on the caller's stream until the join
+        if (sA0 != stream) (void)hipStreamWaitEvent(sA0, cx->fork, 0);
+        (void)hipStreamWaitEvent(sA1, cx->fork, 0);
+        prof_mark(1, false, sA0);
+        prof_mark(2, false, sA1);
+        for (int k = 0; k < nstage; ++k) {
+            if ((rc = launch_fac<0>(p, fac_lds_bytes(h, (int)V, 0), sA0, started, bound[k], bound[k + 1], fstate))) return rc;
+            if ((rc = launch_fac<1>(p, fac_lds_bytes(h, (int)V, 1), sA1, started, bound[k], bound[k + 1], bstate))) return rc;
+            if ((e = hipEventRecord(cx->evf[k], sA0)) != hipSuccess || (e = hipEventRecord(cx->evb[k], sA1)) != hipSuccess) {
+                set_error(std::string("hipEventRecord(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+            }
+        }
+        prof_mark(1, true, sA0);
+        prof_mark(2, true, sA1);
+    } else if (fac) {
         // factored resident recursions: one CU per utterance and direction, nothing to exchange
         hipStream_t sb = side(0);
         prof_mark(1, false, stream);
-        if ((rc = launch_fac<0>(p, fac_lds_bytes(h, (int)V, 0), stream, started))) return rc;
+        if ((rc = launch_fac<0>(p, fac_lds_bytes(h, (int)V, 0), stream, started, 0, (int)T, fstate))) return rc;
         prof_mark(1, true, stream);
         prof_mark(2, false, sb);
-        if ((rc = launch_fac<1>(p, fac_lds_bytes(h, (int)V, 1), sb, started))) return rc;
+        if ((rc = launch_fac<1>(p, fac_lds_bytes(h, (int)V, 1), sb, started, 0, (int)T, bstate))) return rc;
         prof_mark(2, true, sb);
     } else if (res) {
         // register-resident recursions: K CUs per utterance and direction, exchanging the state vector
@@ -2364,17 +2427,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // (HBM-bound, small workgroups that share CUs happily); a second, cheap grad pass then subtracts
     // the numerator posteriors.  Otherwise all four recursions run side by side and grad is one pass.
     static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
-    // Factored den kernels: 2B workgroups, one CU each.  While they leave half of the chip free (2B <= CUs/2)
-    // everything else runs BESIDE them (below); otherwise the numerator follows the den kernels as for K > 1 --
-    // workgroups of the grad pass that wait for den progress must never keep a queued den workgroup off a CU.
-    static const bool no_overlap = getenv("CRF_NO_OVERLAP") && atoi(getenv("CRF_NO_OVERLAP")) != 0;          // diagnostics
-    // A grad pass whose workgroups SPIN on the den kernels' progress (CRF_PROGRESSIVE=1, experiments only) is
-    // faster on a quiet device but not safe: with many launches queued ahead, running den kernels were observed
-    // to stop for seconds (queue oversubscription -> the scheduler swaps queues out) while the waiting
-    // workgroups kept their queue busy; only the time-out ended it.  One kernel must never wait for another.
-    static const bool no_progressive = !(getenv("CRF_PROGRESSIVE") && atoi(getenv("CRF_PROGRESSIVE")) != 0);
-    const bool fac_overlap = fac && !serial && !no_overlap && have_flags && 2 * B <= ncu_dev / 2;
-    const bool split = ctc && den && !fac_overlap && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && (fac || h->dev.res.K > 1))) && !serial;
+    const bool split = ctc && den && !staged && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && (fac || h->dev.res.K > 1))) && !serial;
     auto join_all = [&]() -> int {
         for (int i = 0; i < 3; ++i)
             if (used[i]) {
@@ -2388,17 +2441,11 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         return CRF_OK;
     };
     const dim3 ggrid((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B);
-    // The denominator half of the grad pass has a streaming kernel (index pairs in registers, rows
-    // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
-    const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
-    const bool fast_den = den && w.Rq <= 4 * kGDRowRegs * kGDThreads && w.Rb <= 4 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
-                          gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
-    auto launch_grad_den = [&](hipStream_t st = nullptr, const int *prog = nullptr) -> int {
+    auto launch_grad_den = [&](hipStream_t st = nullptr, int stage = 0) -> int {
         if (!st) st = stream;
-        p.prog = prog;
+        p.gd_stage = stage;
         const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + 4 * rup64((int)V) + kGDFrames + rup64(gnc)) * sizeof(float);
-        const unsigned nblk = (unsigned)((T + kGDFrames - 1) / kGDFrames);
-        const dim3 gg = prog ? dim3(nblk * (unsigned)B) : dim3(nblk, (unsigned)B);
+        const dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
         static std::atomic<size_t> set1{0}, set2{0};
         if (gnc <= kGDThreads) {
             if (l > set1.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set1 = l; }
@@ -2410,9 +2457,6 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad_den_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
     };
-    // numerator half of the grad pass: streaming kernel when the vocabulary fits its registers
-    const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
-                          !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
     auto launch_grad_ctc = [&](int phase, hipStream_t st = nullptr) -> int {  // phase 2: subtract from the den half; 0: plain CTC (writes)
         if (!st) st = stream;
         p.grad_phase = phase;
@@ -2426,33 +2470,32 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad(ctc): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
     };
-    if (fac_overlap && ctc && fast_den && fast_ctc) {
-        // Factored den kernels use one CU per recursion: half the chip.  The numerator chains AND the numerator
-        // half of the grad pass run beside them on the other half, behind a gate that waits until every den
-        // workgroup holds its CU; the den half of the grad pass then ADDS to what the numerator half wrote.
-        hipStream_t s1 = side(1), s2 = side(2);
-        const int target = 2 * (int)B;
-        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s1, started, target);
-        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s2, started, target);
+    if (staged) {
+        hipStream_t s1 = sB0, s2 = sB1;
+        (void)hipStreamWaitEvent(s1, cx->fork, 0);
+        (void)hipStreamWaitEvent(s2, cx->fork, 0);
+        if (!use_mask) {   // no CU masks: hold the numerator back until the den workgroups have their CUs
+            hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s1, started, 2 * (int)B);
+            hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s2, started, 2 * (int)B);
+        }
         if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), s1, max_label_len))) return rc;
         if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), s2, max_label_len))) return rc;
-        if ((e = hipEventRecord(cx->join[2], s2)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->join[2], 0)) != hipSuccess) {
+        if ((e = hipEventRecord(cx->jm[0], s2)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->jm[0], 0)) != hipSuccess) {
             set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
         }
-        used[2] = false;
         prof_mark(5, false, s1);
-        if ((rc = launch_grad_ctc(0, s1))) return rc;
-        // ... and so does the den half: behind the numerator half on the same side stream, in readiness order,
-        // every workgroup waiting for the den kernels' progress counters to pass its 16 frames
+        if ((rc = launch_grad_ctc(0, s1))) return rc;          // writes -c_ctc * gamma_ctc; the den half then adds
         p.grad_den_acc = 1;
-        if (!no_progressive) {
-            if ((rc = launch_grad_den(s1, started + 63))) return rc;
-            prof_mark(5, true, s1);
-            if ((rc = join_all())) return rc;
-        } else {
-            if ((rc = join_all())) return rc;
-            if ((rc = launch_grad_den())) return rc;
-            prof_mark(5, true, stream);
+        for (int k = 0; k < nstage; ++k) {
+            if ((e = hipStreamWaitEvent(s1, cx->evf[k], 0)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->evb[k], 0)) != hipSuccess) {
+                set_error(std::string("hipStreamWaitEvent(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+            }
+            if ((rc = launch_grad_den(s1, k + 1))) return rc;
+        }
+        prof_mark(5, true, s1);
+        // join: the caller's stream continues after the last grad launch (which is behind every den segment)
+        if ((e = hipEventRecord(cx->jm[1], s1)) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->jm[1], 0)) != hipSuccess) {
+            set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
         }
     } else if (!split) {
         if (ctc) {

@@ -146,6 +146,47 @@ def _ptr(t: Optional[torch.Tensor]):
     return _vp(0) if t is None else _vp(t.data_ptr())
 
 
+class _PinnedRing:
+    """A few pinned int32 staging buffers per device, reused round-robin: a copy from PAGEABLE memory makes the
+    host wait for the stream (the next call could not be enqueued while this one runs); from pinned memory it
+    is asynchronous.  A slot is reused only after the event of its last copy has completed."""
+
+    SLOTS = 8
+
+    def __init__(self):
+        self.buf = [None] * self.SLOTS
+        self.ev = [None] * self.SLOTS
+        self.i = 0
+
+    def stage(self, src: torch.Tensor, dev: torch.device) -> torch.Tensor:
+        k = self.i
+        self.i = (k + 1) % self.SLOTS
+        n = src.numel()
+        if self.ev[k] is not None:
+            self.ev[k].synchronize()
+        if self.buf[k] is None or self.buf[k].numel() < n:
+            self.buf[k] = torch.empty(max(n, 4096), dtype=torch.int32).pin_memory()
+        self.buf[k][:n].copy_(src)
+        out = self.buf[k][:n].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.ev[k] = ev
+        return out
+
+
+_RINGS = {}
+
+
+def _h2d_async(src: torch.Tensor, dev: torch.device) -> torch.Tensor:
+    if src.is_cuda:
+        return src
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ring = _RINGS.get(key)
+    if ring is None:
+        ring = _RINGS[key] = _PinnedRing()
+    return ring.stage(src, dev)
+
+
 def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch.Tensor,
                  ly: Optional[torch.Tensor], c_den: float, c_ctc: float, graph: Optional[int],
                  want_costs: bool = False):
@@ -166,12 +207,13 @@ def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch
         lab32 = labels.to(torch.int32).reshape(-1)
         if lab32.numel() == 0:
             lab32 = torch.zeros(1, dtype=torch.int32)
-        # one H2D copy for all integer metadata (the reference issues ~5, gpu_ctc.h:143-229)
-        meta = torch.cat([lx32.cpu().reshape(-1), ly_cpu.reshape(-1), off.reshape(-1), lab32.cpu()]).to(dev, non_blocking=True)
+        # one H2D copy for all integer metadata (the reference issues ~5, gpu_ctc.h:143-229), through pinned
+        # staging so that it does not serialise the host with the stream
+        meta = _h2d_async(torch.cat([lx32.cpu().reshape(-1), ly_cpu.reshape(-1), off.reshape(-1), lab32.cpu()]), dev)
         lx_d, ly_d, off_d, lab_d = meta[:N], meta[N:2 * N], meta[2 * N:3 * N], meta[3 * N:]
     else:
         max_l = 0
-        lx_d = lx32.to(dev, non_blocking=True)
+        lx_d = _h2d_async(lx32.cpu().reshape(-1), dev) if not lx32.is_cuda else lx32
         ly_d = off_d = lab_d = None
         meta = lx_d
     gh = _vp(graph) if (graph and c_den != 0.0) else _vp(0)
