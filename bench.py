@@ -148,7 +148,7 @@ def main():
         except Exception:
             traffic = None
     gstats = ctc_crf._C.graph_stats(ctc_crf._C.graph_for(dev))
-    kname = ("crf_res_chain_kernel<%d>" if gstats["res_K"] > 0 else "crf_chain_kernel<%d>") % (0 if dom == "den_fwd_chain" else 1)
+    kname = ("crf_fac_chain_kernel<%d>" if gstats.get("fac") else "crf_res_chain_kernel<%d>" if gstats["res_K"] > 0 else "crf_chain_kernel<%d>") % (0 if dom == "den_fwd_chain" else 1)
     roofline = {
         "bound": "hbm", "kernel": "%s (%s)" % (kname, dom),
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -214,7 +214,9 @@ def main():
                                    f"H={args.histories}, d={args.fanout}, seed 0): S={dims['S']} states, "
                                    f"A={dims['A']} arcs, P={dims['P']} (dst,label) pairs; "
                                    f"{'ragged lx' if args.ragged else 'lx = T'}, ly = lx//6, lamb={args.lamb}",
-                       "den_kernels": (f"register-resident, K={gstats['res_K']} CUs per recursion" if gstats["res_K"] > 0 else "streaming"),
+                       "den_kernels": ("factored register-resident, 1 CU per recursion, launched in segments (the roofline kernel's "
+                                       "duration is the span of its segments)" if gstats.get("fac") else
+                                       f"register-resident, K={gstats['res_K']} CUs per recursion" if gstats["res_K"] > 0 else "streaming"),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch sharded, no data-path collective)"},
             "loss": round(loss_val, 6),
             "roofline": roofline,

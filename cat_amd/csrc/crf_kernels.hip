@@ -1501,9 +1501,7 @@ __global__ void crf_gate_kernel(const int *started, int target) {
         if (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
         __builtin_amdgcn_s_sleep(64);
     }
-#ifdef CRF_TIMING
-    atomicAdd(&g_tm[16000], 1ull);
-#endif
+    // timed out: nothing depends on this for correctness
 }
 
 // One kernel per recursion so each keeps its own (small) set of live kernel arguments in SGPRs; the
@@ -2027,11 +2025,7 @@ struct DevCtx {
     hipStream_t side[3]{};
     hipEvent_t fork{}, join[3]{};
     int *flags = nullptr;   // fine-grained (uncached, cross-XCD coherent) words: error word, start counter
-    // Two disjoint halves of the chip (CU-masked streams): the factored den recursions -- one workgroup per CU,
-    // relaunched segment by segment -- keep half A to themselves; the numerator chains and both halves of the
-    // grad pass, thousands of short workgroups that would otherwise grab every CU a den segment frees, run on B.
-    hipStream_t mA[2]{}, mB[2]{};
-    bool masked = false;
+    // events of the staged schedule: after every den segment (forward / backward), and two joins
     hipEvent_t evf[kMaxStages]{}, evb[kMaxStages]{}, jm[4]{};
 };
 constexpr int kFlagInts = 16384;
@@ -2063,20 +2057,6 @@ static int get_ctx(DevCtx **out) {
         void *fl = nullptr;
         if (hipExtMallocWithFlags(&fl, kFlagInts * sizeof(int), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); fl = nullptr; }
         c.flags = (int *)fl;
-        int ncu = 0;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (getenv("CRF_CU_MASK") && atoi(getenv("CRF_CU_MASK")) != 0 && ncu >= 64 && ncu % 32 == 0 && ncu / 32 <= 32) {
-            // bit i of the mask = CU i in the driver's enumeration; 16 of every 32 gave 128 distinct CUs spread over
-            // all 8 XCDs on the MI355X (checked with HW_REG_HW_ID / XCC_ID); the complement gives the other 128
-            uint32_t ma[32], mb[32];
-            for (int i = 0; i < ncu / 32; ++i) { ma[i] = 0x0000ffffu; mb[i] = 0xffff0000u; }
-            bool ok = true;
-            for (int i = 0; i < 2 && ok; ++i)
-                ok = hipExtStreamCreateWithCUMask(&c.mA[i], (uint32_t)(ncu / 32), ma) == hipSuccess &&
-                     hipExtStreamCreateWithCUMask(&c.mB[i], (uint32_t)(ncu / 32), mb) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-            c.masked = ok;
-        }
         for (int i = 0; i < kMaxStages; ++i) {
             (void)hipEventCreateWithFlags(&c.evf[i], hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&c.evb[i], hipEventDisableTiming);
@@ -2335,7 +2315,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
                           !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
     // Factored den kernels: 2B workgroups, one CU each.  While that is at most half of the chip, everything else
-    // runs BESIDE them: den recursions on the CU-masked half A, numerator chains and grad pass on half B.  The
+    // runs BESIDE them on the other half: numerator chains, their grad half, and the den half of the grad pass.  The
     // den half of the grad pass needs rows of BOTH recursions, which work towards each other; it is released
     // in stages: the recursions are launched in `nstage` segments, an event after each, and the grad launch of
     // stage k (ordered behind the events of segment k) takes the 16-frame blocks that segment completed.
@@ -2344,15 +2324,12 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // workgroups kept their queue busy -- one kernel must never wait for another.)
     static const bool no_overlap = getenv("CRF_NO_OVERLAP") && atoi(getenv("CRF_NO_OVERLAP")) != 0;   // diagnostics
     static const int stages_env = getenv("CRF_STAGES") ? atoi(getenv("CRF_STAGES")) : 4;
-    static const bool use_mask = getenv("CRF_CU_MASK") && atoi(getenv("CRF_CU_MASK")) != 0;
-    const bool staged = fac && ctc && fast_den && fast_ctc && !serial && !no_overlap && cx && cx->flags && (!use_mask || cx->masked) &&
-                        2 * B <= ncu_dev / 2;
-    // streams of the staged schedule: den forward / backward segments, and two for everything else
+    const bool staged = fac && ctc && fast_den && fast_ctc && !serial && !no_overlap && cx && cx->flags && 2 * B <= ncu_dev / 2;
+    // streams of the staged schedule: den forward / backward segments, and two for everything else.  (Tried:
+    // CU-masked streams, hipExtStreamCreateWithCUMask, to keep the den recursions and the rest on disjoint halves
+    // of the chip -- every queue of the process got slower, +1.5 ms per call; the start gate below does the job.)
     hipStream_t sA0 = stream, sA1 = stream, sB0 = stream, sB1 = stream;
-    if (staged) {
-        if (use_mask) { sA0 = cx->mA[0]; sA1 = cx->mA[1]; sB0 = cx->mB[0]; sB1 = cx->mB[1]; }
-        else { sA0 = stream; sA1 = cx->side[0]; sB0 = cx->side[1]; sB1 = cx->side[2]; }
-    }
+    if (staged) { sA1 = cx->side[0]; sB0 = cx->side[1]; sB1 = cx->side[2]; }
     // Segment bounds: nothing can be released before the two recursions have met, so the first segment is half of
     // the frames; the second half is cut into `stages_env` pieces (each relaunch costs ~40 us; the last piece's
     // blocks are the tail left after the recursions end).
@@ -2373,7 +2350,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     for (int k = 0; k <= nstage && k < 16; ++k) p.gd_bound[k] = bound[k];
     float *fstate = (float *)(base + w.off_state), *bstate = fstate + B * w.state_stride;
     if (staged) {
-        // den segments on the masked A streams; nothing of this call runs on the caller's stream until the join
+        // den forward segments on the caller's stream, backward segments on side stream 0
         if (sA0 != stream) (void)hipStreamWaitEvent(sA0, cx->fork, 0);
         (void)hipStreamWaitEvent(sA1, cx->fork, 0);
         prof_mark(1, false, sA0);
@@ -2474,10 +2451,9 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         hipStream_t s1 = sB0, s2 = sB1;
         (void)hipStreamWaitEvent(s1, cx->fork, 0);
         (void)hipStreamWaitEvent(s2, cx->fork, 0);
-        if (!use_mask) {   // no CU masks: hold the numerator back until the den workgroups have their CUs
-            hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s1, started, 2 * (int)B);
-            hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s2, started, 2 * (int)B);
-        }
+        // hold the numerator back (briefly, bounded) until the den workgroups have their CUs
+        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s1, started, 2 * (int)B);
+        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s2, started, 2 * (int)B);
         if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), s1, max_label_len))) return rc;
         if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), s2, max_label_len))) return rc;
         if ((e = hipEventRecord(cx->jm[0], s2)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->jm[0], 0)) != hipSuccess) {

@@ -45,6 +45,11 @@ def main():
         shutil.copy(ks[0], os.path.join(PROF, f"round1_{tag}_kernel_stats.csv"))
     traffic, sq = {}, {}
     fe, wr, s = counters(tag, "fetch"), counters(tag, "write"), counters(tag, "sq")
+    def nsteps(acc, what):   # calls of the loss in that profiling pass = launches of the finalize kernel
+        for k, cs in acc.items():
+            if "crf_finalize_kernel" in k and what in cs:
+                return max(1, len(cs[what]))
+        return 1
     for k in sorted(set(fe) | set(wr)):
         if "crf" not in k:
             continue
@@ -52,9 +57,12 @@ def main():
         if "FETCH_SIZE" in fe.get(k, {}):
             v = fe[k]["FETCH_SIZE"]
             traffic[k]["FETCH_SIZE_KB_avg_per_launch"] = round(sum(v) / len(v), 1)
+            traffic[k]["FETCH_SIZE_KB_per_call"] = round(sum(v) / nsteps(fe, "FETCH_SIZE"), 1)
+            traffic[k]["launches_per_call"] = round(len(v) / nsteps(fe, "FETCH_SIZE"), 2)
         if "WRITE_SIZE" in wr.get(k, {}):
             v = wr[k]["WRITE_SIZE"]
             traffic[k]["WRITE_SIZE_KB_avg_per_launch"] = round(sum(v) / len(v), 1)
+            traffic[k]["WRITE_SIZE_KB_per_call"] = round(sum(v) / nsteps(wr, "WRITE_SIZE"), 1)
     for k in sorted(s):
         if "crf" in k:
             sq[k] = {c: int(sum(v) / len(v)) for c, v in sorted(s[k].items())}
@@ -67,14 +75,14 @@ def main():
     }
     json.dump(doc, open(os.path.join(PROF, f"round1_{tag}_pmc.json"), "w"), indent=1)
     tr = {}
-    for k, v in traffic.items():
-        if "crf_res_chain_kernel<0>" in k:
-            tr["den_fwd_chain"] = int((v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024)
-        if "crf_res_chain_kernel<1>" in k:
-            tr["den_bwd_chain"] = int((v.get("FETCH_SIZE_KB_avg_per_launch", 0) + v.get("WRITE_SIZE_KB_avg_per_launch", 0)) * 1024)
+    for k, v in traffic.items():   # HBM bytes of one whole recursion = all its segment launches of one call
+        if "crf_res_chain_kernel<0>" in k or "crf_fac_chain_kernel<0>" in k:
+            tr["den_fwd_chain"] = int((v.get("FETCH_SIZE_KB_per_call", 0) + v.get("WRITE_SIZE_KB_per_call", 0)) * 1024)
+        if "crf_res_chain_kernel<1>" in k or "crf_fac_chain_kernel<1>" in k:
+            tr["den_bwd_chain"] = int((v.get("FETCH_SIZE_KB_per_call", 0) + v.get("WRITE_SIZE_KB_per_call", 0)) * 1024)
     if tr:
-        tr["source"] = (f"profiles/round1_{tag}_pmc.json: (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; the chain kernels' "
-                        "reads are small and not 16-byte streams, so FETCH_SIZE is not doubled")
+        tr["source"] = (f"profiles/round1_{tag}_pmc.json: (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per call of the loss, summed over the "
+                        "recursion's segment launches; the chain kernels' reads are small and not 16-byte streams, so FETCH_SIZE is not doubled")
         json.dump(tr, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(tr, indent=1))
     for k, v in traffic.items():
