@@ -1265,6 +1265,9 @@ struct FacParams {
     int *Eout;                  // EQ (fwd) or EB (bwd)
     int *started;               // workgroups of the den kernels that have started (gate for the numerator chains)
     int i0, i1;                 // iterations of this launch (segment)
+    int nb;                     // stage bounds (iterations), bound[0] = 0 < ... < bound[nb-1] >= T; nb <= 1: no stage flags
+    int bound[16];
+    int *stage_cnt;             // [16] fine-grained counters: += 1 per utterance when the rows of all iterations < bound[k] are in memory
     float *state;               // [B][rup64(G) + 64] parked state vector and exponent between segments
     const int4 *frow_meta;
     const float *x_start, *x_end;
@@ -1278,7 +1281,9 @@ struct FacParams {
     int *cb_F;
 };
 
-template <int DIR>
+// FLAG: publish stage flags and store rows write-through (one instantiation per use: the frame loop has no
+// run-time switch for it)
+template <int DIR, bool FLAG>
 __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FacDirDev &L = p.L;
@@ -1365,8 +1370,24 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // arcs and tables have landed (see crf_res_chain_kernel)
 
+    // Stage flags (p.nb > 1): when the recursion reaches iteration bound[k], the rows of all earlier iterations
+    // are made visible device-wide (they are stored write-through; every wave drains its stores, then a barrier)
+    // and a counter in fine-grained memory is bumped.  The host has queued the grad launch of stage k behind a
+    // STREAM-level wait on that counter (hipStreamWaitValue32: the command processor polls, no wave spins, the
+    // launch is not even dispatched before) -- so the grad pass follows the recursions without a relaunch.
+    constexpr bool flagged = FLAG;
+    int next_stage = 1;
+    int next_bound = (FLAG && p.nb > 1) ? p.bound[1] : 0x7fffffff;   // iteration at which the next stage is published
+    auto publish_stage = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.stage_cnt + next_stage, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ++next_stage;
+        next_bound = next_stage < p.nb ? p.bound[next_stage] : 0x7fffffff;
+    };
     auto frame = [&](const int par, int i) __attribute__((always_inline)) {
         const int t = DIR == 0 ? i : lx - 1 - i;
+        if (FLAG && i == next_bound) publish_stage();
         const bool tm_on = b == 3 && i >= 100 && i < 228 && wave == 0;
         const int tm_i = (DIR * 4) * 1024 + (i - 100) * 8;
         CRF_TM(tm_on, tm_i + 0);
@@ -1418,8 +1439,13 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
                             const float rv = (acc.x + acc.y) * sc;                      // q_t[pair of the main state]
                             const float uold = *(const float *)(xb + (m.x & 0xffff));   // U_t of the row's pair
                             const float qt = __int_as_float(m.z) * uold * sc;           // q_t[pair of the tail state]
-                            *(float *)((char *)Orow + r4) = rv;
-                            *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
+                            if (flagged) {   // write-through: the grad pass reads the rows from other XCDs while this kernel runs
+                                __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store((unsigned *)((char *)Orow + r4 + 4u * (unsigned)R), __float_as_uint(qt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                *(float *)((char *)Orow + r4) = rv;
+                                *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
+                            }
                             const float Lp = EPu[(unsigned)m.x >> 16] * rv;              // a_{t+1}[main]
                             const float Ap = EPu[m.w] * qt;                             // a_{t+1}[tail]
                             const float Up = Ap + Lp;
@@ -1433,7 +1459,12 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
                             f32x2 bv;                                                    // b_t of the two states
                             bv.x = fmaf(__int_as_float(m.y), z0, craw) * sc;
                             bv.y = fmaf(__int_as_float(m.z), z1, craw) * sc;
-                            *(f32x2 *)((char *)Orow + 2u * r4) = bv;
+                            if (flagged)
+                                __hip_atomic_store((unsigned long long *)((char *)Orow + 2u * r4),
+                                                   (unsigned long long)__float_as_uint(bv.x) | ((unsigned long long)__float_as_uint(bv.y) << 32),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else
+                                *(f32x2 *)((char *)Orow + 2u * r4) = bv;
                             f32x2 zv;                                                    // z_{t-1} of the pairs entering them
                             zv.x = EPu[m.w & 0xffff] * bv.x;
                             zv.y = EPu[(unsigned)m.w >> 16] * bv.y;
@@ -1473,6 +1504,8 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         if (tid == 0) state[Gp] = __int_as_float(E);
         return;
     }
+    if (flagged)
+        while (next_stage < p.nb) publish_stage();           // the rest (at least the last stage: bound = T)
     if (DIR == 0) {
         const float *Xf = X + (lx & 1) * Gp;
         float part = 0.f;
@@ -2146,12 +2179,13 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     return (size_t)2 * rup64(L.G) * 4 + (size_t)L.R * 16 +
            ((size_t)2 * rup64(V + 1) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
 }
-template <int DIR>
-static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *state) {
+template <int DIR, bool FLAG = false>
+static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *state,
+                      int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
     static std::atomic<size_t> lds_set{0};
     hipError_t e;
     if (lds > lds_set.load()) {
-        if ((e = hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
+        if ((e = hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
             set_error(std::string("hipFuncSetAttribute(fac chain): ") + hipGetErrorString(e));
             return CRF_ERR_HIP;
         }
@@ -2164,11 +2198,13 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
     p.started = started; p.i0 = i0; p.i1 = i1; p.state = state;
+    p.nb = nb; p.stage_cnt = stage_cnt;
+    for (int k = 0; k < 16; ++k) p.bound[k] = (bound && k < nb) ? bound[k] : 0;
     p.frow_meta = F.frow_meta; p.x_start = F.x_start; p.x_end = F.x_end;
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
-    hipLaunchKernelGGL(crf_fac_chain_kernel<DIR>, dim3((unsigned)lp.B), dim3(kResThreads), lds, st, p);
+    hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG>), dim3((unsigned)lp.B), dim3(kResThreads), lds, st, p);
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }
@@ -2323,7 +2359,13 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // but with many launches queued ahead the den kernels were observed to stop for seconds while the waiting
     // workgroups kept their queue busy -- one kernel must never wait for another.)
     static const bool no_overlap = getenv("CRF_NO_OVERLAP") && atoi(getenv("CRF_NO_OVERLAP")) != 0;   // diagnostics
-    static const int stages_env = getenv("CRF_STAGES") ? atoi(getenv("CRF_STAGES")) : 4;
+    // how stage k of the grad pass is released: a stream-level wait on a counter the running recursions bump
+    // (default), or -- CRF_SEGMENTS=1, and automatically if hipStreamWaitValue32 is refused -- by cutting the
+    // recursions into one launch per stage with an event after each (~40 us per relaunch, state parked in HBM)
+    static std::atomic<bool> use_segments{getenv("CRF_SEGMENTS") && atoi(getenv("CRF_SEGMENTS")) != 0};
+    const bool segmode = use_segments.load();
+    static const int stages_env = getenv("CRF_STAGES") ? atoi(getenv("CRF_STAGES")) : 0;
+    const int pieces = stages_env > 0 ? stages_env : (segmode ? 4 : 12);   // measured: 4 / 8 / 12 pieces -> call 4.06 / 3.98 / 3.93 ms (flags)
     const bool staged = fac && ctc && fast_den && fast_ctc && !serial && !no_overlap && cx && cx->flags && 2 * B <= ncu_dev / 2;
     // streams of the staged schedule: den forward / backward segments, and two for everything else.  (Tried:
     // CU-masked streams, hipExtStreamCreateWithCUMask, to keep the den recursions and the rest on disjoint halves
@@ -2338,7 +2380,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     bound[1] = (int)T;
     if (staged && T >= 256) {
         const int half = (int)((T / 2 + kGDFrames - 1) / kGDFrames * kGDFrames);
-        const int nshort = std::max(1, std::min(std::min(stages_env, kMaxStages - 1), (int)((T - half) / 32)));
+        const int nshort = std::max(1, std::min(std::min(pieces, kMaxStages - 2), (int)((T - half) / 32)));
         int piece = (int)((T - half + nshort - 1) / nshort);
         piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
         nstage = 1;
@@ -2355,11 +2397,16 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         (void)hipStreamWaitEvent(sA1, cx->fork, 0);
         prof_mark(1, false, sA0);
         prof_mark(2, false, sA1);
-        for (int k = 0; k < nstage; ++k) {
-            if ((rc = launch_fac<0>(p, fac_lds_bytes(h, (int)V, 0), sA0, started, bound[k], bound[k + 1], fstate))) return rc;
-            if ((rc = launch_fac<1>(p, fac_lds_bytes(h, (int)V, 1), sA1, started, bound[k], bound[k + 1], bstate))) return rc;
-            if ((e = hipEventRecord(cx->evf[k], sA0)) != hipSuccess || (e = hipEventRecord(cx->evb[k], sA1)) != hipSuccess) {
-                set_error(std::string("hipEventRecord(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+        if (!segmode) {
+            if ((rc = launch_fac<0, true>(p, fac_lds_bytes(h, (int)V, 0), sA0, started, 0, (int)T, fstate, nstage + 1, bound, cx->flags + 16))) return rc;
+            if ((rc = launch_fac<1, true>(p, fac_lds_bytes(h, (int)V, 1), sA1, started, 0, (int)T, bstate, nstage + 1, bound, cx->flags + 32))) return rc;
+        } else {
+            for (int k = 0; k < nstage; ++k) {
+                if ((rc = launch_fac<0>(p, fac_lds_bytes(h, (int)V, 0), sA0, started, bound[k], bound[k + 1], fstate))) return rc;
+                if ((rc = launch_fac<1>(p, fac_lds_bytes(h, (int)V, 1), sA1, started, bound[k], bound[k + 1], bstate))) return rc;
+                if ((e = hipEventRecord(cx->evf[k], sA0)) != hipSuccess || (e = hipEventRecord(cx->evb[k], sA1)) != hipSuccess) {
+                    set_error(std::string("hipEventRecord(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+                }
             }
         }
         prof_mark(1, true, sA0);
@@ -2463,12 +2510,27 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if ((rc = launch_grad_ctc(0, s1))) return rc;          // writes -c_ctc * gamma_ctc; the den half then adds
         p.grad_den_acc = 1;
         for (int k = 0; k < nstage; ++k) {
-            if ((e = hipStreamWaitEvent(s1, cx->evf[k], 0)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->evb[k], 0)) != hipSuccess) {
+            if (!segmode) {
+                if ((e = hipStreamWaitValue32(s1, cx->flags + 16 + k + 1, (uint32_t)B, hipStreamWaitValueGte, 0xffffffffu)) != hipSuccess ||
+                    (e = hipStreamWaitValue32(s1, cx->flags + 32 + k + 1, (uint32_t)B, hipStreamWaitValueGte, 0xffffffffu)) != hipSuccess) {
+                    // not available here: from the next call on, segments.  This call: wait for the recursions to END
+                    (void)hipGetLastError();
+                    use_segments = true;
+                    if ((e = hipEventRecord(cx->evf[0], sA0)) != hipSuccess || (e = hipEventRecord(cx->evb[0], sA1)) != hipSuccess ||
+                        (e = hipStreamWaitEvent(s1, cx->evf[0], 0)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->evb[0], 0)) != hipSuccess) {
+                        set_error(std::string("hipStreamWaitEvent: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+                    }
+                }
+            } else if ((e = hipStreamWaitEvent(s1, cx->evf[k], 0)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->evb[k], 0)) != hipSuccess) {
                 set_error(std::string("hipStreamWaitEvent(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
             }
             if ((rc = launch_grad_den(s1, k + 1))) return rc;
         }
         prof_mark(5, true, s1);
+        // the backward recursion (side stream 0) ends after its last stage flag: logZ from the backward side
+        if ((e = hipEventRecord(cx->jm[2], sA1)) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->jm[2], 0)) != hipSuccess) {
+            set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+        }
         // join: the caller's stream continues after the last grad launch (which is behind every den segment)
         if ((e = hipEventRecord(cx->jm[1], s1)) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->jm[1], 0)) != hipSuccess) {
             set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
