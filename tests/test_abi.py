@@ -82,3 +82,40 @@ def test_graph_compiler_host_only(tmp_path, golden_dir):
     core._lib.crf_graph_destroy(ctypes.c_void_p(h))
     ws = core._lib.crf_workspace_bytes(ctypes.c_void_p(0), 4, 100, 72, 10)
     assert ws > 4 * 100 * 72 * 4
+
+
+def test_register_resident_layouts_host_only(tmp_path, golden_dir):
+    """The two register-resident layouts, built on the host (device = -1): the generic one fits the metric graph
+    into K = 2 CUs per recursion; the factored one recognises the T o LM structure without being told (every LM
+    history appears as (g, blank) and (g, token): H matched pairs, one fused backward row per pair), halves the
+    arc slots and fits ONE CU per recursion; graphs without that structure keep the generic layout."""
+    import ctc_crf
+    core = ctc_crf._C
+    p = os.path.join(str(tmp_path), "m.fst")
+    H, d = 2048, 24
+    synth_den_lm(72, H, d, seed=0, path=p)
+    h = core.compile_graph_host_only(p)
+    st = core.graph_stats(h)
+    core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+    cap = 512 * 30 * 4                                   # arc slots of one workgroup: 512 threads x 30 chunks x 4
+    assert st["res_K"] == 2 and st["A"] <= st["res_fwd_slots"] <= 2 * cap and st["A"] <= st["res_bwd_slots"] <= 2 * cap
+    assert st["fac"] == 1
+    assert H - 2 <= st["fac_matched_pairs"] <= H and H - 2 <= st["fac_fused_rows"] <= H
+    assert st["fac_fwd_slots"] <= cap and st["fac_bwd_slots"] <= cap            # K = 1
+    assert st["fac_fwd_slots"] < 0.6 * st["res_fwd_slots"] and st["fac_bwd_slots"] < 0.6 * st["res_bwd_slots"]
+    assert st["fac_Gf"] * 4 <= 65536 and st["fac_Gb"] * 4 <= 65536              # 16-bit LDS byte offsets
+    # the reference's own 9-state test graph and random graphs: no (tail, main) structure -> generic layout only
+    for name in ["den_lm_fixture.fst"] + [f"rand{i}.fst" for i in range(6)]:
+        h = core.compile_graph_host_only(os.path.join(golden_dir, name))
+        st = core.graph_stats(h)
+        core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+        assert st["res_K"] >= 1
+        assert st["fac"] in (0, 1)
+    # CRF_NO_FACTORED keeps the generic layout (read at graph creation)
+    os.environ["CRF_NO_FACTORED"] = "1"
+    try:
+        h = core.compile_graph_host_only(p)
+        assert core.graph_stats(h)["fac"] == 0
+        core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+    finally:
+        os.environ.pop("CRF_NO_FACTORED")
