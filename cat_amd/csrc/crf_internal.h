@@ -46,6 +46,9 @@ constexpr int kResW = 4;
 constexpr int kResNCH = 30;
 constexpr int kResWords = kResNCH * 6;
 constexpr int kResMaxK = 4;
+// second geometry of the factored kernels: 12 waves = 3 per SIMD, 21 chunks per thread (<= 168 VGPRs)
+constexpr int kFac3Threads = 768;
+constexpr int kFac3NCH = 21;
 
 struct ResDirDev {
     const unsigned *arcs;    // [K][kResWords][kResThreads]
@@ -89,8 +92,8 @@ struct ResDev {
 // Graphs without that structure (or with states entered by several labels) keep the generic layout.
 // ---------------------------------------------------------------------------------------------
 struct FacDirDev {
-    const unsigned *arcs;    // [kResWords][kResThreads]
-    const uint4 *wave_info;  // [kResWaves] {slice-end mask, chunks used, first row id, unused}
+    const unsigned *arcs;    // [words][threads]
+    const uint4 *wave_info;  // [waves] {slice-end mask, chunks used, first row id, unused}
     int R;                   // rows incl. padding (multiple of 64)
     int G;                   // gather-vector entries (floats) incl. the sink pair at [G-2, G-1]
 };
@@ -101,6 +104,7 @@ struct FacDev {
     const int4 *frow_meta;     // [Rf] {U byte offset | main label << 16, L offset | A offset << 16, tail weight bits, tail label}
                                //      plain rows: U = A = sink, tail weight 0
     int NT;                    // unused (0)
+    int threads;               // workgroup size the tables were built for: 768 (21 chunks per thread) or 512 (30)
     const float *x_start, *x_end;   // [Gf]
     // backward: rows = one or two states with common out-arcs; z entry of output o of row r = 2r + o.
     const int4 *brow_meta;     // [Rb] {extra-arc z byte offset 0 | offset 1 << 16, weight 0 bits, weight 1 bits, label 0 | label 1 << 16}

@@ -836,6 +836,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
 constexpr int kEpRegsR = 2;   // emission-row prefetch registers (V <= 2*512 for the resident kernels)
 constexpr int kPoll = 4;      // granules polled concurrently per thread
 
+template <int NW = kResWaves>
 __device__ __forceinline__ float res_block_sum(float v, float *red, int tid) {
     v = wave_sum(v);
     sync_lds();
@@ -843,26 +844,27 @@ __device__ __forceinline__ float res_block_sum(float v, float *red, int tid) {
     sync_lds();
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kResWaves; ++i) s += red[i];
+    for (int i = 0; i < NW; ++i) s += red[i];
     return s;
 }
-template <typename P>
+template <int NW = kResWaves, typename P>
 __device__ __forceinline__ double res_mx_total(const P &p, int b, int lx, double *red, int tid) {
     double part = 0.0;
-    for (int t = tid; t < lx; t += kResThreads) part += (double)p.mx[(int64_t)b * p.T + t];
+    for (int t = tid; t < lx; t += NW * kWave) part += (double)p.mx[(int64_t)b * p.T + t];
     part = wave_sum_d(part);
     sync_lds();
     if ((tid & 63) == 0) red[tid >> 6] = part;
     sync_lds();
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < kResWaves; ++i) s += red[i];
+    for (int i = 0; i < NW; ++i) s += red[i];
     return s;
 }
+template <int NW = kResWaves>
 __device__ __forceinline__ float res_frame_max(const float *wm) {
     float m = wm[0];
 #pragma unroll
-    for (int i = 1; i < kResWaves; ++i) m = fmaxf(m, wm[i]);
+    for (int i = 1; i < NW; ++i) m = fmaxf(m, wm[i]);
     return m;
 }
 
@@ -930,8 +932,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // The 4*kResBatch gathers of a batch; the products are chained FMAs into the row accumulator (measured:
 // the frame loop is bound by instruction issue as much as by LDS -- one packed instruction less per
 // chunk than "multiply, FMA, add" was worth 3%).
-#define CRF_RES_GATHER(g01, g23, A, xb, c0)                                                               \
-    _Pragma("unroll") for (int ci = 0; ci < kResBatch; ++ci) {                                            \
+#define CRF_RES_GATHER(g01, g23, A, xb, c0) CRF_RES_GATHER_N(g01, g23, A, xb, c0, kResBatch)
+#define CRF_RES_GATHER_N(g01, g23, A, xb, c0, NB_)                                                        \
+    _Pragma("unroll") for (int ci = 0; ci < (NB_); ++ci) {                                            \
         const int c = (c0) + ci;                                                                          \
         const unsigned i01 = A[6 * c], i23 = A[6 * c + 1];                                                \
         g01[ci].x = *(const float *)(xb + (i01 & 0xffffu)); g01[ci].y = *(const float *)(xb + (i01 >> 16)); \
@@ -1283,8 +1286,12 @@ struct FacParams {
 
 // FLAG: publish stage flags and store rows write-through (one instantiation per use: the frame loop has no
 // run-time switch for it)
-template <int DIR, bool FLAG>
-__global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p) {
+// NTH threads with NCH chunks of arcs each, gathered in batches of NB chunks: 512 x 30 (2 waves per SIMD) or
+// 768 x 21 (3 waves per SIMD at <= 168 VGPRs -- the frame is latency-bound, a third wave fills the gaps).
+template <int DIR, bool FLAG, int NTH, int NCH, int NB>
+__global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
+    constexpr int NW = NTH / kWave;
+    static_assert(NCH % NB == 0, "chunks per thread must be a multiple of the batch");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FacDirDev &L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1297,15 +1304,15 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     float *X = lds;                                          // [2][Gp]
     char *RMc = (char *)(X + 2 * Gp);                        // int4[R]
     float *EP = (float *)(RMc + (size_t)R * 16);             // [2][Vp]
-    float *wm = EP + 2 * Vp;                                 // [2][kResWaves]
-    double *red = (double *)(wm + 2 * kResWaves);            // [kResWaves]
+    float *wm = EP + 2 * Vp;                                 // [2][NW]
+    double *red = (double *)(wm + 2 * NW);            // [NW]
     if (tid == 0 && p.started && p.i0 == 0) atomicAdd(p.started, 1);   // this workgroup holds its CU: see crf_gate_kernel
 
-    unsigned A[kResWords];
+    unsigned A[(NCH * 6)];
     {
         const unsigned *src = L.arcs + tid;
 #pragma unroll
-        for (int i = 0; i < kResWords; ++i) A[i] = src[(size_t)i * kResThreads];
+        for (int i = 0; i < (NCH * 6); ++i) A[i] = src[(size_t)i * NTH];
     }
     const uint4 wi = L.wave_info[wave];
     const unsigned ends = __builtin_amdgcn_readfirstlane(wi.x);
@@ -1313,7 +1320,7 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
     {
         int4 *RM = (int4 *)RMc;
-        for (int r = tid; r < R; r += kResThreads) {
+        for (int r = tid; r < R; r += NTH) {
             int4 m = DIR == 0 ? p.frow_meta[r] : p.brow_meta[r];
             if (DIR == 1) {
                 const int l0 = (short)(m.w & 0xffff), l1 = m.w >> 16;       // -1 = no label: emission 0 at EP[V]
@@ -1332,10 +1339,10 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     const int par0 = i0 & 1;
     int E = kScaleExp;
     float zpart = 0.f;
-    for (int s = tid; s < 2 * Gp; s += kResThreads) X[s] = 0.f;
+    for (int s = tid; s < 2 * Gp; s += NTH) X[s] = 0.f;
     if (tid < 2) EP[tid * Vp + V] = 0.f;
     if (lx > 0)
-        for (int v = tid; v < V; v += kResThreads) {
+        for (int v = tid; v < V; v += NTH) {
             if (DIR == 0) EP[par0 * Vp + v] = p.ep[(bt0 + i0) * V + v];                 // e'_t of the first frame
             else {
                 const int t = lx - 1 - i0;                                             // first frame of this segment
@@ -1348,24 +1355,24 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         float m0 = 0.f;
         if (i0 > 0) {                                        // resume
             float *Xc = X + par0 * Gp;
-            for (int s = tid; s < G; s += kResThreads) { const float v = state[s]; Xc[s] = v; m0 = fmaxf(m0, v); }
+            for (int s = tid; s < G; s += NTH) { const float v = state[s]; Xc[s] = v; m0 = fmaxf(m0, v); }
             E = __float_as_int(state[Gp]);
         } else if (DIR == 0) {
-            for (int s = tid; s < G; s += kResThreads) { const float v = p.x_start[s] * pow2f(kScaleExp); X[s] = v; m0 = fmaxf(m0, v); }
+            for (int s = tid; s < G; s += NTH) { const float v = p.x_start[s] * pow2f(kScaleExp); X[s] = v; m0 = fmaxf(m0, v); }
         } else if (lx > 0) {
-            for (int z = tid; z < G; z += kResThreads) {
+            for (int z = tid; z < G; z += NTH) {
                 const int l = p.z_lab[z];
                 const float v = EP[l < 0 ? V : l] * (p.z_end[z] * pow2f(kScaleExp));
                 X[z] = v; m0 = fmaxf(m0, v);
             }
             float *BProw = p.Out + (bt0 + lx - 1) * p.Rout;
-            for (int r = tid; r < 2 * R; r += kResThreads) BProw[r] = p.brow_end[r] * pow2f(kScaleExp);
+            for (int r = tid; r < 2 * R; r += NTH) BProw[r] = p.brow_end[r] * pow2f(kScaleExp);
             if (tid == 0) p.Eout[bt0 + lx - 1] = E;
         } else {
-            for (int r = tid; r < 2 * R; r += kResThreads) zpart += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
+            for (int r = tid; r < 2 * R; r += NTH) zpart += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
         }
         m0 = wave_max(m0);
-        if (lane == 0) wm[par0 * kResWaves + wave] = m0;
+        if (lane == 0) wm[par0 * NW + wave] = m0;
     }
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // arcs and tables have landed (see crf_res_chain_kernel)
@@ -1403,9 +1410,9 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         if (pre) {
             const float *er = p.ep + (bt0 + tpre) * V;
 #pragma unroll
-            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; epn[q] = v < V ? er[v] : 0.f; }
+            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; epn[q] = v < V ? er[v] : 0.f; }
         }
-        const int ksc = rescale_exp(res_frame_max(wm + par * kResWaves));
+        const int ksc = rescale_exp(res_frame_max<NW>(wm + par * NW));
         const float sc = pow2f(ksc);
         float *Orow;
         if (DIR == 0) {
@@ -1426,12 +1433,12 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         CRF_TM(tm_on, tm_i + 1);
         unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
 #pragma unroll
-        for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
+        for (int c0 = 0; c0 < NCH; c0 += NB) {
             if (c0 < nch_f) {
-                f32x2 g01[kResBatch], g23[kResBatch];
-                CRF_RES_GATHER(g01, g23, A, xb, c0);
+                f32x2 g01[NB], g23[NB];
+                CRF_RES_GATHER_N(g01, g23, A, xb, c0, NB);
 #pragma unroll
-                for (int ci = 0; ci < kResBatch; ++ci) {
+                for (int ci = 0; ci < NB; ++ci) {
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
                     if (ends_f >> (c0 + ci) & 1u) {
                         const int4 m = *(const int4 *)(RMc + 4u * r4);
@@ -1486,11 +1493,11 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
         }
 #endif
         mymax = wave_max(mymax);
-        if (lane == 0) wm[(1 - par) * kResWaves + wave] = mymax;
+        if (lane == 0) wm[(1 - par) * NW + wave] = mymax;
         if (pre) {
             float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;
 #pragma unroll
-            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * kResThreads; if (v < V) EPw[v] = epn[q]; }
+            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; if (v < V) EPw[v] = epn[q]; }
         }
         CRF_TM(tm_on, tm_i + 3);
         sync_lds();
@@ -1500,7 +1507,7 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     for (int i = i0; i < i1; ++i) frame(i & 1, i);
     if (i1 < lx) {                                           // not the last segment of this utterance: park the state
         const float *Xc = X + (i1 & 1) * Gp;
-        for (int s = tid; s < G; s += kResThreads) state[s] = Xc[s];
+        for (int s = tid; s < G; s += NTH) state[s] = Xc[s];
         if (tid == 0) state[Gp] = __int_as_float(E);
         return;
     }
@@ -1509,18 +1516,18 @@ __global__ __launch_bounds__(kResThreads) void crf_fac_chain_kernel(FacParams p)
     if (DIR == 0) {
         const float *Xf = X + (lx & 1) * Gp;
         float part = 0.f;
-        for (int s = tid; s < G; s += kResThreads) part += Xf[s] * p.x_end[s];
-        const float zs = res_block_sum(part, (float *)red, tid);
-        const double mxs = res_mx_total(p, b, lx, red, tid);
+        for (int s = tid; s < G; s += NTH) part += Xf[s] * p.x_end[s];
+        const float zs = res_block_sum<NW>(part, (float *)red, tid);
+        const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
         if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); }
     } else {
         if (lx > 0) {
             __syncthreads();  // drains vmcnt: this workgroup's own stores to the spare row are visible to it
             const float *r0 = p.Row0 + (int64_t)b * p.Rout;
-            for (int r = tid; r < 2 * R; r += kResThreads) zpart += p.brow_start[r] * r0[r];
+            for (int r = tid; r < 2 * R; r += NTH) zpart += p.brow_start[r] * r0[r];
         }
-        const float zb = res_block_sum(zpart, (float *)red, tid);
-        const double mxs = res_mx_total(p, b, lx, red, tid);
+        const float zb = res_block_sum<NW>(zpart, (float *)red, tid);
+        const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
         if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E; p.cb_mxs[b] = mxs; }
     }
 }
@@ -2176,22 +2183,28 @@ static int launch_res(const LossParams &lp, size_t lds, int b0, int nb, hipStrea
 static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     const FacDev &F = h->dev.fac;
     const FacDirDev &L = dir == 0 ? F.f : F.b;
+    const int nw = F.threads / kWave;
     return (size_t)2 * rup64(L.G) * 4 + (size_t)L.R * 16 +
-           ((size_t)2 * rup64(V + 1) + 2 * kResWaves + 2 * kResWaves + 16) * sizeof(float);
+           ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }
+constexpr int kFac3Batch = 3;
 template <int DIR, bool FLAG = false>
 static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *state,
                       int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
-    static std::atomic<size_t> lds_set{0};
+    static std::atomic<size_t> lds_set{0}, lds_set3{0};
     hipError_t e;
-    if (lds > lds_set.load()) {
-        if ((e = hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
+    const FacDev &F = lp.g.fac;
+    const bool g3 = F.threads == kFac3Threads;
+    std::atomic<size_t> &ls = g3 ? lds_set3 : lds_set;
+    if (lds > ls.load()) {
+        e = g3 ? hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+               : hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kResThreads, kResNCH, kResBatch>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
             set_error(std::string("hipFuncSetAttribute(fac chain): ") + hipGetErrorString(e));
             return CRF_ERR_HIP;
         }
-        lds_set = lds;
+        ls = lds;
     }
-    const FacDev &F = lp.g.fac;
     FacParams p{};
     p.L = DIR == 0 ? F.f : F.b;
     p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
@@ -2204,7 +2217,8 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
-    hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG>), dim3((unsigned)lp.B), dim3(kResThreads), lds, st, p);
+    if (g3) hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch>), dim3((unsigned)lp.B), dim3(kFac3Threads), lds, st, p);
+    else hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kResThreads, kResNCH, kResBatch>), dim3((unsigned)lp.B), dim3(kResThreads), lds, st, p);
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }

@@ -21,6 +21,11 @@ namespace {
 
 typedef std::vector<std::vector<std::pair<int, float>>> Rows;
 
+// geometry of one resident workgroup: threads, waves, chunks per thread (registers), words per thread
+struct Geom { int threads, waves, nch, words; };
+constexpr Geom kGeomRes{kResThreads, kResWaves, kResNCH, kResWords};
+constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3NCH, kFac3NCH * 6};
+
 struct DirOut {
     std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
     std::vector<uint4> wave_info; // [K][kResWaves]
@@ -35,9 +40,9 @@ inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / 
 
 // Step 1: decide where every row lives (CU, wave, slice, lane) from the row LENGTHS only.
 struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; };
-bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices) {
-    o->arcs.assign((size_t)K * kResWords * kResThreads, 0u);
-    o->wave_info.assign((size_t)K * kResWaves, uint4{0u, 0u, 0u, 0u});
+bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm = kGeomRes) {
+    o->arcs.assign((size_t)K * gm.words * gm.threads, 0u);
+    o->wave_info.assign((size_t)K * gm.waves, uint4{0u, 0u, 0u, 0u});
     o->rid_of_row.assign(rows.size(), -1);
     o->row_of.clear();
     o->cu_row_off.assign((size_t)K + 1, 0);
@@ -58,25 +63,25 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         // registers are ~97% full for the benchmark graph, so balance-first heuristics do not even fit).
         // Step 2: a deterministic annealing over single moves and pair swaps lowers the maximum wave cost.
         const int kEpiCost = getenv("CRF_RES_EPI") ? atoi(getenv("CRF_RES_EPI")) : 4;  // slice end, in chunks
-        std::vector<int> wave_of(nsl, -1), load(kResWaves, 0), cnt(kResWaves, 0);
+        std::vector<int> wave_of(nsl, -1), load(gm.waves, 0), cnt(gm.waves, 0);
         bool packed = true;
         for (int j = 0; j < nsl && packed; ++j) {
             int best = -1;
-            for (int w = 0; w < kResWaves; ++w) {
-                if (load[w] + len[j] > kResNCH) continue;
+            for (int w = 0; w < gm.waves; ++w) {
+                if (load[w] + len[j] > gm.nch) continue;
                 if (best < 0 || load[w] > load[best]) best = w;
             }
             if (best < 0) { packed = false; break; }
             wave_of[j] = best; load[best] += len[j]; cnt[best]++;
         }
-        std::vector<std::vector<int>> lists(kResWaves);
-        std::vector<int> cost(kResWaves, 0);
+        std::vector<std::vector<int>> lists(gm.waves);
+        std::vector<int> cost(gm.waves, 0);
         if (packed) {
             auto wcost = [&](int w) { return load[w] + kEpiCost * cnt[w]; };
             // objective: (max cost, sum of squares) lexicographically, folded into one number
             auto objective = [&]() {
                 int64_t mx = 0, sq = 0;
-                for (int w = 0; w < kResWaves; ++w) { const int64_t c = wcost(w); mx = std::max(mx, c); sq += c * c; }
+                for (int w = 0; w < gm.waves; ++w) { const int64_t c = wcost(w); mx = std::max(mx, c); sq += c * c; }
                 return mx * 1000000 + sq;
             };
             uint64_t rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)nsl << 32) ^ (uint64_t)k;
@@ -88,8 +93,8 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                 const double temp = 4.0e6 * (1.0 - (double)it / iters);  // in objective units: a few chunks of max cost at the start
                 const int ja = (int)(rnd() % (uint64_t)nsl), a_ = wave_of[ja];
                 if (rnd() & 1) {  // move
-                    const int b_ = (int)(rnd() % kResWaves);
-                    if (b_ == a_ || load[b_] + len[ja] > kResNCH) continue;
+                    const int b_ = (int)(rnd() % gm.waves);
+                    if (b_ == a_ || load[b_] + len[ja] > gm.nch) continue;
                     load[a_] -= len[ja]; cnt[a_]--; load[b_] += len[ja]; cnt[b_]++; wave_of[ja] = b_;
                     const int64_t nw = objective();
                     if (nw <= cur || (double)(rnd() % 1000000) / 1e6 < std::exp(-(double)(nw - cur) / std::max(temp, 1.0))) cur = nw;
@@ -98,7 +103,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                     const int jb = (int)(rnd() % (uint64_t)nsl), b_ = wave_of[jb];
                     if (b_ == a_ || len[ja] == len[jb]) continue;
                     const int d = len[ja] - len[jb];
-                    if (load[b_] + d > kResNCH || load[a_] - d > kResNCH) continue;
+                    if (load[b_] + d > gm.nch || load[a_] - d > gm.nch) continue;
                     load[a_] -= d; load[b_] += d; wave_of[ja] = b_; wave_of[jb] = a_;
                     const int64_t nw = objective();
                     if (nw <= cur || (double)(rnd() % 1000000) / 1e6 < std::exp(-(double)(nw - cur) / std::max(temp, 1.0))) cur = nw;
@@ -110,19 +115,19 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
             std::fill(load.begin(), load.end(), 0);
             std::fill(cnt.begin(), cnt.end(), 0);
             for (int j = 0; j < nsl; ++j) { lists[wave_of[j]].push_back(j); load[wave_of[j]] += len[j]; cnt[wave_of[j]]++; }
-            for (int w = 0; w < kResWaves; ++w) cost[w] = wcost(w);
+            for (int w = 0; w < gm.waves; ++w) cost[w] = wcost(w);
             if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"))) {
                 fprintf(stderr, "[res_layout] lens:");
                 for (int j = 0; j < nsl; ++j) fprintf(stderr, " %d", len[j]);
                 fprintf(stderr, "\n[res_layout] K=%d cu=%d:", K, k);
-                for (int w = 0; w < kResWaves; ++w) fprintf(stderr, " w%d(%dch,%zusl)", w, load[w], lists[w].size());
+                for (int w = 0; w < gm.waves; ++w) fprintf(stderr, " w%d(%dch,%zusl)", w, load[w], lists[w].size());
                 fprintf(stderr, "\n");
             }
         }
         if (!packed) return false;  // does not fit with this K
         o->est_cost = std::max(o->est_cost, *std::max_element(cost.begin(), cost.end()));
         int rid = o->cu_row_off[k];
-        for (int w = 0; w < kResWaves; ++w) {
+        for (int w = 0; w < gm.waves; ++w) {
             unsigned ends = 0;
             int c0 = 0;
             const int wave_row0 = rid;
@@ -140,7 +145,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                 rid += kWave;
                 c0 += len[j];
             }
-            o->wave_info[(size_t)k * kResWaves + w] = uint4{ends, (unsigned)c0, (unsigned)wave_row0, 0u};
+            o->wave_info[(size_t)k * gm.waves + w] = uint4{ends, (unsigned)c0, (unsigned)wave_row0, 0u};
         }
         o->cu_row_off[(size_t)k + 1] = rid;
     }
@@ -157,7 +162,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
 // Padding gathers (weight 0) broadcast the address of a real lane of their half.
 // `stride`: bytes per gather index (4: one float per gather; 8: an entry PAIR per gather, ds_read_b64, whose
 // bank class is again index mod 32 -- 64 banks, two per lane).
-void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, int stride = 4) {
+void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, int stride = 4, const Geom &gm = kGeomRes) {
     const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
     for (const SliceAt &sl : slices) {
         const int NI = sl.len * kResW;
@@ -282,11 +287,11 @@ void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, 
                     const int off16 = real ? place[ins][lane].first * stride : (first_real >= 0 ? place[ins][first_real].first * stride : 0);
                     const float wv = real ? place[ins][lane].second : 0.f;
                     const size_t t = (size_t)sl.w * kWave + lane;
-                    unsigned &iw = o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + (slot >> 1)) * kResThreads + t];
+                    unsigned &iw = o->arcs[((size_t)sl.k * gm.words + (size_t)c * 6 + (slot >> 1)) * gm.threads + t];
                     iw |= (unsigned)(off16 & 0xffff) << ((slot & 1) * 16);
                     unsigned wb;
                     memcpy(&wb, &wv, 4);
-                    o->arcs[((size_t)sl.k * kResWords + (size_t)c * 6 + 2 + slot) * kResThreads + t] = wb;
+                    o->arcs[((size_t)sl.k * gm.words + (size_t)c * 6 + 2 + slot) * gm.threads + t] = wb;
                 }
             }
             o->slots += kWave;
@@ -594,9 +599,9 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // =================================================================================================
 // Factored layout (crf_internal.h: FacDev).
 // =================================================================================================
-int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
-                   const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
-                   const std::vector<float> &end_lin) {
+static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
+                               const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
+                               const std::vector<float> &end_lin, bool allow3, bool *retry512) {
     FacDev &F = h->dev.fac;
     F = FacDev{};
     if ((getenv("CRF_NO_FACTORED") && atoi(getenv("CRF_NO_FACTORED"))) || (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT")))) return CRF_OK;
@@ -714,10 +719,16 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             else fsub[i].push_back({ent[s], a[u].second});
         }
     }
+    // Geometry: 768 threads x 21 chunks (3 waves per SIMD at <= 168 VGPRs) when both directions fit it, else
+    // 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces the latter.
+    const Geom *gm = allow3 ? &kGeomFac3 : &kGeomRes;
     DirOut fo;
     std::vector<SliceAt> fslices;
-    if (!place_rows(fsub, std::vector<int>(fsub.size(), 0), 1, &fo, &fslices)) return give_up("forward rows do not fit one CU");
-    pack_arcs(fsub, fslices, &fo, 4);
+    if (!place_rows(fsub, std::vector<int>(fsub.size(), 0), 1, &fo, &fslices, *gm)) {
+        if (allow3) { *retry512 = true; return CRF_OK; }
+        return give_up("forward rows do not fit one CU");
+    }
+    pack_arcs(fsub, fslices, &fo, 4, *gm);
     const int Rf = fo.cu_row_off[1];
     const int NT = 0;
     std::vector<int> fpos(P, -1);   // position of pair p in the Q row: main rows [0, Rf), their tails [Rf, 2 Rf)
@@ -788,7 +799,10 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     for (size_t i = 0; i < brow.size(); ++i) bsub[i] = brow[i].arcs;   // pair ids for now; lengths are all placement needs
     DirOut bo;
     std::vector<SliceAt> bslices;
-    if (!place_rows(bsub, std::vector<int>(bsub.size(), 0), 1, &bo, &bslices)) return give_up("backward rows do not fit one CU");
+    if (!place_rows(bsub, std::vector<int>(bsub.size(), 0), 1, &bo, &bslices, *gm)) {
+        if (allow3) { *retry512 = true; return CRF_OK; }   // both directions then use the larger per-thread budget
+        return give_up("backward rows do not fit one CU");
+    }
     const int Rb = bo.cu_row_off[1], Gb = 2 * Rb + 2, zsink = 2 * Rb;
     if ((size_t)Gb * 4 > 65536) return give_up("backward gather vector > 64 KiB");
     std::vector<int> zpos(S, -1);   // BP / z position of state s: 2*rid + output
@@ -801,7 +815,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     auto zof_pair = [&](int p) { return zpos[pair_dst[p]]; };
     for (auto &row : bsub)
         for (auto &a : row) a.first = zof_pair(a.first);
-    pack_arcs(bsub, bslices, &bo, 4);
+    pack_arcs(bsub, bslices, &bo, 4, *gm);
     const int noLab = -1;
     std::vector<int4> brow_meta(Rb, int4{(zsink * 4) | ((zsink * 4) << 16), 0, 0, (noLab & 0xffff) | (noLab << 16)});
     std::vector<float> brow_start((size_t)2 * Rb, 0.f), brow_end((size_t)2 * Rb, 0.f), z_end(Gb, 0.f);
@@ -844,7 +858,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
                 (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb;
-    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1;
+    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads;
     int rc;
     if ((rc = up(h, fo.arcs, &F.f.arcs)) || (rc = up(h, fo.wave_info, &F.f.wave_info)) || (rc = up(h, bo.arcs, &F.b.arcs)) ||
         (rc = up(h, bo.wave_info, &F.b.wave_info)) || (rc = up(h, frow_meta, &F.frow_meta)) ||
@@ -855,6 +869,19 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         return rc;
     F.ok = 1;
     return CRF_OK;
+}
+
+
+int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
+                   const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
+                   const std::vector<float> &end_lin) {
+    // Geometry: 768 threads x 21 chunks (3 waves per SIMD at <= 168 VGPRs) when both directions fit it, else
+    // 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces the latter.
+    const bool want3 = !(getenv("CRF_FAC_THREADS") && atoi(getenv("CRF_FAC_THREADS")) == 512);
+    bool retry = false;
+    int rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, want3, &retry);
+    if (rc == CRF_OK && retry) rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, false, &retry);
+    return rc;
 }
 
 }  // namespace crf
