@@ -96,6 +96,7 @@ struct FacDirDev {
     const uint4 *wave_info;  // [waves] {slice-end mask, chunks used, first row id, unused}
     int R;                   // rows incl. padding (multiple of 64)
     int G;                   // gather-vector entries (floats) incl. the sink pair at [G-2, G-1]
+    int dup;                 // byte distance of the SECOND copy of the gathered entries (other LDS banks), see pack_arcs
 };
 struct FacDev {
     int ok;                    // 0 = not available for this graph

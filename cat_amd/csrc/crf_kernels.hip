@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/ctc_crf_hip.h"
 #include "crf_internal.h"
@@ -68,6 +69,7 @@ struct LossParams {
     double *cb_mxs;               // [B]
     int *cb_F;                    // [B]
     int *err;                     // [1] set if an exchange timed out
+    int *clear; int nclear;       // words the prep kernel zeroes (error word, start and stage counters of the factored schedule)
     float *Row0;                  // [B][Rb] spare rows (b_0 of the resident backward recursion)
     float *gvec;                  // streaming kernels, graphs too large for LDS: [B][3*Sp + 4*Pr] state vectors in global memory
     int grad_stage;               // crf_grad_kernel: 1 = stage the Q / BP rows in LDS, 0 = gather them from global memory
@@ -179,6 +181,10 @@ __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     const int lane = threadIdx.x & 63;
+    // the counters of the staged schedule start at zero in every call (a memset in the stream cost two more
+    // dispatches between this kernel and the recursions)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < p.nclear; i += 256) __hip_atomic_store(p.clear + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= (int64_t)p.B * p.T) return;
     const int b = (int)(f / p.T), t = (int)(f % p.T);
@@ -191,6 +197,14 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     float *er = p.ep + f * p.V;
     for (int v = lane; v < p.V; v += 64) er[v] = exp_scaled(row[v] - m, kEpExp);
     if (lane == 0) p.mx[f] = m;
+}
+
+// crf_stage_i32: the integer metadata of a call (labels, lengths, offsets) come from the host; a kernel reads
+// them from PINNED host memory and writes the device copy.  A DMA copy in the caller's stream took ~0.15 ms to
+// start between two calls (rocprofv3 timeline), and on its own stream it would need a fifth hardware queue.
+__global__ __launch_bounds__(256) void crf_stage_i32_kernel(int *__restrict__ dst, const int *__restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
 // block-wide helpers for the 1024-thread chain workgroups --------------------------------------
@@ -1298,6 +1312,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = (int)blockIdx.x;
     const int V = p.V, lx = p.lx[b], G = L.G, R = L.R;
+    const unsigned dup = (unsigned)L.dup;                   // second copy of the gathered entries, other banks (res_layout.cpp pack_arcs)
     const int Vp = rup64(V + 1), Gp = rup64(G);
     const int XB = Gp * 4;                                   // bytes per state vector
     const int64_t bt0 = (int64_t)b * p.T;
@@ -1405,7 +1420,11 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
         char *xnb = (char *)lds + (1 - par) * XB;
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
         const int tpre = DIR == 0 ? t + 1 : t - 2;
+        #ifdef CRF_EXP_NOEP
+        const bool pre = false;
+#else
         const bool pre = DIR == 0 ? (t + 1 < lx) : (t >= 2);
+#endif
         float epn[kEpRegsR];
         if (pre) {
             const float *er = p.ep + (bt0 + tpre) * V;
@@ -1457,6 +1476,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                             const float Ap = EPu[m.w] * qt;                             // a_{t+1}[tail]
                             const float Up = Ap + Lp;
                             *(float *)(xnb + (m.x & 0xffff)) = Up;
+                            *(float *)(xnb + (m.x & 0xffff) + dup) = Up;
                             *(float *)(xnb + (m.y & 0xffff)) = Lp;
                             *(float *)(xnb + ((unsigned)m.y >> 16)) = Ap;
                             mymax = fmaxf(mymax, Up);
@@ -1476,6 +1496,8 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                             zv.x = EPu[m.w & 0xffff] * bv.x;
                             zv.y = EPu[(unsigned)m.w >> 16] * bv.y;
                             *(f32x2 *)(xnb + 2u * r4) = zv;
+                            typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                            *(f32x2u *)(xnb + 2u * r4 + dup) = zv;   // the copy's distance is an odd number of floats: ds_write2_b32
                             mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
                         }
                         acc = f32x2{0.f, 0.f};
@@ -2310,13 +2332,24 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string(what) + ": " + hipGetErrorString(e)); return CRF_ERR_HIP; }
 
     const int64_t frames = B * T;
+    // fork: the four recursions are independent; den forward (the longest) stays on the caller's
+    // stream, the others go to side streams and are joined before the grad pass.
+    static const bool serial = getenv("CRF_SERIAL_CHAINS") && atoi(getenv("CRF_SERIAL_CHAINS")) != 0;
+    DevCtx *cx = nullptr;
+    int rc;
+    if (!serial && (rc = get_ctx(&cx))) return rc;
+    // factored path: error word, start counter and progress counters live in fine-grained memory (get_ctx);
+    // the prep kernel clears them
+    const bool have_flags = fac && cx && cx->flags && 64 + 2 * B <= kFlagInts;
+    p.clear = nullptr; p.nclear = 0;
+    if (have_flags) { p.err = cx->flags; p.clear = cx->flags; p.nclear = (int)(64 + 2 * B); }
     for (bool &u : g_prof.used) u = false;
     prof_mark(7, false, stream);
     prof_mark(0, false, stream);
     hipLaunchKernelGGL(crf_prep_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
     prof_mark(0, true, stream);
     LAUNCH_CHECK("crf_prep_kernel");
-    if (res) {  // exchange granules (tags) and the error word start at zero in every call
+    if (res && !have_flags) {  // exchange granules (tags) and the error word start at zero in every call
         if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256 + 8 * (size_t)B, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
     }
 
@@ -2327,13 +2360,7 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         }
         lds_set_grad = lds_grad;
     }
-    // fork: the four recursions are independent; den forward (the longest) stays on the caller's
-    // stream, the others go to side streams and are joined before the grad pass.
-    static const bool serial = getenv("CRF_SERIAL_CHAINS") && atoi(getenv("CRF_SERIAL_CHAINS")) != 0;
-    DevCtx *cx = nullptr;
-    int rc;
-    if (!serial) {
-        if ((rc = get_ctx(&cx))) return rc;
+    if (!serial) {   // side streams start behind the prep kernel (and its clear of the counters)
         if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess) { set_error("hipEventRecord(fork)"); return CRF_ERR_HIP; }
     }
     bool used[3] = {false, false, false};
@@ -2343,13 +2370,6 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         (void)hipStreamWaitEvent(cx->side[i], cx->fork, 0);
         return cx->side[i];
     };
-    // factored path: error word, start counter and progress counters live in fine-grained memory (get_ctx)
-    const bool have_flags = fac && cx && cx->flags && 64 + 2 * B <= kFlagInts;
-    if (have_flags) {
-        p.err = cx->flags;
-        if ((e = hipMemsetAsync(cx->flags, 0, (size_t)(64 + 2 * B) * sizeof(int), stream)) != hipSuccess) { set_error("hipMemsetAsync(flags)"); return CRF_ERR_HIP; }
-        if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess) { set_error("hipEventRecord(fork)"); return CRF_ERR_HIP; }  // side streams start after the clear
-    }
     int *started = p.err + 1;   // workgroups of the den kernels that hold a CU (cleared with the error word)
     int ncu_dev = 256;
     {
@@ -2393,13 +2413,33 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     int nstage = 1;
     bound[1] = (int)T;
     if (staged && T >= 256) {
+        // CRF_TAIL="32,16": shorter LAST pieces.  Measured: no gain -- a grad workgroup walks its 16 frames one after
+        // the other (~75 us alone on the chip), so a short piece takes as long as a 64-iteration one.
+        static const std::vector<int> tail_env = [] {
+            std::vector<int> v;
+            const char *s = getenv("CRF_TAIL");
+            for (const char *q = s ? s : ""; *q;) {
+                const int n = atoi(q);
+                if (n > 0) v.push_back((n + kGDFrames - 1) / kGDFrames * kGDFrames);
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            return v;
+        }();
         const int half = (int)((T / 2 + kGDFrames - 1) / kGDFrames * kGDFrames);
-        const int nshort = std::max(1, std::min(std::min(pieces, kMaxStages - 2), (int)((T - half) / 32)));
-        int piece = (int)((T - half + nshort - 1) / nshort);
+        int tail_sum = 0;
+        for (int n : tail_env) tail_sum += n;
+        const bool with_tail = !segmode && !tail_env.empty() && T - half >= tail_sum + 64 && (int)tail_env.size() + 3 <= kMaxStages;
+        const int ntail = with_tail ? (int)tail_env.size() : 0;
+        const int body_end = (int)T - (with_tail ? tail_sum : 0);
+        const int nshort = std::max(1, std::min(std::min(pieces, kMaxStages - 2 - ntail), (body_end - half) / 32));
+        int piece = (body_end - half + nshort - 1) / nshort;
         piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
         nstage = 1;
         bound[1] = half;
-        while (bound[nstage] < T && nstage < kMaxStages) { bound[nstage + 1] = std::min((int)T, bound[nstage] + piece); ++nstage; }
+        while (bound[nstage] < body_end && nstage < kMaxStages - ntail) { bound[nstage + 1] = std::min(body_end, bound[nstage] + piece); ++nstage; }
+        bound[nstage] = body_end;
+        for (int k = 0; k < ntail; ++k) { bound[nstage + 1] = std::min((int)T, bound[nstage] + tail_env[k]); ++nstage; }
         bound[nstage] = (int)T;
     }
     p.gd_nb = nstage + 1;
@@ -2599,6 +2639,15 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     g_prof.have = g_prof.on;
     LAUNCH_CHECK("crf_finalize_kernel");
 #undef LAUNCH_CHECK
+    return CRF_OK;
+}
+
+int crf_stage_i32(int32_t *dst_dev, const int32_t *src_pinned_host, int64_t n, void *stream) {
+    if (n <= 0) return CRF_OK;
+    if (!dst_dev || !src_pinned_host) { set_error("crf_stage_i32: null pointer"); return CRF_ERR_ARG; }
+    hipLaunchKernelGGL(crf_stage_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst_dev, src_pinned_host, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("crf_stage_i32: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }
 

@@ -162,8 +162,14 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
 // Padding gathers (weight 0) broadcast the address of a real lane of their half.
 // `stride`: bytes per gather index (4: one float per gather; 8: an entry PAIR per gather, ds_read_b64, whose
 // bank class is again index mod 32 -- 64 banks, two per lane).
-void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, int stride = 4, const Geom &gm = kGeomRes) {
+// `dup_n`, `dup_off` (factored layout): entries [0, dup_n) exist TWICE in the gather vector, the second copy at
+// entry + dup_off, i.e. on other banks (dup_off mod 32 != 0): every gather of such an entry may read either copy.
+// With one copy the best order of a lane's arcs still leaves (busiest bank of the half-wave over the slice) - (slice
+// length) extra cycles -- 44 % on the benchmark graph; with a choice of two banks per arc nearly all of it goes.
+void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, int stride = 4, const Geom &gm = kGeomRes,
+               int dup_n = 0, int dup_off = 0) {
     const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
+    auto alt = [&](int idx) { return idx < 0 ? -1 : idx < dup_n ? idx + dup_off : (idx >= dup_off && idx < dup_off + dup_n) ? idx - dup_off : -1; };
     for (const SliceAt &sl : slices) {
         const int NI = sl.len * kResW;
         std::vector<std::vector<std::pair<int, float>>> rem(kWave);
@@ -171,31 +177,162 @@ void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, 
         // place[ins][lane] = arc (index, weight) or index -1
         std::vector<std::vector<std::pair<int, float>>> place(NI, std::vector<std::pair<int, float>>(kWave, {-1, 0.f}));
         std::vector<std::vector<int>> cnt(NI, std::vector<int>(2 * 32, 0));  // lanes per (half, bank)
-        for (int ins = 0; ins < NI; ++ins)
-            for (int half = 0; half < 2; ++half) {
-                int occupant[32];
-                for (int b = 0; b < 32; ++b) occupant[b] = -1;
-                int lanes[32];
-                for (int l = 0; l < 32; ++l) lanes[l] = half * 32 + l;
-                std::stable_sort(lanes, lanes + 32, [&](int a, int b) { return rem[a].size() < rem[b].size(); });
-                for (int li = 0; li < 32; ++li) {
-                    const int lane = lanes[li];
-                    auto &rv = rem[lane];
-                    if (rv.empty()) continue;
-                    size_t best = 0;
-                    int best_cost = 1 << 30;
-                    for (size_t q = 0; q < (arrange ? rv.size() : (size_t)1); ++q) {
-                        const int bank = rv[q].first & 31;
-                        const int cost = occupant[bank] == rv[q].first ? 0 : cnt[ins][half * 32 + bank];
-                        if (cost < best_cost) { best_cost = cost; best = q; if (!cost) break; }
+        if (!arrange) {
+            for (int ins = 0; ins < NI; ++ins)
+                for (int half = 0; half < 2; ++half) {
+                    int occupant[32];
+                    for (int b = 0; b < 32; ++b) occupant[b] = -1;
+                    int lanes[32];
+                    for (int l = 0; l < 32; ++l) lanes[l] = half * 32 + l;
+                    std::stable_sort(lanes, lanes + 32, [&](int a, int b) { return rem[a].size() < rem[b].size(); });
+                    for (int li = 0; li < 32; ++li) {
+                        const int lane = lanes[li];
+                        auto &rv = rem[lane];
+                        if (rv.empty()) continue;
+                        size_t best = 0;
+                        int best_cost = 1 << 30;
+                        bool best_alt = false;
+                        for (size_t q = 0; q < (arrange ? rv.size() : (size_t)1) && best_cost; ++q)
+                            for (int c = 0; c < 2; ++c) {
+                                const int idx = c ? alt(rv[q].first) : rv[q].first;
+                                if (idx < 0 || (c && !arrange)) continue;
+                                const int bank = idx & 31;
+                                const int cost = occupant[bank] == idx ? 0 : cnt[ins][half * 32 + bank];
+                                if (cost < best_cost) { best_cost = cost; best = q; best_alt = c != 0; if (!cost) break; }
+                            }
+                        if (best_alt) rv[best].first = alt(rv[best].first);
+                        place[ins][lane] = rv[best];
+                        const int bank = rv[best].first & 31;
+                        if (occupant[bank] != rv[best].first) cnt[ins][half * 32 + bank]++;
+                        if (occupant[bank] < 0) occupant[bank] = rv[best].first;
+                        rv.erase(rv.begin() + (long)best);
                     }
-                    place[ins][lane] = rv[best];
-                    const int bank = rv[best].first & 31;
-                    if (occupant[bank] != rv[best].first) cnt[ins][half * 32 + bank]++;
-                    if (occupant[bank] < 0) occupant[bank] = rv[best].first;
-                    rv.erase(rv.begin() + (long)best);
                 }
+        } else {
+            // pass 1: per half-wave, (a) choose the copy of every arc so that the 32 banks carry equal numbers of
+            // this slice's gathers, (b) colour the bipartite multigraph lanes x banks with NI colours (Koenig: possible
+            // when no lane and no bank has more than NI edges; alternating-path recolouring) -- colour = position, so
+            // every gather is conflict-free -- and (c) put the edges of over-full banks into their lanes' free
+            // positions, the k-th surplus edge of every bank into the same positions where possible (a gather
+            // costs its BUSIEST bank: two banks with two addresses each cost one extra cycle, not two).
+            for (int half = 0; half < 2; ++half) {
+                struct Edge { int lane, idx, bank, col; float w; bool over; };
+                std::vector<Edge> ed;
+                int load[32] = {0};
+                for (int l = 0; l < 32; ++l)
+                    for (auto &a : rem[half * 32 + l]) {
+                        Edge e{half * 32 + l, a.first, a.first & 31, -1, a.second, false};
+                        const int al = alt(e.idx);
+                        if (al >= 0 && load[al & 31] < load[e.bank]) { e.idx = al; e.bank = al & 31; }
+                        ++load[e.bank];
+                        ed.push_back(e);
+                    }
+                // (a) balance: move one arc along a CHAIN of banks (an arc of bank u whose other copy is on bank v is
+                // an edge u -> v) from a bank to one that carries at least two fewer -- breadth-first, until no bank has one
+                for (int iter = 0; iter < 4096; ++iter) {
+                    int order[32];
+                    for (int b = 0; b < 32; ++b) order[b] = b;
+                    std::stable_sort(order, order + 32, [&](int x, int y) { return load[x] > load[y]; });
+                    bool moved = false;
+                    for (int oi = 0; oi < 32 && !moved; ++oi) {
+                        const int b0 = order[oi];
+                        int via[32];                              // edge (index into ed) that reached the bank
+                        for (int b = 0; b < 32; ++b) via[b] = -2;
+                        via[b0] = -1;
+                        std::vector<int> queue{b0};
+                        int found = -1;
+                        for (size_t qi = 0; qi < queue.size() && found < 0; ++qi) {
+                            const int u = queue[qi];
+                            for (size_t i = 0; i < ed.size() && found < 0; ++i) {
+                                if (ed[i].bank != u) continue;
+                                const int al = alt(ed[i].idx);
+                                if (al < 0) continue;
+                                const int v = al & 31;
+                                if (via[v] != -2) continue;
+                                via[v] = (int)i;
+                                if (load[v] + 2 <= load[b0]) found = v; else queue.push_back(v);
+                            }
+                        }
+                        if (found < 0) continue;
+                        for (int v = found; v != b0;) {           // move one arc along every edge of the chain
+                            Edge &e = ed[via[v]];
+                            const int u = e.bank;
+                            --load[u]; e.idx = alt(e.idx); e.bank = e.idx & 31; ++load[e.bank];
+                            v = u;
+                        }
+                        moved = true;
+                    }
+                    if (!moved) break;
+                }
+                for (int b = 0; b < 32; ++b) {                   // surplus edges of over-full banks
+                    int surplus = load[b] - NI;
+                    for (size_t i = ed.size(); i-- > 0 && surplus > 0;)
+                        if (ed[i].bank == b) { ed[i].over = true; --surplus; }
+                }
+                if (getenv("CRF_PACK_DEBUG")) {
+                    int mx = 0, nover = 0, tot = 0; for (int b = 0; b < 32; ++b) { mx = std::max(mx, load[b]); tot += load[b]; }
+                    for (auto &e : ed) nover += e.over;
+                    int nalt = 0; for (auto &e : ed) nalt += alt(e.idx) >= 0;
+                    fprintf(stderr, "[pack] w%d c0=%d half %d: NI=%d edges=%d (avg/bank %.1f) max bank %d surplus %d with-alt %d\n", sl.w, sl.c0, half, NI, tot, tot / 32.0, mx, nover, nalt);
+                }
+                std::vector<int> lane_c((size_t)32 * NI, -1), bank_c((size_t)32 * NI, -1);   // edge at (node, colour)
+                auto LC = [&](int lane, int c) -> int & { return lane_c[(size_t)(lane & 31) * NI + c]; };
+                auto BC = [&](int bank, int c) -> int & { return bank_c[(size_t)bank * NI + c]; };
+                for (size_t i = 0; i < ed.size(); ++i) {         // (b)
+                    Edge &e = ed[i];
+                    if (e.over) continue;
+                    int a = -1, b = -1, both = -1;
+                    for (int c = 0; c < NI; ++c) {
+                        const bool fl = LC(e.lane, c) < 0, fb = BC(e.bank, c) < 0;
+                        if (fl && fb) { both = c; break; }
+                        if (fl && a < 0) a = c;
+                        if (fb && b < 0) b = c;
+                    }
+                    if (both < 0) {
+                        // colour a is free at the lane, b at the bank: swap a <-> b along the path that starts with the
+                        // bank's a-edge (it cannot end in this lane, which has no a-edge), then a is free at both
+                        std::vector<int> path;
+                        int node = e.bank, col = a;
+                        bool at_bank = true;
+                        for (;;) {
+                            const int e2 = at_bank ? BC(node, col) : LC(node, col);
+                            if (e2 < 0) break;
+                            path.push_back(e2);
+                            node = at_bank ? ed[e2].lane : ed[e2].bank;
+                            at_bank = !at_bank;
+                            col = col == a ? b : a;
+                        }
+                        for (int e2 : path) { LC(ed[e2].lane, ed[e2].col) = -1; BC(ed[e2].bank, ed[e2].col) = -1; }
+                        for (int e2 : path) { ed[e2].col = ed[e2].col == a ? b : a; LC(ed[e2].lane, ed[e2].col) = e2; BC(ed[e2].bank, ed[e2].col) = e2; }
+                        both = a;
+                    }
+                    e.col = both;
+                    LC(e.lane, both) = (int)i;
+                    BC(e.bank, both) = (int)i;
+                }
+                std::vector<int> extra(NI, 0);                   // (c): positions that already cost a second cycle
+                for (size_t i = 0; i < ed.size(); ++i) {
+                    Edge &e = ed[i];
+                    if (!e.over) continue;
+                    int best = -1, best_key = 1 << 30;
+                    for (int c = 0; c < NI; ++c) {
+                        if (LC(e.lane, c) >= 0) continue;
+                        int same = 0;                             // addresses already on this bank in position c
+                        for (size_t j = 0; j < ed.size(); ++j) if (ed[j].col == c && ed[j].bank == e.bank && ed[j].idx != e.idx) ++same;
+                        const int cost_after = std::max(extra[c], same);   // extra cycles of position c afterwards
+                        const int key = (cost_after - extra[c]) * 1024 + (extra[c] ? 0 : 1) * 32 + same;
+                        if (key < best_key) { best_key = key; best = c; }
+                    }
+                    if (best < 0) continue;                       // cannot happen: a lane has at most NI arcs
+                    int same = 0;
+                    for (size_t j = 0; j < ed.size(); ++j) if (ed[j].col == best && ed[j].bank == e.bank && ed[j].idx != e.idx) ++same;
+                    extra[best] = std::max(extra[best], same);
+                    e.col = best;
+                    LC(e.lane, best) = (int)i;
+                }
+                for (auto &e : ed) if (e.col >= 0) place[e.col][e.lane] = {e.idx, e.w};
             }
+        }
         // pass 2: local search on the TRUE cost.  A half-wave gather takes as many LDS cycles as its busiest
         // bank has distinct addresses, so what counts is sum over (position, half) of that maximum -- not the
         // number of colliding lanes (ten 2-way collisions in one gather cost one extra cycle, the same ten
@@ -222,7 +359,7 @@ void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, 
             std::vector<int> hc(2 * NI), hcoll(2 * NI);
             for (int ins = 0; ins < NI; ++ins)
                 for (int hh = 0; hh < 2; ++hh) hc[2 * ins + hh] = half_cost(ins, hh * 32, &hcoll[2 * ins + hh]);
-            for (int pass = 0; pass < 6; ++pass) {
+            for (int pass = 0; pass < (dup_n ? 12 : 6); ++pass) {
                 bool any = false;
                 for (int i1 = 0; i1 < NI; ++i1)
                     for (int hh = 0; hh < 2; ++hh) {
@@ -239,6 +376,19 @@ void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, 
                                 if (idx2 >= 0 && (idx2 & 31) == b1 && idx2 != place[i1][lane].first) ++same;
                             }
                             if (!same) continue;
+                            if (alt(place[i1][lane].first) >= 0) {   // the other copy of this entry
+                                const int keep = place[i1][lane].first, cb = hcoll[2 * i1 + hh];
+                                place[i1][lane].first = alt(keep);
+                                int c1;
+                                const int n1 = half_cost(i1, h, &c1);
+                                if (n1 < hc[2 * i1 + hh] || (n1 == hc[2 * i1 + hh] && c1 < cb)) {
+                                    hc[2 * i1 + hh] = n1; hcoll[2 * i1 + hh] = c1;
+                                    any = true;
+                                    if (hc[2 * i1 + hh] <= 1) break;
+                                    continue;
+                                }
+                                place[i1][lane].first = keep;
+                            }
                             for (int i2 = 0; i2 < NI; ++i2) {
                                 if (i2 == i1 || place[i2][lane].first < 0) continue;
                                 if (((place[i2][lane].first ^ place[i1][lane].first) & 31) == 0) continue;
@@ -688,13 +838,20 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) is_tail[tail_of[s]] = 1;
     // entries: [U of every pair][L of every pair][A of every pair][plain states][sink]
     std::vector<int> entU(S, -1), ent(S, -1);   // entU: by main state; ent: a[s] itself (L, A or plain)
+    // ... and a SECOND copy of the U entries (and the sink, which padding rows write) behind everything, on
+    // other banks: [U][sink][L][A][plain] [pad] [U'][sink'] -- see pack_arcs
+    static const int bank_shift = getenv("CRF_FAC_BANK_SHIFT") ? atoi(getenv("CRF_FAC_BANK_SHIFT")) & 31 : 5;
+    static const bool no_dup = getenv("CRF_FAC_NO_DUP") && atoi(getenv("CRF_FAC_NO_DUP"));
     int nent = 0;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) entU[s] = nent++;
+    const int nU = nent;
+    const int sink = nent++;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) ent[s] = nent++;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) ent[tail_of[s]] = nent++;
     for (int s = 0; s < S; ++s) if (ent[s] < 0) ent[s] = nent++;
-    const int sink = nent;
-    const int Gf = nent + 1;
+    int fdup = 0;                                        // entries between the two copies
+    if (!no_dup) { fdup = nent; while ((fdup & 31) != bank_shift) ++fdup; }
+    const int Gf = fdup ? fdup + nU + 1 : nent;
     if ((size_t)Gf * 4 > 65536) return give_up("forward gather vector > 64 KiB");
     const int64_t nsolo = 0;
     // rows: every pair except the tail rows
@@ -728,7 +885,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         if (allow3) { *retry512 = true; return CRF_OK; }
         return give_up("forward rows do not fit one CU");
     }
-    pack_arcs(fsub, fslices, &fo, 4, *gm);
+    pack_arcs(fsub, fslices, &fo, 4, *gm, fdup ? nU : 0, fdup);
     const int Rf = fo.cu_row_off[1];
     const int NT = 0;
     std::vector<int> fpos(P, -1);   // position of pair p in the Q row: main rows [0, Rf), their tails [Rf, 2 Rf)
@@ -753,6 +910,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         x_end[ent[s]] = end_lin[s];
         if (tail_of[s] >= 0) x_start[entU[s]] = start_lin[s] + start_lin[tail_of[s]];
     }
+    if (fdup) for (int u = 0; u < nU; ++u) x_start[fdup + u] = x_start[u];
     std::vector<int4> ftail(1, int4{0, 0, 0, 0});
     std::vector<int> tail_rows;   // (statistics only)
     for (int s = 0; s < S; ++s) if (is_tail[s]) tail_rows.push_back(s);
@@ -803,7 +961,10 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         if (allow3) { *retry512 = true; return CRF_OK; }   // both directions then use the larger per-thread budget
         return give_up("backward rows do not fit one CU");
     }
-    const int Rb = bo.cu_row_off[1], Gb = 2 * Rb + 2, zsink = 2 * Rb;
+    const int Rb = bo.cu_row_off[1], Gb0 = 2 * Rb + 2, zsink = 2 * Rb;
+    int bdup = 0;                                        // second copy of every z entry: [z (2 Rb)][sink pair] [pad] [z'][sink']
+    if (!no_dup) { bdup = Gb0; while ((bdup & 31) != bank_shift) ++bdup; }
+    const int Gb = bdup ? bdup + Gb0 : Gb0;
     if ((size_t)Gb * 4 > 65536) return give_up("backward gather vector > 64 KiB");
     std::vector<int> zpos(S, -1);   // BP / z position of state s: 2*rid + output
     for (int rid = 0; rid < Rb; ++rid) {
@@ -815,7 +976,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     auto zof_pair = [&](int p) { return zpos[pair_dst[p]]; };
     for (auto &row : bsub)
         for (auto &a : row) a.first = zof_pair(a.first);
-    pack_arcs(bsub, bslices, &bo, 4, *gm);
+    pack_arcs(bsub, bslices, &bo, 4, *gm, bdup ? 2 * Rb : 0, bdup);
     const int noLab = -1;
     std::vector<int4> brow_meta(Rb, int4{(zsink * 4) | ((zsink * 4) << 16), 0, 0, (noLab & 0xffff) | (noLab << 16)});
     std::vector<float> brow_start((size_t)2 * Rb, 0.f), brow_end((size_t)2 * Rb, 0.f), z_end(Gb, 0.f);
@@ -835,6 +996,8 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             z_lab[2 * rid + 1] = l1; z_end[2 * rid + 1] = end_lin[br.s1];
         }
     }
+
+    if (bdup) for (int z = 0; z < 2 * Rb; ++z) { z_lab[bdup + z] = z_lab[z]; z_end[bdup + z] = z_end[z]; }
 
     // ---- 5. grad pass list: one (Q position, BP position) per pair, label-sorted (pairs already are), chunked
     const int max_lab = *std::max_element(pair_lab.begin(), pair_lab.end());
@@ -857,7 +1020,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (verbose)
         fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
                 (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
-    F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb;
+    F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
     F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads;
     int rc;
     if ((rc = up(h, fo.arcs, &F.f.arcs)) || (rc = up(h, fo.wave_info, &F.f.wave_info)) || (rc = up(h, bo.arcs, &F.b.arcs)) ||

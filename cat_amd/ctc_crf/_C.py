@@ -43,12 +43,14 @@ _lib.crf_profile_read.argtypes = [ctypes.POINTER(_f32), ctypes.c_int]
 _lib.crf_profile_read.restype = ctypes.c_int
 _lib.crf_timing_read.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
 _lib.crf_timing_read.restype = ctypes.c_int
+_lib.crf_stage_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+_lib.crf_stage_i32.restype = ctypes.c_int
 _lib.crf_last_error.restype = ctypes.c_char_p
 _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
-    "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_profile_enable", "crf_profile_read", "crf_timing_read",
+    "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
     "crf_last_error", "crf_version",
 )
 
@@ -148,8 +150,12 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class _PinnedRing:
     """A few pinned int32 staging buffers per device, reused round-robin: a copy from PAGEABLE memory makes the
-    host wait for the stream (the next call could not be enqueued while this one runs); from pinned memory it
-    is asynchronous.  A slot is reused only after the event of its last copy has completed."""
+    host wait for the stream (the next call could not be enqueued while this one runs).  The device copy is
+    made by a KERNEL that reads the pinned buffer (crf_stage_i32): a DMA copy in the caller's stream left the
+    GPU idle for ~0.15 ms between two calls while the copy engine started (rocprofv3 timeline), and a copy
+    stream of its own would be the process's fifth stream -- HIP maps streams onto four hardware queues, two of
+    the loss's own side streams then share one and the numerator recursions run one after the other.
+    A slot is reused only after the event of its last copy has completed."""
 
     SLOTS = 8
 
@@ -167,9 +173,12 @@ class _PinnedRing:
         if self.buf[k] is None or self.buf[k].numel() < n:
             self.buf[k] = torch.empty(max(n, 4096), dtype=torch.int32).pin_memory()
         self.buf[k][:n].copy_(src)
-        out = self.buf[k][:n].to(dev, non_blocking=True)
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev):
+            _check(_lib.crf_stage_i32(_vp(out.data_ptr()), _vp(self.buf[k].data_ptr()), n, _vp(cur.cuda_stream)))
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
+        ev.record(cur)
         self.ev[k] = ev
         return out
 

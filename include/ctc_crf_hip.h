@@ -103,6 +103,12 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *log_probs_dev, const int32
                      float *costs_ctc_dev, int32_t *invalid_dev, void *workspace_dev,
                      int64_t workspace_bytes, void *stream);
 
+/* Replaces the cudaMemcpyAsync calls that bring labels, label lengths and input lengths to the device
+ * (gpu_ctc.h:143-229; `input_lengths.cuda()`, ctc_crf/__init__.py:73): copies n int32 from PINNED host
+ * memory (hipHostMalloc / torch pin_memory: device-accessible) to device memory with a kernel on `stream` --
+ * no DMA engine start-up between two calls.  The host buffer must stay untouched until the stream has passed. */
+int crf_stage_i32(int32_t *dst_dev, const int32_t *src_pinned_host, int64_t n, void *stream);
+
 /* Diagnostics (no reference counterpart; the reference has no profiler hooks).
  * crf_profile_enable(1): every following crf_loss_fwd_bwd on this thread brackets each of its
  * kernel launches with HIP events on the stream the kernel is launched on.
