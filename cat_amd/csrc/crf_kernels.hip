@@ -60,6 +60,7 @@ struct LossParams {
     int gNC;
     int res;                      // 1: register-resident den kernels (g.res), 0: streaming kernels
     int gd_stage, gd_nb;          // crf_grad_den_kernel: process only the 16-frame blocks completed by den segment `gd_stage` (0 = all)
+    int gd_nf;                    // > 0: the launch holds only 2 * gd_nf candidate blocks per utterance (see the kernel)
     int gd_bound[16];             //   segment k (1-based) runs the recursion iterations [gd_bound[k-1], gd_bound[k])
     int grad_den_acc;             // crf_grad_den_kernel: add to the row (the numerator half has written it) instead of writing
     int grad_phase;               // crf_grad_kernel: 0 = den and ctc in one pass, 1 = den part only (writes), 2 = ctc part only (subtracts)
@@ -1679,14 +1680,36 @@ constexpr int kGDEpRegs = 4;                                      // V <= 4*256
 // the rows AND the emission row of frame t+1 are requested while frame t is reduced, the per-frame
 // exponents are read once per workgroup, and the barriers are LDS-only (sync_lds) -- __syncthreads()
 // would drain vmcnt, i.e. wait for the prefetch it has just issued (that alone was ~2/3 of this kernel).
-template <int NCPT>
-__global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) {
+#ifndef CRF_GD_MINW
+#define CRF_GD_MINW 1   // 4: 128 VGPRs (spills 25) for a fourth workgroup per CU -- measured slower/faster: see DESIGN.md
+#endif
+template <int NCPT, int EPR>
+__global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW : 1) void crf_grad_den_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
     const int tid = threadIdx.x;
-    const int b = blockIdx.y, blk = blockIdx.x;
+    const int b = blockIdx.y;
+    int blk = blockIdx.x;
     const int V = p.V;
     const int lx = p.lx[b], Rq = p.Rq, Rb = p.Rb, NC = p.gNC;
+    if (p.gd_nf > 0) {
+        // Compact launch of stage k > 1: the blocks a stage completes are two short runs -- those whose last frame
+        // the FORWARD recursion reached in this stage, from block bound[k-1]/16 on, and those whose first frame the
+        // BACKWARD recursion reached, from block (lx-1-bound[k])/16 on -- so the launch holds gd_nf candidates of
+        // each run instead of every block of the utterance (94 per utterance, of which 6 had work: each of the
+        // others held a workgroup slot and 37 KB of LDS for the ~2 us it takes to find that out).  The runs are
+        // taken one block wider than needed on both sides; the exact test below decides, and a block of both runs
+        // is taken by the forward one.
+        const int k = p.gd_stage, nf = p.gd_nf;
+        const int flo = p.gd_bound[k - 1] / kGDFrames - 1;
+        const int blo = (lx - 1 - p.gd_bound[k]) / kGDFrames - 1;
+        if (blk < nf) blk = flo + blk;
+        else {
+            blk = blo + (blk - nf);
+            if (blk >= flo && blk < flo + nf) return;
+        }
+        if (blk < 0 || blk * kGDFrames >= p.T) return;
+    }
     const int Vp = rup64(V);
     float *Qs = lds, *Bs = Qs + rup64(Rq + 1), *gd = Bs + rup64(Rb + 1);    // Qs[Rq] = 0: target of padding index pairs
     float *nrm = gd + 4 * Vp;                                               // [4] per-frame normalisers; gd: [4][Vp] label sums, both in rotation
@@ -1717,15 +1740,18 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
             const int c = tid + i * kGDThreads;
             const int j0 = c < NC ? p.gchunk[c] : 0;
             const int clen = c < NC ? p.gchunk[c + 1] - j0 : 0;
-            unsigned short gqv[kChunk], gbv[kChunk];
 #pragma unroll
-            for (int j = 0; j < kChunk; ++j) {
-                const int jj = min(j0 + j, nlist - 1);
-                gqv[j] = (unsigned short)p.gq[jj];
-                gbv[j] = (unsigned short)p.gb[jj];
+            for (int h = 0; h < kChunk; h += 16) {   // in two halves: 64 loads in flight were the register peak of the kernel
+                unsigned short gqv[16], gbv[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int jj = min(j0 + h + j, nlist - 1);
+                    gqv[j] = (unsigned short)p.gq[jj];
+                    gbv[j] = (unsigned short)p.gb[jj];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) idx[i][h + j] = h + j < clen ? ((unsigned)gqv[j] | (unsigned)gbv[j] << 16) : (unsigned)Rq;
             }
-#pragma unroll
-            for (int j = 0; j < kChunk; ++j) idx[i][j] = j < clen ? ((unsigned)gqv[j] | (unsigned)gbv[j] << 16) : (unsigned)Rq;
         }
     }
     // label of each chunk: the per-label chunk ranges, inverted once per workgroup.  The chunk sums of a
@@ -1760,7 +1786,7 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
     // rows are multiples of 64 floats and 256-byte aligned: 16-byte loads, prefetched one frame ahead
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 qr[kGDRowRegs], br[kGDRowRegs];
-    float ern[kGDEpRegs], rwn[kGDEpRegs];   // next frame's emissions and (accumulate mode) grad row
+    float ern[EPR], rwn[EPR];   // next frame's emissions and (accumulate mode) grad row
 #define CRF_GD_FETCH(t)                                                                                  \
     {                                                                                                    \
         const f32x4 *Qr = (const f32x4 *)(p.Q + (bt0 + (t)) * Rq), *Br = (const f32x4 *)(p.BP + (bt0 + (t)) * Rb); \
@@ -1771,7 +1797,7 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
         }                                                                                                \
         const float *er_ = p.ep + (bt0 + (t)) * V;                                                       \
         const float *gr_ = p.grad + (bt0 + (t)) * V;                                                     \
-        _Pragma("unroll") for (int q = 0; q < kGDEpRegs; ++q) {                                          \
+        _Pragma("unroll") for (int q = 0; q < EPR; ++q) {                                          \
             const int v = tid + q * kGDThreads;                                                          \
             ern[q] = v < V ? er_[v] : 0.f;                                                               \
             rwn[q] = (p.grad_den_acc && v < V) ? gr_[v] : 0.f;                                           \
@@ -1783,12 +1809,12 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
         if (4 * r < Rq) ((f32x4 *)Qs)[r] = qr[i];                                                        \
         if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];                                                        \
     }
-    float erc[kGDEpRegs], rwc[kGDEpRegs];
+    float erc[EPR], rwc[EPR];
     if (t0 < tl) {
         CRF_GD_FETCH(t0);
         CRF_GD_STAGE();
 #pragma unroll
-        for (int q = 0; q < kGDEpRegs; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
+        for (int q = 0; q < EPR; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
     }
     sync_lds();
     const bool tm_on = blockIdx.x == 40 && blockIdx.y == 3 && tid < 64;
@@ -1814,7 +1840,7 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
             if (!(segm[i] >> 31)) atomicAdd(&gsum[clab[i]], sv);
         }
 #pragma unroll
-        for (int q = 0; q < kGDEpRegs; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
+        for (int q = 0; q < EPR; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
             const int v = tid + q * kGDThreads;
             if (v < V) gzero[v] = 0.f;
         }
@@ -1830,17 +1856,17 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
         // gamma[t][v] = u_v / sum_v u_v with u_v = e'_t[v] * (label sum): the posteriors of a frame sum to 1, so
         // the frame normalises itself -- no logZ, no per-frame exponents, hence no dependence on the END of the
         // recursions (the pass runs beside them).  e' is taken without its 2^kEpExp (range: label sums reach 2^50).
-        float u[kGDEpRegs], part = 0.f;
+        float u[EPR], part = 0.f;
 #pragma unroll
-        for (int q = 0; q < kGDEpRegs; ++q) {
+        for (int q = 0; q < EPR; ++q) {
             const int v = tid + q * kGDThreads;
             u[q] = v < V ? (erc[q] * pow2f(-kEpExp)) * gsum[v] : 0.f;
             part += u[q];
             erc[q] = ern[q];
         }
-        float rw[kGDEpRegs];
+        float rw[EPR];
 #pragma unroll
-        for (int q = 0; q < kGDEpRegs; ++q) { rw[q] = rwc[q]; rwc[q] = rwn[q]; }
+        for (int q = 0; q < EPR; ++q) { rw[q] = rwc[q]; rwc[q] = rwn[q]; }
         part = wave_sum(part);
         if ((tid & 63) == 0 && part != 0.f) atomicAdd(&nrm[t & 3], part);
         CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
@@ -1850,7 +1876,7 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
         const float inv = nv > 0.f ? p.c_den / nv : 0.f;
         float *row = p.grad + (bt0 + t) * V;
 #pragma unroll
-        for (int q = 0; q < kGDEpRegs; ++q) {
+        for (int q = 0; q < EPR; ++q) {
             const int v = tid + q * kGDThreads;
             if (v < V) row[v] = rw[q] + u[q] * inv;   // rw = 0 unless accumulating onto the numerator half
         }
@@ -1875,6 +1901,10 @@ __global__ __launch_bounds__(kGDThreads) void crf_grad_den_kernel(LossParams p) 
 // parity of its tid: odd threads own label positions, even threads blanks.
 // ---------------------------------------------------------------------------------------------
 constexpr int kGCThreads = 256, kGCFrames = 16, kGCRegs = 16, kGCVRegs = 4;  // 2L+1 <= 4096, V <= 1024
+// REGS: label positions per thread (2L+1 <= REGS * 256).  The kernel is latency-bound (a workgroup walks its 16
+// frames one after the other), so what counts is how many workgroups a CU holds: with 16 positions per thread (three
+// fp64 arrays) that is 3, with 2 positions -- utterances of up to 255 labels -- 8.
+template <int REGS>
 __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1889,20 +1919,20 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
     const int *ul = p.labels + p.lab_off[b];
     const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
     const int t0 = blockIdx.x * kGCFrames, t1 = min(t0 + kGCFrames, p.T), tl = min(t1, lx);
-    int mylab[kGCRegs];
+    int mylab[REGS];
 #pragma unroll
-    for (int i = 0; i < kGCRegs; ++i) {
+    for (int i = 0; i < REGS; ++i) {
         const int s = tid + i * kGCThreads;
         mylab[i] = (s < Sx && (s & 1)) ? ul[s >> 1] : 0;
     }
     if (tid < kGCFrames)
         fcs[tid] = (t0 + tid < tl && zc > 0.0) ? ldexp(invc, ezc - p.ECA[bt0 + t0 + tid] - p.ECB[bt0 + t0 + tid]) : 0.0;
-    double an[kGCRegs], bn[kGCRegs];
+    double an[REGS], bn[REGS];
     float rown[kGCVRegs];
 #define CRF_GC_FETCH(t)                                                                          \
     {                                                                                            \
         const double *Ar = p.CA + (bt0 + (t)) * p.Sc, *Br = p.CB + (bt0 + (t)) * p.Sc;           \
-        _Pragma("unroll") for (int i = 0; i < kGCRegs; ++i) {                                    \
+        _Pragma("unroll") for (int i = 0; i < REGS; ++i) {                                    \
             const int s = tid + i * kGCThreads;                                                  \
             if (s < Sx) { an[i] = Ar[s]; bn[i] = Br[s]; }                                        \
         }                                                                                        \
@@ -1916,10 +1946,10 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
     }
 #define CRF_GC_CONSUME()                                                                         \
     {                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < kGCRegs; ++i) prod[i] = (tid + i * kGCThreads < Sx) ? an[i] * bn[i] : 0.0; \
+        _Pragma("unroll") for (int i = 0; i < REGS; ++i) prod[i] = (tid + i * kGCThreads < Sx) ? an[i] * bn[i] : 0.0; \
         _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) rowc[q] = rown[q];                  \
     }
-    double prod[kGCRegs];
+    double prod[REGS];
     float rowc[kGCVRegs];
 #pragma unroll
     for (int q = 0; q < kGCVRegs; ++q) rown[q] = 0.f;
@@ -1938,7 +1968,7 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
         if (zc > 0.0) {
             float blank = 0.f;
 #pragma unroll
-            for (int i = 0; i < kGCRegs; ++i)
+            for (int i = 0; i < REGS; ++i)
                 if (tid + i * kGCThreads < Sx) {
                     const float pr = (float)(prod[i] * fc);  // a posterior, in [0,1]
                     if (tid & 1) atomicAdd(&g[mylab[i]], pr);
@@ -2406,40 +2436,34 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     // of the chip -- every queue of the process got slower, +1.5 ms per call; the start gate below does the job.)
     hipStream_t sA0 = stream, sA1 = stream, sB0 = stream, sB1 = stream;
     if (staged) { sA1 = cx->side[0]; sB0 = cx->side[1]; sB1 = cx->side[2]; }
-    // Segment bounds: nothing can be released before the two recursions have met, so the first segment is half of
-    // the frames; the second half is cut into `stages_env` pieces (each relaunch costs ~40 us; the last piece's
-    // blocks are the tail left after the recursions end).
+    // Stage bounds.  Nothing can be released before the two recursions have met, so the first stage ends at half of
+    // the frames or later; after that a piece of `piece` iterations releases 2 * piece / 16 frame blocks per
+    // utterance.  The grad pass has half of the chip and is bandwidth-bound there (~2 TB/s against the 1.9 TB/s the
+    // two recursions produce), so it just keeps up; what is left when the recursions end is the lag of about one
+    // stage plus the last stage.  Measured (B=64, T=1500): pieces of 64 / 96 / 128 iterations -> step 3.69 / 3.72 /
+    // 3.70 ms, 32 / 48 / 80 -> 4.19 / 3.90 / 3.96 (more launches, and pieces that are not a multiple of 4 blocks
+    // leave partial rounds).  CRF_PIECE / CRF_STAGES override (segment mode: 4 pieces, each relaunch costs ~40 us).
     int bound[kMaxStages + 1] = {0};
     int nstage = 1;
     bound[1] = (int)T;
     if (staged && T >= 256) {
-        // CRF_TAIL="32,16": shorter LAST pieces.  Measured: no gain -- a grad workgroup walks its 16 frames one after
-        // the other (~75 us alone on the chip), so a short piece takes as long as a 64-iteration one.
-        static const std::vector<int> tail_env = [] {
-            std::vector<int> v;
-            const char *s = getenv("CRF_TAIL");
-            for (const char *q = s ? s : ""; *q;) {
-                const int n = atoi(q);
-                if (n > 0) v.push_back((n + kGDFrames - 1) / kGDFrames * kGDFrames);
-                while (*q && *q != ',') ++q;
-                if (*q == ',') ++q;
-            }
-            return v;
-        }();
         const int half = (int)((T / 2 + kGDFrames - 1) / kGDFrames * kGDFrames);
-        int tail_sum = 0;
-        for (int n : tail_env) tail_sum += n;
-        const bool with_tail = !segmode && !tail_env.empty() && T - half >= tail_sum + 64 && (int)tail_env.size() + 3 <= kMaxStages;
-        const int ntail = with_tail ? (int)tail_env.size() : 0;
-        const int body_end = (int)T - (with_tail ? tail_sum : 0);
-        const int nshort = std::max(1, std::min(std::min(pieces, kMaxStages - 2 - ntail), (body_end - half) / 32));
-        int piece = (body_end - half + nshort - 1) / nshort;
-        piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
+        int piece, first = half;
+        if (stages_env > 0 || segmode) {
+            const int nshort = std::max(1, std::min(std::min(pieces, kMaxStages - 2), (int)(T - half) / 32));
+            piece = ((int)T - half + nshort - 1) / nshort;
+            piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
+        } else {
+            piece = 4 * kGDFrames;
+            while ((kMaxStages - 2) * piece < (int)T - half && piece < (int)T) piece += 4 * kGDFrames;   // the stage counters cover T - half
+            static const int piece_env = getenv("CRF_PIECE") ? atoi(getenv("CRF_PIECE")) : 0;
+            if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
+            const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
+            first = std::max(half, ((int)T - body + kGDFrames - 1) / kGDFrames * kGDFrames);
+        }
         nstage = 1;
-        bound[1] = half;
-        while (bound[nstage] < body_end && nstage < kMaxStages - ntail) { bound[nstage + 1] = std::min(body_end, bound[nstage] + piece); ++nstage; }
-        bound[nstage] = body_end;
-        for (int k = 0; k < ntail; ++k) { bound[nstage + 1] = std::min((int)T, bound[nstage] + tail_env[k]); ++nstage; }
+        bound[1] = first;
+        while (bound[nstage] < T && nstage < kMaxStages - 1) { bound[nstage + 1] = std::min((int)T, bound[nstage] + piece); ++nstage; }
         bound[nstage] = (int)T;
     }
     p.gd_nb = nstage + 1;
@@ -2523,14 +2547,23 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if (!st) st = stream;
         p.gd_stage = stage;
         const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + 4 * rup64((int)V) + kGDFrames + rup64(gnc)) * sizeof(float);
-        const dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
-        static std::atomic<size_t> set1{0}, set2{0};
-        if (gnc <= kGDThreads) {
-            if (l > set1.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set1 = l; }
-            hipLaunchKernelGGL(crf_grad_den_kernel<1>, gg, dim3(kGDThreads), l, st, p);
+        dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
+        p.gd_nf = 0;
+        static const bool full_grid = getenv("CRF_GD_FULL_GRID") && atoi(getenv("CRF_GD_FULL_GRID"));
+        if (stage > 1 && !full_grid) {   // (stage 1 is the middle of every utterance: all blocks are candidates)
+            p.gd_nf = (p.gd_bound[stage] - p.gd_bound[stage - 1] + kGDFrames - 1) / kGDFrames + 3;
+            if (2 * p.gd_nf < (int)gg.x) gg.x = (unsigned)(2 * p.gd_nf); else p.gd_nf = 0;
+        }
+        static std::atomic<size_t> set1{0}, set2{0}, set3{0};
+        if (gnc <= kGDThreads && V <= kGDThreads) {   // small vocabulary: 128 VGPRs, a fourth workgroup per CU
+            if (l > set3.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set3 = l; }
+            hipLaunchKernelGGL((crf_grad_den_kernel<1, 1>), gg, dim3(kGDThreads), l, st, p);
+        } else if (gnc <= kGDThreads) {
+            if (l > set1.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1, kGDEpRegs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set1 = l; }
+            hipLaunchKernelGGL((crf_grad_den_kernel<1, kGDEpRegs>), gg, dim3(kGDThreads), l, st, p);
         } else {
-            if (l > set2.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set2 = l; }
-            hipLaunchKernelGGL(crf_grad_den_kernel<2>, gg, dim3(kGDThreads), l, st, p);
+            if (l > set2.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<2, kGDEpRegs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set2 = l; }
+            hipLaunchKernelGGL((crf_grad_den_kernel<2, kGDEpRegs>), gg, dim3(kGDThreads), l, st, p);
         }
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad_den_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
@@ -2541,7 +2574,10 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
         if (fast_ctc) {
             const size_t l = (size_t)4 * rup64((int)V) * sizeof(float) + kGCFrames * sizeof(double);
             const dim3 gg((unsigned)((T + kGCFrames - 1) / kGCFrames), (unsigned)B);
-            hipLaunchKernelGGL(crf_grad_ctc_kernel, gg, dim3(kGCThreads), l, st, p);
+            const int Sxm = 2 * (int)max_label_len + 1;
+            if (Sxm <= 2 * kGCThreads) hipLaunchKernelGGL(crf_grad_ctc_kernel<2>, gg, dim3(kGCThreads), l, st, p);
+            else if (Sxm <= 4 * kGCThreads) hipLaunchKernelGGL(crf_grad_ctc_kernel<4>, gg, dim3(kGCThreads), l, st, p);
+            else hipLaunchKernelGGL(crf_grad_ctc_kernel<kGCRegs>, gg, dim3(kGCThreads), l, st, p);
         } else {
             hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, st, p);
         }
