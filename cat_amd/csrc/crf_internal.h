@@ -48,7 +48,9 @@ constexpr int kResWords = kResNCH * 6;
 constexpr int kResMaxK = 4;
 // second geometry of the factored kernels: 12 waves = 3 per SIMD, 21 chunks per thread (<= 168 VGPRs)
 constexpr int kFac3Threads = 768;
-constexpr int kFac3NCH = 21;
+constexpr int kFac3NCH = 21;       // chunk slots (6 words each) per thread: 20 hold arcs, the last holds row constants
+constexpr int kFac3ArcCh = 20;     // chunks of arcs per thread
+constexpr int kFac3MaxSl = 3;      // slices (row epilogues) per wave: two words of row constants each, at word kFac3ArcCh * 6 on
 
 struct ResDirDev {
     const unsigned *arcs;    // [K][kResWords][kResThreads]

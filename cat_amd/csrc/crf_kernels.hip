@@ -1306,7 +1306,16 @@ struct FacParams {
 template <int DIR, bool FLAG, int NTH, int NCH, int NB>
 __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
     constexpr int NW = NTH / kWave;
-    static_assert(NCH % NB == 0, "chunks per thread must be a multiple of the batch");
+    // 768-thread geometry: the last chunk slot of a thread holds ROW CONSTANTS instead of arcs -- two words for each of
+    // the (at most three) rows the lane finishes per frame -- and the entries of a row sit where its row id says
+    // (res_layout.cpp, "implicit"): a row epilogue asks for everything it needs from LDS in ONE round trip.  With a
+    // table of row constants in LDS it was a chain of three (constants -> the values they point to -> emissions),
+    // ~320 cycles of a wave's time per slice, 70 % of the frame loop (timing build).
+    constexpr bool RC = NTH == kFac3Threads;
+    constexpr int NCHA = RC ? kFac3ArcCh : NCH;              // chunk slots that hold arcs
+    constexpr int RCW = NCHA * 6;                            // first row-constant word
+    static_assert(NCHA % NB == 0, "chunks per thread must be a multiple of the batch");
+
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FacDirDev &L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1325,16 +1334,22 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
     if (tid == 0 && p.started && p.i0 == 0) atomicAdd(p.started, 1);   // this workgroup holds its CU: see crf_gate_kernel
 
     unsigned A[(NCH * 6)];
-    {
-        const unsigned *src = L.arcs + tid;
+    unsigned rc00 = 0, rc01 = 0, rc10 = 0, rc11 = 0, rc20 = 0, rc21 = 0;   // row constants of the lane's (up to) three rows: scalars,
+    {                                                                      // not array elements (a select between array elements
+        const unsigned *src = L.arcs + tid;                               // becomes a variable index and the array leaves the registers)
 #pragma unroll
-        for (int i = 0; i < (NCH * 6); ++i) A[i] = src[(size_t)i * NTH];
+        for (int i = 0; i < (RC ? RCW : NCH * 6); ++i) A[i] = src[(size_t)i * NTH];
+        if (RC) {
+            rc00 = src[(size_t)(RCW + 0) * NTH]; rc01 = src[(size_t)(RCW + 1) * NTH];
+            rc10 = src[(size_t)(RCW + 2) * NTH]; rc11 = src[(size_t)(RCW + 3) * NTH];
+            rc20 = src[(size_t)(RCW + 4) * NTH]; rc21 = src[(size_t)(RCW + 5) * NTH];
+        }
     }
     const uint4 wi = L.wave_info[wave];
     const unsigned ends = __builtin_amdgcn_readfirstlane(wi.x);
     const int nch = __builtin_amdgcn_readfirstlane(wi.y);
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
-    {
+    if (!RC) {
         int4 *RM = (int4 *)RMc;
         for (int r = tid; r < R; r += NTH) {
             int4 m = DIR == 0 ? p.frow_meta[r] : p.brow_meta[r];
@@ -1344,6 +1359,14 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
             }
             RM[r] = m;
         }
+    } else if (DIR == 1) {
+        f32x2 *RW = (f32x2 *)RMc;                            // the weights of the two extra arcs of a row
+        for (int r = tid; r < R; r += NTH) { const int4 m = p.brow_meta[r]; RW[r] = f32x2{__int_as_float(m.y), __int_as_float(m.z)}; }
+        auto fix = [&](unsigned w) {                         // labels: 0xffff = none -> emission 0 at EP[V]
+            const unsigned l0 = w & 0xffffu, l1 = w >> 16;
+            return (l0 == 0xffffu ? (unsigned)V : l0) | ((l1 == 0xffffu ? (unsigned)V : l1) << 16);
+        };
+        rc01 = fix(rc01); rc11 = fix(rc11); rc21 = fix(rc21);
     }
     // One launch runs the iterations [i0, i1) of the recursion ("segment"): the host cuts a long recursion into
     // a few launches so that the grad pass can be released stage by stage with stream events (a kernel that
@@ -1453,14 +1476,63 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
         CRF_TM(tm_on, tm_i + 1);
         unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
 #pragma unroll
-        for (int c0 = 0; c0 < NCH; c0 += NB) {
+        for (int c0 = 0; c0 < NCHA; c0 += NB) {
+            constexpr int nb = NB;
             if (c0 < nch_f) {
                 f32x2 g01[NB], g23[NB];
-                CRF_RES_GATHER_N(g01, g23, A, xb, c0, NB);
+                CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb);
 #pragma unroll
-                for (int ci = 0; ci < NB; ++ci) {
+                for (int ci = 0; ci < nb; ++ci) {
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
                     if (ends_f >> (c0 + ci) & 1u) {
+                        if constexpr (RC) {
+                            const unsigned ks = (unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u));   // slice number (uniform)
+                            // (masks, not ?: -- the compiler turns a three-way select of registers by a uniform index
+                            // into an indexed array, which it then cannot keep in registers)
+                            const unsigned s0 = 0u - (unsigned)(ks == 0), s1 = 0u - (unsigned)(ks == 1), s2 = 0u - (unsigned)(ks >= 2);
+                            const unsigned k0 = (rc00 & s0) | (rc10 & s1) | (rc20 & s2);
+                            const unsigned k1 = (rc01 & s0) | (rc11 & s1) | (rc21 & s2);
+                            if (DIR == 0) {   // k0 = main label | tail label << 16, k1 = tail weight; U, L, A at rid, R + rid, 2R + rid
+                                const float uold = *(const float *)(xb + r4);                   // U_t of the row's pair
+                                const float em = EPu[k0 & 0xffffu], et = EPu[k0 >> 16];
+                                const float rv = (acc.x + acc.y) * sc;                          // q_t[pair of the main state]
+                                const float qt = __uint_as_float(k1) * uold * sc;               // q_t[pair of the tail state]
+                                if (flagged) {
+                                    __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store((unsigned *)((char *)Orow + r4 + 4u * (unsigned)R), __float_as_uint(qt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                } else {
+                                    *(float *)((char *)Orow + r4) = rv;
+                                    *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
+                                }
+                                const float Lp = em * rv, Ap = et * qt, Up = Ap + Lp;           // a_{t+1}[main], [tail], their sum
+                                *(float *)(xnb + r4) = Up;
+                                *(float *)(xnb + r4 + dup) = Up;
+                                *(float *)(xnb + r4 + 4u * (unsigned)R) = Lp;
+                                *(float *)(xnb + r4 + 8u * (unsigned)R) = Ap;
+                                mymax = fmaxf(mymax, Up);
+                            } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16
+                                const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
+                                const float e0 = EPu[k1 & 0xffffu], e1 = EPu[k1 >> 16];
+                                const f32x2 w01 = *(const f32x2 *)(RMc + 2u * r4);
+                                const float craw = acc.x + acc.y;                               // common out-arcs of the row's states
+                                f32x2 bv;                                                        // b_t of the two states
+                                bv.x = fmaf(w01.x, z0, craw) * sc;
+                                bv.y = fmaf(w01.y, z1, craw) * sc;
+                                if (flagged)
+                                    __hip_atomic_store((unsigned long long *)((char *)Orow + 2u * r4),
+                                                       (unsigned long long)__float_as_uint(bv.x) | ((unsigned long long)__float_as_uint(bv.y) << 32),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                else
+                                    *(f32x2 *)((char *)Orow + 2u * r4) = bv;
+                                f32x2 zv;                                                        // z_{t-1} of the pairs entering them
+                                zv.x = e0 * bv.x;
+                                zv.y = e1 * bv.y;
+                                *(f32x2 *)(xnb + 2u * r4) = zv;
+                                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                                *(f32x2u *)(xnb + 2u * r4 + dup) = zv;
+                                mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
+                            }
+                        } else {
                         const int4 m = *(const int4 *)(RMc + 4u * r4);
                         if (DIR == 0) {
                             const float rv = (acc.x + acc.y) * sc;                      // q_t[pair of the main state]
@@ -1500,6 +1572,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                             typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
                             *(f32x2u *)(xnb + 2u * r4 + dup) = zv;   // the copy's distance is an odd number of floats: ds_write2_b32
                             mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
+                        }
                         }
                         acc = f32x2{0.f, 0.f};
                         r4 += kWave * 4u;
@@ -2239,7 +2312,7 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     return (size_t)2 * rup64(L.G) * 4 + (size_t)L.R * 16 +
            ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }
-constexpr int kFac3Batch = 3;
+constexpr int kFac3Batch = 4;
 template <int DIR, bool FLAG = false>
 static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *state,
                       int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {

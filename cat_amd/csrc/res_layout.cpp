@@ -22,9 +22,9 @@ namespace {
 typedef std::vector<std::vector<std::pair<int, float>>> Rows;
 
 // geometry of one resident workgroup: threads, waves, chunks per thread (registers), words per thread
-struct Geom { int threads, waves, nch, words; };
-constexpr Geom kGeomRes{kResThreads, kResWaves, kResNCH, kResWords};
-constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3NCH, kFac3NCH * 6};
+struct Geom { int threads, waves, nch, words, maxsl; };   // maxsl: slices per wave (0 = any number)
+constexpr Geom kGeomRes{kResThreads, kResWaves, kResNCH, kResWords, 0};
+constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3NCH * 6, kFac3MaxSl};
 
 struct DirOut {
     std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
@@ -39,7 +39,7 @@ struct DirOut {
 inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / kResW)); }
 
 // Step 1: decide where every row lives (CU, wave, slice, lane) from the row LENGTHS only.
-struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; };
+struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; int ord; };   // ord: number of the slice within its wave
 bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm = kGeomRes) {
     o->arcs.assign((size_t)K * gm.words * gm.threads, 0u);
     o->wave_info.assign((size_t)K * gm.waves, uint4{0u, 0u, 0u, 0u});
@@ -68,8 +68,10 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         for (int j = 0; j < nsl && packed; ++j) {
             int best = -1;
             for (int w = 0; w < gm.waves; ++w) {
-                if (load[w] + len[j] > gm.nch) continue;
-                if (best < 0 || load[w] > load[best]) best = w;
+                if (load[w] + len[j] > gm.nch || (gm.maxsl && cnt[w] >= gm.maxsl)) continue;
+                // with a limit on the slices per wave: longest-first onto the LEAST loaded wave (best fit fills a
+                // wave's slice count with long slices and strands the short ones)
+                if (best < 0 || (gm.maxsl ? load[w] < load[best] : load[w] > load[best])) best = w;
             }
             if (best < 0) { packed = false; break; }
             wave_of[j] = best; load[best] += len[j]; cnt[best]++;
@@ -94,7 +96,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                 const int ja = (int)(rnd() % (uint64_t)nsl), a_ = wave_of[ja];
                 if (rnd() & 1) {  // move
                     const int b_ = (int)(rnd() % gm.waves);
-                    if (b_ == a_ || load[b_] + len[ja] > gm.nch) continue;
+                    if (b_ == a_ || load[b_] + len[ja] > gm.nch || (gm.maxsl && cnt[b_] >= gm.maxsl)) continue;
                     load[a_] -= len[ja]; cnt[a_]--; load[b_] += len[ja]; cnt[b_]++; wave_of[ja] = b_;
                     const int64_t nw = objective();
                     if (nw <= cur || (double)(rnd() % 1000000) / 1e6 < std::exp(-(double)(nw - cur) / std::max(temp, 1.0))) cur = nw;
@@ -116,6 +118,22 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
             std::fill(cnt.begin(), cnt.end(), 0);
             for (int j = 0; j < nsl; ++j) { lists[wave_of[j]].push_back(j); load[wave_of[j]] += len[j]; cnt[wave_of[j]]++; }
             for (int w = 0; w < gm.waves; ++w) cost[w] = wcost(w);
+            if (gm.maxsl && gm.waves % 4 == 0 && !(getenv("CRF_RES_NO_SIMD_ORDER") && atoi(getenv("CRF_RES_NO_SIMD_ORDER")))) {
+                // Which wave gets which list: waves w, w + 4, w + 8 share a SIMD, which issues its OLDEST wave first
+                // (timing build: the last wave of a SIMD ends ~1000 cycles after the first, later still when it is
+                // a heavy one).  Heaviest lists to the oldest waves, dealt to the SIMDs in snake order so that the
+                // SIMD sums are even and the lightest lists come last.
+                std::vector<int> order(gm.waves);
+                for (int w = 0; w < gm.waves; ++w) order[w] = w;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+                std::vector<std::vector<int>> nl(gm.waves);
+                std::vector<int> nload(gm.waves), ncnt(gm.waves), ncost(gm.waves);
+                for (int i = 0; i < gm.waves; ++i) {
+                    const int round = i / 4, pos = i % 4, w = round * 4 + ((round & 1) ? 3 - pos : pos);
+                    nl[w] = lists[order[i]]; nload[w] = load[order[i]]; ncnt[w] = cnt[order[i]]; ncost[w] = cost[order[i]];
+                }
+                lists = nl; load = nload; cnt = ncnt; cost = ncost;
+            }
             if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"))) {
                 fprintf(stderr, "[res_layout] lens:");
                 for (int j = 0; j < nsl; ++j) fprintf(stderr, " %d", len[j]);
@@ -131,9 +149,10 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
             unsigned ends = 0;
             int c0 = 0;
             const int wave_row0 = rid;
+            int ord = 0;
             for (int j : lists[w]) {
                 ends |= 1u << (c0 + len[j] - 1);
-                SliceAt sl{k, w, c0, len[j], rid, {}};
+                SliceAt sl{k, w, c0, len[j], rid, {}, ord++};
                 for (int lane = 0; lane < kWave; ++lane) {
                     const size_t pos = (size_t)j * kWave + lane;
                     const int r = pos < mine.size() ? mine[pos] : -1;
@@ -836,7 +855,12 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (nmatched * 4 < S) return give_up("fewer than half of the states form (tail, main) pairs");
     std::vector<char> is_tail(S, 0);
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) is_tail[tail_of[s]] = 1;
-    // entries: [U of every pair][L of every pair][A of every pair][plain states][sink]
+    // Geometry: 768 threads (3 waves per SIMD at <= 168 VGPRs; 20 chunks of arcs and the constants of up to 3 rows per
+    // thread) when both directions fit it, else 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces
+    // the latter.
+    const Geom *gm = allow3 ? &kGeomFac3 : &kGeomRes;
+    const bool implicit = gm->maxsl > 0;   // entries numbered by row id, row constants in registers (below)
+    // entries (512-thread layout): [U of every pair][sink][L of every pair][A of every pair][plain states]
     std::vector<int> entU(S, -1), ent(S, -1);   // entU: by main state; ent: a[s] itself (L, A or plain)
     // ... and a SECOND copy of the U entries (and the sink, which padding rows write) behind everything, on
     // other banks: [U][sink][L][A][plain] [pad] [U'][sink'] -- see pack_arcs
@@ -844,15 +868,11 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     static const bool no_dup = getenv("CRF_FAC_NO_DUP") && atoi(getenv("CRF_FAC_NO_DUP"));
     int nent = 0;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) entU[s] = nent++;
-    const int nU = nent;
-    const int sink = nent++;
+    int nU = nent;
+    int sink = nent++;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) ent[s] = nent++;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) ent[tail_of[s]] = nent++;
     for (int s = 0; s < S; ++s) if (ent[s] < 0) ent[s] = nent++;
-    int fdup = 0;                                        // entries between the two copies
-    if (!no_dup) { fdup = nent; while ((fdup & 31) != bank_shift) ++fdup; }
-    const int Gf = fdup ? fdup + nU + 1 : nent;
-    if ((size_t)Gf * 4 > 65536) return give_up("forward gather vector > 64 KiB");
     const int64_t nsolo = 0;
     // rows: every pair except the tail rows
     std::vector<int> main_rows;
@@ -876,17 +896,42 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             else fsub[i].push_back({ent[s], a[u].second});
         }
     }
-    // Geometry: 768 threads x 21 chunks (3 waves per SIMD at <= 168 VGPRs) when both directions fit it, else
-    // 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces the latter.
-    const Geom *gm = allow3 ? &kGeomFac3 : &kGeomRes;
     DirOut fo;
     std::vector<SliceAt> fslices;
     if (!place_rows(fsub, std::vector<int>(fsub.size(), 0), 1, &fo, &fslices, *gm)) {
         if (allow3) { *retry512 = true; return CRF_OK; }
         return give_up("forward rows do not fit one CU");
     }
-    pack_arcs(fsub, fslices, &fo, 4, *gm, fdup ? nU : 0, fdup);
     const int Rf = fo.cu_row_off[1];
+    if (implicit) {
+        // 768-thread layout: the entries of a row are where its row id says -- U at rid, L at Rf + rid, A at 2 Rf + rid
+        // (then the states nobody enters, a zero entry for padding gathers, and the second copy of the U entries) -- so
+        // a row epilogue needs no table to find them: what is left of the row constants (two labels, the tail weight)
+        // lives in two registers per slice.  The epilogue was a chain of three LDS round trips (constants -> the
+        // values they point to -> emissions), 70 % of the frame loop in the timing build.
+        std::vector<int> remap(nent, -1);
+        std::vector<int> nentU(S, -1), nentS(S, -1);
+        for (size_t r = 0; r < main_rows.size(); ++r) {
+            const int rid = fo.rid_of_row[r], s = pair_dst[main_rows[r]];
+            nentS[s] = Rf + rid;
+            if (tail_of[s] >= 0) { nentU[s] = rid; nentS[tail_of[s]] = 2 * Rf + rid; }
+        }
+        int nx = 3 * Rf;
+        for (int s = 0; s < S; ++s) if (nentS[s] < 0) nentS[s] = nx++;
+        const int nsink = nx++;
+        for (int s = 0; s < S; ++s) { remap[ent[s]] = nentS[s]; if (entU[s] >= 0) remap[entU[s]] = nentU[s]; }
+        remap[sink] = nsink;
+        for (auto &row : fsub) for (auto &a : row) a.first = remap[a.first];
+        ent = nentS; entU = nentU; sink = nsink; nent = nx; nU = Rf;
+    }
+    int fdup = 0;                                        // entries between the two copies
+    if (!no_dup) { fdup = nent; while ((fdup & 31) != bank_shift) ++fdup; }
+    const int Gf = fdup ? fdup + nU + 1 : nent;
+    if ((size_t)Gf * 4 > 65536) {
+        if (allow3) { *retry512 = true; return CRF_OK; }
+        return give_up("forward gather vector > 64 KiB");
+    }
+    pack_arcs(fsub, fslices, &fo, 4, *gm, fdup ? nU : 0, fdup);
     const int NT = 0;
     std::vector<int> fpos(P, -1);   // position of pair p in the Q row: main rows [0, Rf), their tails [Rf, 2 Rf)
     std::vector<int4> frow_meta(Rf, int4{sink * 4, (sink * 4) | ((sink * 4) << 16), 0, 0});   // padding rows: all to the sink
@@ -903,6 +948,16 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             frow_meta[rid] = int4{(sink * 4) | (pair_lab[p] << 16), (ent[s] * 4) | ((sink * 4) << 16), 0, 0};
         }
     }
+    if (implicit)   // row constants of the slice number `ord` of a wave: words (kFac3ArcCh * 6 + 2 * ord) and the next of its threads
+        for (const SliceAt &sl : fslices)
+            for (int lane = 0; lane < kWave; ++lane) {
+                const int rid = sl.rid0 + lane, r = fo.row_of[rid];
+                if (r < 0) continue;
+                const int4 m = frow_meta[rid];
+                const size_t t = (size_t)sl.w * kWave + lane, w0 = (size_t)kFac3ArcCh * 6 + 2 * (size_t)sl.ord;
+                fo.arcs[w0 * gm->threads + t] = ((unsigned)m.x >> 16) | ((unsigned)m.w << 16);   // main label | tail label << 16
+                fo.arcs[(w0 + 1) * gm->threads + t] = (unsigned)m.z;                             // tail weight (0: no tail)
+            }
     const int Rq = 2 * Rf;
     std::vector<float> x_start(Gf, 0.f), x_end(Gf, 0.f);
     for (int s = 0; s < S; ++s) {
@@ -910,7 +965,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         x_end[ent[s]] = end_lin[s];
         if (tail_of[s] >= 0) x_start[entU[s]] = start_lin[s] + start_lin[tail_of[s]];
     }
-    if (fdup) for (int u = 0; u < nU; ++u) x_start[fdup + u] = x_start[u];
+    if (fdup) for (int u = 0; u < nU; ++u) x_start[fdup + u] = x_start[u];   // (implicit layout: nU = Rf, unused U slots are 0)
     std::vector<int4> ftail(1, int4{0, 0, 0, 0});
     std::vector<int> tail_rows;   // (statistics only)
     for (int s = 0; s < S; ++s) if (is_tail[s]) tail_rows.push_back(s);
@@ -998,6 +1053,15 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     }
 
     if (bdup) for (int z = 0; z < 2 * Rb; ++z) { z_lab[bdup + z] = z_lab[z]; z_end[bdup + z] = z_end[z]; }
+    if (implicit)   // row constants in registers: {extra-arc z offsets, labels (0xffff = none)}; the two extra weights stay in LDS
+        for (const SliceAt &sl : bslices)
+            for (int lane = 0; lane < kWave; ++lane) {
+                const int rid = sl.rid0 + lane;
+                const int4 m = brow_meta[rid];
+                const size_t t = (size_t)sl.w * kWave + lane, w0 = (size_t)kFac3ArcCh * 6 + 2 * (size_t)sl.ord;
+                bo.arcs[w0 * gm->threads + t] = (unsigned)m.x;
+                bo.arcs[(w0 + 1) * gm->threads + t] = (unsigned)m.w;
+            }
 
     // ---- 5. grad pass list: one (Q position, BP position) per pair, label-sorted (pairs already are), chunked
     const int max_lab = *std::max_element(pair_lab.begin(), pair_lab.end());

@@ -55,12 +55,13 @@ def main():
             v = [rows[f + 1][0] - rows[f][0] for f in range(127)]
             print(f"   {'frame total':32s} median {statistics.median(v):8.0f} cyc")
     print("per-wave compute time (cycles, median of 8 frames) vs chunks / slices of the wave:")
+    nw = 12 if fac else 8
     for d, dn in enumerate(("fwd", "bwd")):
-        for k in range(2):
+        for k in range(1 if fac else 2):
             line = []
-            for w in range(8):
+            st = [tm[12288 + 1024 + (d * 4 + k) * 8 + f] for f in range(8)]
+            for w in range(nw):
                 o = 12288 + ((d * 4 + k) * 8 + w) * 16
-                st = [tm[12288 + 1024 + (d * 4 + k) * 8 + f] for f in range(8)]
                 v = [tm[o + f] - st[f] for f in range(8)]
                 line.append(f"w{w}: {statistics.median(v):5.0f} ({tm[o + 8]:2d}ch,{tm[o + 9]:2d}sl)")
             print(f"   den {dn} CU {k}: " + "  ".join(line))
