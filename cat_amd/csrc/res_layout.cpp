@@ -1008,6 +1008,16 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             if (!fused) { brow.push_back(BRow{s, -1, out_arcs_of_state[s], -1, -1, 0.f, 0.f}); done[s] = 1; }
         }
     }
+    // Rows in label order (rows of equal length keep it through the placement): the 32 lanes of a half-wave then look up
+    // the emission of one or two labels in their epilogue -- a broadcast -- instead of up to 32 (bank conflicts).  The
+    // forward rows are pairs, which are label-sorted already.
+    {
+        auto key = [&](const BRow &r) {
+            const int l0 = pair_of[r.s0] >= 0 ? pair_lab[pair_of[r.s0]] : -1, l1 = (r.s1 >= 0 && pair_of[r.s1] >= 0) ? pair_lab[pair_of[r.s1]] : -1;
+            return std::max(l0, l1);
+        };
+        std::stable_sort(brow.begin(), brow.end(), [&](const BRow &a, const BRow &b) { return key(a) < key(b); });
+    }
     Rows bsub(brow.size());
     for (size_t i = 0; i < brow.size(); ++i) bsub[i] = brow[i].arcs;   // pair ids for now; lengths are all placement needs
     DirOut bo;
