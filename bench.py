@@ -214,8 +214,8 @@ def main():
                                    f"H={args.histories}, d={args.fanout}, seed 0): S={dims['S']} states, "
                                    f"A={dims['A']} arcs, P={dims['P']} (dst,label) pairs; "
                                    f"{'ragged lx' if args.ragged else 'lx = T'}, ly = lx//6, lamb={args.lamb}",
-                       "den_kernels": ("factored register-resident, 1 CU per recursion, launched in segments (the roofline kernel's "
-                                       "duration is the span of its segments)" if gstats.get("fac") else
+                       "den_kernels": ("factored register-resident, 1 CU per recursion and utterance, one launch each; the grad "
+                                       "pass follows them in stages released by stream-level waits" if gstats.get("fac") else
                                        f"register-resident, K={gstats['res_K']} CUs per recursion" if gstats["res_K"] > 0 else "streaming"),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch sharded, no data-path collective)"},
             "loss": round(loss_val, 6),

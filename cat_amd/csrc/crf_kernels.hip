@@ -1431,6 +1431,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
         ++next_stage;
         next_bound = next_stage < p.nb ? p.bound[next_stage] : 0x7fffffff;
     };
+    float epn[kEpRegsR] = {};                               // next emission row, in flight across the frame (waves that hold emissions only)
     auto frame = [&](const int par, int i) __attribute__((always_inline)) {
         const int t = DIR == 0 ? i : lx - 1 - i;
         if (FLAG && i == next_bound) publish_stage();
@@ -1444,16 +1445,13 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
         char *xnb = (char *)lds + (1 - par) * XB;
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
         const int tpre = DIR == 0 ? t + 1 : t - 2;
-        #ifdef CRF_EXP_NOEP
-        const bool pre = false;
-#else
-        const bool pre = DIR == 0 ? (t + 1 < lx) : (t >= 2);
-#endif
-        float epn[kEpRegsR];
+        // (only the waves that hold emissions take part in the prefetch: the compiler waits for vmcnt(0) around these
+        // loads -- i.e. for the acknowledgement of the previous frame's row stores -- and the other waves need not)
+        const bool pre = (DIR == 0 ? (t + 1 < lx) : (t >= 2)) && wave * kWave < V;
         if (pre) {
             const float *er = p.ep + (bt0 + tpre) * V;
 #pragma unroll
-            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; epn[q] = v < V ? er[v] : 0.f; }
+            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; if (v < V) epn[q] = er[v]; }
         }
         const int ksc = rescale_exp(res_frame_max<NW>(wm + par * NW));
         const float sc = pow2f(ksc);
@@ -2312,7 +2310,13 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     return (size_t)2 * rup64(L.G) * 4 + (size_t)L.R * 16 +
            ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }
-constexpr int kFac3Batch = 4;
+#ifndef CRF_FAC3_NB_F
+#define CRF_FAC3_NB_F 4
+#endif
+#ifndef CRF_FAC3_NB_B
+#define CRF_FAC3_NB_B 4
+#endif
+#define kFac3Batch (DIR == 0 ? CRF_FAC3_NB_F : CRF_FAC3_NB_B)   // chunks gathered per batch (20 chunks of arcs per thread)
 template <int DIR, bool FLAG = false>
 static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *state,
                       int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
