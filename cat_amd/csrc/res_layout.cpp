@@ -81,8 +81,15 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         if (packed) {
             auto wcost = [&](int w) { return load[w] + kEpiCost * cnt[w]; };
             // objective: (max cost, sum of squares) lexicographically, folded into one number
+            const bool by_simd = gm.maxsl && gm.waves % 4 == 0 && !(getenv("CRF_RES_NO_SIMD_ORDER") && atoi(getenv("CRF_RES_NO_SIMD_ORDER")));
             auto objective = [&]() {
                 int64_t mx = 0, sq = 0;
+                if (by_simd) {   // waves w, w + 4, w + 8 share a SIMD and take turns on it: what the frame waits for is the busiest SIMD
+                    int64_t g[4] = {0, 0, 0, 0};
+                    for (int w = 0; w < gm.waves; ++w) { const int64_t c = wcost(w); g[w & 3] += c; sq += c * c; }
+                    for (int i = 0; i < 4; ++i) mx = std::max(mx, g[i]);
+                    return mx * 1000000 + sq;
+                }
                 for (int w = 0; w < gm.waves; ++w) { const int64_t c = wcost(w); mx = std::max(mx, c); sq += c * c; }
                 return mx * 1000000 + sq;
             };
@@ -118,21 +125,19 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
             std::fill(cnt.begin(), cnt.end(), 0);
             for (int j = 0; j < nsl; ++j) { lists[wave_of[j]].push_back(j); load[wave_of[j]] += len[j]; cnt[wave_of[j]]++; }
             for (int w = 0; w < gm.waves; ++w) cost[w] = wcost(w);
-            if (gm.maxsl && gm.waves % 4 == 0 && !(getenv("CRF_RES_NO_SIMD_ORDER") && atoi(getenv("CRF_RES_NO_SIMD_ORDER")))) {
-                // Which wave gets which list: waves w, w + 4, w + 8 share a SIMD, which issues its OLDEST wave first
-                // (timing build: the last wave of a SIMD ends ~1000 cycles after the first, later still when it is
-                // a heavy one).  Heaviest lists to the oldest waves, dealt to the SIMDs in snake order so that the
-                // SIMD sums are even and the lightest lists come last.
-                std::vector<int> order(gm.waves);
-                for (int w = 0; w < gm.waves; ++w) order[w] = w;
-                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-                std::vector<std::vector<int>> nl(gm.waves);
-                std::vector<int> nload(gm.waves), ncnt(gm.waves), ncost(gm.waves);
-                for (int i = 0; i < gm.waves; ++i) {
-                    const int round = i / 4, pos = i % 4, w = round * 4 + ((round & 1) ? 3 - pos : pos);
-                    nl[w] = lists[order[i]]; nload[w] = load[order[i]]; ncnt[w] = cnt[order[i]]; ncost[w] = cost[order[i]];
+            if (by_simd) {
+                // Within a SIMD the OLDEST wave is issued first (timing build: the last wave of a SIMD ends ~1000 cycles
+                // after the first, later still when it is a heavy one): heaviest list to the lowest wave id.
+                for (int g = 0; g < 4; ++g) {
+                    std::vector<int> ws;
+                    for (int w = g; w < gm.waves; w += 4) ws.push_back(w);
+                    std::vector<int> order = ws;
+                    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+                    std::vector<std::vector<int>> nl;
+                    std::vector<int> nload, ncnt, ncost;
+                    for (int w : order) { nl.push_back(lists[w]); nload.push_back(load[w]); ncnt.push_back(cnt[w]); ncost.push_back(cost[w]); }
+                    for (size_t i = 0; i < ws.size(); ++i) { lists[ws[i]] = nl[i]; load[ws[i]] = nload[i]; cnt[ws[i]] = ncnt[i]; cost[ws[i]] = ncost[i]; }
                 }
-                lists = nl; load = nload; cnt = ncnt; cost = ncost;
             }
             if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"))) {
                 fprintf(stderr, "[res_layout] lens:");
