@@ -114,6 +114,8 @@ struct FacDev {
     const int *z_lab;          // [Gb] label of each z entry (V = none)
     const float *z_end;        // [Gb] exp(end weight) of the entry's state
     const float *brow_start, *brow_end;  // [2*Rb] per output
+    const int *bx_idx; const float *bx_w; int nbx; float bx_se;   // states without a row (nobody enters them): z entry and start * weight of each
+                               // of their arcs, added to the backward logZ after the last frame; bx_se = their start * end (empty utterance)
     // grad pass
     const int *gq, *gb, *chunk_off, *lab_chunk_off;
     int NC;

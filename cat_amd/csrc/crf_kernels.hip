@@ -1294,6 +1294,7 @@ struct FacParams {
     const int4 *brow_meta;
     const int *z_lab;
     const float *z_end, *brow_start, *brow_end;
+    const int *bx_idx; const float *bx_w; int nbx; float bx_se;   // rowless states of the backward recursion (FacDev)
     float *cb_part;
     double *cb_mxs;
     int *cb_F;
@@ -1431,6 +1432,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
         ++next_stage;
         next_bound = next_stage < p.nb ? p.bound[next_stage] : 0x7fffffff;
     };
+    float last_sc = 1.f;                                     // scale of the last frame (rowless states, after the loop)
     float epn[kEpRegsR] = {};                               // next emission row, in flight across the frame (waves that hold emissions only)
     auto frame = [&](const int par, int i) __attribute__((always_inline)) {
         const int t = DIR == 0 ? i : lx - 1 - i;
@@ -1455,6 +1457,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
         }
         const int ksc = rescale_exp(res_frame_max<NW>(wm + par * NW));
         const float sc = pow2f(ksc);
+        if (DIR == 1) last_sc = sc;
         float *Orow;
         if (DIR == 0) {
             E += ksc;
@@ -1619,7 +1622,11 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
             __syncthreads();  // drains vmcnt: this workgroup's own stores to the spare row are visible to it
             const float *r0 = p.Row0 + (int64_t)b * p.Rout;
             for (int r = tid; r < 2 * R; r += NTH) zpart += p.brow_start[r] * r0[r];
-        }
+            // states without a row: b_0 = (sum over their arcs of w * z_0) * (scale of the last frame); z_0 is the vector the
+            // last frame read
+            const float *Xl = X + ((lx - 1) & 1) * Gp;
+            for (int a = tid; a < p.nbx; a += NTH) zpart += p.bx_w[a] * Xl[p.bx_idx[a]] * last_sc;
+        } else if (tid == 0) zpart += p.bx_se * pow2f(kScaleExp);
         const float zb = res_block_sum<NW>(zpart, (float *)red, tid);
         const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
         if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E; p.cb_mxs[b] = mxs; }
@@ -2336,6 +2343,7 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     }
     FacParams p{};
     p.L = DIR == 0 ? F.f : F.b;
+    p.bx_idx = F.bx_idx; p.bx_w = F.bx_w; p.nbx = F.nbx; p.bx_se = F.bx_se;
     p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;

@@ -979,11 +979,41 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     struct BRow { int s0, s1; std::vector<std::pair<int, float>> arcs; int e0 = -1, e1 = -1; float w0 = 0.f, w1 = 0.f; };  // arcs: (pair, w)
     std::vector<BRow> brow;
     int64_t nfused = 0;
+    // States that no arc enters are never gathered: their b_t is needed once, at t = 0, for logZ of the backward
+    // recursion (costs_beta).  They get no row; the kernel adds start * sum_arcs w * z_0 after its last frame (bx list).
+    // In T o LM that is the start state -- and with 2^k histories the row it does not take is the one that would have
+    // opened another slice of 64 rows for itself.
+    std::vector<int> bx_idx;
+    std::vector<float> bx_w;
+    float bx_se = 0.f;
+    std::vector<char> no_row(S, 0);
+    for (int s = 0; s < S; ++s)
+        if (pair_of[s] < 0 && mate[s] < 0) { no_row[s] = 1; bx_se += start_lin[s] * end_lin[s]; }
+    // ... and the states the forward matching left alone may still share a backward row (common out-arcs, at most one
+    // extra arc each): (history 0, blank) and (history 0, token) in T o LM, whose forward structure the start state spoils
+    std::vector<int> bmate = mate;
+    {
+        std::vector<int> alone;
+        for (int s = 0; s < S; ++s) if (mate[s] < 0 && !no_row[s]) alone.push_back(s);
+        if (alone.size() <= 64)
+            for (size_t i = 0; i < alone.size(); ++i)
+                for (size_t j = i + 1; j < alone.size() && bmate[alone[i]] < 0; ++j) {
+                    const int s = alone[i], m = alone[j];
+                    if (bmate[m] >= 0) continue;
+                    std::vector<std::pair<int, unsigned>> a, b, common;
+                    for (auto &x : out_arcs_of_state[s]) a.push_back({x.first, wbits(x.second)});
+                    for (auto &x : out_arcs_of_state[m]) b.push_back({x.first, wbits(x.second)});
+                    std::sort(a.begin(), a.end());
+                    std::sort(b.begin(), b.end());
+                    std::set_intersection(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(common));
+                    if (!common.empty() && a.size() - common.size() <= 1 && b.size() - common.size() <= 1) { bmate[s] = m; bmate[m] = s; }
+                }
+    }
     {
         std::vector<char> done(S, 0);
         for (int s = 0; s < S; ++s) {
-            if (done[s]) continue;
-            const int m = mate[s];
+            if (done[s] || no_row[s]) continue;
+            const int m = bmate[s];
             bool fused = false;
             if (m > s) {
                 std::vector<std::pair<int, unsigned>> a, b;
@@ -1046,6 +1076,10 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     auto zof_pair = [&](int p) { return zpos[pair_dst[p]]; };
     for (auto &row : bsub)
         for (auto &a : row) a.first = zof_pair(a.first);
+    for (int s = 0; s < S; ++s)   // rowless states: b_0[s] * start[s] = start[s] * sum over their arcs of w * z_0[pair]
+        if (no_row[s] && start_lin[s] != 0.f)
+            for (auto &a : out_arcs_of_state[s]) { bx_idx.push_back(zof_pair(a.first)); bx_w.push_back(a.second * start_lin[s]); }
+    if (bx_idx.empty()) { bx_idx.push_back(zsink); bx_w.push_back(0.f); }
     pack_arcs(bsub, bslices, &bo, 4, *gm, bdup ? 2 * Rb : 0, bdup);
     const int noLab = -1;
     std::vector<int4> brow_meta(Rb, int4{(zsink * 4) | ((zsink * 4) << 16), 0, 0, (noLab & 0xffff) | (noLab << 16)});
@@ -1099,6 +1133,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (verbose)
         fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
                 (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
+    F.nbx = (int)bx_idx.size(); F.bx_se = bx_se;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
     F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads;
     int rc;
@@ -1106,7 +1141,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         (rc = up(h, bo.wave_info, &F.b.wave_info)) || (rc = up(h, frow_meta, &F.frow_meta)) ||
         (rc = up(h, x_start, &F.x_start)) || (rc = up(h, x_end, &F.x_end)) || (rc = up(h, brow_meta, &F.brow_meta)) ||
         (rc = up(h, z_lab, &F.z_lab)) || (rc = up(h, z_end, &F.z_end)) || (rc = up(h, brow_start, &F.brow_start)) ||
-        (rc = up(h, brow_end, &F.brow_end)) || (rc = up(h, gq, &F.gq)) || (rc = up(h, gb, &F.gb)) ||
+        (rc = up(h, brow_end, &F.brow_end)) || (rc = up(h, bx_idx, &F.bx_idx)) || (rc = up(h, bx_w, &F.bx_w)) || (rc = up(h, gq, &F.gq)) || (rc = up(h, gb, &F.gb)) ||
         (rc = up(h, gchunk, &F.chunk_off)) || (rc = up(h, glab, &F.lab_chunk_off)))
         return rc;
     F.ok = 1;
