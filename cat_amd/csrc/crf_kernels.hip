@@ -2523,11 +2523,12 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     if (staged) { sA1 = cx->side[0]; sB0 = cx->side[1]; sB1 = cx->side[2]; }
     // Stage bounds.  Nothing can be released before the two recursions have met, so the first stage ends at half of
     // the frames or later; after that a piece of `piece` iterations releases 2 * piece / 16 frame blocks per
-    // utterance.  The grad pass has half of the chip and is bandwidth-bound there (~2 TB/s against the 1.9 TB/s the
-    // two recursions produce), so it just keeps up; what is left when the recursions end is the lag of about one
-    // stage plus the last stage.  Measured (B=64, T=1500): pieces of 64 / 96 / 128 iterations -> step 3.69 / 3.72 /
-    // 3.70 ms, 32 / 48 / 80 -> 4.19 / 3.90 / 3.96 (more launches, and pieces that are not a multiple of 4 blocks
-    // leave partial rounds).  CRF_PIECE / CRF_STAGES override (segment mode: 4 pieces, each relaunch costs ~40 us).
+    // utterance.  The grad pass has half of the chip and is bandwidth-bound there (~2 TB/s against the 2.2 TB/s the
+    // two recursions produce), with a fixed cost per stage (launch, the workgroups' set-up, partial rounds); what is
+    // left when the recursions end is its backlog plus the last stage.  Measured (B=64, T=1500, recursions 2.95 ms):
+    // pieces of 32 / 48 / 64 / 96 / 128 / 192 / 256 / 384 iterations -> step 3.88 / 3.62 / 3.42 / 3.38 / 3.33 / 3.35 /
+    // 3.41 / 3.53 ms; pieces that shrink towards the end (256,192,128,96,64 ...) were no better than equal ones.
+    // CRF_PIECE / CRF_STAGES override (segment mode: 4 pieces, each relaunch costs ~40 us).
     int bound[kMaxStages + 1] = {0};
     int nstage = 1;
     bound[1] = (int)T;
@@ -2539,8 +2540,8 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
             piece = ((int)T - half + nshort - 1) / nshort;
             piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
         } else {
-            piece = 4 * kGDFrames;
-            while ((kMaxStages - 2) * piece < (int)T - half && piece < (int)T) piece += 4 * kGDFrames;   // the stage counters cover T - half
+            piece = 8 * kGDFrames;
+            while ((kMaxStages - 2) * piece < (int)T - half && piece < (int)T) piece += 8 * kGDFrames;   // the stage counters cover T - half
             static const int piece_env = getenv("CRF_PIECE") ? atoi(getenv("CRF_PIECE")) : 0;
             if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
             const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
