@@ -1,0 +1,25 @@
+#!/bin/bash
+# tools/gpu_points.sh TAG -- the other measurement points of SURVEY 8(d): ragged lengths, other batch shapes, small and
+# large synthetic den_lm (one JSON line each, no CPU baseline)
+TAG=${1:-r1}
+OUT=$PWD/gpurun_out; mkdir -p $OUT
+run() { name=$1; shift; timeout 600 python bench.py --no-cpu-baseline "$@" > $OUT/pt_${TAG}_$name.json 2> $OUT/pt_${TAG}_$name.err || tail -3 $OUT/pt_${TAG}_$name.err
+  python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/pt_${TAG}_$name.json"))
+    k = d["roofline"]["kernels_ms"]
+    print("$name: %.0f utt/s, %.3f ms/step, den fwd/bwd %.2f/%.2f ms, S=%s" % (d["value"], d["ms_per_step"], k.get("den_fwd_chain", -1), k.get("den_bwd_chain", -1), d["config"]["workload"].split("S=")[1].split(",")[0]))
+except Exception as e:
+    print("$name: no result", e)
+PY
+}
+run ragged --ragged
+run lamb001 --lamb 0.01
+run B128 --B 128 --steps 10
+run B32 --B 32
+run B16 --B 16
+run C2 --B 32 --T 500
+run T3000 --T 3000 --steps 10
+run small --histories 256 --fanout 16
+run large --histories 8192 --fanout 32 --steps 3 --warmup 1

@@ -76,13 +76,13 @@ def main():
     json.dump(doc, open(os.path.join(PROF, f"round1_{tag}_pmc.json"), "w"), indent=1)
     tr = {}
     for k, v in traffic.items():   # HBM bytes of one whole recursion = all its segment launches of one call
-        if "crf_res_chain_kernel<0>" in k or "crf_fac_chain_kernel<0>" in k:
+        if "crf_res_chain_kernel<0" in k or "crf_fac_chain_kernel<0" in k:
             tr["den_fwd_chain"] = int((v.get("FETCH_SIZE_KB_per_call", 0) + v.get("WRITE_SIZE_KB_per_call", 0)) * 1024)
-        if "crf_res_chain_kernel<1>" in k or "crf_fac_chain_kernel<1>" in k:
+        if "crf_res_chain_kernel<1" in k or "crf_fac_chain_kernel<1" in k:
             tr["den_bwd_chain"] = int((v.get("FETCH_SIZE_KB_per_call", 0) + v.get("WRITE_SIZE_KB_per_call", 0)) * 1024)
     if tr:
-        tr["source"] = (f"profiles/round1_{tag}_pmc.json: (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per call of the loss, summed over the "
-                        "recursion's segment launches; the chain kernels' reads are small and not 16-byte streams, so FETCH_SIZE is not doubled")
+        tr["source"] = (f"profiles/round1_{tag}_pmc.json: (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per call of the loss (one launch per recursion); "
+                        " the chain kernels' reads are small and not 16-byte streams, so FETCH_SIZE is not doubled")
         json.dump(tr, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(tr, indent=1))
     for k, v in traffic.items():
