@@ -53,6 +53,13 @@ struct LossParams {
     float c_den, c_ctc;
     // workspace
     float *ep, *mx;               // [B*T*V] exp(logp - mx), [B*T] row max
+    // fused log_softmax (crf_loss_fwd_bwd_logits): `logp` points to RAW logits of type in_dtype (0 f32, 1 bf16, 2 f16);
+    // log_softmax(x)[v] - rowmax = x[v] - max x, so everything that works on differences to the row maximum is unchanged:
+    // only the per-frame OFFSET that enters the log-likelihoods differs (moff = max x - lse x = -log sum exp(x - max x);
+    // without fusion moff = mx), and the gradient w.r.t. x gets the softmax term of log_softmax's backward
+    // (inv_s = 1 / sum exp(x - max x); applied by the numerator half of the grad pass, which runs once per call).
+    int fused, in_dtype;
+    float *moff, *inv_s;          // [B*T]
     float *Q, *BP;                // [B*T*Rq] q_t[row], [B*T*Rb] b_{t+1}[row]  (scaled)
     int Rq, Rb;                   // their row strides
     const int *gq, *gb;           // label-sorted pair list -> index into a Q row / a BP row
@@ -180,6 +187,14 @@ __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned
 // ---------------------------------------------------------------------------------------------
 // prep: e[b][t][v] = exp(logp[b][t][v] - max_v) * 2^kEpExp, mx[b][t] = max_v   (one wave per frame)
 // ---------------------------------------------------------------------------------------------
+// element `i` of the network output: fp32 log-probs (reference interface) or, fused, raw logits in fp32 / bf16 / fp16
+__device__ __forceinline__ float ld_x(const LossParams &p, int64_t i) {
+    if (p.in_dtype == 0) return p.logp[i];
+    const unsigned short u = ((const unsigned short *)p.logp)[i];
+    if (p.in_dtype == 1) return __uint_as_float((unsigned)u << 16);
+    return (float)__builtin_bit_cast(_Float16, u);
+}
+
 __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     const int lane = threadIdx.x & 63;
     // the counters of the staged schedule start at zero in every call (a memset in the stream cost two more
@@ -190,13 +205,22 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     if (f >= (int64_t)p.B * p.T) return;
     const int b = (int)(f / p.T), t = (int)(f % p.T);
     if (t >= p.lx[b]) return;
-    const float *row = p.logp + f * p.V;
+    const int64_t r0 = f * p.V;
     float m = -INFINITY;
-    for (int v = lane; v < p.V; v += 64) m = fmaxf(m, row[v]);
+    for (int v = lane; v < p.V; v += 64) m = fmaxf(m, ld_x(p, r0 + v));
     m = wave_max(m);
     if (m == -INFINITY) m = 0.f;
     float *er = p.ep + f * p.V;
-    for (int v = lane; v < p.V; v += 64) er[v] = exp_scaled(row[v] - m, kEpExp);
+    float ssum = 0.f;
+    for (int v = lane; v < p.V; v += 64) {
+        const float d = ld_x(p, r0 + v) - m;
+        er[v] = exp_scaled(d, kEpExp);
+        if (p.fused) ssum += __expf(d);
+    }
+    if (p.fused) {
+        ssum = wave_sum(ssum);
+        if (lane == 0) { p.moff[f] = -logf(ssum); p.inv_s[f] = 1.f / ssum; }   // (moff == mx without fusion: same array)
+    }
     if (lane == 0) p.mx[f] = m;
 }
 
@@ -231,7 +255,7 @@ __device__ __forceinline__ double block_sum_d(double v, double *red, int tid) {
 }
 __device__ __forceinline__ double mx_total(const LossParams &p, int b, int lx, double *red, int tid) {
     double part = 0.0;
-    for (int t = tid; t < lx; t += kChainThreads) part += (double)p.mx[(int64_t)b * p.T + t];
+    for (int t = tid; t < lx; t += kChainThreads) part += (double)p.moff[(int64_t)b * p.T + t];
     return block_sum_d(part, red, tid);
 }
 __device__ __forceinline__ float frame_max(const float *wm) {
@@ -527,7 +551,7 @@ __device__ __forceinline__ float ctc_block_sum(float v, float *red, int tid) {
 }
 __device__ __forceinline__ double ctc_mx_total(const LossParams &p, int b, int lx, double *red, int tid) {
     double part = 0.0;
-    for (int t = tid; t < lx; t += kCtcThreads) part += (double)p.mx[(int64_t)b * p.T + t];
+    for (int t = tid; t < lx; t += kCtcThreads) part += (double)p.moff[(int64_t)b * p.T + t];
     part = wave_sum_d(part);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = part;
@@ -609,7 +633,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
     // The frame maximum used for the (exact, power-of-two) rescale is taken from the values as they are
     // WRITTEN: one barrier per frame instead of a separate reduction pass plus barrier.
     {   // t = 0 (gpu_ctc_kernels.h:146-152)
-        const float *lr = p.logp + bt0 * V;
+        const int64_t lr0 = bt0 * V;
         const float m0 = p.mx[bt0];
         double *CArow = p.CA + bt0 * p.Sc;
         double vmax = 0.0;
@@ -617,7 +641,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         for (int i = 0; i < NR; ++i) {
             const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
-                const double v = (s < 2 && s < Sx) ? exp_scaled_d(lr[mylab[i]] - m0) * pow2d(kScaleExpD) : 0.0;
+                const double v = (s < 2 && s < Sx) ? exp_scaled_d(ld_x(p, lr0 + mylab[i]) - m0) * pow2d(kScaleExpD) : 0.0;
                 A[s] = v;
                 A[Sxp + s] = 0.0;
                 if (s < Sx) CArow[s] = v;
@@ -642,10 +666,10 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
     auto fetch1 = [&](auto SET, auto F, int t) __attribute__((always_inline)) {
         constexpr int st = decltype(SET)::value, f = decltype(F)::value;
         if (t < lx) {
-            const float *row = p.logp + (bt0 + t) * V;
+            const int64_t row0 = (bt0 + t) * V;
             mr[st][f] = p.mx[bt0 + t + vz];
 #pragma unroll
-            for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? row[mylab[i]] : 0.f;
+            for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? ld_x(p, row0 + mylab[i]) : 0.f;
         }
     };
     auto fetch4 = [&](auto SET, int t) __attribute__((always_inline)) {
@@ -747,7 +771,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     }
     int F_ = kScaleExpD;
     {   // t = lx-1
-        const float *lr = p.logp + (bt0 + lx - 1) * V;
+        const int64_t lr0 = (bt0 + lx - 1) * V;
         const float ml = p.mx[bt0 + lx - 1];
         double *CBrow = p.CB + (bt0 + lx - 1) * p.Sc;
         double vmax = 0.0;
@@ -756,7 +780,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
             const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
                 const double bx = (s < Sx && s >= Sx - 2) ? pow2d(kScaleExpD) : 0.0;
-                const double y = s < Sx ? exp_scaled_d(lr[mylab[i]] - ml) * bx : 0.0;
+                const double y = s < Sx ? exp_scaled_d(ld_x(p, lr0 + mylab[i]) - ml) * bx : 0.0;
                 Y[s] = y;
                 Y[Sxp + s] = 0.0;
                 if (s < Sx) CBrow[s] = bx;
@@ -775,10 +799,10 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     auto fetch1 = [&](auto SET, auto F, int t) __attribute__((always_inline)) {
         constexpr int st = decltype(SET)::value, f = decltype(F)::value;
         if (t >= 0) {
-            const float *row = p.logp + (bt0 + t) * V;
+            const int64_t row0 = (bt0 + t) * V;
             mr[st][f] = p.mx[bt0 + t + vz];
 #pragma unroll
-            for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? row[mylab[q]] : 0.f;
+            for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? ld_x(p, row0 + mylab[q]) : 0.f;
         }
     };
     auto fetch4 = [&](auto SET, int t) __attribute__((always_inline)) {  // frames t, t-1, t-2, t-3
@@ -1739,6 +1763,8 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
             float o = accumulate ? row[v] : 0.f;
             if (do_den) o = p.c_den * gd[v];
             if (do_ctc) o -= p.c_ctc * gc[v];
+            // fused log_softmax: d/dx = d/dlogp - softmax(x) * sum_v d/dlogp[v]; the posteriors of a frame sum to 1
+            if (do_ctc && p.fused) o -= (p.c_den - (zc > 0.0 ? p.c_ctc : 0.f)) * (p.ep[(bt0 + t) * V + v] * pow2f(-kEpExp)) * p.inv_s[bt0 + t];
             row[v] = o;
         }
         __syncthreads();
@@ -1996,6 +2022,7 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
     const int ezc = p.ctc_ez[b], Sx = 2 * p.ly[b] + 1;
     const int *ul = p.labels + p.lab_off[b];
     const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
+    const float ksm = p.c_den - (zc > 0.0 ? p.c_ctc : 0.f);   // fused log_softmax: sum over v of d loss / d logp[t][v]
     const int t0 = blockIdx.x * kGCFrames, t1 = min(t0 + kGCFrames, p.T), tl = min(t1, lx);
     int mylab[REGS];
 #pragma unroll
@@ -2019,6 +2046,16 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
             _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) {                               \
                 const int v = tid + q * kGCThreads;                                              \
                 rown[q] = v < V ? row_[v] : 0.f;                                                 \
+            }                                                                                    \
+        } else if (p.fused) {                                                                    \
+            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) rown[q] = 0.f;                  \
+        }                                                                                        \
+        if (p.fused) {   /* softmax term of log_softmax's backward, folded into the row the frame starts from */ \
+            const float *er_ = p.ep + (bt0 + (t)) * V;                                           \
+            const float ks_ = ksm * pow2f(-kEpExp) * p.inv_s[bt0 + (t)];                         \
+            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) {                               \
+                const int v = tid + q * kGCThreads;                                              \
+                if (v < V) rown[q] -= ks_ * er_[v];                                              \
             }                                                                                    \
         }                                                                                        \
     }
@@ -2121,7 +2158,7 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
 // host side
 // ---------------------------------------------------------------------------------------------
 struct WsLayout {
-    int64_t off_ep, off_mx, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_xch, off_row0, total;
+    int64_t off_ep, off_mx, off_moff, off_invs, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_xch, off_row0, total;
     int64_t xch_bytes;
     int64_t Rq, Rb;
     bool res, gv, fac;
@@ -2150,6 +2187,8 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.Rb = h ? (w.fac ? h->dev.fac.Rbp : w.res ? h->dev.res.b.R : h->dev.Pr) : 0;
     w.off_ep = o; o = al(o + B * T * V * 4);
     w.off_mx = o; o = al(o + B * T * 4);
+    w.off_moff = o; o = al(o + B * T * 4);   // fused log_softmax only (crf_loss_fwd_bwd_logits)
+    w.off_invs = o; o = al(o + B * T * 4);
     w.off_Q = o; o = al(o + B * T * w.Rq * 4);
     w.off_BP = o; o = al(o + B * T * w.Rb * 4);
     w.off_EQ = o; o = al(o + B * T * 4);
@@ -2299,7 +2338,7 @@ static int launch_res(const LossParams &lp, size_t lds, int b0, int nb, hipStrea
     p.K = R.K; p.B = lp.B; p.T = lp.T; p.V = lp.V; p.b0 = b0;
     p.rows_cu_max = DIR == 0 ? lp.res_lds_rows_f : lp.res_lds_rows_b;
     p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.Gf = R.f.G; p.Gb = R.b.G;
-    p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
+    p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.moff;   // (the resident kernels use it for the log-likelihood offset only)
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
     p.xch = lp.xch; p.err = lp.err;
     p.x_start = R.x_start; p.x_end = R.x_end; p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
@@ -2345,7 +2384,7 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.L = DIR == 0 ? F.f : F.b;
     p.bx_idx = F.bx_idx; p.bx_w = F.bx_w; p.nbx = F.nbx; p.bx_se = F.bx_se;
     p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
-    p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.mx;
+    p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.moff;   // (the resident kernels use it for the log-likelihood offset only)
     p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
     p.started = started; p.i0 = i0; p.i1 = i1; p.state = state;
     p.nb = nb; p.stage_cnt = stage_cnt;
@@ -2371,7 +2410,33 @@ int64_t crf_workspace_bytes(const crf_graph *g, int64_t B, int64_t T, int64_t V,
     return ws_layout(g ? g->h : nullptr, B, T, V, Sc).total;
 }
 
+static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dtype, const int32_t *labels, const int32_t *lab_off,
+                     const int32_t *lx, const int32_t *ly, int64_t B, int64_t T, int64_t V,
+                     int64_t max_label_len, float c_den, float c_ctc, float *grad, float *loss,
+                     float *costs_den, float *costs_beta, float *costs_ctc, int32_t *invalid, void *ws,
+                     int64_t ws_bytes, void *stream_);
+
 int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *labels, const int32_t *lab_off,
+                     const int32_t *lx, const int32_t *ly, int64_t B, int64_t T, int64_t V,
+                     int64_t max_label_len, float c_den, float c_ctc, float *grad, float *loss,
+                     float *costs_den, float *costs_beta, float *costs_ctc, int32_t *invalid, void *ws,
+                     int64_t ws_bytes, void *stream_) {
+    return loss_impl(g, logp, 0, 0, labels, lab_off, lx, ly, B, T, V, max_label_len, c_den, c_ctc, grad, loss, costs_den, costs_beta,
+                     costs_ctc, invalid, ws, ws_bytes, stream_);
+}
+
+int crf_loss_fwd_bwd_logits(const crf_graph *g, const void *logits, int dtype, const int32_t *labels, const int32_t *lab_off,
+                            const int32_t *lx, const int32_t *ly, int64_t B, int64_t T, int64_t V,
+                            int64_t max_label_len, float c_den, float c_ctc, float *grad, float *loss,
+                            float *costs_den, float *costs_beta, float *costs_ctc, int32_t *invalid, void *ws,
+                            int64_t ws_bytes, void *stream_) {
+    if (dtype < 0 || dtype > 2) { set_error("crf_loss_fwd_bwd_logits: dtype must be 0 (f32), 1 (bf16) or 2 (f16)"); return CRF_ERR_ARG; }
+    if (c_ctc == 0.f) { set_error("crf_loss_fwd_bwd_logits: the fused log_softmax needs the numerator pass (c_ctc != 0)"); return CRF_ERR_UNSUPPORTED; }
+    return loss_impl(g, (const float *)logits, 1, dtype, labels, lab_off, lx, ly, B, T, V, max_label_len, c_den, c_ctc, grad, loss,
+                     costs_den, costs_beta, costs_ctc, invalid, ws, ws_bytes, stream_);
+}
+
+static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dtype, const int32_t *labels, const int32_t *lab_off,
                      const int32_t *lx, const int32_t *ly, int64_t B, int64_t T, int64_t V,
                      int64_t max_label_len, float c_den, float c_ctc, float *grad, float *loss,
                      float *costs_den, float *costs_beta, float *costs_ctc, int32_t *invalid, void *ws,
@@ -2415,6 +2480,8 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *logp, const int32_t *label
     p.c_den = c_den; p.c_ctc = c_ctc;
     char *base = (char *)ws;
     p.ep = (float *)(base + w.off_ep); p.mx = (float *)(base + w.off_mx);
+    p.fused = fused; p.in_dtype = in_dtype;
+    p.moff = fused ? (float *)(base + w.off_moff) : p.mx; p.inv_s = (float *)(base + w.off_invs);
     p.Q = (float *)(base + w.off_Q); p.BP = (float *)(base + w.off_BP);
     p.Rq = (int)w.Rq; p.Rb = (int)w.Rb; p.res = fac ? 2 : res ? 1 : 0; p.grad_stage = grad_stage ? 1 : 0;
     if (fac) {

@@ -37,6 +37,9 @@ _lib.crf_workspace_bytes.restype = _i64
 _lib.crf_loss_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _f32,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
 _lib.crf_loss_fwd_bwd.restype = ctypes.c_int
+_lib.crf_loss_fwd_bwd_logits.argtypes = [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _f32,
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
+_lib.crf_loss_fwd_bwd_logits.restype = ctypes.c_int
 _lib.crf_profile_enable.argtypes = [ctypes.c_int]
 _lib.crf_profile_enable.restype = None
 _lib.crf_profile_read.argtypes = [ctypes.POINTER(_f32), ctypes.c_int]
@@ -50,7 +53,7 @@ _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
-    "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
+    "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
     "crf_last_error", "crf_version",
 )
 
@@ -196,15 +199,23 @@ def _h2d_async(src: torch.Tensor, dev: torch.device) -> torch.Tensor:
     return ring.stage(src, dev)
 
 
+_FUSED_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
 def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch.Tensor,
                  ly: Optional[torch.Tensor], c_den: float, c_ctc: float, graph: Optional[int],
-                 want_costs: bool = False):
+                 want_costs: bool = False, fused: bool = False):
     """One call of the hot path (include/ctc_crf_hip.h ``crf_loss_fwd_bwd``).
 
     logits [N,T,V] f32 on the GPU, contiguous; labels/lx/ly int32 on CPU (as CAT passes them,
     cat/ctc/train.py:176-190) or on the GPU.  Returns (loss[1], grad[N,T,V], extras dict).
     """
-    assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 3
+    assert logits.is_cuda and logits.is_contiguous() and logits.dim() == 3
+    if fused:   # raw network output, log_softmax fused in (crf_loss_fwd_bwd_logits)
+        if logits.dtype not in _FUSED_DTYPES:
+            raise RuntimeError(f"fused log_softmax: expect float32, bfloat16 or float16 network output, got {logits.dtype}")
+    else:
+        assert logits.dtype == torch.float32
     dev = logits.device
     N, T, V = logits.shape
     lx32 = lx.to(torch.int32)
@@ -228,15 +239,20 @@ def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch
     gh = _vp(graph) if (graph and c_den != 0.0) else _vp(0)
     ws_bytes = _lib.crf_workspace_bytes(gh, N, T, V, max_l)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    grad = torch.empty_like(logits)
+    grad = torch.empty(logits.shape, dtype=torch.float32, device=dev)
     out = torch.empty(1 + 3 * N, dtype=torch.float32, device=dev)
     invalid = torch.empty(N, dtype=torch.int32, device=dev) if c_ctc != 0.0 else None
     loss, c_alpha, c_beta, c_ctc_t = out[:1], out[1:1 + N], out[1 + N:1 + 2 * N], out[1 + 2 * N:]
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev):
-        rc = _lib.crf_loss_fwd_bwd(gh, _ptr(logits), _ptr(lab_d), _ptr(off_d), _ptr(lx_d), _ptr(ly_d),
-                                   N, T, V, max_l, c_den, c_ctc, _ptr(grad), _ptr(loss), _ptr(c_alpha),
-                                   _ptr(c_beta), _ptr(c_ctc_t), _ptr(invalid), _ptr(ws), ws_bytes, _vp(stream))
+        if fused:
+            rc = _lib.crf_loss_fwd_bwd_logits(gh, _ptr(logits), _FUSED_DTYPES[logits.dtype], _ptr(lab_d), _ptr(off_d), _ptr(lx_d),
+                                              _ptr(ly_d), N, T, V, max_l, c_den, c_ctc, _ptr(grad), _ptr(loss), _ptr(c_alpha),
+                                              _ptr(c_beta), _ptr(c_ctc_t), _ptr(invalid), _ptr(ws), ws_bytes, _vp(stream))
+        else:
+            rc = _lib.crf_loss_fwd_bwd(gh, _ptr(logits), _ptr(lab_d), _ptr(off_d), _ptr(lx_d), _ptr(ly_d),
+                                       N, T, V, max_l, c_den, c_ctc, _ptr(grad), _ptr(loss), _ptr(c_alpha),
+                                       _ptr(c_beta), _ptr(c_ctc_t), _ptr(invalid), _ptr(ws), ws_bytes, _vp(stream))
     _check(rc)
     del meta
     extras = dict(costs_alpha=c_alpha, costs_beta=c_beta, costs_ctc=c_ctc_t, invalid=invalid) if want_costs else {}

@@ -66,16 +66,41 @@ class _CTC_CRF(Function):
         return ctx.grads * grad_output.to(ctx.grads.device), None, None, None, None, None, None
 
 
+class _CTC_CRF_LOGITS(Function):
+    """_CTC_CRF with the log_softmax in front of it fused in (the caller's
+    ``logits = torch.log_softmax(netout, -1)`` + ``criterion(logits.float(), ...)``, cat/ctc/train.py:174-186):
+    takes the RAW network output in fp32 / bf16 / fp16, the loss is that of log_softmax(netout), the gradient
+    is d loss / d netout (log_softmax's backward included), computed in fp32 and returned in netout's dtype."""
+
+    @staticmethod
+    def forward(ctx, netout, labels, input_lengths, label_lengths, lamb=0.1, size_average=True):
+        netout = netout.contiguous()
+        batch_size = netout.size(0)
+        s = 1.0 / batch_size if size_average else 1.0
+        costs, grads, _ = core.loss_fwd_bwd(netout, labels, input_lengths, label_lengths, s, s * (1.0 + lamb),
+                                            core.graph_for(netout.device), fused=True)
+        ctx.grads = grads
+        ctx.out_dtype = netout.dtype
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return (ctx.grads * grad_output.to(ctx.grads.device)).to(ctx.out_dtype), None, None, None, None, None, None
+
+
 class CTC_CRF_LOSS(Module):
-    def __init__(self, lamb: float = 0.1, size_average: bool = True):
+    def __init__(self, lamb: float = 0.1, size_average: bool = True, fuse_log_softmax: bool = False):
         """
         lamb (float): weight for auxiliary CTC loss, final loss = lamb * loss_ctc + loss_crf
         size_average (bool): whether to do average over batch size dimension.
+        fuse_log_softmax (bool, not in the reference): ``forward`` takes the RAW network output (fp32, bf16 or
+            fp16) instead of log-probs; log_softmax and its backward run inside the loss kernels.
         """
         super(CTC_CRF_LOSS, self).__init__()
-        self.ctc_crf = _CTC_CRF.apply
+        self.ctc_crf = _CTC_CRF_LOGITS.apply if fuse_log_softmax else _CTC_CRF.apply
         self.lamb = lamb
         self.size_average = size_average
+        self.fuse_log_softmax = fuse_log_softmax
 
     def forward(self, logits, labels, lx, ly) -> torch.FloatTensor:
         """
@@ -85,7 +110,10 @@ class CTC_CRF_LOSS(Module):
         ly (torch.IntTensor) : size (N, ), on CPU
         """
         assert len(labels.size()) == 1
-        assert logits.dtype == torch.float, f"expect logits to be torch.float object, instead: {logits.dtype}"
+        if self.fuse_log_softmax:
+            assert logits.dtype in (torch.float, torch.bfloat16, torch.float16), f"expect float/bfloat16/float16 network output, instead: {logits.dtype}"
+        else:
+            assert logits.dtype == torch.float, f"expect logits to be torch.float object, instead: {logits.dtype}"
         assert labels.dtype == torch.int, f"expect labels to be torch.int object, instead: {labels.dtype}"
         assert lx.dtype == torch.int, f"expect lx to be torch.int object, instead: {lx.dtype}"
         assert ly.dtype == torch.int, f"expect ly to be torch.int object, instead: {ly.dtype}"
@@ -143,9 +171,11 @@ _CTX_CACHE: Dict[Tuple[str, int], CRFContext] = {}
 
 
 def ctc_crf_loss(log_probs: torch.Tensor, labels: torch.Tensor, frame_lens: torch.Tensor,
-                 label_lens: torch.Tensor, den_lm: str, lamb: float = 0.1, size_average: bool = True) -> torch.Tensor:
+                 label_lens: torch.Tensor, den_lm: str, lamb: float = 0.1, size_average: bool = True,
+                 fuse_log_softmax: bool = False) -> torch.Tensor:
     """Functional CTC-CRF loss (BASELINE.json north_star signature).  Lazily builds and caches the
-    CRFContext for (den_lm, device) exactly as AMTrainer does (cat/ctc/train.py:180-182)."""
+    CRFContext for (den_lm, device) exactly as AMTrainer does (cat/ctc/train.py:180-182).
+    fuse_log_softmax=True: ``log_probs`` is the raw network output (fp32 / bf16 / fp16), see _CTC_CRF_LOGITS."""
     dev = log_probs.device
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (os.path.abspath(den_lm), idx)
@@ -155,5 +185,8 @@ def ctc_crf_loss(log_probs: torch.Tensor, labels: torch.Tensor, frame_lens: torc
         for k in [k for k in _CTX_CACHE if k[1] == idx]:  # one graph per device, like the reference
             del _CTX_CACHE[k]
         ctx = _CTX_CACHE[key] = CRFContext(den_lm, idx)
+    if fuse_log_softmax:
+        return _CTC_CRF_LOGITS.apply(log_probs, labels.int().cpu(), frame_lens.int().cpu(), label_lens.int().cpu(),
+                                     lamb, size_average)
     return _CTC_CRF.apply(log_probs.float(), labels.int().cpu(), frame_lens.int().cpu(), label_lens.int().cpu(),
                           lamb, size_average)

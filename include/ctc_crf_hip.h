@@ -109,6 +109,21 @@ int crf_loss_fwd_bwd(const crf_graph *g, const float *log_probs_dev, const int32
  * no DMA engine start-up between two calls.  The host buffer must stay untouched until the stream has passed. */
 int crf_stage_i32(int32_t *dst_dev, const int32_t *src_pinned_host, int64_t n, void *stream);
 
+/* crf_loss_fwd_bwd with the log_softmax in front of it fused in.  Replaces, in addition,
+ *   logits = torch.log_softmax(netout, dim=-1)   and   criterion(logits.float(), ...)   (cat/ctc/train.py:174-186)
+ * and log_softmax's backward: `logits_dev` are the RAW network outputs [B][T][V], dtype 0 = fp32, 1 = bf16, 2 = fp16
+ * (upcast in registers; the recursions, costs and the gradient stay fp32/fp64), and
+ *   grad_dev[b][t][v] = d loss / d logits[b][t][v]
+ *                     = (c_den gamma_den - c_ctc gamma_ctc) - softmax(logits)[v] * sum_v (c_den gamma_den - c_ctc gamma_ctc)
+ * in fp32.  Everything else as crf_loss_fwd_bwd; c_ctc must not be 0 (the softmax term rides on the numerator half of
+ * the grad pass).  Costs are those of log_softmax(logits). */
+int crf_loss_fwd_bwd_logits(const crf_graph *g, const void *logits_dev, int dtype, const int32_t *labels_dev,
+                            const int32_t *label_off_dev, const int32_t *lx_dev, const int32_t *ly_dev,
+                            int64_t B, int64_t T, int64_t V, int64_t max_label_len, float c_den, float c_ctc,
+                            float *grad_dev, float *loss_dev, float *costs_den_dev, float *costs_beta_dev,
+                            float *costs_ctc_dev, int32_t *invalid_dev, void *workspace_dev,
+                            int64_t workspace_bytes, void *stream);
+
 /* Diagnostics (no reference counterpart; the reference has no profiler hooks).
  * crf_profile_enable(1): every following crf_loss_fwd_bwd on this thread brackets each of its
  * kernel launches with HIP events on the stream the kernel is launched on.

@@ -131,6 +131,42 @@ def test_synth_vs_oracle_ragged(crf, tmp_path, seed, B, T, vocab, hist, fan, mod
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+def test_fused_log_softmax(crf, tmp_path, mode, dtype):
+    """``CTC_CRF_LOSS(fuse_log_softmax=True)(netout, ...)`` against the unfused path behind torch's own
+    log_softmax (cat/ctc/train.py:174-186), loss and d loss / d netout, for fp32 / bf16 / fp16 network outputs (the
+    unfused reference sees the same rounded values, upcast), ragged lengths, one invalid utterance (L + repeats > T)."""
+    g, fst = small_synth(tmp_path, 24, 96, 8, 3)
+    _, labels, lx, ly = make_batch(g, 4, 48, 24, seed=11, ragged=True)
+    lx = np.array(lx); ly = np.array(ly); labels = list(labels)
+    ly0 = int(ly[0])
+    lx[0] = max(1, ly0 - 1)                                   # utterance 0: more labels than frames -> invalid numerator
+    rng = np.random.default_rng(5)
+    raw = torch.tensor(rng.normal(size=(4, 48, 24)) * 3.0, dtype=torch.float32).to(getattr(torch, dtype))
+    lab_t, lx_t, ly_t = (torch.tensor(a, dtype=torch.int32) for a in (labels, lx, ly))
+    with _mode(mode):
+        ctx = crf.CRFContext(fst, 0)
+    xf = raw.cuda().requires_grad_(True)
+    lf = crf.CTC_CRF_LOSS(lamb=0.1, fuse_log_softmax=True)(xf, lab_t, lx_t, ly_t)
+    lf.backward()
+    xu = raw.float().cuda().requires_grad_(True)
+    lu = crf.CTC_CRF_LOSS(lamb=0.1)(torch.log_softmax(xu, -1), lab_t, lx_t, ly_t)
+    lu.backward()
+    assert xf.grad.dtype == raw.dtype
+    assert abs(lf.item() - lu.item()) <= TOL * abs(lu.item())
+    tol = TOL if dtype == "float32" else 1e-2                 # the fused gradient is rounded to the input's dtype at the end
+    assert rel_err(xf.grad.float().cpu().numpy(), xu.grad.cpu().numpy()) <= tol
+    # rows sum to zero (softmax Jacobian) and are zero beyond the utterance's length
+    gsum = xf.grad.float().sum(-1).abs().max().item()
+    assert gsum <= (1e-5 if dtype == "float32" else 2e-2)
+    for b in range(4):
+        assert xf.grad[b, int(lx[b]):].abs().max().item() == 0.0 if int(lx[b]) < 48 else True
+    f2 = crf.ctc_crf_loss(xf.detach(), lab_t, lx_t, ly_t, fst, fuse_log_softmax=True)
+    assert abs(f2.item() - lf.item()) <= 1e-6 * abs(lf.item())
+    del ctx
+
+
 def test_factored_schedules(crf, tmp_path):
     """The factored den kernels run everything else BESIDE them while 2B workgroups leave half of the CUs free
     (B = 3 here and in the tests above) and fall back to 'numerator after denominator' for larger batches
