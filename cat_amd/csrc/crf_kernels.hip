@@ -668,8 +668,14 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         if (t < lx) {
             const int64_t row0 = (bt0 + t) * V;
             mr[st][f] = p.mx[bt0 + t + vz];
+            if (p.in_dtype == 0) {   // (one uniform branch around the batch: the fp32 loads stay as they were)
+                const float *row = p.logp + row0;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? ld_x(p, row0 + mylab[i]) : 0.f;
+                for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? row[mylab[i]] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? ld_x(p, row0 + mylab[i]) : 0.f;
+            }
         }
     };
     auto fetch4 = [&](auto SET, int t) __attribute__((always_inline)) {
@@ -801,8 +807,14 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         if (t >= 0) {
             const int64_t row0 = (bt0 + t) * V;
             mr[st][f] = p.mx[bt0 + t + vz];
+            if (p.in_dtype == 0) {
+                const float *row = p.logp + row0;
 #pragma unroll
-            for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? ld_x(p, row0 + mylab[q]) : 0.f;
+                for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? row[mylab[q]] : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? ld_x(p, row0 + mylab[q]) : 0.f;
+            }
         }
     };
     auto fetch4 = [&](auto SET, int t) __attribute__((always_inline)) {  // frames t, t-1, t-2, t-3
