@@ -195,33 +195,46 @@ __device__ __forceinline__ float ld_x(const LossParams &p, int64_t i) {
     return (float)__builtin_bit_cast(_Float16, u);
 }
 
+// G lanes per frame (16 for small vocabularies: four frames per wave -- with a whole wave per 72-entry row the kernel ran
+// at a quarter of the HBM rate; 64 otherwise).
+template <int G>
 __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
-    const int lane = threadIdx.x & 63;
+    const int sub = threadIdx.x & (G - 1);
     // the counters of the staged schedule start at zero in every call (a memset in the stream cost two more
     // dispatches between this kernel and the recursions)
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < p.nclear; i += 256) __hip_atomic_store(p.clear + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t f = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
     if (f >= (int64_t)p.B * p.T) return;
     const int b = (int)(f / p.T), t = (int)(f % p.T);
-    if (t >= p.lx[b]) return;
+    if (t >= p.lx[b]) return;                     // (whole groups of G lanes leave together)
+    auto gmax = [](float v) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, G));
+        return v;
+    };
+    auto gsum = [](float v) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+        return v;
+    };
     const int64_t r0 = f * p.V;
     float m = -INFINITY;
-    for (int v = lane; v < p.V; v += 64) m = fmaxf(m, ld_x(p, r0 + v));
-    m = wave_max(m);
+    for (int v = sub; v < p.V; v += G) m = fmaxf(m, ld_x(p, r0 + v));
+    m = gmax(m);
     if (m == -INFINITY) m = 0.f;
     float *er = p.ep + f * p.V;
     float ssum = 0.f;
-    for (int v = lane; v < p.V; v += 64) {
+    for (int v = sub; v < p.V; v += G) {
         const float d = ld_x(p, r0 + v) - m;
         er[v] = exp_scaled(d, kEpExp);
         if (p.fused) ssum += __expf(d);
     }
     if (p.fused) {
-        ssum = wave_sum(ssum);
-        if (lane == 0) { p.moff[f] = -logf(ssum); p.inv_s[f] = 1.f / ssum; }   // (moff == mx without fusion: same array)
+        ssum = gsum(ssum);
+        if (sub == 0) { p.moff[f] = -logf(ssum); p.inv_s[f] = 1.f / ssum; }   // (moff == mx without fusion: same array)
     }
-    if (lane == 0) p.mx[f] = m;
+    if (sub == 0) p.mx[f] = m;
 }
 
 // crf_stage_i32: the integer metadata of a call (labels, lengths, offsets) come from the host; a kernel reads
@@ -2540,7 +2553,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     for (bool &u : g_prof.used) u = false;
     prof_mark(7, false, stream);
     prof_mark(0, false, stream);
-    hipLaunchKernelGGL(crf_prep_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
+    if (V <= 256) hipLaunchKernelGGL(crf_prep_kernel<16>, dim3((unsigned)((frames + 15) / 16)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(crf_prep_kernel<64>, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
     prof_mark(0, true, stream);
     LAUNCH_CHECK("crf_prep_kernel");
     if (res && !have_flags) {  // exchange granules (tags) and the error word start at zero in every call
