@@ -171,6 +171,23 @@ def main():
         "arc_stream_bytes_reference_style": 2 * B * int(max(lx)) * dims["A"] * 12,
     }
 
+    # attainable HBM rate on this device ("confirm on the box"): a 1 GiB device-to-device copy, read + write
+    try:
+        buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(buf)
+        dst.copy_(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            dst.copy_(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        roofline["ceilings"]["hbm_copy_GBs_measured"] = round(4 * 2 * buf.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del buf, dst
+    except Exception:  # informational only
+        pass
+
     # --- optional: the same step behind a DDP stand-in acoustic head (N > 1 only) -------------
     ddp_info = None
     if world > 1:
