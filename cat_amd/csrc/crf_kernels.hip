@@ -1353,7 +1353,9 @@ struct FacParams {
 // run-time switch for it)
 // NTH threads with NCH chunks of arcs each, gathered in batches of NB chunks: 512 x 30 (2 waves per SIMD) or
 // 768 x 21 (3 waves per SIMD at <= 168 VGPRs -- the frame is latency-bound, a third wave fills the gaps).
-template <int DIR, bool FLAG, int NTH, int NCH, int NB>
+// ML: some rows are cut into pieces on adjacent lanes (graphs with long rows; a separate instantiation, the check costs the
+// row epilogue of the others 2 %)
+template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML>
 __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
     constexpr int NW = NTH / kWave;
     // 768-thread geometry: the last chunk slot of a thread holds ROW CONSTANTS instead of arcs -- two words for each of
@@ -1399,6 +1401,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
     const unsigned ends = __builtin_amdgcn_readfirstlane(wi.x);
     const int nch = __builtin_amdgcn_readfirstlane(wi.y);
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
+    const unsigned lgbits = __builtin_amdgcn_readfirstlane(wi.w);   // 3 bits per slice: its rows are cut into 2^lg pieces on adjacent lanes
     if (!RC) {
         int4 *RM = (int4 *)RMc;
         for (int r = tid; r < R; r += NTH) {
@@ -1535,17 +1538,29 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                 for (int ci = 0; ci < nb; ++ci) {
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
                     if (ends_f >> (c0 + ci) & 1u) {
+                        const unsigned ks = (unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u));   // slice number (uniform)
+                        // rows longer than a lane's registers lie on 2^lg adjacent lanes (res_layout.cpp place_rows): a butterfly
+                        // leaves the row's sum in every lane of the group, the first one owns the outputs
+                        float tot = acc.x + acc.y;
+                        if constexpr (ML) {
+                            const unsigned lg = (lgbits >> (3u * ks)) & 7u;
+                            if (lg) {
+#pragma unroll
+                                for (int q = 0; q < 6; ++q)
+                                    if ((unsigned)q < lg) tot += __shfl_xor(tot, 1 << q, 64);
+                            }
+                        }
                         if constexpr (RC) {
-                            const unsigned ks = (unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u));   // slice number (uniform)
                             // (masks, not ?: -- the compiler turns a three-way select of registers by a uniform index
                             // into an indexed array, which it then cannot keep in registers)
                             const unsigned s0 = 0u - (unsigned)(ks == 0), s1 = 0u - (unsigned)(ks == 1), s2 = 0u - (unsigned)(ks >= 2);
                             const unsigned k0 = (rc00 & s0) | (rc10 & s1) | (rc20 & s2);
                             const unsigned k1 = (rc01 & s0) | (rc11 & s1) | (rc21 & s2);
+
                             if (DIR == 0) {   // k0 = main label | tail label << 16, k1 = tail weight; U, L, A at rid, R + rid, 2R + rid
                                 const float uold = *(const float *)(xb + r4);                   // U_t of the row's pair
                                 const float em = EPu[k0 & 0xffffu], et = EPu[k0 >> 16];
-                                const float rv = (acc.x + acc.y) * sc;                          // q_t[pair of the main state]
+                                const float rv = tot * sc;                                      // q_t[pair of the main state]
                                 const float qt = __uint_as_float(k1) * uold * sc;               // q_t[pair of the tail state]
                                 if (flagged) {
                                     __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1564,7 +1579,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                                 const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
                                 const float e0 = EPu[k1 & 0xffffu], e1 = EPu[k1 >> 16];
                                 const f32x2 w01 = *(const f32x2 *)(RMc + 2u * r4);
-                                const float craw = acc.x + acc.y;                               // common out-arcs of the row's states
+                                const float craw = tot;                                         // common out-arcs of the row's states
                                 f32x2 bv;                                                        // b_t of the two states
                                 bv.x = fmaf(w01.x, z0, craw) * sc;
                                 bv.y = fmaf(w01.y, z1, craw) * sc;
@@ -1585,7 +1600,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                         } else {
                         const int4 m = *(const int4 *)(RMc + 4u * r4);
                         if (DIR == 0) {
-                            const float rv = (acc.x + acc.y) * sc;                      // q_t[pair of the main state]
+                            const float rv = tot * sc;                                  // q_t[pair of the main state]
                             const float uold = *(const float *)(xb + (m.x & 0xffff));   // U_t of the row's pair
                             const float qt = __int_as_float(m.z) * uold * sc;           // q_t[pair of the tail state]
                             if (flagged) {   // write-through: the grad pass reads the rows from other XCDs while this kernel runs
@@ -1604,7 +1619,7 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                             *(float *)(xnb + ((unsigned)m.y >> 16)) = Ap;
                             mymax = fmaxf(mymax, Up);
                         } else {
-                            const float craw = acc.x + acc.y;                           // common out-arcs of the row's states
+                            const float craw = tot;                                     // common out-arcs of the row's states
                             const float z0 = *(const float *)(xb + (m.x & 0xffff)), z1 = *(const float *)(xb + ((unsigned)m.x >> 16));
                             f32x2 bv;                                                    // b_t of the two states
                             bv.x = fmaf(__int_as_float(m.y), z0, craw) * sc;
@@ -2391,14 +2406,15 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
 template <int DIR, bool FLAG = false>
 static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *state,
                       int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
-    static std::atomic<size_t> lds_set{0}, lds_set3{0};
+    static std::atomic<size_t> lds_set{0}, lds_set3{0}, lds_set3m{0};
     hipError_t e;
     const FacDev &F = lp.g.fac;
-    const bool g3 = F.threads == kFac3Threads;
-    std::atomic<size_t> &ls = g3 ? lds_set3 : lds_set;
+    const bool g3 = F.threads == kFac3Threads, ml = F.multilane != 0;
+    std::atomic<size_t> &ls = g3 ? (ml ? lds_set3m : lds_set3) : lds_set;
     if (lds > ls.load()) {
-        e = g3 ? hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-               : hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kResThreads, kResNCH, kResBatch>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = g3 ? (ml ? hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                     : hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+               : hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kResThreads, kResNCH, kResBatch, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error(std::string("hipFuncSetAttribute(fac chain): ") + hipGetErrorString(e));
             return CRF_ERR_HIP;
@@ -2418,8 +2434,9 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
-    if (g3) hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch>), dim3((unsigned)lp.B), dim3(kFac3Threads), lds, st, p);
-    else hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kResThreads, kResNCH, kResBatch>), dim3((unsigned)lp.B), dim3(kResThreads), lds, st, p);
+    if (g3 && ml) hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch, true>), dim3((unsigned)lp.B), dim3(kFac3Threads), lds, st, p);
+    else if (g3) hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch, false>), dim3((unsigned)lp.B), dim3(kFac3Threads), lds, st, p);
+    else hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kResThreads, kResNCH, kResBatch, true>), dim3((unsigned)lp.B), dim3(kResThreads), lds, st, p);
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }

@@ -22,9 +22,10 @@ namespace {
 typedef std::vector<std::vector<std::pair<int, float>>> Rows;
 
 // geometry of one resident workgroup: threads, waves, chunks per thread (registers), words per thread
-struct Geom { int threads, waves, nch, words, maxsl; };   // maxsl: slices per wave (0 = any number)
-constexpr Geom kGeomRes{kResThreads, kResWaves, kResNCH, kResWords, 0};
-constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3NCH * 6, kFac3MaxSl};
+struct Geom { int threads, waves, nch, words, maxsl, multilane; };   // maxsl: slices per wave (0 = any number); multilane: long rows on adjacent lanes
+constexpr Geom kGeomRes{kResThreads, kResWaves, kResNCH, kResWords, 0, 0};
+constexpr Geom kGeomFac512{kResThreads, kResWaves, kResNCH, kResWords, 0, 1};   // factored layout, 512 threads (row constants in LDS)
+constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3NCH * 6, kFac3MaxSl, 1};
 
 struct DirOut {
     std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
@@ -39,7 +40,8 @@ struct DirOut {
 inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / kResW)); }
 
 // Step 1: decide where every row lives (CU, wave, slice, lane) from the row LENGTHS only.
-struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; int ord; };   // ord: number of the slice within its wave
+struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; int ord; int lg = 0; };   // ord: number of the slice within its wave;
+                                                      // lg > 0: every row of the slice is cut into 2^lg pieces on 2^lg adjacent lanes
 bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm = kGeomRes) {
     o->arcs.assign((size_t)K * gm.words * gm.threads, 0u);
     o->wave_info.assign((size_t)K * gm.waves, uint4{0u, 0u, 0u, 0u});
@@ -52,9 +54,34 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         std::vector<int> mine;
         for (size_t r = 0; r < rows.size(); ++r) if (row_cu[r] == k) mine.push_back((int)r);
         std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return rows[a].size() > rows[b].size(); });
-        const int nsl = (int)((mine.size() + kWave - 1) / kWave);
-        std::vector<int> len(nsl);
-        for (int j = 0; j < nsl; ++j) len[j] = chunks_of(rows[mine[(size_t)j * kWave]].size());
+        // Rows too long for one lane (more than gm.nch chunks; n-gram LMs: the low-order history states are entered
+        // from hundreds of histories): cut into 2^lg equal pieces on 2^lg ADJACENT lanes of one slice; the kernel adds
+        // the pieces with a butterfly over those lanes before the row epilogue (every lane of the group then holds
+        // the row's sum; all but the first are ordinary padding rows as far as their outputs are concerned).  One lg
+        // per slice.  Factored layouts only (gm.multilane): the generic layout splits long rows into sub-rows with
+        // virtual copies of their entry instead (build_resident) -- fine for a long tail, hopeless for an n-gram LM.
+        std::vector<std::vector<int>> lanes;                  // per slice: row of each lane (-1 = none)
+        std::vector<int> len, lgs;
+        {
+            auto lg_of = [&](int r) {
+                int lg = 0;
+                while (gm.multilane && lg < 6 && (chunks_of(rows[r].size()) + (1 << lg) - 1) / (1 << lg) > gm.nch) ++lg;
+                return lg;
+            };
+            size_t i = 0;
+            while (i < mine.size()) {
+                const int lg = lg_of(mine[i]), per = kWave >> lg;
+                std::vector<int> ln(kWave, -1);
+                int mx = 1, n = 0;
+                while (i < mine.size() && n < per && lg_of(mine[i]) == lg) {
+                    for (int q = 0; q < (1 << lg); ++q) ln[(size_t)n * (1 << lg) + q] = mine[i];
+                    mx = std::max(mx, (chunks_of(rows[mine[i]].size()) + (1 << lg) - 1) / (1 << lg));
+                    ++n; ++i;
+                }
+                lanes.push_back(ln); len.push_back(mx); lgs.push_back(lg);
+            }
+        }
+        const int nsl = (int)lanes.size();
         // slices (sorted by length) -> waves with the register capacity as bin size.  What is balanced is
         // the TIME of a wave, measured on the MI355X (tools/timing_probe.py) as roughly linear in its chunks
         // plus a fixed price per slice end (row epilogue: emission lookup, stores, publish) worth several
@@ -147,7 +174,15 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                 fprintf(stderr, "\n");
             }
         }
-        if (!packed) return false;  // does not fit with this K
+        if (!packed) {
+            if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"))) {
+                int tot = 0;
+                for (int j = 0; j < nsl; ++j) tot += len[j];
+                fprintf(stderr, "[res_layout] K=%d cu=%d does not fit: %d slices, %d chunks in all, capacity %d waves x %d chunks%s\n", K, k, nsl, tot,
+                        gm.waves, gm.nch, gm.maxsl ? " (3 slices per wave)" : "");
+            }
+            return false;  // does not fit with this K
+        }
         o->est_cost = std::max(o->est_cost, *std::max_element(cost.begin(), cost.end()));
         int rid = o->cu_row_off[k];
         for (int w = 0; w < gm.waves; ++w) {
@@ -155,21 +190,23 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
             int c0 = 0;
             const int wave_row0 = rid;
             int ord = 0;
+            unsigned lgbits = 0;
             for (int j : lists[w]) {
                 ends |= 1u << (c0 + len[j] - 1);
-                SliceAt sl{k, w, c0, len[j], rid, {}, ord++};
+                lgbits |= (unsigned)lgs[j] << (3 * ord);
+                SliceAt sl{k, w, c0, len[j], rid, {}, ord++, lgs[j]};
                 for (int lane = 0; lane < kWave; ++lane) {
-                    const size_t pos = (size_t)j * kWave + lane;
-                    const int r = pos < mine.size() ? mine[pos] : -1;
+                    const int r = lanes[j][lane];
+                    const bool first = r >= 0 && (lane & ((1 << lgs[j]) - 1)) == 0;   // the lane that owns the row's outputs
                     sl.rows.push_back(r);
-                    o->row_of.push_back(r);
-                    if (r >= 0) o->rid_of_row[r] = rid + lane;
+                    o->row_of.push_back(first ? r : -1);
+                    if (first) o->rid_of_row[r] = rid + lane;
                 }
                 slices->push_back(sl);
                 rid += kWave;
                 c0 += len[j];
             }
-            o->wave_info[(size_t)k * gm.waves + w] = uint4{ends, (unsigned)c0, (unsigned)wave_row0, 0u};
+            o->wave_info[(size_t)k * gm.waves + w] = uint4{ends, (unsigned)c0, (unsigned)wave_row0, lgbits};
         }
         o->cu_row_off[(size_t)k + 1] = rid;
     }
@@ -197,7 +234,12 @@ void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, 
     for (const SliceAt &sl : slices) {
         const int NI = sl.len * kResW;
         std::vector<std::vector<std::pair<int, float>>> rem(kWave);
-        for (int lane = 0; lane < kWave; ++lane) if (sl.rows[lane] >= 0) rem[lane] = rows[sl.rows[lane]];
+        for (int lane = 0; lane < kWave; ++lane)
+            if (sl.rows[lane] >= 0) {
+                const auto &row = rows[sl.rows[lane]];
+                const int np = 1 << sl.lg, q = lane & (np - 1);
+                for (size_t i = (size_t)q; i < row.size(); i += (size_t)np) rem[lane].push_back(row[i]);   // piece q of np
+            }
         // place[ins][lane] = arc (index, weight) or index -1
         std::vector<std::vector<std::pair<int, float>>> place(NI, std::vector<std::pair<int, float>>(kWave, {-1, 0.f}));
         std::vector<std::vector<int>> cnt(NI, std::vector<int>(2 * 32, 0));  // lanes per (half, bank)
@@ -863,7 +905,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // Geometry: 768 threads (3 waves per SIMD at <= 168 VGPRs; 20 chunks of arcs and the constants of up to 3 rows per
     // thread) when both directions fit it, else 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces
     // the latter.
-    const Geom *gm = allow3 ? &kGeomFac3 : &kGeomRes;
+    const Geom *gm = allow3 ? &kGeomFac3 : &kGeomFac512;
     const bool implicit = gm->maxsl > 0;   // entries numbered by row id, row constants in registers (below)
     // entries (512-thread layout): [U of every pair][sink][L of every pair][A of every pair][plain states]
     std::vector<int> entU(S, -1), ent(S, -1);   // entU: by main state; ent: a[s] itself (L, A or plain)
@@ -1134,6 +1176,9 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
                 (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
     F.nbx = (int)bx_idx.size(); F.bx_se = bx_se;
+    F.multilane = 0;
+    for (auto &wi : fo.wave_info) if (wi.w) F.multilane = 1;
+    for (auto &wi : bo.wave_info) if (wi.w) F.multilane = 1;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
     F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads;
     int rc;

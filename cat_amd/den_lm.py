@@ -11,7 +11,7 @@ The loader used by the product is the C++ one in cat_amd/csrc/fst_graph.cpp (``c
 files written here go through it, so writer and loader check each other.
 """
 import struct
-from typing import Dict, Optional
+from typing import Dict, Iterable, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -134,3 +134,169 @@ def random_labels_from_graph(g: Dict, length: int, rng: np.random.Generator) -> 
         s = int(dst[k])
     del prev
     return np.asarray(out, dtype=np.int32)
+
+
+# ------------------------------------------------------------------------------------------------
+# den_lm tool-chain without Kaldi / OpenFst.  Replaces the pipeline of
+# cat/utils/tool/prep_den_lm.sh:40-51:
+#     corpus2index | chain-est-phone-lm --ngram-order=N --no-prune-ngram-order=M  ->  token_lm.fst
+#     build_ctc_topo.py | fstcompile | fstarcsort                                 ->  T.fst
+#     fstcompose T.fst token_lm.fst | fstdeterminizestar --use-log=true           ->  den_lm.fst
+# PARITY UNPINNED: Kaldi is not in /root/reference, so its estimator cannot be run or read here.  What is
+# reproduced is the CONTRACT the loss relies on: an epsilon-free, input-deterministic acceptor over
+# ilabel = token + 1 (build_ctc_topo.py:6-11) in the tropical/log convention cost = -log p, whose language is
+# (CTC topology) o (un-smoothed n-gram LM of the training transcripts with history-state pruning).
+# ------------------------------------------------------------------------------------------------
+def estimate_token_lm(seqs: Iterable[Sequence[int]], vocab_size: int, ngram_order: int = 4,
+                      no_prune_ngram_order: int = 3, num_extra_states: int = 250) -> Dict:
+    """Un-smoothed n-gram LM over tokens 1..vocab_size-1 (0 = blank never occurs in transcripts), as a
+    deterministic acceptor without epsilons -- the kind of LM `chain-est-phone-lm` builds for the denominator:
+    a state is a history (tuple of up to ngram_order-1 previous tokens); all histories of fewer than
+    ``no_prune_ngram_order`` tokens are kept, of the longer ones the ``num_extra_states`` most frequent (plus
+    their suffixes); a position whose history is not kept is counted in its longest kept suffix.  Counts are
+    collected by running the transcripts through that automaton, so every transition a transcript takes
+    exists and every state's probabilities (tokens + end of sentence) sum to one.
+
+    Returns dict(num_states, start, tok_in[g] (-1 for the start state), arcs[g] = [(token, next, logp)], final[g])."""
+    seqs = [tuple(int(t) for t in s) for s in seqs]
+    for s in seqs:
+        for t in s:
+            if not (1 <= t < vocab_size):
+                raise ValueError(f"token {t} outside 1..{vocab_size - 1} (0 is the blank)")
+    N = max(1, int(ngram_order))
+    hist_count: Dict[tuple, int] = {}
+    for s in seqs:
+        for i in range(len(s) + 1):                      # history in front of token i (or of the end)
+            h = s[max(0, i - (N - 1)):i]
+            hist_count[h] = hist_count.get(h, 0) + 1
+    keep = {()}
+    for h in hist_count:
+        if len(h) < max(1, no_prune_ngram_order):
+            keep.add(h)
+    extra = sorted((h for h in hist_count if len(h) >= max(1, no_prune_ngram_order)),
+                   key=lambda h: (-hist_count[h], h))[:max(0, num_extra_states)]
+    for h in extra:
+        for k in range(len(h) + 1):                      # suffix-closed
+            keep.add(h[k:])
+
+    def lks(h):                                           # longest kept suffix
+        h = h[max(0, len(h) - (N - 1)):]
+        for k in range(len(h) + 1):
+            if h[k:] in keep:
+                return h[k:]
+        return ()
+
+    counts: Dict[tuple, Dict[int, int]] = {}
+    for s in seqs:
+        st = ()
+        for t in s:
+            counts.setdefault(st, {})
+            counts[st][t] = counts[st].get(t, 0) + 1
+            st = lks(st + (t,))
+        counts.setdefault(st, {})
+        counts[st][0] = counts[st].get(0, 0) + 1          # end of sentence
+    states = sorted(counts, key=lambda h: (len(h), h))
+    sid = {h: i for i, h in enumerate(states)}
+    arcs, final, tok_in = [], [], []
+    for h in states:
+        tot = float(sum(counts[h].values()))
+        a = []
+        for t, c in sorted(counts[h].items()):
+            if t == 0:
+                continue
+            a.append((t, sid[lks(h + (t,))], float(np.log(c / tot))))
+        arcs.append(a)
+        final.append(float(np.log(counts[h][0] / tot)) if counts[h].get(0, 0) else -np.inf)
+        tok_in.append(h[-1] if h else -1)
+    return dict(num_states=len(states), start=sid[()], tok_in=tok_in, arcs=arcs, final=final, histories=states)
+
+
+def compose_ctc_topo(lm: Dict, vocab_size: int, path: Optional[str] = None) -> Dict:
+    """CTC topology (build_ctc_topo.py:48-60: blank self-loop, token self-loop, token -> blank, token -> other
+    token) composed with a deterministic, epsilon-free token LM (`estimate_token_lm`).  Composed states:
+    (LM state g, last) with last in {nothing yet (start only), blank, the token just emitted}; an LM arc
+    g --t--> g' becomes (g, *) --t--> (g', t), except from (g, t) itself (a repeated token needs a blank in
+    between).  The result is input-deterministic and epsilon-free -- what fstdeterminizestar is called for in the
+    reference -- and every state is entered with one label.
+    Returns the arc arrays in reference conventions (see `synth_den_lm`); writes an OpenFst binary to ``path``."""
+    g0 = lm["start"]
+    ids: Dict[Tuple[int, int], int] = {}
+
+    def sid(g, last):                                     # last: -1 = nothing emitted yet, 0 = blank, t >= 1 = token t
+        k = (g, last)
+        if k not in ids:
+            ids[k] = len(ids)
+        return ids[k]
+
+    sid(g0, -1)
+    src, dst, lab, w = [], [], [], []
+    fin: Dict[int, float] = {}
+    todo, seen = [(g0, -1)], {(g0, -1)}
+    while todo:
+        g, last = todo.pop()
+        s = sid(g, last)
+        fin[s] = lm["final"][g]
+
+        def arc(d, label, weight):
+            src.append(s); dst.append(sid(*d)); lab.append(label); w.append(weight)
+            if d not in seen:
+                seen.add(d); todo.append(d)
+        if last >= 1:
+            arc((g, last), last, 0.0)                     # token self-loop
+        arc((g, 0), 0, 0.0)                               # blank (self-loop of (g, blank))
+        for t, g2, lp in lm["arcs"][g]:
+            if not (1 <= t < vocab_size):
+                raise ValueError("LM token outside the vocabulary")
+            if t == last:
+                continue
+            arc((g2, t), t, lp)
+    S = len(ids)
+    order = np.argsort(np.asarray(src), kind="stable")
+    end_w = np.full(S, -np.inf, dtype=np.float32)
+    for s, f in fin.items():
+        end_w[s] = f
+    g = dict(S=S, A=len(src), start=0, vocab=int(vocab_size),
+             src=np.asarray(src, dtype=np.int32)[order], dst=np.asarray(dst, dtype=np.int32)[order],
+             lab=np.asarray(lab, dtype=np.int32)[order], w=np.asarray(w, dtype=np.float32)[order],
+             start_w=np.full(S, -np.inf, dtype=np.float32), end_w=end_w)
+    g["start_w"][0] = 0.0
+    if path is not None:
+        cost_final = np.where(np.isfinite(g["end_w"]), -g["end_w"], np.inf).astype(np.float32)
+        write_fst(path, S, 0, g["src"], g["dst"], g["lab"] + 1, g["lab"] + 1, -g["w"], cost_final)
+    return g
+
+
+def prep_den_lm(seqs: Iterable[Sequence[int]], vocab_size: int, path: str, ngram_order: int = 4,
+                no_prune_ngram_order: int = 3, num_extra_states: int = 250) -> Dict:
+    """text (token ids) -> den_lm.fst: the whole of cat/utils/tool/prep_den_lm.sh without Kaldi/OpenFst."""
+    lm = estimate_token_lm(seqs, vocab_size, ngram_order, no_prune_ngram_order, num_extra_states)
+    return compose_ctc_topo(lm, vocab_size, path)
+
+
+def _main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="prepare the denominator LM for CRF training (prep_den_lm.sh without Kaldi): "
+                                             "one transcript per line, space-separated token ids (1..vocab_size-1; an optional "
+                                             "leading utterance id that is not an integer is skipped)")
+    ap.add_argument("r_specifier", help="input text with token ids ('-' = stdin)")
+    ap.add_argument("w_specifier", help="output den_lm.fst")
+    ap.add_argument("--vocab-size", type=int, required=True, help="vocabulary size including the blank (id 0)")
+    ap.add_argument("--ngram-order", type=int, default=4)
+    ap.add_argument("--no-prune-ngram-order", type=int, default=3)
+    ap.add_argument("--num-extra-lm-states", type=int, default=250)
+    a = ap.parse_args(argv)
+    import sys
+    fh = sys.stdin if a.r_specifier == "-" else open(a.r_specifier)
+    seqs = []
+    for line in fh:
+        f = line.split()
+        if f and not f[0].lstrip("-").isdigit():
+            f = f[1:]
+        if f:
+            seqs.append([int(x) for x in f])
+    g = prep_den_lm(seqs, a.vocab_size, a.w_specifier, a.ngram_order, a.no_prune_ngram_order, a.num_extra_lm_states)
+    print(f"{a.w_specifier}: {g['S']} states, {g['A']} arcs from {len(seqs)} transcripts")
+
+
+if __name__ == "__main__":
+    _main()

@@ -1,0 +1,111 @@
+"""den_lm tool-chain without Kaldi/OpenFst (cat_amd/den_lm.py: estimate_token_lm, compose_ctc_topo, prep_den_lm;
+SURVEY 8f-2, reference cat/utils/tool/prep_den_lm.sh:40-51).  The reference's own tools are not available, so these
+tests pin the CONTRACT: a normalised, deterministic n-gram automaton that accepts every training transcript, and a
+composed graph whose denominator (oracle, through the product's own FST reader) equals a brute-force sum over all
+CTC paths of  p(path | x) * P_LM(collapse(path))."""
+import itertools
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from cat_amd import den_lm
+from oracle import fst_io
+
+
+def _walk(lm, seq):
+    g, lp = lm["start"], 0.0
+    for t in seq:
+        nxt = [(g2, w) for (tt, g2, w) in lm["arcs"][g] if tt == t]
+        if not nxt:
+            return -math.inf
+        assert len(nxt) == 1                              # deterministic
+        g, lp = nxt[0][0], lp + nxt[0][1]
+    return lp + lm["final"][g]
+
+
+def _corpus(seed, n, vocab, maxlen):
+    rng = np.random.default_rng(seed)
+    # a first-order source so that higher-order histories carry information
+    trans = rng.dirichlet(np.ones(vocab - 1) * 0.5, size=vocab)
+    out = []
+    for _ in range(n):
+        L, s, prev = int(rng.integers(1, maxlen + 1)), [], 0
+        for _ in range(L):
+            prev = 1 + int(rng.choice(vocab - 1, p=trans[prev]))
+            s.append(prev)
+        out.append(s)
+    return out
+
+
+@pytest.mark.parametrize("order,noprune,extra", [(1, 1, 0), (2, 2, 0), (3, 2, 4), (4, 3, 250)])
+def test_token_lm_is_a_normalised_deterministic_automaton(order, noprune, extra):
+    seqs = _corpus(order, 300, 7, 10)
+    lm = den_lm.estimate_token_lm(seqs, 7, order, noprune, extra)
+    for g in range(lm["num_states"]):
+        toks = [t for t, _, _ in lm["arcs"][g]]
+        assert len(toks) == len(set(toks))                # one arc per token
+        tot = sum(math.exp(w) for _, _, w in lm["arcs"][g]) + (math.exp(lm["final"][g]) if math.isfinite(lm["final"][g]) else 0.0)
+        assert abs(tot - 1.0) < 1e-9
+        for t, g2, _ in lm["arcs"][g]:
+            assert order == 1 or lm["tok_in"][g2] == t    # a (non-empty) history is entered by its last token
+            assert len(lm["histories"][g2]) <= max(0, order - 1)
+    for s in seqs:                                        # every training transcript is accepted
+        assert math.isfinite(_walk(lm, s))
+    # the probabilities of all strings up to some length sum to <= 1 and the mass of the training set is substantial
+    if order == 1:
+        assert lm["num_states"] == 1
+
+
+def test_state_pruning():
+    seqs = _corpus(5, 500, 6, 12)
+    full = den_lm.estimate_token_lm(seqs, 6, 4, 3, 10 ** 6)
+    small = den_lm.estimate_token_lm(seqs, 6, 4, 3, 3)
+    assert small["num_states"] < full["num_states"]
+    assert all(len(h) <= 3 for h in small["histories"]) and () in set(small["histories"])
+    assert sum(len(h) == 3 for h in small["histories"]) <= 3      # at most num_extra_states full-order histories
+    # more context can only raise the training likelihood of an ML-estimated n-gram
+    ll_full = sum(_walk(full, s) for s in seqs)
+    ll_small = sum(_walk(small, s) for s in seqs)
+    assert ll_full >= ll_small - 1e-9
+
+
+def test_composed_graph_equals_brute_force_sum_over_ctc_paths(tmp_path):
+    V, T = 4, 5
+    seqs = _corpus(2, 200, V, 4)
+    lm = den_lm.estimate_token_lm(seqs, V, 3, 2, 50)
+    p = str(tmp_path / "den_lm.fst")
+    g = den_lm.prep_den_lm(seqs, V, p, 3, 2, 50)
+    assert os.path.getsize(p) > 0
+    gr = fst_io.read_fst(p)                               # what the loss would load
+    assert gr["S"] == g["S"] and gr["A"] == g["A"]
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(1, T, V)).astype(np.float32)
+    logp = x - np.log(np.exp(x).sum(-1, keepdims=True))
+    ref = float(oracle.den(gr, logp, np.array([T], dtype=np.int32), precision="f64")[1][0])   # costs_alpha = logZ
+    tot = 0.0
+    for pi in itertools.product(range(V), repeat=T):
+        seq, prev = [], -1
+        for v in pi:                                      # CTC collapse: merge repeats, drop blanks
+            if v != prev and v != 0:
+                seq.append(v)
+            prev = v
+        lw = _walk(lm, seq)
+        if math.isfinite(lw):
+            tot += math.exp(lw + sum(float(logp[0, t, v]) for t, v in enumerate(pi)))
+    assert abs(ref - math.log(tot)) <= 1e-6 * max(1.0, abs(ref))
+
+
+def test_cli_and_bad_input(tmp_path):
+    txt = tmp_path / "text.ids"
+    txt.write_text("utt1 1 2 3 2\nutt2 2 2 1\n3 1\n")
+    out = tmp_path / "den.fst"
+    den_lm._main([str(txt), str(out), "--vocab-size", "4", "--ngram-order", "3", "--no-prune-ngram-order", "2"])
+    g = fst_io.read_fst(str(out))
+    assert g["S"] > 2 and int(g["lab"].max()) <= 3
+    with pytest.raises(ValueError):
+        den_lm.estimate_token_lm([[1, 4]], 4)             # token outside the vocabulary
+    with pytest.raises(ValueError):
+        den_lm.estimate_token_lm([[0, 1]], 4)             # the blank is not a transcript token

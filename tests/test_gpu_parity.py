@@ -167,6 +167,45 @@ def test_fused_log_softmax(crf, tmp_path, mode, dtype):
     del ctx
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode):
+    """A den_lm ESTIMATED from text (cat_amd.den_lm.prep_den_lm) has the in-degree profile of a real
+    n-gram LM: the low-order history states are entered from hundreds of states.  The factored layout cuts such rows
+    into pieces on adjacent lanes (butterfly sum in the kernel); all kernel families against the fp64 oracle."""
+    from cat_amd import den_lm
+    V = 40
+    rng = np.random.default_rng(7)
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(1500):
+        L, sq, a, b = int(rng.integers(8, 30)), [], 0, 0
+        for _ in range(L):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
+        seqs.append(sq)
+    p = str(tmp_path / "den_est.fst")
+    den_lm.prep_den_lm(seqs, V, p, 4, 3, 150)
+    g = fst_io.read_fst(p)
+    indeg = np.bincount(g["dst"], minlength=g["S"]).max()
+    assert indeg > 100                                        # longer than one lane's 80 arcs
+    B, T = 3, 60
+    logits = rng.normal(size=(B, T, V)).astype(np.float32) * 2.0
+    logits = logits - np.log(np.exp(logits).sum(-1, keepdims=True))
+    lx = np.array([60, 47, 33], dtype=np.int32)
+    labels, ly = [], []
+    for b in range(B):
+        lab = seqs[b][:max(1, int(lx[b]) // 6)]
+        labels += lab; ly.append(len(lab))
+    ref = oracle.ctc_crf(g, logits, np.array(labels, dtype=np.int32), lx, np.array(ly, dtype=np.int32), lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode=mode)
+    if mode == "factored":
+        with _mode(mode):
+            ctx = crf.CRFContext(p, 0)
+        assert crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))["fac"] == 1
+        del ctx
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
 def test_factored_schedules(crf, tmp_path):
     """The factored den kernels run everything else BESIDE them while 2B workgroups leave half of the CUs free
     (B = 3 here and in the tests above) and fall back to 'numerator after denominator' for larger batches
