@@ -65,7 +65,10 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         {
             auto lg_of = [&](int r) {
                 int lg = 0;
-                while (gm.multilane && lg < 6 && (chunks_of(rows[r].size()) + (1 << lg) - 1) / (1 << lg) > gm.nch) ++lg;
+                const int n = chunks_of(rows[r].size());
+                if (!gm.multilane || n <= gm.nch) return 0;
+                // pieces of at most half a lane's budget: long pieces (a 30-chunk slice fills a wave) pack badly
+                while (lg < 6 && (n + (1 << lg) - 1) / (1 << lg) > (gm.nch + 1) / 2) ++lg;
                 return lg;
             };
             size_t i = 0;
@@ -180,6 +183,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                 for (int j = 0; j < nsl; ++j) tot += len[j];
                 fprintf(stderr, "[res_layout] K=%d cu=%d does not fit: %d slices, %d chunks in all, capacity %d waves x %d chunks%s\n", K, k, nsl, tot,
                         gm.waves, gm.nch, gm.maxsl ? " (3 slices per wave)" : "");
+                fprintf(stderr, "[res_layout]   slice lengths (lg):"); for (int j = 0; j < nsl; ++j) fprintf(stderr, " %d(%d)", len[j], lgs[j]); fprintf(stderr, "\n");
             }
             return false;  // does not fit with this K
         }
@@ -817,7 +821,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // =================================================================================================
 static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
                                const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
-                               const std::vector<float> &end_lin, bool allow3, bool *retry512) {
+                               const std::vector<float> &end_lin, bool allow3, bool *retry512, bool use_dup, bool *retry_nodup) {
     FacDev &F = h->dev.fac;
     F = FacDev{};
     if ((getenv("CRF_NO_FACTORED") && atoi(getenv("CRF_NO_FACTORED"))) || (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT")))) return CRF_OK;
@@ -912,7 +916,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // ... and a SECOND copy of the U entries (and the sink, which padding rows write) behind everything, on
     // other banks: [U][sink][L][A][plain] [pad] [U'][sink'] -- see pack_arcs
     static const int bank_shift = getenv("CRF_FAC_BANK_SHIFT") ? atoi(getenv("CRF_FAC_BANK_SHIFT")) & 31 : 5;
-    static const bool no_dup = getenv("CRF_FAC_NO_DUP") && atoi(getenv("CRF_FAC_NO_DUP"));
+    const bool no_dup = !use_dup || (getenv("CRF_FAC_NO_DUP") && atoi(getenv("CRF_FAC_NO_DUP")));
     int nent = 0;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) entU[s] = nent++;
     int nU = nent;
@@ -1175,6 +1179,14 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (verbose)
         fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
                 (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
+    {   // LDS of the recursion kernels (crf_kernels.hip fac_lds_bytes; emission rows etc. budgeted for V <= 1000): two state
+        // vectors + 16 bytes per row.  Too much with the second copy of the gathered entries: build again without it.
+        auto need = [](int G, int R) { return (size_t)2 * ((G + 63) / 64 * 64) * 4 + (size_t)R * 16 + 10240; };
+        if (std::max(need(Gf, Rf), need(Gb, Rb)) > (size_t)160 * 1024) {
+            if (!no_dup) { *retry_nodup = true; return CRF_OK; }
+            return give_up("state vectors and row constants exceed the LDS");
+        }
+    }
     F.nbx = (int)bx_idx.size(); F.bx_se = bx_se;
     F.multilane = 0;
     for (auto &wi : fo.wave_info) if (wi.w) F.multilane = 1;
@@ -1200,9 +1212,14 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     // Geometry: 768 threads x 21 chunks (3 waves per SIMD at <= 168 VGPRs) when both directions fit it, else
     // 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces the latter.
     const bool want3 = !(getenv("CRF_FAC_THREADS") && atoi(getenv("CRF_FAC_THREADS")) == 512);
-    bool retry = false;
-    int rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, want3, &retry);
-    if (rc == CRF_OK && retry) rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, false, &retry);
+    bool retry = false, nodup = false;
+    int rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, want3, &retry, true, &nodup);
+    if (rc == CRF_OK && nodup) { nodup = false; rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, want3, &retry, false, &nodup); }
+    if (rc == CRF_OK && retry) {
+        nodup = false;
+        rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, false, &retry, true, &nodup);
+        if (rc == CRF_OK && nodup) rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, false, &retry, false, &nodup);
+    }
     return rc;
 }
 
