@@ -1600,8 +1600,9 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                         } else {
                         const int4 m = *(const int4 *)(RMc + 4u * r4);
                         if (DIR == 0) {
-                            const float rv = tot * sc;                                  // q_t[pair of the main state]
                             const float uold = *(const float *)(xb + (m.x & 0xffff));   // U_t of the row's pair
+                            const float em = EPu[(unsigned)m.x >> 16], et = EPu[m.w];   // (requested together: one LDS round trip)
+                            const float rv = tot * sc;                                  // q_t[pair of the main state]
                             const float qt = __int_as_float(m.z) * uold * sc;           // q_t[pair of the tail state]
                             if (flagged) {   // write-through: the grad pass reads the rows from other XCDs while this kernel runs
                                 __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1610,17 +1611,18 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                                 *(float *)((char *)Orow + r4) = rv;
                                 *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
                             }
-                            const float Lp = EPu[(unsigned)m.x >> 16] * rv;              // a_{t+1}[main]
-                            const float Ap = EPu[m.w] * qt;                             // a_{t+1}[tail]
+                            const float Lp = em * rv;                                   // a_{t+1}[main]
+                            const float Ap = et * qt;                                   // a_{t+1}[tail]
                             const float Up = Ap + Lp;
                             *(float *)(xnb + (m.x & 0xffff)) = Up;
-                            *(float *)(xnb + (m.x & 0xffff) + dup) = Up;
+                            if (dup) *(float *)(xnb + (m.x & 0xffff) + dup) = Up;
                             *(float *)(xnb + (m.y & 0xffff)) = Lp;
                             *(float *)(xnb + ((unsigned)m.y >> 16)) = Ap;
                             mymax = fmaxf(mymax, Up);
                         } else {
                             const float craw = tot;                                     // common out-arcs of the row's states
                             const float z0 = *(const float *)(xb + (m.x & 0xffff)), z1 = *(const float *)(xb + ((unsigned)m.x >> 16));
+                            const float e0 = EPu[m.w & 0xffff], e1 = EPu[(unsigned)m.w >> 16];
                             f32x2 bv;                                                    // b_t of the two states
                             bv.x = fmaf(__int_as_float(m.y), z0, craw) * sc;
                             bv.y = fmaf(__int_as_float(m.z), z1, craw) * sc;
@@ -1631,11 +1633,11 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
                             else
                                 *(f32x2 *)((char *)Orow + 2u * r4) = bv;
                             f32x2 zv;                                                    // z_{t-1} of the pairs entering them
-                            zv.x = EPu[m.w & 0xffff] * bv.x;
-                            zv.y = EPu[(unsigned)m.w >> 16] * bv.y;
+                            zv.x = e0 * bv.x;
+                            zv.y = e1 * bv.y;
                             *(f32x2 *)(xnb + 2u * r4) = zv;
                             typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-                            *(f32x2u *)(xnb + 2u * r4 + dup) = zv;   // the copy's distance is an odd number of floats: ds_write2_b32
+                            if (dup) *(f32x2u *)(xnb + 2u * r4 + dup) = zv;   // the copy's distance is an odd number of floats: ds_write2_b32
                             mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
                         }
                         }
