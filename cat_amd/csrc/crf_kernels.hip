@@ -1829,8 +1829,9 @@ constexpr int kGDEpRegs = 4;                                      // V <= 4*256
 #ifndef CRF_GD_MINW
 #define CRF_GD_MINW 1   // 4: 128 VGPRs (spills 25) for a fourth workgroup per CU -- measured slower/faster: see DESIGN.md
 #endif
-template <int NCPT, int EPR>
-__global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW : 1) void crf_grad_den_kernel(LossParams p) {
+// NT threads: 256, or 512 for graphs whose rows do not fit 256 threads' prefetch registers (5 float4 each per row)
+template <int NCPT, int EPR, int NT = kGDThreads>
+__global__ __launch_bounds__(NT, (NCPT == 1 && EPR == 1 && NT == kGDThreads) ? CRF_GD_MINW : 1) void crf_grad_den_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
     const int tid = threadIdx.x;
@@ -1883,7 +1884,7 @@ __global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW :
         const int nlist = p.gchunk[NC];
 #pragma unroll
         for (int i = 0; i < NCPT; ++i) {
-            const int c = tid + i * kGDThreads;
+            const int c = tid + i * NT;
             const int j0 = c < NC ? p.gchunk[c] : 0;
             const int clen = c < NC ? p.gchunk[c + 1] - j0 : 0;
 #pragma unroll
@@ -1903,9 +1904,9 @@ __global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW :
     // label of each chunk: the per-label chunk ranges, inverted once per workgroup.  The chunk sums of a
     // label are combined with LDS float adds -- a per-label loop over its chunks made one thread (the blank
     // label owns a third of all pairs) walk 64 chunks in every frame, half the time of this kernel.
-    for (int v = tid; v <= g.max_label && v < V; v += kGDThreads)
+    for (int v = tid; v <= g.max_label && v < V; v += NT)
         for (int c = p.glab[v]; c < p.glab[v + 1]; ++c) clab_s[c] = v;
-    for (int v = tid; v < 4 * Vp; v += kGDThreads) gd[v] = 0.f;
+    for (int v = tid; v < 4 * Vp; v += NT) gd[v] = 0.f;
     if (tid == 0) Qs[Rq] = 0.f;
     __syncthreads();
     // Chunks are label-sorted, so the lanes of a wave that share a label are neighbours: a segmented
@@ -1916,7 +1917,7 @@ __global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW :
     const int lane = tid & 63;
 #pragma unroll
     for (int i = 0; i < NCPT; ++i) {
-        const int c = tid + i * kGDThreads;
+        const int c = tid + i * NT;
         clab[i] = c < NC ? clab_s[c] : -1;
         segm[i] = 0;
 #pragma unroll
@@ -1937,21 +1938,21 @@ __global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW :
     {                                                                                                    \
         const f32x4 *Qr = (const f32x4 *)(p.Q + (bt0 + (t)) * Rq), *Br = (const f32x4 *)(p.BP + (bt0 + (t)) * Rb); \
         _Pragma("unroll") for (int i = 0; i < kGDRowRegs; ++i) {                                         \
-            const int r = tid + i * kGDThreads;                                                          \
+            const int r = tid + i * NT;                                                          \
             qr[i] = 4 * r < Rq ? Qr[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
             br[i] = 4 * r < Rb ? Br[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
         }                                                                                                \
         const float *er_ = p.ep + (bt0 + (t)) * V;                                                       \
         const float *gr_ = p.grad + (bt0 + (t)) * V;                                                     \
         _Pragma("unroll") for (int q = 0; q < EPR; ++q) {                                          \
-            const int v = tid + q * kGDThreads;                                                          \
+            const int v = tid + q * NT;                                                          \
             ern[q] = v < V ? er_[v] : 0.f;                                                               \
             rwn[q] = (p.grad_den_acc && v < V) ? gr_[v] : 0.f;                                           \
         }                                                                                                \
     }
 #define CRF_GD_STAGE()                                                                                  \
     _Pragma("unroll") for (int i = 0; i < kGDRowRegs; ++i) {                                             \
-        const int r = tid + i * kGDThreads;                                                              \
+        const int r = tid + i * NT;                                                              \
         if (4 * r < Rq) ((f32x4 *)Qs)[r] = qr[i];                                                        \
         if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];                                                        \
     }
@@ -1987,7 +1988,7 @@ __global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW :
         }
 #pragma unroll
         for (int q = 0; q < EPR; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
-            const int v = tid + q * kGDThreads;
+            const int v = tid + q * NT;
             if (v < V) gzero[v] = 0.f;
         }
         if (tid == 0) nrm[(t + 2) & 3] = 0.f;
@@ -2005,7 +2006,7 @@ __global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW :
         float u[EPR], part = 0.f;
 #pragma unroll
         for (int q = 0; q < EPR; ++q) {
-            const int v = tid + q * kGDThreads;
+            const int v = tid + q * NT;
             u[q] = v < V ? (erc[q] * pow2f(-kEpExp)) * gsum[v] : 0.f;
             part += u[q];
             erc[q] = ern[q];
@@ -2023,7 +2024,7 @@ __global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW :
         float *row = p.grad + (bt0 + t) * V;
 #pragma unroll
         for (int q = 0; q < EPR; ++q) {
-            const int v = tid + q * kGDThreads;
+            const int v = tid + q * NT;
             if (v < V) row[v] = rw[q] + u[q] * inv;   // rw = 0 unless accumulating onto the numerator half
         }
     }
@@ -2032,7 +2033,7 @@ __global__ __launch_bounds__(kGDThreads, (NCPT == 1 && EPR == 1) ? CRF_GD_MINW :
     if (!p.grad_den_acc)
         for (int t = max(t0, tl); t < t1; ++t) {  // frames past the utterance's length: zero rows
             float *row = p.grad + (bt0 + t) * V;
-            for (int v = tid; v < V; v += kGDThreads) row[v] = 0.f;
+            for (int v = tid; v < V; v += NT) row[v] = 0.f;
         }
 }
 
@@ -2606,7 +2607,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     // The denominator half of the grad pass has a streaming kernel (index pairs in registers, rows
     // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
     const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
-    const bool fast_den = den && w.Rq <= 4 * kGDRowRegs * kGDThreads && w.Rb <= 4 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
+    const bool gd_wide = den && (w.Rq > 4 * kGDRowRegs * kGDThreads || w.Rb > 4 * kGDRowRegs * kGDThreads);   // 512-thread grad workgroups
+    const bool fast_den = den && w.Rq <= 8 * kGDRowRegs * kGDThreads && w.Rb <= 8 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
                           gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
     // numerator half of the grad pass: streaming kernel when the vocabulary fits its registers
     const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
@@ -2752,8 +2754,11 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             p.gd_nf = (p.gd_bound[stage] - p.gd_bound[stage - 1] + kGDFrames - 1) / kGDFrames + 3;
             if (2 * p.gd_nf < (int)gg.x) gg.x = (unsigned)(2 * p.gd_nf); else p.gd_nf = 0;
         }
-        static std::atomic<size_t> set1{0}, set2{0}, set3{0};
-        if (gnc <= kGDThreads && V <= kGDThreads) {   // small vocabulary: 128 VGPRs, a fourth workgroup per CU
+        static std::atomic<size_t> set1{0}, set2{0}, set3{0}, set5{0};
+        if (gd_wide) {   // rows of more than 5120 floats: 512 threads per workgroup (one chunk per thread up to 512 chunks)
+            if (l > set5.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1, 2, 2 * kGDThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set5 = l; }
+            hipLaunchKernelGGL((crf_grad_den_kernel<1, 2, 2 * kGDThreads>), gg, dim3(2 * kGDThreads), l, st, p);
+        } else if (gnc <= kGDThreads && V <= kGDThreads) {   // small vocabulary: 128 VGPRs, a fourth workgroup per CU
             if (l > set3.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set3 = l; }
             hipLaunchKernelGGL((crf_grad_den_kernel<1, 1>), gg, dim3(kGDThreads), l, st, p);
         } else if (gnc <= kGDThreads) {

@@ -206,6 +206,23 @@ def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode):
     assert rel_err(grad, ref["grad"]) <= TOL
 
 
+def test_wide_rows_grad_kernel(crf, tmp_path):
+    """More than 2 560 forward rows: the per-frame rows (Q, BP) exceed 5 120 floats and the denominator half of the
+    grad pass runs with 512-thread workgroups; factored layout, against the fp64 oracle (short T, ragged)."""
+    g, p = small_synth(tmp_path, 48, 3000, 8, 21)
+    B, T, V = 3, 40, 48
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=4, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    with _mode("factored"):
+        ctx = crf.CRFContext(p, 0)
+    st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+    assert st["fac"] == 1 and st["fac_fwd_slots"] > 0
+    del ctx
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode="factored")
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
 def test_factored_schedules(crf, tmp_path):
     """The factored den kernels run everything else BESIDE them while 2B workgroups leave half of the CUs free
     (B = 3 here and in the tests above) and fall back to 'numerator after denominator' for larger batches

@@ -46,3 +46,7 @@ n = 10
 for _ in range(n): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"B={B} T={T}: {dt * 1e3:.3f} ms/step, {B / dt:.0f} utt/s")
+ctc_crf._C.profile_enable(True)
+step()
+print("kernels (ms):", {k: round(v, 3) for k, v in ctc_crf._C.profile_read().items() if v >= 0})
+ctc_crf._C.profile_enable(False)
