@@ -119,3 +119,31 @@ def test_register_resident_layouts_host_only(tmp_path, golden_dir):
         core._lib.crf_graph_destroy(ctypes.c_void_p(h))
     finally:
         os.environ.pop("CRF_NO_FACTORED")
+
+
+def test_factored_layout_takes_an_estimated_ngram_graph(tmp_path):
+    """A den_lm estimated from text (cat_amd.den_lm.prep_den_lm) has rows far longer than one lane's 80 arcs -- the
+    low-order history states are entered from hundreds of states.  The factored layout must still take it (rows cut
+    into pieces on adjacent lanes) instead of falling back to the streaming kernels; host only."""
+    import numpy as np
+    import ctc_crf
+    from cat_amd import den_lm
+    core = ctc_crf._C
+    V = 40
+    rng = np.random.default_rng(3)
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(1200):
+        L, sq, a, b = int(rng.integers(8, 30)), [], 0, 0
+        for _ in range(L):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
+        seqs.append(sq)
+    p = os.path.join(str(tmp_path), "est.fst")
+    g = den_lm.prep_den_lm(seqs, V, p, 4, 3, 150)
+    h = core.compile_graph_host_only(p)
+    st = core.graph_stats(h)
+    core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+    assert st["S"] == g["S"] and st["A"] == g["A"]
+    assert st["max_in_deg"] > 80                          # longer than a lane
+    assert st["fac"] == 1 and st["fac_fwd_slots"] > 0 and st["fac_bwd_slots"] > 0
+    assert st["fac_matched_pairs"] >= (st["S"] - 1) // 2 - 2
