@@ -16,6 +16,12 @@ Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel, HIP-event time
 the same step behind a DDP-wrapped stand-in acoustic head (RCCL all-reduce of its gradients over
 xGMI) and reports it as `ddp_head` -- extra information, never `value`.
 """
+import os as _os
+# One HIP hardware queue per stream: the loss uses four streams and RCCL adds its own; with HIP's default of four
+# hardware queues two of them would share one and kernels meant to run side by side would run one after the other
+# (measured with a fifth stream in the process: the numerator recursions serialised).  Must be set before HIP starts.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import argparse
 import json
 import os

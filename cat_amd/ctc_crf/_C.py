@@ -4,6 +4,12 @@
 There is NO CPU fallback and no PyTorch fallback: if the HIP library is missing the import fails,
 and every call goes through the C ABI of include/ctc_crf_hip.h.
 """
+import os as _os
+# One HIP hardware queue per stream (see crf_loss_fwd_bwd's schedule: four streams that must run side by side; HIP's
+# default is four queues for ALL streams of the process, RCCL and torch side streams included).  Only effective if the
+# HIP runtime has not started yet; measured neutral when nothing else competes.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import ctypes
 import os
 from typing import Dict, Optional
