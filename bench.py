@@ -85,7 +85,7 @@ def main():
 
     import ctc_crf
     from cat_amd.den_lm import synth_den_lm
-    from tests.util import make_batch
+    from cat_amd.synth import make_batch
 
     # synthetic den_lm (seed 0, identical on every rank) written as an OpenFst binary and loaded
     # through the product's own reader -- the same path CRFContext takes in CAT

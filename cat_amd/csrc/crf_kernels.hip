@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -1044,8 +1045,7 @@ constexpr int kResXB = 32768;                 // bytes per state-vector buffer  
 constexpr int kResGmax = kResXB / 4;
 
 template <int DIR>
-__global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void res_chain_body(const ResParams &p, float *lds, const int bx, const int gx) {
     const ResDirDev &L = p.L;
     const int K = p.K;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
     // protocol is placement-independent).
     int b, k;
     {
-        const int x = (int)blockIdx.x, total = (int)gridDim.x, full = total / (8 * K) * (8 * K);
+        const int x = bx, total = gx, full = total / (8 * K) * (8 * K);
         if (x < full) { const int grp = x / (8 * K), within = x % (8 * K); k = within / 8; b = p.b0 + grp * 8 + within % 8; }
         else { const int y = x - full; k = y % K; b = p.b0 + full / K + y / K; }
     }
@@ -1311,6 +1311,15 @@ __global__ __launch_bounds__(kResThreads) void crf_res_chain_kernel(ResParams p)
     }
 }
 
+// Forward and backward recursion of a group of utterances as ONE grid (the first half of the blocks runs the forward
+// recursion): one launch, one stream -- the loss no longer needs a hardware queue per recursion.
+__global__ __launch_bounds__(kResThreads) void crf_res_pair_kernel(ResParams pf, ResParams pb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int half = (int)gridDim.x >> 1;
+    if ((int)blockIdx.x < half) res_chain_body<0>(pf, lds, (int)blockIdx.x, half);
+    else res_chain_body<1>(pb, lds, (int)blockIdx.x - half, half);
+}
+
 // =============================================================================================
 // FACTORED resident recursions (crf_internal.h: FacDev, res_layout.cpp: build_factored): one compute unit
 // per recursion and utterance, no exchange.  Same arithmetic and scaling as crf_res_chain_kernel, same arc
@@ -1356,7 +1365,7 @@ struct FacParams {
 // ML: some rows are cut into pieces on adjacent lanes (graphs with long rows; a separate instantiation, the check costs the
 // row epilogue of the others 2 %)
 template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML>
-__global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
+__device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, const int b) {
     constexpr int NW = NTH / kWave;
     // 768-thread geometry: the last chunk slot of a thread holds ROW CONSTANTS instead of arcs -- two words for each of
     // the (at most three) rows the lane finishes per frame -- and the entries of a row sit where its row id says
@@ -1368,11 +1377,9 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
     constexpr int RCW = NCHA * 6;                            // first row-constant word
     static_assert(NCHA % NB == 0, "chunks per thread must be a multiple of the batch");
 
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const FacDirDev &L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = (int)blockIdx.x;
     const int V = p.V, lx = p.lx[b], G = L.G, R = L.R;
     const unsigned dup = (unsigned)L.dup;                   // second copy of the gathered entries, other banks (res_layout.cpp pack_arcs)
     const int Vp = rup64(V + 1), Gp = rup64(G);
@@ -1699,6 +1706,20 @@ __global__ __launch_bounds__(NTH) void crf_fac_chain_kernel(FacParams p) {
     }
 }
 
+// Both recursions of every utterance as ONE grid of 2B workgroups (block x < B: forward recursion of utterance x,
+// else the backward recursion of utterance x - B).  One launch on one stream: the two directions used to be two
+// kernels on two streams, which ran side by side only while those streams sat on different hardware queues -- not
+// guaranteed inside a training process (HIP maps all streams of a process onto GPU_MAX_HW_QUEUES = 4 queues; with
+// RCCL's and torch's streams around, the recursions were observed to run one after the other: 5.3 instead of 3.25 ms).
+// NBF / NBB: chunks gathered per batch, forward / backward.
+template <bool FLAG, int NTH, int NCH, int NBF, int NBB, bool ML>
+__global__ __launch_bounds__(NTH) void crf_fac_pair_kernel(FacParams pf, FacParams pb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int B = pf.B;
+    if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML>(pf, lds, (int)blockIdx.x);
+    else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML>(pb, lds, (int)blockIdx.x - B);
+}
+
 // Holds a (side) stream until `target` workgroups of the den kernels have started, i.e. own their compute
 // units: the numerator chains launched behind it then land on the remaining CUs instead of scattering over
 // all of them and keeping den workgroups (which need a whole CU's registers) waiting.  Bounded: after ~0.2 ms
@@ -1711,17 +1732,21 @@ __global__ void crf_gate_kernel(const int *started, int target) {
     // timed out: nothing depends on this for correctness
 }
 
-// One kernel per recursion so each keeps its own (small) set of live kernel arguments in SGPRs; the
-// four launches are issued on forked HIP streams and run concurrently (crf_loss_fwd_bwd).
-// NR (numerator roles only): ctc states per thread, chosen by the host from the batch's longest label sequence.
-template <int ROLE, bool GV = false, int NR = kCtcRegs>
-__global__ __launch_bounds__(ROLE >= 2 ? kCtcThreads : kChainThreads) void crf_chain_kernel(LossParams p) {
+// Streaming denominator recursions and the numerator chains: forward and backward of every utterance in ONE grid of 2B
+// workgroups each (block x < B: forward).  The two grids (denominator pair, numerator pair) are independent and run side
+// by side on the caller's stream and one side stream (crf_loss_fwd_bwd).
+template <bool GV>
+__global__ __launch_bounds__(kChainThreads) void crf_den_pair_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = (int)blockIdx.x;
-    if (ROLE == 0) den_forward<GV>(p, b, lds);
-    else if (ROLE == 1) den_backward<GV>(p, b, lds);
-    else if (ROLE == 2) ctc_forward<NR>(p, b, lds);
-    else ctc_backward<NR>(p, b, lds);
+    if ((int)blockIdx.x < p.B) den_forward<GV>(p, (int)blockIdx.x, lds);
+    else den_backward<GV>(p, (int)blockIdx.x - p.B, lds);
+}
+// NR: ctc states per thread, chosen by the host from the batch's longest label sequence.
+template <int NR>
+__global__ __launch_bounds__(kCtcThreads) void crf_ctc_pair_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x < p.B) ctc_forward<NR>(p, (int)blockIdx.x, lds);
+    else ctc_backward<NR>(p, (int)blockIdx.x - p.B, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2269,54 +2294,109 @@ static size_t chain_lds_bytes(const HostGraph *h, int V, int Sc, int role, bool 
     return fl * sizeof(float);
 }
 
-// Side streams + events used to run the four recursions concurrently (fork/join around the
-// caller's stream).  One set per device, created on first use.
+// ---------------------------------------------------------------------------------------------
+// Per-(device, caller stream) context: ONE side stream, the fork/join events and a few flag words.
+// A call needs two streams at most -- the caller's (denominator recursions: forward and backward are one grid) and
+// one side stream (numerator recursions, then the grad pass that follows the recursions in stages).  Nothing is
+// shared between two caller streams or two devices, so calls on different streams / from different host threads do
+// not touch each other's events or counters; calls on ONE stream are ordered by the stream (the counters of call
+// n+1 are cleared by its prep kernel, which runs after call n has joined everything back into that stream).
+// ---------------------------------------------------------------------------------------------
 constexpr int kMaxStages = 16;
+constexpr int kFlagInts = 2048;
+constexpr int kMaxDev = 64;
 struct DevCtx {
-    bool init = false;
-    hipStream_t side[3]{};
-    hipEvent_t fork{}, join[3]{};
-    int *flags = nullptr;   // fine-grained (uncached, cross-XCD coherent) words: error word, start counter
-    // events of the staged schedule: after every den segment (forward / backward), and two joins
-    hipEvent_t evf[kMaxStages]{}, evb[kMaxStages]{}, jm[4]{};
+    std::mutex mu;            // one call at a time is ENQUEUED through a context (host side only; nothing waits on the GPU)
+    int dev = 0;
+    hipStream_t owner{};
+    hipStream_t side{};       // null: no side stream that runs beside the owner was found -> everything on the owner's stream
+    hipEvent_t fork{}, join{}, ev[kMaxStages]{}, evb[kMaxStages]{};
+    int *flags = nullptr;     // fine-grained (uncached, cross-XCD coherent) words: [0] error word, [1] start counter, [16..32) stage counters
+    bool warned = false;
 };
-constexpr int kFlagInts = 16384;
-static DevCtx g_ctx[64];
 static std::mutex g_ctx_mu;
+static std::vector<DevCtx *> g_ctxs;
 
-static int get_ctx(DevCtx **out) {
+// Do two streams run side by side?  HIP maps every stream of the process onto GPU_MAX_HW_QUEUES (default 4) hardware
+// queues; two streams on one queue run their kernels one after the other.  Two single-wave kernels shake hands through
+// fine-grained memory: each raises its flag and waits (bounded, ~0.5 ms) for the other's.  Both see the other only if
+// they were resident at the same time.
+__global__ void crf_probe_kernel(int *flags, int me, int other) {
+    __hip_atomic_store(flags + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int saw = 0;
+    for (int spins = 0; spins < 400 && !saw; ++spins) {
+        saw = __hip_atomic_load(flags + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!saw) __builtin_amdgcn_s_sleep(64);
+    }
+    __hip_atomic_store(flags + 2 + me, saw ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int get_ctx(hipStream_t owner, DevCtx **out) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess || dev < 0 || dev >= 64) { set_error("hipGetDevice failed"); return CRF_ERR_HIP; }
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDev) { set_error("hipGetDevice failed"); return CRF_ERR_HIP; }
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    DevCtx &c = g_ctx[dev];
-    if (!c.init) {
-        for (int i = 0; i < 3; ++i) {
-            if ((e = hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking)) != hipSuccess ||
-                (e = hipEventCreateWithFlags(&c.join[i], hipEventDisableTiming)) != hipSuccess) {
-                set_error(std::string("stream/event create: ") + hipGetErrorString(e));
-                return CRF_ERR_HIP;
-            }
-        }
-        if ((e = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming)) != hipSuccess) {
-            set_error(std::string("event create: ") + hipGetErrorString(e));
-            return CRF_ERR_HIP;
-        }
-        // Words that one kernel polls while another, on a different XCD, updates them must not be cached in
-        // the poller's L2 (the per-XCD L2s are not coherent with each other; an `sc1` load bypasses only L1, so
-        // a poller kept re-reading its own stale line -- seen as multi-second stalls of the grad pass):
-        // fine-grained device memory is uncached in L2.
-        void *fl = nullptr;
-        if (hipExtMallocWithFlags(&fl, kFlagInts * sizeof(int), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); fl = nullptr; }
-        c.flags = (int *)fl;
-        for (int i = 0; i < kMaxStages; ++i) {
-            (void)hipEventCreateWithFlags(&c.evf[i], hipEventDisableTiming);
-            (void)hipEventCreateWithFlags(&c.evb[i], hipEventDisableTiming);
-        }
-        for (int i = 0; i < 4; ++i) (void)hipEventCreateWithFlags(&c.jm[i], hipEventDisableTiming);
-        c.init = true;
+    for (DevCtx *c : g_ctxs)
+        if (c->dev == dev && c->owner == owner) { *out = c; return CRF_OK; }
+    DevCtx *c = new DevCtx();
+    c->dev = dev; c->owner = owner;
+    // Words that one kernel polls while another, on a different XCD, updates them must not be cached in the poller's
+    // L2 (the per-XCD L2s are not coherent with each other): fine-grained device memory is uncached in L2.
+    void *fl = nullptr;
+    if (hipExtMallocWithFlags(&fl, kFlagInts * sizeof(int), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); fl = nullptr; }
+    c->flags = (int *)fl;
+    if ((e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming)) != hipSuccess) {
+        set_error(std::string("event create: ") + hipGetErrorString(e));
+        delete c;
+        return CRF_ERR_HIP;
     }
-    *out = &c;
+    for (int i = 0; i < kMaxStages; ++i) {
+        (void)hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c->evb[i], hipEventDisableTiming);
+    }
+    // The side stream: the first of a few candidates that demonstrably runs beside the owner's stream (once per
+    // context; the owner's stream is drained first so that both probe kernels start at once).  CRF_NO_SIDE_STREAM=1
+    // skips it (everything then runs on the caller's stream, one kernel after the other).
+    const bool want_side = !(getenv("CRF_NO_SIDE_STREAM") && atoi(getenv("CRF_NO_SIDE_STREAM")));
+    if (want_side && c->flags) {
+        (void)hipStreamSynchronize(owner);
+        for (int tries = 0; tries < 6 && !c->side; ++tries) {
+            hipStream_t cand{};
+            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            int res[4] = {0, 0, 0, 0};
+            bool ran = hipMemset(c->flags, 0, sizeof(res)) == hipSuccess;
+            hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, owner, c->flags, 0, 1);
+            hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, cand, c->flags, 1, 0);
+            ran = ran && hipStreamSynchronize(cand) == hipSuccess && hipStreamSynchronize(owner) == hipSuccess &&
+                  hipMemcpy(res, c->flags, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess;
+            if (ran && res[2] == 1 && res[3] == 1) c->side = cand;
+            else { (void)hipGetLastError(); (void)hipStreamDestroy(cand); }
+        }
+    } else if (want_side) {   // no fine-grained memory for the probe: take a stream on trust
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->side = nullptr; }
+    }
+    if (want_side && !c->side && !c->warned) {
+        fprintf(stderr, "[ctc_crf_hip] no stream of this process runs beside the caller's stream (all hardware queues shared?): "
+                        "the loss runs its kernels one after the other on the caller's stream -- correct, but slower; "
+                        "raise GPU_MAX_HW_QUEUES before the HIP runtime starts\n");
+        c->warned = true;
+    }
+    g_ctxs.push_back(c);
+    *out = c;
+    return CRF_OK;
+}
+
+// Dynamic LDS above 64 KiB must be opted into per kernel AND per device (hipFuncSetAttribute acts on the current
+// device's copy of the function): high-water mark per device.
+struct LdsMark { std::atomic<size_t> v[kMaxDev]; };
+static int ensure_lds(const void *fn, size_t bytes, LdsMark &m, const char *what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { set_error("hipGetDevice failed"); return CRF_ERR_HIP; }
+    if (bytes <= m.v[dev].load()) return CRF_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute(") + what + "): " + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    m.v[dev] = bytes;
     return CRF_OK;
 }
 
@@ -2337,58 +2417,64 @@ static void prof_mark(int slot, bool stop, hipStream_t st) {
     g_prof.used[slot] = true;
 }
 
-template <int ROLE, bool GV = false, int NR = kCtcRegs>
-static int launch_chain(const LossParams &p, size_t lds, hipStream_t st) {
-    static std::atomic<size_t> lds_set{0};  // dynamic LDS above 64 KiB must be opted into; only raised
+// streaming denominator recursions, forward + backward in one grid (profile slots 1 and 2 both time this launch)
+template <bool GV>
+static int launch_den_pair(const LossParams &p, size_t lds, hipStream_t st) {
+    static LdsMark mark;
+    int rc;
+    if ((rc = ensure_lds((const void *)crf_den_pair_kernel<GV>, lds, mark, "den pair"))) return rc;
+    prof_mark(1, false, st); prof_mark(2, false, st);
+    hipLaunchKernelGGL((crf_den_pair_kernel<GV>), dim3((unsigned)(2 * p.B)), dim3(kChainThreads), lds, st, p);
+    prof_mark(1, true, st); prof_mark(2, true, st);
     hipError_t e;
-    if (lds > lds_set.load()) {
-        if ((e = hipFuncSetAttribute((const void *)crf_chain_kernel<ROLE, GV, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
-            set_error(std::string("hipFuncSetAttribute(chain): ") + hipGetErrorString(e));
-            return CRF_ERR_HIP;
-        }
-        lds_set = lds;
-    }
-    prof_mark(1 + ROLE, false, st);
-    hipLaunchKernelGGL((crf_chain_kernel<ROLE, GV, NR>), dim3((unsigned)p.B), dim3(ROLE >= 2 ? kCtcThreads : kChainThreads), lds, st, p);
-    prof_mark(1 + ROLE, true, st);
-    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_den_pair_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }
-// numerator chains: states per thread from the longest label sequence of the batch
-template <int ROLE>
-static int launch_ctc(const LossParams &p, size_t lds, hipStream_t st, int64_t max_label_len) {
+// numerator chains, forward + backward in one grid (profile slots 3 and 4); states per thread from the longest label sequence
+template <int NR>
+static int launch_ctc_pair_nr(const LossParams &p, size_t lds, hipStream_t st) {
+    static LdsMark mark;
+    int rc;
+    if ((rc = ensure_lds((const void *)crf_ctc_pair_kernel<NR>, lds, mark, "ctc pair"))) return rc;
+    prof_mark(3, false, st); prof_mark(4, false, st);
+    hipLaunchKernelGGL((crf_ctc_pair_kernel<NR>), dim3((unsigned)(2 * p.B)), dim3(kCtcThreads), lds, st, p);
+    prof_mark(3, true, st); prof_mark(4, true, st);
+    hipError_t e;
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_ctc_pair_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return CRF_OK;
+}
+static int launch_ctc_pair(const LossParams &p, size_t lds, hipStream_t st, int64_t max_label_len) {
     const int64_t ni = (2 * max_label_len + 1 + kCtcThreads - 1) / kCtcThreads;
-    if (ni <= 1) return launch_chain<ROLE, false, 1>(p, lds, st);
-    if (ni <= 2) return launch_chain<ROLE, false, 2>(p, lds, st);
-    if (ni <= 4) return launch_chain<ROLE, false, 4>(p, lds, st);
-    return launch_chain<ROLE, false, kCtcRegs>(p, lds, st);
+    if (ni <= 1) return launch_ctc_pair_nr<1>(p, lds, st);
+    if (ni <= 2) return launch_ctc_pair_nr<2>(p, lds, st);
+    if (ni <= 4) return launch_ctc_pair_nr<4>(p, lds, st);
+    return launch_ctc_pair_nr<kCtcRegs>(p, lds, st);
 }
 
-template <int DIR>
-static int launch_res(const LossParams &lp, size_t lds, int b0, int nb, hipStream_t st) {
-    static std::atomic<size_t> lds_set{0};
-    hipError_t e;
-    if (lds > lds_set.load()) {
-        if ((e = hipFuncSetAttribute((const void *)crf_res_chain_kernel<DIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) {
-            set_error(std::string("hipFuncSetAttribute(res chain): ") + hipGetErrorString(e));
-            return CRF_ERR_HIP;
-        }
-        lds_set = lds;
-    }
+static ResParams res_params(const LossParams &lp, int dir, int b0) {
     const ResDev &R = lp.g.res;
     ResParams p{};
-    p.L = DIR == 0 ? R.f : R.b;
+    p.L = dir == 0 ? R.f : R.b;
     p.K = R.K; p.B = lp.B; p.T = lp.T; p.V = lp.V; p.b0 = b0;
-    p.rows_cu_max = DIR == 0 ? lp.res_lds_rows_f : lp.res_lds_rows_b;
-    p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.Gf = R.f.G; p.Gb = R.b.G;
+    p.rows_cu_max = dir == 0 ? lp.res_lds_rows_f : lp.res_lds_rows_b;
+    p.Rout = dir == 0 ? lp.Rq : lp.Rb; p.Gf = R.f.G; p.Gb = R.b.G;
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.moff;   // (the resident kernels use it for the log-likelihood offset only)
-    p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
+    p.Out = dir == 0 ? lp.Q : lp.BP; p.Eout = dir == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
     p.xch = lp.xch; p.err = lp.err;
     p.x_start = R.x_start; p.x_end = R.x_end; p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.z_lab = R.z_lab; p.z_end = R.z_end; p.brow_start = R.brow_start; p.brow_end = R.brow_end; p.bcsr = R.bcsr;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
-    hipLaunchKernelGGL(crf_res_chain_kernel<DIR>, dim3((unsigned)(nb * R.K)), dim3(kResThreads), lds, st, p);
-    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_res_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return p;
+}
+// generic register-resident recursions of the utterances [b0, b0 + nb): 2 * nb * K workgroups, forward first
+static int launch_res_pair(const LossParams &lp, size_t lds, int b0, int nb, hipStream_t st) {
+    static LdsMark mark;
+    int rc;
+    if ((rc = ensure_lds((const void *)crf_res_pair_kernel, lds, mark, "res pair"))) return rc;
+    const ResParams pf = res_params(lp, 0, b0), pb = res_params(lp, 1, b0);
+    hipLaunchKernelGGL(crf_res_pair_kernel, dim3((unsigned)(2 * nb * lp.g.res.K)), dim3(kResThreads), lds, st, pf, pb);
+    hipError_t e;
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_res_pair_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }
 
@@ -2405,31 +2491,14 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
 #ifndef CRF_FAC3_NB_B
 #define CRF_FAC3_NB_B 4
 #endif
-#define kFac3Batch (DIR == 0 ? CRF_FAC3_NB_F : CRF_FAC3_NB_B)   // chunks gathered per batch (20 chunks of arcs per thread)
-template <int DIR, bool FLAG = false>
-static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *state,
-                      int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
-    static std::atomic<size_t> lds_set{0}, lds_set3{0}, lds_set3m{0};
-    hipError_t e;
+static FacParams fac_params(const LossParams &lp, int dir, int *started, int i0, int i1, float *state, int nb, const int *bound, int *stage_cnt) {
     const FacDev &F = lp.g.fac;
-    const bool g3 = F.threads == kFac3Threads, ml = F.multilane != 0;
-    std::atomic<size_t> &ls = g3 ? (ml ? lds_set3m : lds_set3) : lds_set;
-    if (lds > ls.load()) {
-        e = g3 ? (ml ? hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                     : hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-               : hipFuncSetAttribute((const void *)crf_fac_chain_kernel<DIR, FLAG, kResThreads, kResNCH, kResBatch, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error(std::string("hipFuncSetAttribute(fac chain): ") + hipGetErrorString(e));
-            return CRF_ERR_HIP;
-        }
-        ls = lds;
-    }
     FacParams p{};
-    p.L = DIR == 0 ? F.f : F.b;
+    p.L = dir == 0 ? F.f : F.b;
     p.bx_idx = F.bx_idx; p.bx_w = F.bx_w; p.nbx = F.nbx; p.bx_se = F.bx_se;
-    p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = DIR == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
+    p.B = lp.B; p.T = lp.T; p.V = lp.V; p.Rout = dir == 0 ? lp.Rq : lp.Rb; p.NT = F.NT; p.Rf = F.f.R;
     p.lx = lp.lx; p.ep = lp.ep; p.mx = lp.moff;   // (the resident kernels use it for the log-likelihood offset only)
-    p.Out = DIR == 0 ? lp.Q : lp.BP; p.Eout = DIR == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
+    p.Out = dir == 0 ? lp.Q : lp.BP; p.Eout = dir == 0 ? lp.EQ : lp.EB; p.Row0 = lp.Row0;
     p.started = started; p.i0 = i0; p.i1 = i1; p.state = state;
     p.nb = nb; p.stage_cnt = stage_cnt;
     for (int k = 0; k < 16; ++k) p.bound[k] = (bound && k < nb) ? bound[k] : 0;
@@ -2437,10 +2506,35 @@ static int launch_fac(const LossParams &lp, size_t lds, hipStream_t st, int *sta
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
-    if (g3 && ml) hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch, true>), dim3((unsigned)lp.B), dim3(kFac3Threads), lds, st, p);
-    else if (g3) hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kFac3Threads, kFac3NCH, kFac3Batch, false>), dim3((unsigned)lp.B), dim3(kFac3Threads), lds, st, p);
-    else hipLaunchKernelGGL((crf_fac_chain_kernel<DIR, FLAG, kResThreads, kResNCH, kResBatch, true>), dim3((unsigned)lp.B), dim3(kResThreads), lds, st, p);
-    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac_chain_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return p;
+}
+// factored recursions, iterations [i0, i1) of both directions as one grid of 2B workgroups; FLAG: publish stage counters
+// (both directions bump the same counters: a stage is complete at 2B) and store the rows write-through
+template <bool FLAG>
+static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *fstate, float *bstate,
+                           int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
+    static LdsMark m3, m3m, m5;
+    const FacDev &F = lp.g.fac;
+    const bool g3 = F.threads == kFac3Threads, ml = F.multilane != 0;
+    const FacParams pf = fac_params(lp, 0, started, i0, i1, fstate, nb, bound, stage_cnt);
+    const FacParams pb = fac_params(lp, 1, started, i0, i1, bstate, nb, bound, stage_cnt);
+    const dim3 grid((unsigned)(2 * lp.B));
+    int rc;
+    if (g3 && ml) {
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true>;
+        if ((rc = ensure_lds((const void *)k, lds, m3m, "fac pair"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else if (g3) {
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, false>;
+        if ((rc = ensure_lds((const void *)k, lds, m3, "fac pair"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else {
+        auto *k = crf_fac_pair_kernel<FLAG, kResThreads, kResNCH, kResBatch, kResBatch, true>;
+        if ((rc = ensure_lds((const void *)k, lds, m5, "fac pair"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kResThreads), lds, st, pf, pb);
+    }
+    hipError_t e;
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac_pair_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }
 
@@ -2559,17 +2653,19 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string(what) + ": " + hipGetErrorString(e)); return CRF_ERR_HIP; }
 
     const int64_t frames = B * T;
-    // fork: the four recursions are independent; den forward (the longest) stays on the caller's
-    // stream, the others go to side streams and are joined before the grad pass.
-    static const bool serial = getenv("CRF_SERIAL_CHAINS") && atoi(getenv("CRF_SERIAL_CHAINS")) != 0;
+    // Two streams at most: the caller's and one side stream of this (device, caller stream)'s context.  Forward and
+    // backward recursions are one grid each (denominator pair, numerator pair); the two grids are independent.
+    static const bool serial_env = getenv("CRF_SERIAL_CHAINS") && atoi(getenv("CRF_SERIAL_CHAINS")) != 0;
     DevCtx *cx = nullptr;
     int rc;
-    if (!serial && (rc = get_ctx(&cx))) return rc;
-    // factored path: error word, start counter and progress counters live in fine-grained memory (get_ctx);
-    // the prep kernel clears them
-    const bool have_flags = fac && cx && cx->flags && 64 + 2 * B <= kFlagInts;
+    if ((rc = get_ctx(stream, &cx))) return rc;
+    std::lock_guard<std::mutex> call_lock(cx->mu);
+    const bool serial = serial_env || !cx->side;              // no side stream: everything in order on the caller's stream
+    hipStream_t side = serial ? stream : cx->side;
+    // error word, start counter and stage counters live in fine-grained memory (get_ctx); the prep kernel clears them
+    const bool have_flags = cx->flags != nullptr;
     p.clear = nullptr; p.nclear = 0;
-    if (have_flags) { p.err = cx->flags; p.clear = cx->flags; p.nclear = (int)(64 + 2 * B); }
+    if (have_flags) { p.err = cx->flags; p.clear = cx->flags; p.nclear = 64; }
     for (bool &u : g_prof.used) u = false;
     prof_mark(7, false, stream);
     prof_mark(0, false, stream);
@@ -2577,33 +2673,32 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     else hipLaunchKernelGGL(crf_prep_kernel<64>, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
     prof_mark(0, true, stream);
     LAUNCH_CHECK("crf_prep_kernel");
-    if (res && !have_flags) {  // exchange granules (tags) and the error word start at zero in every call
+    if (res && !fac && (w.xch_bytes > 0 || !have_flags)) {  // exchange granules (tags) and the error word start at zero in every call
         if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256 + 8 * (size_t)B, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
     }
 
-    static std::atomic<size_t> lds_set_grad{0};
-    if (lds_grad > lds_set_grad.load()) {
-        if ((e = hipFuncSetAttribute((const void *)crf_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grad)) != hipSuccess) {
-            set_error(std::string("hipFuncSetAttribute(grad): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+    static LdsMark lds_mark_grad;
+    if ((rc = ensure_lds((const void *)crf_grad_kernel, lds_grad, lds_mark_grad, "grad"))) return rc;
+    bool forked = false, side_used = false;
+    auto fork_side = [&]() -> int {   // the side stream starts behind everything queued on the caller's stream so far
+        if (serial || forked) return CRF_OK;
+        if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess || (e = hipStreamWaitEvent(side, cx->fork, 0)) != hipSuccess) {
+            set_error(std::string("fork: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
         }
-        lds_set_grad = lds_grad;
-    }
-    if (!serial) {   // side streams start behind the prep kernel (and its clear of the counters)
-        if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess) { set_error("hipEventRecord(fork)"); return CRF_ERR_HIP; }
-    }
-    bool used[3] = {false, false, false};
-    auto side = [&](int i) -> hipStream_t {
-        if (serial) return stream;
-        used[i] = true;
-        (void)hipStreamWaitEvent(cx->side[i], cx->fork, 0);
-        return cx->side[i];
+        forked = side_used = true;
+        return CRF_OK;
+    };
+    auto join_side = [&]() -> int {   // the caller's stream continues behind everything queued on the side stream so far
+        if (serial || !side_used) return CRF_OK;
+        if ((e = hipEventRecord(cx->join, side)) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->join, 0)) != hipSuccess) {
+            set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+        }
+        forked = false;
+        return CRF_OK;
     };
     int *started = p.err + 1;   // workgroups of the den kernels that hold a CU (cleared with the error word)
     int ncu_dev = 256;
-    {
-        int devid = 0;
-        if (hipGetDevice(&devid) == hipSuccess) (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, devid);
-    }
+    (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, cx->dev);
     // The denominator half of the grad pass has a streaming kernel (index pairs in registers, rows
     // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
     const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
@@ -2614,10 +2709,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
                           !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
     // Factored den kernels: 2B workgroups, one CU each.  While that is at most half of the chip, everything else
-    // runs BESIDE them on the other half: numerator chains, their grad half, and the den half of the grad pass.  The
-    // den half of the grad pass needs rows of BOTH recursions, which work towards each other; it is released
-    // in stages: the recursions are launched in `nstage` segments, an event after each, and the grad launch of
-    // stage k (ordered behind the events of segment k) takes the 16-frame blocks that segment completed.
+    // runs BESIDE them on the other half, on the side stream: numerator chains, their grad half, and the den half of
+    // the grad pass.  The den half of the grad pass needs rows of BOTH recursions, which work towards each other; it
+    // is released in stages: the recursions bump a counter at every stage bound, the grad launch of stage k is queued
+    // behind a STREAM-level wait on that counter and takes the 16-frame blocks the stage completed.
     // (A grad pass that SPINS on progress counters of the running den kernels is faster still on a quiet device,
     // but with many launches queued ahead the den kernels were observed to stop for seconds while the waiting
     // workgroups kept their queue busy -- one kernel must never wait for another.)
@@ -2629,12 +2724,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const bool segmode = use_segments.load();
     static const int stages_env = getenv("CRF_STAGES") ? atoi(getenv("CRF_STAGES")) : 0;
     const int pieces = stages_env > 0 ? stages_env : (segmode ? 4 : 12);   // measured: 4 / 8 / 12 pieces -> call 4.06 / 3.98 / 3.93 ms (flags)
-    const bool staged = fac && ctc && fast_den && fast_ctc && !serial && !no_overlap && cx && cx->flags && 2 * B <= ncu_dev / 2;
-    // streams of the staged schedule: den forward / backward segments, and two for everything else.  (Tried:
-    // CU-masked streams, hipExtStreamCreateWithCUMask, to keep the den recursions and the rest on disjoint halves
-    // of the chip -- every queue of the process got slower, +1.5 ms per call; the start gate below does the job.)
-    hipStream_t sA0 = stream, sA1 = stream, sB0 = stream, sB1 = stream;
-    if (staged) { sA1 = cx->side[0]; sB0 = cx->side[1]; sB1 = cx->side[2]; }
+    const bool staged = fac && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && 2 * B <= ncu_dev / 2;
     // Stage bounds.  Nothing can be released before the two recursions have met, so the first stage ends at half of
     // the frames or later; after that a piece of `piece` iterations releases 2 * piece / 16 frame blocks per
     // utterance.  The grad pass has half of the chip and is bandwidth-bound there (~2 TB/s against the 2.2 TB/s the
@@ -2669,82 +2759,11 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.gd_nb = nstage + 1;
     for (int k = 0; k <= nstage && k < 16; ++k) p.gd_bound[k] = bound[k];
     float *fstate = (float *)(base + w.off_state), *bstate = fstate + B * w.state_stride;
-    if (staged) {
-        // den forward segments on the caller's stream, backward segments on side stream 0
-        if (sA0 != stream) (void)hipStreamWaitEvent(sA0, cx->fork, 0);
-        (void)hipStreamWaitEvent(sA1, cx->fork, 0);
-        prof_mark(1, false, sA0);
-        prof_mark(2, false, sA1);
-        if (!segmode) {
-            if ((rc = launch_fac<0, true>(p, fac_lds_bytes(h, (int)V, 0), sA0, started, 0, (int)T, fstate, nstage + 1, bound, cx->flags + 16))) return rc;
-            if ((rc = launch_fac<1, true>(p, fac_lds_bytes(h, (int)V, 1), sA1, started, 0, (int)T, bstate, nstage + 1, bound, cx->flags + 32))) return rc;
-        } else {
-            for (int k = 0; k < nstage; ++k) {
-                if ((rc = launch_fac<0>(p, fac_lds_bytes(h, (int)V, 0), sA0, started, bound[k], bound[k + 1], fstate))) return rc;
-                if ((rc = launch_fac<1>(p, fac_lds_bytes(h, (int)V, 1), sA1, started, bound[k], bound[k + 1], bstate))) return rc;
-                if ((e = hipEventRecord(cx->evf[k], sA0)) != hipSuccess || (e = hipEventRecord(cx->evb[k], sA1)) != hipSuccess) {
-                    set_error(std::string("hipEventRecord(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
-                }
-            }
-        }
-        prof_mark(1, true, sA0);
-        prof_mark(2, true, sA1);
-    } else if (fac) {
-        // factored resident recursions: one CU per utterance and direction, nothing to exchange
-        hipStream_t sb = side(0);
-        prof_mark(1, false, stream);
-        if ((rc = launch_fac<0>(p, fac_lds_bytes(h, (int)V, 0), stream, started, 0, (int)T, fstate))) return rc;
-        prof_mark(1, true, stream);
-        prof_mark(2, false, sb);
-        if ((rc = launch_fac<1>(p, fac_lds_bytes(h, (int)V, 1), sb, started, 0, (int)T, bstate))) return rc;
-        prof_mark(2, true, sb);
-    } else if (res) {
-        // register-resident recursions: K CUs per utterance and direction, exchanging the state vector
-        // through L2 every frame.  With K > 1 every workgroup of a launch must be resident at once
-        // (its peers spin on it), so the batch goes in groups of at most CUs/(2K) utterances.
-        const int K = h->dev.res.K;
-        int ncu = 256;
-        int devid = 0;
-        if (hipGetDevice(&devid) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid);
-        const int grp = K > 1 ? std::max(1, ncu / (2 * K)) : (int)B;
-        hipStream_t sb = side(0);
-        prof_mark(1, false, stream);
-        prof_mark(2, false, sb);
-        for (int b0 = 0; b0 < (int)B; b0 += grp) {
-            const int nb = std::min(grp, (int)B - b0);
-            if ((rc = launch_res<0>(p, res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), b0, nb, stream))) return rc;
-            if ((rc = launch_res<1>(p, res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b), b0, nb, sb))) return rc;
-        }
-        prof_mark(1, true, stream);
-        prof_mark(2, true, sb);
-    } else if (den && gv) {
-        if ((rc = launch_chain<0, true>(p, chain_lds_bytes(h, (int)V, Sc, 0, true), stream))) return rc;
-        if ((rc = launch_chain<1, true>(p, chain_lds_bytes(h, (int)V, Sc, 1, true), side(0)))) return rc;
-    } else if (den) {
-        if ((rc = launch_chain<0>(p, chain_lds_bytes(h, (int)V, Sc, 0), stream))) return rc;
-        if ((rc = launch_chain<1>(p, chain_lds_bytes(h, (int)V, Sc, 1), side(0)))) return rc;
-    }
-    // Resident den kernels with K > 1 own every CU (one workgroup per CU, peers spin on each other), so the
-    // numerator recursions cannot run beside them.  They run beside the DEN HALF of the grad pass instead
-    // (HBM-bound, small workgroups that share CUs happily); a second, cheap grad pass then subtracts
-    // the numerator posteriors.  Otherwise all four recursions run side by side and grad is one pass.
-    static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
-    const bool split = ctc && den && !staged && (ctc_after_env >= 0 ? ctc_after_env != 0 : (res && (fac || h->dev.res.K > 1))) && !serial;
-    auto join_all = [&]() -> int {
-        for (int i = 0; i < 3; ++i)
-            if (used[i]) {
-                if ((e = hipEventRecord(cx->join[i], cx->side[i])) != hipSuccess ||
-                    (e = hipStreamWaitEvent(stream, cx->join[i], 0)) != hipSuccess) {
-                    set_error(std::string("join: ") + hipGetErrorString(e));
-                    return CRF_ERR_HIP;
-                }
-                used[i] = false;
-            }
-        return CRF_OK;
-    };
+    const size_t lds_fac = fac ? std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1)) : 0;
+    const size_t lds_ctc = chain_lds_bytes(h, (int)V, Sc, 2);
+
     const dim3 ggrid((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B);
-    auto launch_grad_den = [&](hipStream_t st = nullptr, int stage = 0) -> int {
-        if (!st) st = stream;
+    auto launch_grad_den = [&](hipStream_t st, int stage) -> int {
         p.gd_stage = stage;
         const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + 4 * rup64((int)V) + kGDFrames + rup64(gnc)) * sizeof(float);
         dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
@@ -2754,25 +2773,25 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             p.gd_nf = (p.gd_bound[stage] - p.gd_bound[stage - 1] + kGDFrames - 1) / kGDFrames + 3;
             if (2 * p.gd_nf < (int)gg.x) gg.x = (unsigned)(2 * p.gd_nf); else p.gd_nf = 0;
         }
-        static std::atomic<size_t> set1{0}, set2{0}, set3{0}, set5{0};
+        static LdsMark set1, set2, set3, set5;
+        int r2;
         if (gd_wide) {   // rows of more than 5120 floats: 512 threads per workgroup (one chunk per thread up to 512 chunks)
-            if (l > set5.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1, 2, 2 * kGDThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set5 = l; }
+            if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<1, 2, 2 * kGDThreads>, l, set5, "grad den"))) return r2;
             hipLaunchKernelGGL((crf_grad_den_kernel<1, 2, 2 * kGDThreads>), gg, dim3(2 * kGDThreads), l, st, p);
-        } else if (gnc <= kGDThreads && V <= kGDThreads) {   // small vocabulary: 128 VGPRs, a fourth workgroup per CU
-            if (l > set3.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set3 = l; }
+        } else if (gnc <= kGDThreads && V <= kGDThreads) {   // small vocabulary
+            if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<1, 1>, l, set3, "grad den"))) return r2;
             hipLaunchKernelGGL((crf_grad_den_kernel<1, 1>), gg, dim3(kGDThreads), l, st, p);
         } else if (gnc <= kGDThreads) {
-            if (l > set1.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<1, kGDEpRegs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set1 = l; }
+            if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<1, kGDEpRegs>, l, set1, "grad den"))) return r2;
             hipLaunchKernelGGL((crf_grad_den_kernel<1, kGDEpRegs>), gg, dim3(kGDThreads), l, st, p);
         } else {
-            if (l > set2.load()) { (void)hipFuncSetAttribute((const void *)crf_grad_den_kernel<2, kGDEpRegs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l); set2 = l; }
+            if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<2, kGDEpRegs>, l, set2, "grad den"))) return r2;
             hipLaunchKernelGGL((crf_grad_den_kernel<2, kGDEpRegs>), gg, dim3(kGDThreads), l, st, p);
         }
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad_den_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
     };
-    auto launch_grad_ctc = [&](int phase, hipStream_t st = nullptr) -> int {  // phase 2: subtract from the den half; 0: plain CTC (writes)
-        if (!st) st = stream;
+    auto launch_grad_ctc = [&](int phase, hipStream_t st) -> int {  // phase 2: subtract from the den half; 0: plain CTC (writes)
         p.grad_phase = phase;
         if (fast_ctc) {
             const size_t l = (size_t)4 * rup64((int)V) * sizeof(float) + kGCFrames * sizeof(double);
@@ -2787,88 +2806,117 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad(ctc): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
     };
-    if (staged) {
-        hipStream_t s1 = sB0, s2 = sB1;
-        (void)hipStreamWaitEvent(s1, cx->fork, 0);
-        (void)hipStreamWaitEvent(s2, cx->fork, 0);
-        // hold the numerator back (briefly, bounded) until the den workgroups have their CUs
-        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s1, started, 2 * (int)B);
-        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, s2, started, 2 * (int)B);
-        if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), s1, max_label_len))) return rc;
-        if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), s2, max_label_len))) return rc;
-        if ((e = hipEventRecord(cx->jm[0], s2)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->jm[0], 0)) != hipSuccess) {
-            set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+    // the denominator recursions of the whole batch on `st` (every layout; both directions per launch)
+    auto launch_den = [&](hipStream_t st) -> int {
+        prof_mark(1, false, st); prof_mark(2, false, st);
+        int r2 = CRF_OK;
+        if (fac) {
+            r2 = launch_fac_pair<false>(p, lds_fac, st, started, 0, (int)T, fstate, bstate);
+        } else if (res) {
+            // K CUs per utterance and direction exchange the state vector through L2 every frame.  With K > 1 every
+            // workgroup of a launch must be resident at once (its peers spin on it): groups of at most CUs/(2K) utterances.
+            const int K = h->dev.res.K;
+            const int grp = K > 1 ? std::max(1, ncu_dev / (2 * K)) : (int)B;
+            const size_t l = std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b));
+            for (int b0 = 0; b0 < (int)B && !r2; b0 += grp) r2 = launch_res_pair(p, l, b0, std::min(grp, (int)B - b0), st);
+        } else if (gv) {
+            return launch_den_pair<true>(p, std::max(chain_lds_bytes(h, (int)V, Sc, 0, true), chain_lds_bytes(h, (int)V, Sc, 1, true)), st);
+        } else {
+            return launch_den_pair<false>(p, std::max(chain_lds_bytes(h, (int)V, Sc, 0), chain_lds_bytes(h, (int)V, Sc, 1)), st);
         }
-        prof_mark(5, false, s1);
-        if ((rc = launch_grad_ctc(0, s1))) return rc;          // writes -c_ctc * gamma_ctc; the den half then adds
+        prof_mark(1, true, st); prof_mark(2, true, st);
+        return r2;
+    };
+
+    if (staged) {
+        // caller's stream: the denominator pair.  Side stream, behind a short bounded start gate: numerator pair, its
+        // grad half (writes -c_ctc * gamma_ctc), then the den half of the grad pass stage by stage (adds gamma_den).
+        if ((rc = fork_side())) return rc;
+        prof_mark(1, false, stream); prof_mark(2, false, stream);
+        if (!segmode) {
+            if ((rc = launch_fac_pair<true>(p, lds_fac, stream, started, 0, (int)T, fstate, bstate, nstage + 1, bound, cx->flags + 16))) return rc;
+        } else {
+            for (int k = 0; k < nstage; ++k) {
+                if ((rc = launch_fac_pair<false>(p, lds_fac, stream, started, bound[k], bound[k + 1], fstate, bstate))) return rc;
+                if ((e = hipEventRecord(cx->ev[k], stream)) != hipSuccess) { set_error(std::string("hipEventRecord(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+            }
+        }
+        prof_mark(1, true, stream); prof_mark(2, true, stream);
+        // hold the numerator back (briefly, bounded) until the den workgroups have their CUs
+        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, side, started, 2 * (int)B);
+        if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
+        prof_mark(5, false, side);
+        if ((rc = launch_grad_ctc(0, side))) return rc;
         p.grad_den_acc = 1;
         for (int k = 0; k < nstage; ++k) {
             if (!segmode) {
-                if ((e = hipStreamWaitValue32(s1, cx->flags + 16 + k + 1, (uint32_t)B, hipStreamWaitValueGte, 0xffffffffu)) != hipSuccess ||
-                    (e = hipStreamWaitValue32(s1, cx->flags + 32 + k + 1, (uint32_t)B, hipStreamWaitValueGte, 0xffffffffu)) != hipSuccess) {
+                if ((e = hipStreamWaitValue32(side, cx->flags + 16 + k + 1, (uint32_t)(2 * B), hipStreamWaitValueGte, 0xffffffffu)) != hipSuccess) {
                     // not available here: from the next call on, segments.  This call: wait for the recursions to END
                     (void)hipGetLastError();
                     use_segments = true;
-                    if ((e = hipEventRecord(cx->evf[0], sA0)) != hipSuccess || (e = hipEventRecord(cx->evb[0], sA1)) != hipSuccess ||
-                        (e = hipStreamWaitEvent(s1, cx->evf[0], 0)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->evb[0], 0)) != hipSuccess) {
+                    if ((e = hipEventRecord(cx->ev[0], stream)) != hipSuccess || (e = hipStreamWaitEvent(side, cx->ev[0], 0)) != hipSuccess) {
                         set_error(std::string("hipStreamWaitEvent: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
                     }
                 }
-            } else if ((e = hipStreamWaitEvent(s1, cx->evf[k], 0)) != hipSuccess || (e = hipStreamWaitEvent(s1, cx->evb[k], 0)) != hipSuccess) {
+            } else if ((e = hipStreamWaitEvent(side, cx->ev[k], 0)) != hipSuccess) {
                 set_error(std::string("hipStreamWaitEvent(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
             }
-            if ((rc = launch_grad_den(s1, k + 1))) return rc;
+            if ((rc = launch_grad_den(side, k + 1))) return rc;
         }
-        prof_mark(5, true, s1);
-        // the backward recursion (side stream 0) ends after its last stage flag: logZ from the backward side
-        if ((e = hipEventRecord(cx->jm[2], sA1)) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->jm[2], 0)) != hipSuccess) {
-            set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+        prof_mark(5, true, side);
+        if ((rc = join_side())) return rc;   // the last grad launch is behind every stage of the recursions
+    } else if (den && ctc && !serial) {
+        // Denominator pair on the caller's stream, numerator pair beside it on the side stream -- unless the den
+        // workgroups own every CU (register-resident layouts with 2B (x K) >= CUs): then the numerator recursions run
+        // beside the DEN HALF of the grad pass instead (HBM-bound, small workgroups that share CUs happily).
+        static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
+        const bool after = ctc_after_env >= 0 ? ctc_after_env != 0 : (res && (fac || h->dev.res.K > 1));
+        if (!after) {
+            if ((rc = fork_side())) return rc;
+            if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
+            if ((rc = launch_den(stream))) return rc;
+            if ((rc = join_side())) return rc;
+            prof_mark(5, false, stream);
+            if (fast_den) {
+                if ((rc = launch_grad_den(stream, 0))) return rc;
+                if ((rc = launch_grad_ctc(2, stream))) return rc;
+            } else {
+                p.grad_phase = 0;
+                hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+                LAUNCH_CHECK("crf_grad_kernel");
+            }
+            prof_mark(5, true, stream);
+        } else {
+            if ((rc = launch_den(stream))) return rc;
+            if ((rc = fork_side())) return rc;            // numerator pair starts when the den recursions have drained
+            if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
+            prof_mark(5, false, stream);
+            if (fast_den) {
+                if ((rc = launch_grad_den(stream, 0))) return rc;
+            } else {
+                p.grad_phase = 1;
+                hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+                LAUNCH_CHECK("crf_grad_kernel(den)");
+            }
+            if ((rc = join_side())) return rc;
+            if ((rc = launch_grad_ctc(2, stream))) return rc;
+            prof_mark(5, true, stream);
         }
-        // join: the caller's stream continues after the last grad launch (which is behind every den segment)
-        if ((e = hipEventRecord(cx->jm[1], s1)) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->jm[1], 0)) != hipSuccess) {
-            set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
-        }
-    } else if (!split) {
-        if (ctc) {
-            if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), den ? side(1) : stream, max_label_len))) return rc;
-            if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2), max_label_len))) return rc;
-        }
-        if ((rc = join_all())) return rc;
+    } else {
+        // one stream: den only (gpu_den), numerator only (gpu_ctc / WARP_CTC_LOSS), or no side stream available
+        if (den && (rc = launch_den(stream))) return rc;
+        if (ctc && (rc = launch_ctc_pair(p, lds_ctc, stream, max_label_len))) return rc;
         prof_mark(5, false, stream);
-        if (fast_den) {
-            if ((rc = launch_grad_den())) return rc;
-            if (ctc && (rc = launch_grad_ctc(2))) return rc;
+        if (den && fast_den) {
+            if ((rc = launch_grad_den(stream, 0))) return rc;
+            if (ctc && (rc = launch_grad_ctc(2, stream))) return rc;
         } else if (!den && fast_ctc) {
-            if ((rc = launch_grad_ctc(0))) return rc;
+            if ((rc = launch_grad_ctc(0, stream))) return rc;
         } else {
             p.grad_phase = 0;
             hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+            LAUNCH_CHECK("crf_grad_kernel");
         }
-        prof_mark(5, true, stream);
-        LAUNCH_CHECK("crf_grad_kernel");
-    } else {
-        // the numerator recursions start as soon as ONE of the two den kernels (the backward one, on side
-        // stream 0) has drained and freed its half of the CUs; the den half of the grad pass follows the
-        // forward den kernel on the caller's stream
-        if ((e = hipEventRecord(cx->fork, cx->side[0])) != hipSuccess) { set_error("hipEventRecord(fork2)"); return CRF_ERR_HIP; }
-        if ((rc = launch_ctc<2>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(1), max_label_len))) return rc;
-        if ((rc = launch_ctc<3>(p, chain_lds_bytes(h, (int)V, Sc, 2), side(2), max_label_len))) return rc;
-        {   // join side 0 (den backward) only; sides 1, 2 are joined after the den grad pass
-            if ((e = hipEventRecord(cx->join[0], cx->side[0])) != hipSuccess || (e = hipStreamWaitEvent(stream, cx->join[0], 0)) != hipSuccess) {
-                set_error(std::string("join: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
-            }
-            used[0] = false;
-        }
-        prof_mark(5, false, stream);
-        if (fast_den) {
-            if ((rc = launch_grad_den())) return rc;
-        } else {
-            p.grad_phase = 1;
-            hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
-            LAUNCH_CHECK("crf_grad_kernel(den)");
-        }
-        if ((rc = join_all())) return rc;
-        if ((rc = launch_grad_ctc(2))) return rc;
         prof_mark(5, true, stream);
     }
     prof_mark(6, false, stream);

@@ -4,12 +4,6 @@
 There is NO CPU fallback and no PyTorch fallback: if the HIP library is missing the import fails,
 and every call goes through the C ABI of include/ctc_crf_hip.h.
 """
-import os as _os
-# One HIP hardware queue per stream (see crf_loss_fwd_bwd's schedule: four streams that must run side by side; HIP's
-# default is four queues for ALL streams of the process, RCCL and torch side streams included).  Only effective if the
-# HIP runtime has not started yet; measured neutral when nothing else competes.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import ctypes
 import os
 from typing import Dict, Optional
@@ -143,6 +137,15 @@ def release_env(gpus: torch.Tensor) -> None:
             _lib.crf_graph_destroy(_vp(h))
 
 
+def release_handles(handles: Dict[int, int]) -> None:
+    """Release exactly the graphs a CRFContext created: a device whose graph has been replaced since (a second
+    CRFContext on the same device) is left alone -- the replacement already destroyed the old tables."""
+    for dev, h in handles.items():
+        if _GRAPHS.get(dev) == h:
+            _GRAPHS.pop(dev)
+            _lib.crf_graph_destroy(_vp(h))
+
+
 def graph_for(device: torch.device) -> int:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     h = _GRAPHS.get(idx)
@@ -207,6 +210,32 @@ def _h2d_async(src: torch.Tensor, dev: torch.device) -> torch.Tensor:
 
 _FUSED_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
+# Debug aid for the parity tests (CRF_DEBUG_POISON_WS=1): fill the workspace with NaN bit patterns before every call, so
+# that a kernel reading a row before its producer has written it cannot pass by finding the previous call's values in the
+# block the caching allocator hands back.
+_POISON_WS = os.environ.get("CRF_DEBUG_POISON_WS", "0") not in ("", "0")
+
+
+def set_debug_poison(on: bool) -> None:
+    global _POISON_WS
+    _POISON_WS = bool(on)
+
+
+def _validate_meta(lx_cpu, ly_cpu, lab_cpu, T: int, V: int) -> None:
+    """Host-resident metadata is checked before the launch (no device sync: these tensors are on the CPU already).
+    The reference does not check: lx > T walks past the buffers, a label >= V indexes the logits out of bounds
+    (gpu_ctc_kernels.h:146-152 reads probs[... + label])."""
+    if lx_cpu.numel() and (int(lx_cpu.min()) < 0 or int(lx_cpu.max()) > T):
+        raise RuntimeError(f"frame lengths must lie in [0, T={T}], got [{int(lx_cpu.min())}, {int(lx_cpu.max())}]")
+    if ly_cpu is not None:
+        if ly_cpu.numel() and int(ly_cpu.min()) < 0:
+            raise RuntimeError("negative label length")
+        if int(ly_cpu.sum()) > lab_cpu.numel():
+            raise RuntimeError(f"sum(label_lengths)={int(ly_cpu.sum())} exceeds len(labels)={lab_cpu.numel()}")
+        n = int(ly_cpu.sum())
+        if n and (int(lab_cpu[:n].min()) <= 0 or int(lab_cpu[:n].max()) >= V):
+            raise RuntimeError(f"labels must lie in [1, V-1={V - 1}] (0 is the blank), got [{int(lab_cpu[:n].min())}, {int(lab_cpu[:n].max())}]")
+
 
 def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch.Tensor,
                  ly: Optional[torch.Tensor], c_den: float, c_ctc: float, graph: Optional[int],
@@ -231,6 +260,8 @@ def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch
         max_l = int(ly_cpu.max()) if N > 0 else 0
         off = (torch.cumsum(ly_cpu, 0, dtype=torch.int32) - ly_cpu).to(torch.int32)
         lab32 = labels.to(torch.int32).reshape(-1)
+        if not lx32.is_cuda and not lab32.is_cuda:
+            _validate_meta(lx32, ly_cpu, lab32, T, V)
         if lab32.numel() == 0:
             lab32 = torch.zeros(1, dtype=torch.int32)
         # one H2D copy for all integer metadata (the reference issues ~5, gpu_ctc.h:143-229), through pinned
@@ -239,12 +270,16 @@ def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch
         lx_d, ly_d, off_d, lab_d = meta[:N], meta[N:2 * N], meta[2 * N:3 * N], meta[3 * N:]
     else:
         max_l = 0
+        if not lx32.is_cuda:
+            _validate_meta(lx32, None, None, T, V)
         lx_d = _h2d_async(lx32.cpu().reshape(-1), dev) if not lx32.is_cuda else lx32
         ly_d = off_d = lab_d = None
         meta = lx_d
     gh = _vp(graph) if (graph and c_den != 0.0) else _vp(0)
     ws_bytes = _lib.crf_workspace_bytes(gh, N, T, V, max_l)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if _POISON_WS:
+        ws.fill_(0xFF)   # every float / double / int32 of the workspace reads as NaN / -1
     grad = torch.empty(logits.shape, dtype=torch.float32, device=dev)
     out = torch.empty(1 + 3 * N, dtype=torch.float32, device=dev)
     invalid = torch.empty(N, dtype=torch.int32, device=dev) if c_ctc != 0.0 else None

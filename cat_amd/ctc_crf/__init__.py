@@ -156,15 +156,23 @@ class CRFContext:
         gpus_t = torch.IntTensor(gpus)
         core.init_env(den_lm, gpus_t)
         self._gpus = gpus_t
+        # the graphs THIS context created: __del__ releases these and nothing else (a later context on the same
+        # device replaces the graph; the reference's Release() would free whatever is current, den_calculate.cu:394-425)
+        self._handles = {int(i): core._GRAPHS[int(i)] for i in gpus}
         self.den_lm = den_lm
 
+    def owns_graph(self, idx: int) -> bool:
+        """True while the graph this context loaded on device `idx` is still the device's current graph."""
+        h = getattr(self, '_handles', {}).get(idx)
+        return h is not None and core._GRAPHS.get(idx) == h
+
     def __del__(self):
-        if hasattr(self, '_gpus'):
+        if hasattr(self, '_handles'):
             try:
-                core.release_env(self._gpus)
+                core.release_handles(self._handles)
             except Exception:  # interpreter shutdown
                 pass
-            del self._gpus
+            del self._handles
 
 
 _CTX_CACHE: Dict[Tuple[str, int], CRFContext] = {}
@@ -179,12 +187,12 @@ def ctc_crf_loss(log_probs: torch.Tensor, labels: torch.Tensor, frame_lens: torc
     dev = log_probs.device
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (os.path.abspath(den_lm), idx)
-    cur = core._GRAPHS.get(idx)
     ctx = _CTX_CACHE.get(key)
-    if ctx is None or cur is None:
+    if ctx is None or not ctx.owns_graph(idx):   # not loaded yet, or somebody replaced / released the device's graph
+        ctx = None                                # (drop every reference BEFORE the replacement is created)
         for k in [k for k in _CTX_CACHE if k[1] == idx]:  # one graph per device, like the reference
             del _CTX_CACHE[k]
-        ctx = _CTX_CACHE[key] = CRFContext(den_lm, idx)
+        _CTX_CACHE[key] = CRFContext(den_lm, idx)
     if fuse_log_softmax:
         return _CTC_CRF_LOGITS.apply(log_probs, labels.int().cpu(), frame_lens.int().cpu(), label_lens.int().cpu(),
                                      lamb, size_average)

@@ -3,33 +3,14 @@ import os
 
 import numpy as np
 
-from cat_amd.den_lm import random_labels_from_graph, synth_den_lm, write_fst
+from cat_amd.den_lm import synth_den_lm, write_fst
+from cat_amd.synth import log_softmax_np, make_batch  # noqa: F401  (re-exported: the tests import them from here)
 
 
 def graph_to_file(g, path):
     write_fst(path, g["S"], int(g.get("start", 0)), g["src"], g["dst"], g["lab"] + 1, g["lab"] + 1,
               -g["w"], -g["end_w"])
     return path
-
-
-def log_softmax_np(x):
-    m = x.max(-1, keepdims=True)
-    return (x - m - np.log(np.exp(x - m).sum(-1, keepdims=True))).astype(np.float32)
-
-
-def make_batch(g, B, T, V, seed=0, ragged=True, scale=2.0, label_frac=6, min_len=1):
-    """SURVEY 8d synthetic inputs: log_softmax(N(0,1)*scale); lx ragged in [0.6T, T] sorted descending;
-    ly = lx // label_frac; labels walk the graph."""
-    rng = np.random.default_rng(seed)
-    logits = log_softmax_np(rng.normal(0.0, 1.0, size=(B, T, V)) * scale)
-    if ragged:
-        lx = np.sort(rng.integers(max(min_len, int(0.6 * T)), T + 1, size=B))[::-1].astype(np.int32)
-        lx[0] = T
-    else:
-        lx = np.full(B, T, dtype=np.int32)
-    ly = np.maximum(lx // label_frac, 0).astype(np.int32)
-    labels = np.concatenate([random_labels_from_graph(g, int(n), rng) for n in ly]) if ly.sum() else np.zeros(0, np.int32)
-    return logits, labels.astype(np.int32), lx, ly
 
 
 def rel_err(a, b):

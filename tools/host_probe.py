@@ -4,7 +4,7 @@ If enqueue time ~ GPU time, something on the host blocks on the stream; if it is
 import os, sys, time, tempfile
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.util import make_batch
+from cat_amd.synth import make_batch
 from cat_amd import ctc_crf
 from cat_amd.den_lm import synth_den_lm
 dev = torch.device("cuda:0")

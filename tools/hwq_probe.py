@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctc_crf  # noqa: E402  (sets GPU_MAX_HW_QUEUES=8 unless it is set already)
 import numpy as np, torch  # noqa: E402
 from cat_amd.den_lm import synth_den_lm  # noqa: E402
-from tests.util import make_batch  # noqa: E402
+from cat_amd.synth import make_batch  # noqa: E402
 extra = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dev = torch.device("cuda:0")
 streams = [torch.cuda.Stream(device=dev) for _ in range(extra)]

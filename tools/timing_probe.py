@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import ctc_crf  # noqa: E402
 from cat_amd.ctc_crf import _C  # noqa: E402
 from cat_amd.den_lm import synth_den_lm  # noqa: E402
-from tests.util import make_batch  # noqa: E402
+from cat_amd.synth import make_batch  # noqa: E402
 
 
 def main():
