@@ -109,3 +109,44 @@ def test_cli_and_bad_input(tmp_path):
         den_lm.estimate_token_lm([[1, 4]], 4)             # token outside the vocabulary
     with pytest.raises(ValueError):
         den_lm.estimate_token_lm([[0, 1]], 4)             # the blank is not a transcript token
+
+
+def test_factoring_survives_openfst_style_rewrites(tmp_path):
+    """den_lm files come out of ``fstcompose | fstdeterminizestar --use-log=true`` (cat/utils/tool/prep_den_lm.sh:48-49):
+    state numbers and arc order are whatever those tools leave.  The graph compiler must find the T o LM structure
+    (factored layout: one CU per recursion) under ANY numbering and arc order; a weight-pushed graph (potentials moved
+    along the arcs -- determinizestar does not do this to an input-deterministic graph, but other OpenFst tools would)
+    is still compiled, into the generic layout.  Host-only compile: no GPU needed."""
+    from cat_amd.ctc_crf import _C
+    from tests.util import transform_graph
+
+    def stats(path):
+        h = _C.compile_graph_host_only(path)
+        s = _C.graph_stats(h)
+        _C._lib.crf_graph_destroy(_C._vp(h))
+        return s
+
+    p = str(tmp_path / "orig.fst")
+    g = den_lm.synth_den_lm(72, 512, 12, seed=3, path=p)
+    base = stats(p)
+    assert base["fac"] == 1
+    for seed in (1, 2):
+        q = str(tmp_path / f"renum{seed}.fst")
+        transform_graph(g, q, seed=seed, renumber=True, reorder=True)
+        s = stats(q)
+        assert s["fac"] == 1 and s["fac_matched_pairs"] == base["fac_matched_pairs"]
+        assert s["fac_fwd_slots"] == base["fac_fwd_slots"] and s["fac_bwd_slots"] == base["fac_bwd_slots"]
+    q = str(tmp_path / "pushed.fst")
+    transform_graph(g, q, seed=5, renumber=True, reorder=True, push=True)
+    s = stats(q)
+    assert s["S"] == base["S"] and s["A"] == base["A"] and (s["fac"] == 1 or s["res_K"] >= 1)
+
+
+def test_reference_fixture_layout(golden_dir):
+    """The only Kaldi-made den_lm available (the reference's 9-state test graph, byte-identical copy): which layout it
+    takes is deterministic -- the factored one (4 (tail, main) pairs)."""
+    from cat_amd.ctc_crf import _C
+    h = _C.compile_graph_host_only(os.path.join(golden_dir, "den_lm_fixture.fst"))
+    s = _C.graph_stats(h)
+    _C._lib.crf_graph_destroy(_C._vp(h))
+    assert s["S"] == 9 and s["fac"] == 1 and s["fac_matched_pairs"] == 4

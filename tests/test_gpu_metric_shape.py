@@ -1,0 +1,111 @@
+"""Parity AT THE BENCHMARKED SHAPE (B=64, T=1500, V=72, S=4097: one bench.py step, the staged factored schedule on a
+full chip) against the fp64 oracle -- loss terms and the complete [T, V] gradient of the first / a middle / the last
+utterance -- with the workspace poisoned (NaN bit patterns) before every call and two back-to-back calls on DIFFERENT
+inputs, so that a grad-pass stage released too early cannot pass by finding the previous call's rows in the block the
+caching allocator hands back.  Reference semantics: src/ctc_crf/ctc_crf/__init__.py:60-90."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import fst_io
+from tests.util import make_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def crf():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctc_crf
+    return ctc_crf
+
+
+def _slice(logits, labels, lx, ly, idx):
+    off = np.concatenate([[0], np.cumsum(ly)])
+    lab = np.concatenate([labels[off[i]:off[i + 1]] for i in idx]) if len(idx) else np.zeros(0, np.int32)
+    return logits[idx], lab.astype(np.int32), lx[idx], ly[idx]
+
+
+def test_metric_shape_vs_oracle_poisoned(crf, tmp_path_factory):
+    from cat_amd.den_lm import synth_den_lm
+    p = os.path.join(str(tmp_path_factory.mktemp("denlm")), "den_lm_v72.fst")
+    g = synth_den_lm(72, 2048, 24, 0, path=p)
+    B, T, V, lamb = 64, 1500, 72, 0.1
+    core = crf._C
+    ctx = crf.CRFContext(p, 0)
+    st = core.graph_stats(core.graph_for(torch.device("cuda", 0)))
+    assert st["fac"] == 1                                   # the default (factored, staged) schedule is what is tested
+    batches = [make_batch(g, B, T, V, seed=0, ragged=True), make_batch(g, B, T, V, seed=7, ragged=False)]
+    core.set_debug_poison(True)
+    try:
+        outs = []
+        s = 1.0 / B
+        for lg, lab, lx, ly in batches:                     # back to back, no synchronisation in between
+            x = torch.tensor(lg, device="cuda:0")
+            outs.append(core.loss_fwd_bwd(x, torch.tensor(lab), torch.tensor(lx), torch.tensor(ly), s, s * (1 + lamb),
+                                          core.graph_for(x.device), True))
+        torch.cuda.synchronize()
+        # numerator posteriors alone, to take the staged denominator half out of the combined gradient
+        gctc = []
+        for lg, lab, lx, ly in batches:
+            x = torch.tensor(lg, device="cuda:0")
+            gctc.append(core.loss_fwd_bwd(x, torch.tensor(lab), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)[1])
+    finally:
+        core.set_debug_poison(False)
+    gref = fst_io.read_fst(p)
+    idx = np.array([0, B // 2 - 1, B - 1])
+    for (lg, lab, lx, ly), (loss, grad, ex), gc in zip(batches, outs, gctc):
+        loss = float(loss.item())
+        assert np.isfinite(loss)                            # (an exchange / stage error would turn the loss into NaN)
+        ca, cb, cc = (ex[k].double().cpu().numpy() for k in ("costs_alpha", "costs_beta", "costs_ctc"))
+        assert int(ex["invalid"].sum().item()) == 0
+        assert abs(loss - (ca - (1 + lamb) * cc).sum() / B) <= 1e-5 * abs(loss)
+        assert np.allclose(ca, cb, rtol=3e-5, atol=0)
+        gden = (grad * B + (1 + lamb) * gc).cpu().numpy()   # gamma_den of the staged pass
+        assert gden.min() >= -2e-5
+        for b in range(B):
+            n = int(lx[b])
+            assert np.allclose(gden[b, :n].sum(-1), 1.0, atol=3e-4)
+            assert np.all(grad[b, n:].cpu().numpy() == 0.0)
+        sl = _slice(lg, lab, lx, ly, idx)
+        ref = oracle.ctc_crf(gref, *sl, lamb=lamb, size_average=False, threads=3)
+        g3 = grad[torch.tensor(idx)].cpu().numpy() * B
+        for j, b in enumerate(idx):
+            assert abs(ca[b] - ref["costs_den"][j]) <= TOL * abs(ref["costs_den"][j])
+            assert abs(cc[b] - ref["costs_ctc"][j]) <= TOL * abs(ref["costs_ctc"][j])
+            e = rel_err(g3[j], ref["grad"][j])
+            print(f"utterance {b} (lx={int(lx[b])}): grad err vs fp64 oracle {e:.2e}")
+            assert e <= TOL
+    del ctx
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_fused_log_softmax_vs_oracle(crf, tmp_path, dtype):
+    """The fused log_softmax path against the ORACLE directly (not against the unfused HIP path): numpy fp64
+    log_softmax of the same (rounded) network output, the oracle's loss and d loss / d log_probs, and the chain rule
+    d/dx = g - softmax(x) * sum_v g  (cat/ctc/train.py:174-186 + autograd)."""
+    from tests.util import small_synth
+    g, fst = small_synth(tmp_path, 24, 96, 8, 3)
+    _, labels, lx, ly = make_batch(g, 4, 48, 24, seed=11, ragged=True)
+    rng = np.random.default_rng(5)
+    raw = torch.tensor(rng.normal(size=(4, 48, 24)) * 3.0, dtype=torch.float32).to(getattr(torch, dtype))
+    x64 = raw.double().numpy()
+    m = x64.max(-1, keepdims=True)
+    lse = m + np.log(np.exp(x64 - m).sum(-1, keepdims=True))
+    logp = (x64 - lse).astype(np.float32)
+    ref = oracle.ctc_crf(fst_io.read_fst(fst), logp, labels, lx, ly, lamb=0.1)
+    gl = ref["grad"].astype(np.float64)
+    gx = gl - np.exp(x64 - lse) * gl.sum(-1, keepdims=True)
+    ctx = crf.CRFContext(fst, 0)
+    xf = raw.cuda().requires_grad_(True)
+    lf = crf.CTC_CRF_LOSS(lamb=0.1, fuse_log_softmax=True)(xf, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly))
+    lf.backward()
+    assert abs(lf.item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    tol = TOL if dtype == "float32" else 1e-2               # the gradient is returned in the input's dtype
+    assert rel_err(xf.grad.float().cpu().numpy(), gx) <= tol
+    del ctx

@@ -205,6 +205,31 @@ def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
     assert rel_err(grad, ref["grad"]) <= TOL
 
 
+@pytest.mark.parametrize("push", [False, True])
+def test_rewritten_den_lm_vs_oracle(crf, tmp_path, push):
+    """A den_lm as OpenFst tools leave it (cat/utils/tool/prep_den_lm.sh:48-49): states re-numbered, arcs of a state in
+    another order, optionally weights pushed along the arcs.  Same loss and gradient as the ORIGINAL graph's oracle (the
+    rewrites preserve every path weight; pushing only up to fp32 rounding of the new weights), and the re-numbered
+    graph keeps the factored layout."""
+    from tests.util import transform_graph
+    g, p = small_synth(tmp_path, 24, 96, 8, 13)
+    q = os.path.join(str(tmp_path), "rewritten.fst")
+    g2 = transform_graph(g, q, seed=3, renumber=True, reorder=True, push=push)
+    B, T, V = 4, 60, 24
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=6, ragged=True)
+    ref0 = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    ref = oracle.ctc_crf(g2, logits, labels, lx, ly, lamb=0.1)
+    assert abs(ref["loss"] - ref0["loss"]) <= (1e-4 if push else 1e-6) * abs(ref0["loss"])   # the rewrite itself
+    loss, grad = run_hip(crf, q, logits, labels, lx, ly, lamb=0.1)
+    if not push:
+        with _mode("factored"):
+            ctx = crf.CRFContext(q, 0)
+        assert crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))["fac"] == 1
+        del ctx
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
 def test_wide_rows_grad_kernel(crf, tmp_path):
     """More than 2 560 forward rows: the per-frame rows (Q, BP) exceed 5 120 floats and the denominator half of the
     grad pass runs with 512-thread workgroups; factored layout, against the fp64 oracle (short T, ragged)."""

@@ -42,3 +42,31 @@ def small_synth(tmpdir, vocab=8, histories=16, fanout=4, seed=1):
     p = os.path.join(str(tmpdir), f"synth_v{vocab}_h{histories}_d{fanout}_s{seed}.fst")
     g = synth_den_lm(vocab, histories, fanout, seed, path=p)
     return g, p
+
+
+def transform_graph(g, path, seed=0, renumber=True, reorder=True, push=False):
+    """What OpenFst tools do to a den_lm between composition and the file the loss reads
+    (cat/utils/tool/prep_den_lm.sh:48-49, ``fstcompose | fstdeterminizestar --use-log=true``): states are
+    re-numbered (discovery order), the arcs of a state come in another order, and -- for `push` -- weights are
+    moved along paths by a potential (w' = w + V(dst) - V(src), final' = final - V(s), V(start) = 0), which
+    leaves every path weight, hence the loss, unchanged.  Returns the transformed graph (reference conventions)
+    and writes it to `path`."""
+    rng = np.random.default_rng(seed)
+    S = int(g["S"])
+    src, dst, lab = g["src"].astype(np.int64), g["dst"].astype(np.int64), g["lab"].astype(np.int32)
+    w, end_w = g["w"].astype(np.float64), g["end_w"].astype(np.float64)
+    start = int(g.get("start", 0))
+    if push:
+        pot = rng.normal(0.0, 1.0, size=S)
+        pot[start] = 0.0
+        w = w + pot[dst] - pot[src]
+        end_w = np.where(np.isfinite(end_w), end_w - pot, end_w)
+    perm = rng.permutation(S) if renumber else np.arange(S)          # old id -> new id
+    src, dst = perm[src], perm[dst]
+    end2 = np.empty(S, dtype=np.float64)
+    end2[perm] = end_w
+    order = rng.permutation(len(src)) if reorder else np.arange(len(src))
+    src, dst, lab, w = src[order], dst[order], lab[order], w[order]
+    write_fst(path, S, int(perm[start]), src, dst, lab + 1, lab + 1, -w.astype(np.float32), -end2.astype(np.float32))
+    from oracle import fst_io
+    return fst_io.read_fst(path)

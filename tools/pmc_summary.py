@@ -1,10 +1,11 @@
 """tools/pmc_summary.py TAG -- condense the rocprofv3 outputs of tools/gpu_round.sh + tools/gpu_prof.sh
 (gpurun_out/) into the small summaries kept under profiles/:
 
-    profiles/round1_<TAG>_bench.json          the bench line (with cpu_baseline)
-    profiles/round1_<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary
-    profiles/round1_<TAG>_pmc.json            per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch) and SQ counters
-    profiles/pmc_traffic.json                 HBM bytes per launch of the two den chain kernels (read by bench.py)
+    profiles/round2_<TAG>_bench.json          the bench line (with cpu_baseline)
+    profiles/round2_<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary
+    profiles/round2_<TAG>_pmc.json            per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch) and SQ counters
+    profiles/pmc_traffic.json                 HBM bytes per launch of every loss kernel + the whole-path ratio, KEYED BY
+                                              WORKLOAD (read by bench.py; another workload prints traffic: null)
 """
 import csv
 import glob
@@ -39,10 +40,10 @@ def counters(tag, what):
 def main():
     tag = sys.argv[1]
     os.makedirs(PROF, exist_ok=True)
-    shutil.copy(os.path.join(OUT, f"bench_{tag}.json"), os.path.join(PROF, f"round1_{tag}_bench.json"))
+    shutil.copy(os.path.join(OUT, f"bench_{tag}.json"), os.path.join(PROF, f"round2_{tag}_bench.json"))
     ks = glob.glob(os.path.join(OUT, f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
-        shutil.copy(ks[0], os.path.join(PROF, f"round1_{tag}_kernel_stats.csv"))
+        shutil.copy(ks[0], os.path.join(PROF, f"round2_{tag}_kernel_stats.csv"))
     traffic, sq = {}, {}
     fe, wr, s = counters(tag, "fetch"), counters(tag, "write"), counters(tag, "sq")
     def nsteps(acc, what):   # calls of the loss in that profiling pass = launches of the finalize kernel
@@ -73,17 +74,27 @@ def main():
                 "stream (MI355X_MICROARCH.md HBM section): the grad kernels' row reads are such streams.",
         "traffic": traffic, "sq": sq,
     }
-    json.dump(doc, open(os.path.join(PROF, f"round1_{tag}_pmc.json"), "w"), indent=1)
-    tr = {}
-    for k, v in traffic.items():   # HBM bytes of one whole recursion = all its segment launches of one call
-        if "crf_res_chain_kernel<0" in k or "crf_fac_chain_kernel<0" in k:
-            tr["den_fwd_chain"] = int((v.get("FETCH_SIZE_KB_per_call", 0) + v.get("WRITE_SIZE_KB_per_call", 0)) * 1024)
-        if "crf_res_chain_kernel<1" in k or "crf_fac_chain_kernel<1" in k:
-            tr["den_bwd_chain"] = int((v.get("FETCH_SIZE_KB_per_call", 0) + v.get("WRITE_SIZE_KB_per_call", 0)) * 1024)
-    if tr:
-        tr["source"] = (f"profiles/round1_{tag}_pmc.json: (FETCH_SIZE + WRITE_SIZE) * 1024 bytes per call of the loss (one launch per recursion); "
-                        " the chain kernels' reads are small and not 16-byte streams, so FETCH_SIZE is not doubled")
-        json.dump(tr, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
+    json.dump(doc, open(os.path.join(PROF, f"round2_{tag}_pmc.json"), "w"), indent=1)
+    # bytes per call of the loss, per kernel.  FETCH_SIZE is doubled for the kernels whose reads are wide (16 B / lane)
+    # coalesced streams (MI355X_MICROARCH.md, HBM section): the grad pass reading the Q / BP / CA / CB rows.
+    bench = json.load(open(os.path.join(OUT, f"bench_{tag}.json")))
+    wl = bench["config"]["workload"]
+    import re
+    m = re.search(r"B=(\d+) per GPU, T=(\d+), V=(\d+).*S=(\d+) states, A=(\d+) arcs.*?(ragged lx|lx = T)", wl)
+    key = f"B{m.group(1)}_T{m.group(2)}_V{m.group(3)}_S{m.group(4)}_A{m.group(5)}_{'ragged' if m.group(6) == 'ragged lx' else 'full'}" if m else wl
+    kernels, total = {}, 0
+    for k, v in traffic.items():
+        wide = "crf_grad_den_kernel" in k or "crf_grad_ctc_kernel" in k
+        byts = int((v.get("FETCH_SIZE_KB_per_call", 0) * (2 if wide else 1) + v.get("WRITE_SIZE_KB_per_call", 0)) * 1024)
+        short = k.replace("void ", "").replace("crf::", "").split("<")[0].split("(")[0]
+        kernels[short] = kernels.get(short, 0) + byts
+        total += byts
+    alg = bench["roofline"]["den_fwd_bwd"]["bytes"] + bench["roofline"]["den_fwd_bwd"]["bytes_num"]
+    tr = {"workload": key, "kernels": kernels,
+          "whole_path": {"pmc_bytes_per_call": total, "algorithmic_bytes": alg, "ratio": round(total / max(1, alg), 3)},
+          "source": f"profiles/round2_{tag}_pmc.json: (FETCH_SIZE [x2 for the grad kernels' 16-byte row streams] + WRITE_SIZE) * 1024 bytes "
+                    "per call of the loss, every launch of a kernel summed"}
+    json.dump(tr, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(tr, indent=1))
     for k, v in traffic.items():
         print(k[:60], v)
