@@ -90,6 +90,9 @@ struct LossParams {
     int *den_ez, *ctc_ez;         // [B] their exponents
     float *cost_alpha, *cost_beta, *cost_ctc;  // [B]
     int *invalid;                 // [B]
+    int *redo;                    // [2][B] utterance whose scaled-fp32 denominator lost all its mass (forward / backward): redone by the robust kernels
+    int force_redo;               // CRF_ROBUST=1: every utterance takes the robust path
+    int64_t gvec_stride;          // floats per utterance of `gvec`
     // outputs
     float *grad, *loss, *out_den, *out_beta, *out_ctc;
     int *out_invalid;
@@ -203,8 +206,10 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     const int sub = threadIdx.x & (G - 1);
     // the counters of the staged schedule start at zero in every call (a memset in the stream cost two more
     // dispatches between this kernel and the recursions)
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < p.nclear; i += 256) __hip_atomic_store(p.clear + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.redo) for (int i = threadIdx.x; i < 2 * p.B; i += 256) p.redo[i] = p.force_redo;
+    }
     const int64_t f = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
     if (f >= (int64_t)p.B * p.T) return;
     const int b = (int)(f / p.T), t = (int)(f % p.T);
@@ -373,7 +378,7 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = g.S, V = p.V, Pr = g.Pr, lx = p.lx[b];
     const int Sp = rup64(S), Vp = rup64(V);
-    float *X = GV ? p.gvec + (size_t)b * (3 * (size_t)Sp + 4 * (size_t)Pr) : lds;
+    float *X = GV ? p.gvec + (size_t)b * p.gvec_stride : lds;
     float *EP = GV ? lds : X + 3 * Sp;
     float *wm = EP + 2 * Vp;
     double *red = (double *)(wm + 2 * kChainWaves);
@@ -443,6 +448,7 @@ __device__ __forceinline__ void den_forward(const LossParams &p, int b, float *l
         p.den_zs[b] = zs;
         p.den_ez[b] = E;
         p.cost_alpha[b] = to_log(zs, E, mxs);
+        if (!(zs > 0.f && zs < INFINITY)) p.redo[b] = 1;   // all mass lost in scaled fp32 (or overflow): the robust kernels redo it
     }
 }
 
@@ -457,7 +463,7 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = g.S, V = p.V, Pr = g.Pr, lx = p.lx[b];
     const int Vp = rup64(V);
-    float *Z = GV ? p.gvec + (size_t)b * (3 * (size_t)rup64(S) + 4 * (size_t)Pr) + 3 * (size_t)rup64(S) : lds;
+    float *Z = GV ? p.gvec + (size_t)b * p.gvec_stride + 3 * (size_t)rup64(S) : lds;
     float *BPst = Z + 2 * Pr;
     float *EP = GV ? lds : BPst + 2 * Pr;
     float *wm = EP + 2 * Vp;
@@ -550,7 +556,10 @@ __device__ __forceinline__ void den_backward(const LossParams &p, int b, float *
     }
     const float zb = block_sum(zpart, (float *)red, tid);
     const double mxs = mx_total(p, b, lx, red, tid);
-    if (tid == 0) p.cost_beta[b] = to_log(zb, F, mxs);
+    if (tid == 0) {
+        p.cost_beta[b] = to_log(zb, F, mxs);
+        if (!(zb > 0.f && zb < INFINITY)) p.redo[p.B + b] = 1;
+    }
 }
 
 __device__ __forceinline__ float ctc_block_sum(float v, float *red, int tid) {
@@ -1036,6 +1045,7 @@ struct ResParams {
     float *cb_part;
     double *cb_mxs;
     int *cb_F;
+    int *redo;                  // [2][B], see LossParams
 };
 
 // LDS map of the resident kernels: the two state-vector buffers sit at byte offsets 0 and kResXB; a gather
@@ -1294,7 +1304,7 @@ __device__ __forceinline__ void res_chain_body(const ResParams &p, float *lds, c
             for (int s = tid; s < G; s += kResThreads) part += Xf[s] * p.x_end[s];
             const float zs = res_block_sum(part, (float *)red, tid);
             const double mxs = res_mx_total(p, b, lx, red, tid);
-            if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); }
+            if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); if (!(zs > 0.f && zs < INFINITY)) p.redo[b] = 1; }
         }
     } else {
         if (lx > 0) {  // logZ from the backward side: sum_s start(s) b_0(s) over this CU's rows (written above)
@@ -1356,6 +1366,7 @@ struct FacParams {
     float *cb_part;
     double *cb_mxs;
     int *cb_F;
+    int *redo;                  // [2][B], see LossParams
 };
 
 // FLAG: publish stage flags and store rows write-through (one instantiation per use: the frame loop has no
@@ -1689,7 +1700,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         for (int s = tid; s < G; s += NTH) part += Xf[s] * p.x_end[s];
         const float zs = res_block_sum<NW>(part, (float *)red, tid);
         const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
-        if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); }
+        if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); if (!(zs > 0.f && zs < INFINITY)) p.redo[b] = 1; }
     } else {
         if (lx > 0) {
             __syncthreads();  // drains vmcnt: this workgroup's own stores to the spare row are visible to it
@@ -1702,7 +1713,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         } else if (tid == 0) zpart += p.bx_se * pow2f(kScaleExp);
         const float zb = res_block_sum<NW>(zpart, (float *)red, tid);
         const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
-        if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E; p.cb_mxs[b] = mxs; }
+        if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E; p.cb_mxs[b] = mxs; if (!(zb > 0.f && zb < INFINITY)) p.redo[p.B + b] = 1; }
     }
 }
 
@@ -2191,6 +2202,296 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
         }
 }
 
+// =============================================================================================
+// ROBUST denominator (fallback, rare).  The fast recursions run in fp32 scaled per frame by a power of two and take
+// the emissions as e' = exp(logp - rowmax) * 2^64: an utterance in which, at some frame, EVERY live (state, label)
+// lies more than ~131 nats below the row maximum loses all its mass (logZ = -inf) where the reference's log-domain
+// arithmetic (den_calculate.cu:29-35, 75-103, 189-227) stays finite -- e.g. a peaked network output whose arg-max
+// label the un-smoothed n-gram den_lm forbids.  Such utterances (flagged by the fast kernels, p.redo) are redone here
+// with the emission scale taken from the largest REACHED product instead of the row maximum:
+//     D_t = max over live pairs p of ( d_t[lab_p] + ln q_t[p] ),   d = logp - rowmax   (fp64)
+//     a_{t+1}[dst_p] = exp(d_t[lab_p] - D_t) * 2^20 * q_t[p]
+// so the largest new entry is 2^20 whatever the emissions are; ln(total scale) is carried in fp64.  The rows Q / BP
+// are stored as in the streaming kernels (pair order, first Pr entries of the workspace rows); the grad pass of a
+// frame is a softmax over labels of d_t[v] + ln(sum of its pairs' Q * BP) -- no per-frame exponents needed.
+// One workgroup per flagged utterance and direction; unflagged utterances leave at once.
+// LDS fwd: X[3][Sp] | Ql[Pr] | Dv (double)[Vp] | wm[32] | red[16] (double)      (GV: X and Ql in global memory)
+// LDS bwd: Z[2][Pr] | BPst[2][Pr] | Dv (double)[Vp] | wm[32] | red[16] (double)
+// =============================================================================================
+__device__ __forceinline__ double block_max_d(double v, double *red, int tid) {   // any sign; -inf = nothing
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double m = red[0];
+#pragma unroll
+    for (int i = 1; i < kChainWaves; ++i) m = fmax(m, red[i]);
+    return m;
+}
+__device__ __forceinline__ void load_drow(const LossParams &p, int64_t frame, double *Dv, int tid) {
+    const double mx = (double)p.mx[frame];
+    for (int v = tid; v < p.V; v += kChainThreads) Dv[v] = (double)ld_x(p, frame * p.V + v) - mx;
+}
+
+template <bool GV>
+__device__ __forceinline__ void den_forward_robust(const LossParams &p, int b, float *lds) {
+    const GraphDev &g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = g.S, V = p.V, Pr = g.Pr, lx = p.lx[b];
+    const int Sp = rup64(S), Vp = rup64(V);
+    float *X = GV ? p.gvec + (size_t)b * p.gvec_stride : lds;
+    float *Ql = GV ? X + 3 * (size_t)Sp + 4 * (size_t)Pr : X + 3 * Sp;
+    double *Dv = (double *)(GV ? lds : Ql + Pr);
+    float *wm = (float *)(Dv + Vp);
+    double *red = (double *)(wm + 2 * kChainWaves);
+    const int64_t bt0 = (int64_t)b * p.T;
+    if (lx <= 0) return;                                    // nothing to redo: no emission is involved
+    for (int s = tid; s < 3 * Sp; s += kChainThreads) X[s] = (s < S) ? g.start_lin[s] * pow2f(kScaleExp) : 0.f;
+    double lS = (double)kScaleExp * 0.6931471805599453;     // ln(stored / true)
+    __syncthreads();
+    const int sl0 = g.fwd.wave_off[wave], sl1 = g.fwd.wave_off[wave + 1];
+    for (int t = 0; t < lx; ++t) {
+        float *Xc = X + (t % 3) * Sp, *Xn = X + ((t + 1) % 3) * Sp, *Xz = X + ((t + 2) % 3) * Sp;
+        load_drow(p, bt0 + t, Dv, tid);
+        float m = 0.f;
+        for (int s = tid; s < S; s += kChainThreads) m = fmaxf(m, Xc[s]);
+        m = wave_max(m);
+        if (lane == 0) wm[wave] = m;
+        __syncthreads();
+        const int k = rescale_exp(frame_max(wm));
+        const float sc = pow2f(k);
+        for (int s = tid; s < Sp; s += kChainThreads) Xz[s] = 0.f;
+        float *Qrow = p.Q + (bt0 + t) * p.Rq;
+        double smax = -INFINITY;
+        for (int i = sl0; i < sl1; ++i) {
+            const int j = __builtin_amdgcn_readfirstlane(g.fwd.wave_slices[i]);
+            const int off = __builtin_amdgcn_readfirstlane(g.fwd.slice_off[j]);
+            const int w2 = __builtin_amdgcn_readfirstlane(g.fwd.slice_w2[j]);
+            const int r = j * kWave + lane;
+            const int2 meta = g.pair_meta[r];
+            const float q = ell_row_sum(g.fwd.arcs + off + lane, w2, Xc) * sc;
+            Qrow[r] = q;
+            Ql[r] = q;
+            if (meta.x >= 0 && q > 0.f) smax = fmax(smax, Dv[meta.y & 0xffff] + log((double)q));
+        }
+        const double Dm = block_max_d(smax, red, tid);      // (its barriers also publish Ql)
+        const double Dsh = Dm > -INFINITY ? Dm - (double)kScaleExp * 0.6931471805599453 : 0.0;
+        for (int r = tid; r < Pr; r += kChainThreads) {
+            const int2 meta = g.pair_meta[r];
+            if (meta.x < 0) continue;
+            const float q = Ql[r];
+            const float av = q > 0.f ? (float)(exp(Dv[meta.y & 0xffff] - Dsh) * (double)q) : 0.f;
+            if (meta.y >> 16) Xn[meta.x] = av; else atomicAdd(&Xn[meta.x], av);
+        }
+        lS += (double)k * 0.6931471805599453 - Dsh - (double)p.moff[bt0 + t];
+        __syncthreads();
+    }
+    const float *Xf = X + (lx % 3) * Sp;
+    float part = 0.f;
+    for (int s = tid; s < S; s += kChainThreads) part += Xf[s] * g.end_lin[s];
+    const float zs = block_sum(part, (float *)red, tid);
+    if (tid == 0) {
+        p.den_zs[b] = zs;
+        p.den_ez[b] = 0;
+        p.cost_alpha[b] = zs > 0.f ? (float)(log((double)zs) - lS) : -INFINITY;
+    }
+}
+
+template <bool GV>
+__device__ __forceinline__ void den_backward_robust(const LossParams &p, int b, float *lds) {
+    const GraphDev &g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = g.S, V = p.V, Pr = g.Pr, lx = p.lx[b];
+    const int Vp = rup64(V);
+    float *Z = GV ? p.gvec + (size_t)b * p.gvec_stride + 3 * (size_t)rup64(S) : lds;
+    float *BPst = Z + 2 * Pr;
+    double *Dv = (double *)(GV ? lds : BPst + 2 * Pr);
+    float *wm = (float *)(Dv + Vp);
+    double *red = (double *)(wm + 2 * kChainWaves);
+    const int64_t bt0 = (int64_t)b * p.T;
+    if (lx <= 0) return;
+    for (int r = tid; r < 4 * Pr; r += kChainThreads) Z[r] = 0.f;
+    load_drow(p, bt0 + lx - 1, Dv, tid);
+    __syncthreads();
+    double lSz, lSb = 0.0;                                   // ln(stored / true) of the z vector / of b_t
+    {   // z_{lx-1}[p] = e_{lx-1}[lab_p] * end[dst_p]
+        float *BProw = p.BP + (bt0 + lx - 1) * p.Rb;
+        double smax = -INFINITY;
+        for (int r = tid; r < Pr; r += kChainThreads) {
+            const int2 meta = g.pair_meta[r];
+            const float bv = meta.x >= 0 ? g.end_lin[meta.x] : 0.f;
+            BProw[r] = bv;
+            if (bv > 0.f) smax = fmax(smax, Dv[meta.y & 0xffff] + log((double)bv));
+        }
+        const double Dm = block_max_d(smax, red, tid);
+        const double Dsh = Dm > -INFINITY ? Dm - (double)kScaleExp * 0.6931471805599453 : 0.0;
+        for (int r = tid; r < Pr; r += kChainThreads) {
+            const int2 meta = g.pair_meta[r];
+            const float bv = meta.x >= 0 ? g.end_lin[meta.x] : 0.f;
+            Z[r] = bv > 0.f ? (float)(exp(Dv[meta.y & 0xffff] - Dsh) * (double)bv) : 0.f;
+        }
+        lSz = -Dsh - (double)p.moff[bt0 + lx - 1];
+    }
+    __syncthreads();
+    float zpart = 0.f;
+    const int sl0 = g.bwd.wave_off[wave], sl1 = g.bwd.wave_off[wave + 1];
+    for (int i = 0; i < lx; ++i) {
+        const int t = lx - 1 - i;
+        const float *Zc = Z + (i & 1) * Pr;
+        float *Zn = Z + ((i + 1) & 1) * Pr;
+        float *BPc = BPst + (i & 1) * Pr;
+        if (t >= 1) load_drow(p, bt0 + t - 1, Dv, tid);      // (its last readers are behind the previous iteration's closing barrier)
+        float m = 0.f;
+        for (int r = tid; r < Pr; r += kChainThreads) m = fmaxf(m, Zc[r]);
+        m = wave_max(m);
+        if (lane == 0) wm[wave] = m;
+        if (i > 0) {  // b_{t+1}[dst_p], staged by the previous iteration -> BP[b][t]
+            const float *BPp = BPst + ((i - 1) & 1) * Pr;
+            float *BProw = p.BP + (bt0 + t) * p.Rb;
+            for (int r = tid; r < Pr; r += kChainThreads) BProw[r] = BPp[r];
+        }
+        __syncthreads();
+        const int k = rescale_exp(frame_max(wm));
+        const float sc = pow2f(k);
+        lSb = lSz + (double)k * 0.6931471805599453;
+        for (int ii = sl0; ii < sl1; ++ii) {
+            const int j = __builtin_amdgcn_readfirstlane(g.bwd.wave_slices[ii]);
+            const int off = __builtin_amdgcn_readfirstlane(g.bwd.slice_off[j]);
+            const int w2 = __builtin_amdgcn_readfirstlane(g.bwd.slice_w2[j]);
+            const int4 meta = g.bwd_row_meta[j * kWave + lane];  // {state, #pairs into it, first pair, its label}
+            const float bv = ell_row_sum(g.bwd.arcs + off + lane, w2, Zc) * sc;
+            const int s = meta.x;
+            if (s >= 0) {
+                if (t == 0) zpart += g.start_lin[s] * bv;
+                else if (meta.y == 1) BPc[meta.z] = bv;
+                else for (int pi = g.st_pair_off[s]; pi < g.st_pair_off[s + 1]; ++pi) BPc[g.st_pairs[pi]] = bv;
+            }
+        }
+        if (t >= 1) {
+            __syncthreads();
+            double smax = -INFINITY;
+            for (int r = tid; r < Pr; r += kChainThreads) {
+                const float bv = BPc[r];
+                if (bv > 0.f) smax = fmax(smax, Dv[g.pair_meta[r].y & 0xffff] + log((double)bv));
+            }
+            const double Dm = block_max_d(smax, red, tid);
+            const double Dsh = Dm > -INFINITY ? Dm - (double)kScaleExp * 0.6931471805599453 : 0.0;
+            for (int r = tid; r < Pr; r += kChainThreads) {
+                const float bv = BPc[r];
+                Zn[r] = bv > 0.f ? (float)(exp(Dv[g.pair_meta[r].y & 0xffff] - Dsh) * (double)bv) : 0.f;
+            }
+            lSz = lSb - Dsh - (double)p.moff[bt0 + t - 1];
+        }
+        __syncthreads();
+    }
+    const float zb = block_sum(zpart, (float *)red, tid);
+    if (tid == 0) p.cost_beta[b] = zb > 0.f ? (float)(log((double)zb) - lSb) : -INFINITY;
+}
+
+template <bool GV>
+__global__ __launch_bounds__(kChainThreads) void crf_robust_den_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = (int)blockIdx.x < p.B ? (int)blockIdx.x : (int)blockIdx.x - p.B;
+    if (!(p.redo[b] | p.redo[p.B + b])) return;
+    if ((int)blockIdx.x < p.B) den_forward_robust<GV>(p, b, lds);
+    else den_backward_robust<GV>(p, b, lds);
+}
+
+// grad rows of the redone utterances: gamma_den[t][v] = softmax_v( d_t[v] + ln sum_{p: lab_p = v} Q_t[p] * BP_t[p] ) in fp64,
+// combined with the numerator half exactly as crf_grad_kernel does.  grid (frames-in-parallel, B); rows gathered from L2.
+// LDS: csum[NC] | gl (double)[Vp] | gc[Vp] | red (double)[4]
+__global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const GraphDev &g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.y, V = p.V, Vp = rup64(V), NC = g.NC;
+    if (!(p.redo[b] | p.redo[p.B + b])) return;
+    const int lx = p.lx[b];
+    float *csum = lds;
+    double *gl = (double *)(csum + rup64(NC));
+    float *gc = (float *)(gl + Vp);
+    double *red = (double *)(gc + Vp);
+    const int64_t bt0 = (int64_t)b * p.T;
+    const bool do_ctc = p.c_ctc != 0.f;
+    double zc = 0.0;
+    int ezc = 0, Sx = 0;
+    const int *ul = nullptr;
+    if (do_ctc) { zc = p.ctc_zc[b]; ezc = p.ctc_ez[b]; Sx = 2 * p.ly[b] + 1; ul = p.labels + p.lab_off[b]; }
+    const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
+    auto bmax = [&](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+        __syncthreads();
+        if (lane == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    };
+    auto bsum = [&](double v) {
+        v = wave_sum_d(v);
+        __syncthreads();
+        if (lane == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    for (int t = blockIdx.x; t < p.T; t += gridDim.x) {
+        float *row = p.grad + (bt0 + t) * V;
+        if (t >= lx) {
+            for (int v = tid; v < V; v += kGradThreads) row[v] = 0.f;
+            continue;
+        }
+        const float *Qr = p.Q + (bt0 + t) * p.Rq, *Br = p.BP + (bt0 + t) * p.Rb;
+        for (int c = tid; c < NC; c += kGradThreads) {
+            float s = 0.f;
+            for (int j = g.chunk_off[c]; j < g.chunk_off[c + 1]; ++j) { const int r = g.perm[j]; s += Qr[r] * Br[r]; }
+            csum[c] = s;
+        }
+        for (int v = tid; v < V; v += kGradThreads) gc[v] = 0.f;
+        __syncthreads();
+        const double mx = (double)p.mx[bt0 + t];
+        double lmax = -INFINITY;
+        for (int v = tid; v < V; v += kGradThreads) {
+            float s = 0.f;
+            if (v <= g.max_label)
+                for (int c = g.lab_chunk_off[v]; c < g.lab_chunk_off[v + 1]; ++c) s += csum[c];
+            const double l = s > 0.f ? ((double)ld_x(p, (bt0 + t) * V + v) - mx) + log((double)s) : -INFINITY;
+            gl[v] = l;
+            lmax = fmax(lmax, l);
+        }
+        const double M = bmax(lmax);
+        double part = 0.0;
+        for (int v = tid; v < V; v += kGradThreads) {
+            const double u = M > -INFINITY && gl[v] > -INFINITY ? exp(gl[v] - M) : 0.0;
+            gl[v] = u;
+            part += u;
+        }
+        const double nrm = bsum(part);
+        if (do_ctc && zc > 0.0) {
+            const double *Ar = p.CA + (bt0 + t) * p.Sc, *Bx = p.CB + (bt0 + t) * p.Sc;
+            const double fc = ldexp(invc, ezc - p.ECA[bt0 + t] - p.ECB[bt0 + t]);
+            float blank = 0.f;
+            for (int s = tid; s < Sx; s += kGradThreads) {
+                const float pr = (float)(Ar[s] * Bx[s] * fc);
+                if (s & 1) atomicAdd(&gc[ul[s >> 1]], pr);
+                else blank += pr;
+            }
+            blank = wave_sum(blank);
+            if (lane == 0) atomicAdd(&gc[0], blank);
+        }
+        __syncthreads();
+        for (int v = tid; v < V; v += kGradThreads) {
+            float o = p.c_den * (nrm > 0.0 ? (float)(gl[v] / nrm) : 0.f);
+            if (do_ctc) o -= p.c_ctc * gc[v];
+            if (do_ctc && p.fused)   // log_softmax's backward: - softmax(x)[v] * sum_v d loss / d logp[v]
+                o -= (p.c_den - (zc > 0.0 ? p.c_ctc : 0.f)) * __expf(ld_x(p, (bt0 + t) * V + v) - (float)mx) * p.inv_s[bt0 + t];
+            row[v] = o;
+        }
+        __syncthreads();
+    }
+}
+
 // loss = sum_b(c_den*logZ_b - c_ctc*logp_b); copies the per-utterance costs out (one workgroup)
 __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
     __shared__ double red[4];
@@ -2199,7 +2500,7 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
     for (int b = tid; b < p.B; b += 256) {
         double c = 0.0;
         if (p.c_den != 0.f) {
-            if (p.res) {  // backward partition sum = sum of the K per-CU partials
+            if (p.res && !(p.redo[b] | p.redo[p.B + b])) {  // backward partition sum = sum of the K per-CU partials (redone utterances: written by the robust kernel)
                 float zb = 0.f;
                 const int nk = p.res == 2 ? 1 : p.g.res.K;
                 for (int k = 0; k < nk; ++k) zb += p.cb_part[(size_t)b * kResMaxK + k];
@@ -2230,7 +2531,8 @@ struct WsLayout {
     int64_t xch_bytes;
     int64_t Rq, Rb;
     bool res, gv, fac;
-    int64_t off_gvec, off_state, state_stride;
+    bool gv_robust;              // the robust fallback kernels keep their vectors in global memory too
+    int64_t off_gvec, off_state, state_stride, gvec_stride;
 };
 static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -2246,13 +2548,21 @@ static bool use_factored(const HostGraph *h, int64_t V) {
     return h && h->dev.fac.ok && V <= (int64_t)kEpRegsR * kResThreads;
 }
 
+// LDS of the robust fallback kernels (the larger of the two directions)
+static size_t robust_lds_bytes(const HostGraph *h, int V, bool gv) {
+    const size_t tail = (size_t)rup64(V) * 8 + 2 * kChainWaves * 4 + 16 * 8;
+    if (gv) return tail;
+    return std::max((size_t)3 * rup64(h->dev.S) + h->dev.Pr, (size_t)4 * h->dev.Pr) * 4 + tail;
+}
+
 static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, int64_t Sc) {
     WsLayout w{};
     int64_t o = 0;
     w.fac = use_factored(h, V);
     w.res = w.fac || use_resident(h, V);   // "res": register-resident kernels of either layout
-    w.Rq = h ? (w.fac ? h->dev.fac.Rq : w.res ? h->dev.res.f.R : h->dev.Pr) : 0;
-    w.Rb = h ? (w.fac ? h->dev.fac.Rbp : w.res ? h->dev.res.b.R : h->dev.Pr) : 0;
+    // (rows are at least Pr wide: the robust fallback stores them in pair order, whatever layout the fast kernels use)
+    w.Rq = h ? std::max<int64_t>(w.fac ? h->dev.fac.Rq : w.res ? h->dev.res.f.R : h->dev.Pr, h->dev.Pr) : 0;
+    w.Rb = h ? std::max<int64_t>(w.fac ? h->dev.fac.Rbp : w.res ? h->dev.res.b.R : h->dev.Pr, h->dev.Pr) : 0;
     w.off_ep = o; o = al(o + B * T * V * 4);
     w.off_mx = o; o = al(o + B * T * 4);
     w.off_moff = o; o = al(o + B * T * 4);   // fused log_softmax only (crf_loss_fwd_bwd_logits)
@@ -2271,7 +2581,9 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_xch = o; o = al(o + w.xch_bytes + 256 + 8 * B);   // granules | error word, start counter | per-utterance progress of the two den recursions
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.gv = h && !w.res && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
-    w.off_gvec = o; o = al(o + (w.gv ? B * (3 * (int64_t)rup64(h->dev.S) + 4 * (int64_t)h->dev.Pr) * 4 : 0));
+    w.gv_robust = h && robust_lds_bytes(h, (int)V, false) > 160 * 1024;
+    w.gvec_stride = h ? 3 * (int64_t)rup64(h->dev.S) + 5 * (int64_t)h->dev.Pr : 0;
+    w.off_gvec = o; o = al(o + ((w.gv || w.gv_robust) ? B * w.gvec_stride * 4 : 0));
     // factored recursions launched in segments park their state vector + exponent here: [2 dir][B][stride]
     w.state_stride = w.fac ? rup64(std::max(h->dev.fac.f.G, h->dev.fac.b.G)) + 64 : 0;
     w.off_state = o; o = al(o + 2 * B * w.state_stride * 4);
@@ -2463,7 +2775,7 @@ static ResParams res_params(const LossParams &lp, int dir, int b0) {
     p.xch = lp.xch; p.err = lp.err;
     p.x_start = R.x_start; p.x_end = R.x_end; p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.z_lab = R.z_lab; p.z_end = R.z_end; p.brow_start = R.brow_start; p.brow_end = R.brow_end; p.bcsr = R.bcsr;
-    p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
+    p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F; p.redo = lp.redo;
     return p;
 }
 // generic register-resident recursions of the utterances [b0, b0 + nb): 2 * nb * K workgroups, forward first
@@ -2505,7 +2817,7 @@ static FacParams fac_params(const LossParams &lp, int dir, int *started, int i0,
     p.frow_meta = F.frow_meta; p.x_start = F.x_start; p.x_end = F.x_end;
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
-    p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F;
+    p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F; p.redo = lp.redo;
     return p;
 }
 // factored recursions, iterations [i0, i1) of both directions as one grid of 2B workgroups; FLAG: publish stage counters
@@ -2639,10 +2951,16 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.cb_mxs = p.ctc_zc + B;
     float *pb = (float *)(p.cb_mxs + B);
     p.cb_part = pb + 8 * B; p.cb_F = (int *)(pb + 8 * B + (int64_t)kResMaxK * B);
+    p.redo = (int *)(pb + 16 * B);   // [2][B]
+    // CRF_ROBUST: 0 = never run the robust fallback, 1 = every utterance takes it (tests, or "safe mode"); default: the
+    // utterances the fast kernels flag
+    const int robust_env = getenv("CRF_ROBUST") ? atoi(getenv("CRF_ROBUST")) : -1;   // (read per call: tests switch it)
+    p.force_redo = (den && robust_env == 1) ? 1 : 0;
     p.xch = (unsigned long long *)(base + w.off_xch);
     p.err = (int *)(base + w.off_xch + w.xch_bytes);
     p.Row0 = (float *)(base + w.off_row0);
     p.gvec = (float *)(base + w.off_gvec);
+    p.gvec_stride = w.gvec_stride;
     p.den_zs = pb; p.den_ez = (int *)(pb + B); p.ctc_ez = (int *)(pb + 2 * B);
     p.cost_alpha = pb + 3 * B; p.cost_beta = pb + 4 * B; p.cost_ctc = pb + 5 * B; p.invalid = (int *)(pb + 6 * B);
     p.grad = grad; p.loss = loss; p.out_den = costs_den; p.out_beta = costs_beta; p.out_ctc = costs_ctc;
@@ -2918,6 +3236,25 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             LAUNCH_CHECK("crf_grad_kernel");
         }
         prof_mark(5, true, stream);
+    }
+    if (den && robust_env != 0) {
+        // Fallback for utterances whose scaled-fp32 recursion lost all its mass: redone in a per-frame log-shifted form
+        // (crf_robust_den_kernel).  Workgroups of unflagged utterances leave at once -- two near-empty launches per call.
+        static LdsMark mr, mrg, mg;
+        const bool rgv = w.gv_robust;
+        const size_t lr = robust_lds_bytes(h, (int)V, rgv);
+        if (rgv) {
+            if ((rc = ensure_lds((const void *)crf_robust_den_kernel<true>, lr, mrg, "robust den"))) return rc;
+            hipLaunchKernelGGL(crf_robust_den_kernel<true>, dim3((unsigned)(2 * B)), dim3(kChainThreads), lr, stream, p);
+        } else {
+            if ((rc = ensure_lds((const void *)crf_robust_den_kernel<false>, lr, mr, "robust den"))) return rc;
+            hipLaunchKernelGGL(crf_robust_den_kernel<false>, dim3((unsigned)(2 * B)), dim3(kChainThreads), lr, stream, p);
+        }
+        LAUNCH_CHECK("crf_robust_den_kernel");
+        const size_t lg = (size_t)rup64(h->dev.NC) * 4 + (size_t)rup64((int)V) * 12 + 64;
+        if ((rc = ensure_lds((const void *)crf_robust_grad_kernel, lg, mg, "robust grad"))) return rc;
+        hipLaunchKernelGGL(crf_robust_grad_kernel, dim3(16, (unsigned)B), dim3(kGradThreads), lg, stream, p);
+        LAUNCH_CHECK("crf_robust_grad_kernel");
     }
     prof_mark(6, false, stream);
     hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);

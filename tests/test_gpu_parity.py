@@ -310,6 +310,72 @@ def test_peaked_inputs(crf, tmp_path):
     assert rel_err(grad, ref["grad"]) <= TOL
 
 
+class _env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update({k: str(v) for k, v in self.kw.items()})
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_robust_fallback_forced(crf, tmp_path, mode):
+    """CRF_ROBUST=1: every utterance is redone by the robust (per-frame log-shifted) denominator kernels after the fast
+    ones; ordinary inputs, all three fast families in front, ragged lengths, against the fp64 oracle."""
+    g, p = small_synth(tmp_path, 12, 40, 6, 5)
+    B, T, V = 4, 37, 12
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=8, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    with _env(CRF_ROBUST=1):
+        loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode=mode)
+        with _mode(mode):
+            ctx = crf.CRFContext(p, 0)
+        x = torch.tensor(logits, device="cuda:0")
+        _, gd, ex = crf._C.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, crf._C.graph_for(x.device), True)
+        del ctx
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+    den = oracle.den(fst_io.read_fst(p), logits, lx)
+    assert np.allclose(ex["costs_alpha"].cpu().numpy(), np.asarray(den[1]).ravel(), rtol=TOL, atol=0)
+    assert np.allclose(ex["costs_beta"].cpu().numpy(), np.asarray(den[2]).ravel(), rtol=TOL, atol=0)
+    assert post_err(gd.cpu().numpy(), np.asarray(den[0])) <= TOL
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_underflow_fallback_forbidden_argmax(crf, tmp_path, mode):
+    """The network is certain (300 nats) of a label the den_lm does not contain, in every frame of utterance 0, in a
+    stretch of frames of utterance 1, never in utterance 2: every live (state, label) of such a frame lies 300 nats
+    below the row maximum, the scaled-fp32 recursions lose all their mass there, and the reference's log-domain
+    arithmetic (den_calculate.cu:29-35) does not.  The fast kernels flag such utterances and the robust kernels redo
+    them: finite, and within 1e-4 of the fp64 oracle -- never -inf / NaN where the oracle is finite."""
+    g, p = small_synth(tmp_path, 9, 24, 5, 7)             # tokens 1..8; label 9 exists only in the network output
+    B, T, V = 3, 40, 10
+    rng = np.random.default_rng(21)
+    x = rng.normal(size=(B, T, V)) * 2.0
+    x[0, :, 9] += 300.0
+    x[1, 10:25, 9] += 300.0
+    m = x.max(-1, keepdims=True)
+    logits = (x - m - np.log(np.exp(x - m).sum(-1, keepdims=True))).astype(np.float32)
+    _, labels, lx, ly = make_batch(g, B, T, 9, seed=3, ragged=True)
+    lx[:] = [40, 36, 31]
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    assert np.isfinite(ref["loss"]) and ref["costs_den"].min() < -2000
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode=mode)
+    assert np.isfinite(loss) and np.isfinite(grad).all()
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+    for b in range(B):
+        assert rel_err(grad[b], ref["grad"][b]) <= TOL
+
+
 def test_numerator_extreme_range(crf):
     """Forced alignments through labels ~400 nats below the row max: the numerator runs in fp64
     (range e^+-700) exactly so that this matches the log-domain reference semantics."""
