@@ -124,6 +124,24 @@ struct FacDev {
     int Rbp;                   // BP row stride = 2*Rb
 };
 
+// ---------------------------------------------------------------------------------------------
+// UTTERANCE-MINOR ("batch") layout for graphs that do not fit the register-resident layouts (S = 16 k ... 65 k states,
+// BASELINE config #5): the state vectors live in global memory as [state][utterance], a wave works on one row with the
+// utterances in its lanes, and every arc is read ONCE per frame for the whole batch.  One launch per frame (the kernel
+// boundary is the grid barrier), forward and backward recursion in the same launch.
+// Pairs are numbered in (label, destination) order, so the pairs of a label are a contiguous range (grad pass).
+// ---------------------------------------------------------------------------------------------
+struct BatchDev {
+    int ok;                  // 0: tables not built
+    const int2 *farcs;       // [A] {source state, weight bits}: grouped by pair, the pairs of a destination state adjacent
+    const int *fpair_off;    // [P+1] arc range of the k-th entry of stp
+    const int *st_poff;      // [S+1] range in stp of the pairs entering state s
+    const int2 *stp;         // [P] {pair id, label}, grouped by destination state
+    const int2 *barcs;       // [A] {pair id, weight bits}, grouped by source state
+    const int *bst_off;      // [S+1]
+    const int *lab_off;      // [max_label+2] pair-id range of each label
+};
+
 // The denominator graph as the kernels see it (all pointers device memory).
 // A "pair" is a distinct (destination state, label); pairs are numbered in forward-ELL row order.
 struct GraphDev {
@@ -147,6 +165,7 @@ struct GraphDev {
     int NC;
     ResDev res;
     FacDev fac;
+    BatchDev bat;
 };
 
 struct ResBuildStats { int K = 0; int64_t slots_f = 0, slots_b = 0, conflicts_f = 0, conflicts_b = 0; };

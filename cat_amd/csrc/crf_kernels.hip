@@ -2203,6 +2203,274 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
 }
 
 // =============================================================================================
+// UTTERANCE-MINOR ("batch") denominator for graphs that do not fit the register-resident layouts (crf_internal.h:
+// BatchDev).  The reference runs ANY graph with one launch per frame and one block per utterance, re-reading every arc
+// for every utterance (den_calculate.cu:75-103, 189-227, 443-476); the streaming kernels above do the same from one
+// persistent workgroup per utterance.  Here the batch is the minor dimension of everything:
+//     a_t  [state][u]     z_t [pair][u]     Q_t, BP_t [pair][u]     e'_t [label][u]
+// a wave takes one row (a destination state forward, a source state backward) with the utterances in its lanes (UL
+// utterances x 64/UL arcs of the row side by side), so an arc is fetched ONCE per frame for the whole batch and every
+// gather of a state-vector entry is one contiguous UL*4-byte segment.  One launch per frame -- the kernel boundary is
+// the grid barrier and makes the vectors visible across XCDs -- with the forward step of frame j and the backward step
+// of frame T-j in the same launch.  Scaling: per utterance and frame an exact power of two from the maximum of the
+// vector (atomic max per utterance, three slots in rotation), integer exponents carried per utterance.
+// Backward frames are aligned at the END of the padded batch (iteration i handles frame T-1-i of every utterance); an
+// utterance joins when the iteration reaches its last frame.
+// =============================================================================================
+struct BatchParams {
+    BatchDev g;
+    const float *start_lin, *end_lin;
+    int S, P, B, Bp, T, V, max_label;
+    const int *lx;
+    const float *ep, *moff;        // [B][T][V] e' (prep kernel), [B][T] log-likelihood offset per frame
+    float *ept;                    // [T][V][Bp] e' transposed
+    float *Af, *Zb;                // [2][S][Bp], [2][P][Bp]
+    float *Q, *BP;                 // [T][P][Bp]
+    unsigned *mxf, *mxb;           // [3][Bp] maxima of the vectors (float bits; the values are non-negative)
+    int *Ef, *Fb;                  // [Bp] running exponents
+    float *zs, *zb;                // [Bp] scaled partition sums
+    float *den_zs, *cost_alpha, *cost_beta;
+    int *den_ez, *redo;
+    float *grad;                   // [B][T][V]
+    float c_den;
+    int j;                         // launch number: forward frame j, backward frame T - j
+};
+constexpr int kBatThreads = 256, kBatWaves = kBatThreads / kWave;
+
+// ep [B][T][V] -> ept [T][V][Bp] through a 64 x UL tile in LDS.  grid (ceil(V / 64), T, Bp / UL)
+template <int UL>
+__global__ __launch_bounds__(kBatThreads) void crf_batch_transpose_kernel(BatchParams p) {
+    __shared__ float tile[UL][65];
+    const int v0 = blockIdx.x * 64, t = blockIdx.y, u0 = blockIdx.z * UL, tid = threadIdx.x;
+    for (int i = tid; i < UL * 64; i += kBatThreads) {
+        const int u = i >> 6, v = i & 63;
+        const bool ok = u0 + u < p.B && v0 + v < p.V && t < p.lx[u0 + u];
+        tile[u][v] = ok ? p.ep[((int64_t)(u0 + u) * p.T + t) * p.V + v0 + v] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < UL * 64; i += kBatThreads) {
+        const int v = i / UL, u = i % UL;
+        if (v0 + v < p.V) p.ept[((int64_t)t * p.V + v0 + v) * p.Bp + u0 + u] = tile[u][v];
+    }
+}
+
+// a_0, the slots, the exponents.  grid: enough blocks for S * Bp elements
+__global__ __launch_bounds__(kBatThreads) void crf_batch_init_kernel(BatchParams p) {
+    const int64_t i = (int64_t)blockIdx.x * kBatThreads + threadIdx.x;
+    if (i < (int64_t)p.S * p.Bp) p.Af[i] = p.start_lin[i / p.Bp] * pow2f(kScaleExp);
+    if (blockIdx.x == 0) {
+        float m = 0.f;
+        for (int s = threadIdx.x; s < p.S; s += kBatThreads) m = fmaxf(m, p.start_lin[s]);
+        __shared__ float red[kBatWaves];
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * pow2f(kScaleExp);
+        for (int u = threadIdx.x; u < p.Bp; u += kBatThreads) {
+            p.mxf[u] = __float_as_uint(m); p.mxf[p.Bp + u] = 0u; p.mxf[2 * p.Bp + u] = 0u;
+            p.mxb[u] = 0u; p.mxb[p.Bp + u] = 0u; p.mxb[2 * p.Bp + u] = 0u;
+            p.Ef[u] = kScaleExp; p.Fb[u] = kScaleExp; p.zs[u] = 0.f; p.zb[u] = 0.f;
+        }
+    }
+}
+
+// sum over the AL = 64/UL arc lanes that share an utterance (lanes u, u + UL, u + 2 UL, ...)
+template <int UL>
+__device__ __forceinline__ float arc_lane_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= UL; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int UL>
+__device__ __forceinline__ float arc_lane_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= UL; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// One frame of both recursions.  grid (G, 2 directions, Bp / UL utterance groups); every wave walks rows
+// wave_id, wave_id + total_waves, ...
+template <int UL>
+__global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParams p) {
+    constexpr int AL = 64 / UL;
+    __shared__ float wmax[kBatWaves][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ul = lane % UL, aj = lane / UL;
+    const int u = blockIdx.z * UL + ul;
+    const int dir = blockIdx.y, T = p.T, Bp = p.Bp;
+    const int lx = u < p.B ? p.lx[u] : 0;
+    const int row0 = blockIdx.x * kBatWaves + wave, rstride = gridDim.x * kBatWaves;
+    const BatchDev &g = p.g;
+    float mymax = 0.f;
+    if (dir == 0) {
+        const int t = p.j;
+        if (t >= T) return;
+        const bool active = t < lx;
+        const unsigned mb = p.mxf[(t % 3) * Bp + u];
+        const int k = rescale_exp(__uint_as_float(mb));
+        const float sc = pow2f(k);
+        const float *Ac = p.Af + (size_t)(t & 1) * p.S * Bp;
+        float *An = p.Af + (size_t)((t + 1) & 1) * p.S * Bp;
+        const float *et = p.ept + (size_t)t * p.V * Bp;
+        float *Qt = p.Q + (size_t)t * p.P * Bp;
+        for (int d = row0; d < p.S; d += rstride) {
+            const int k0 = g.st_poff[d], k1 = g.st_poff[d + 1];
+            float acc = 0.f;
+            for (int kk = k0; kk < k1; ++kk) {
+                const int2 pl = g.stp[kk];
+                const int a0 = g.fpair_off[kk], a1 = g.fpair_off[kk + 1];
+                float q = 0.f;
+#pragma unroll 4
+                for (int a = a0 + aj; a < a1; a += AL) {
+                    const int2 arc = g.farcs[a];
+                    q = fmaf(Ac[(size_t)arc.x * Bp + u], __int_as_float(arc.y), q);
+                }
+                q = arc_lane_sum<UL>(q) * sc;
+                if (aj == 0 && active) Qt[(size_t)pl.x * Bp + u] = q;
+                acc = fmaf(et[(size_t)pl.y * Bp + u], q, acc);
+            }
+            // an utterance that has ended keeps its last vector (its logZ is read after the last launch)
+            const float an = active ? acc : Ac[(size_t)d * Bp + u];
+            if (aj == 0) An[(size_t)d * Bp + u] = an;
+            if (active) mymax = fmaxf(mymax, an);
+        }
+        if (blockIdx.x == 0 && wave == 0 && aj == 0) {
+            if (active) p.Ef[u] += k + kEpExp;                    // exponent of a_{t+1}
+            p.mxf[((t + 2) % 3) * Bp + u] = 0u;                    // the slot the launch after next adds to
+        }
+    } else {
+        const int i = p.j - 1, t = T - 1 - i;                      // t = T (nothing active yet) ... 0
+        const bool active = t < lx;                                // b_t of this utterance is computed
+        const bool starts = t - 1 == lx - 1 && lx > 0;             // frame t-1 is its last frame: z_{lx-1} is set up
+        const unsigned mb = p.mxb[(p.j % 3) * Bp + u];
+        const int k = rescale_exp(__uint_as_float(mb));
+        const float sc = pow2f(k);
+        const float *Zc = p.Zb + (size_t)(p.j & 1) * p.P * Bp;
+        float *Zn = p.Zb + (size_t)((p.j + 1) & 1) * p.P * Bp;
+        const float *ep1 = t >= 1 ? p.ept + (size_t)(t - 1) * p.V * Bp : nullptr;
+        float *BPt = t >= 1 ? p.BP + (size_t)(t - 1) * p.P * Bp : nullptr;
+        const unsigned long long any_active = __ballot(active);
+        for (int s = row0; s < p.S; s += rstride) {
+            float bv = 0.f;
+            if (any_active) {
+                const int a0 = g.bst_off[s], a1 = g.bst_off[s + 1];
+#pragma unroll 4
+                for (int a = a0 + aj; a < a1; a += AL) {
+                    const int2 arc = g.barcs[a];
+                    bv = fmaf(Zc[(size_t)arc.x * Bp + u], __int_as_float(arc.y), bv);
+                }
+                bv = arc_lane_sum<UL>(bv) * sc;
+            }
+            if (t == 0) {
+                const float st = p.start_lin[s];
+                if (st != 0.f && active && aj == 0) atomicAdd(&p.zb[u], st * bv);
+            } else {
+                const float out = active ? bv : (starts ? p.end_lin[s] * pow2f(kScaleExp) : 0.f);
+                if (active || starts) {
+                    for (int kk = g.st_poff[s] + aj; kk < g.st_poff[s + 1]; kk += AL) {
+                        const int2 pl = g.stp[kk];
+                        BPt[(size_t)pl.x * Bp + u] = out;
+                        const float z = ep1[(size_t)pl.y * Bp + u] * out;
+                        Zn[(size_t)pl.x * Bp + u] = z;
+                        mymax = fmaxf(mymax, z);
+                    }
+                }
+            }
+        }
+        if (blockIdx.x == 0 && wave == 0 && aj == 0) {
+            if (starts) p.Fb[u] = kScaleExp;
+            else if (active) p.Fb[u] += k + kEpExp;
+            p.mxb[((p.j + 2) % 3) * Bp + u] = 0u;
+        }
+    }
+    // maximum of the vector this launch wrote, per utterance: lanes -> waves -> one atomic per utterance and workgroup
+    mymax = arc_lane_max<UL>(mymax);
+    wmax[wave][lane] = mymax;
+    __syncthreads();
+    if (wave == 0 && aj == 0) {
+        const float m = fmaxf(fmaxf(wmax[0][lane], wmax[1][lane]), fmaxf(wmax[2][lane], wmax[3][lane]));
+        unsigned *slot = (dir == 0 ? p.mxf : p.mxb) + ((p.j + 1) % 3) * Bp + u;
+        if (m > 0.f) atomicMax(slot, __float_as_uint(m));
+    }
+}
+
+// zs[u] = sum_s a_{lx}[s][u] * end[s].  grid (ceil(S / (4 * 64)), 1, Bp / UL): a wave sums 64 states
+template <int UL>
+__global__ __launch_bounds__(kBatThreads) void crf_batch_zsum_kernel(BatchParams p) {
+    constexpr int AL = 64 / UL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ul = lane % UL, aj = lane / UL, u = blockIdx.z * UL + ul;
+    const float *Af = p.Af + (size_t)(p.T & 1) * p.S * p.Bp;
+    const int s0 = (blockIdx.x * kBatWaves + wave) * 64;
+    float acc = 0.f;
+    for (int s = s0 + aj; s < min(s0 + 64, p.S); s += AL) acc = fmaf(Af[(size_t)s * p.Bp + u], p.end_lin[s], acc);
+    acc = arc_lane_sum<UL>(acc);
+    if (aj == 0 && acc != 0.f) atomicAdd(&p.zs[u], acc);
+}
+
+// per utterance: costs from the scaled sums, the exponents and the per-frame offsets; flags for the robust fallback
+__global__ __launch_bounds__(kBatThreads) void crf_batch_cost_kernel(BatchParams p) {
+    __shared__ double red[kBatWaves];
+    const int b = blockIdx.x, tid = threadIdx.x, lx = p.lx[b];
+    double part = 0.0;
+    for (int t = tid; t < lx; t += kBatThreads) part += (double)p.moff[(int64_t)b * p.T + t];
+    part = wave_sum_d(part);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        const double mxs = red[0] + red[1] + red[2] + red[3];
+        float zs = p.zs[b], zb = p.zb[b];
+        int ef = p.Ef[b], fb = p.Fb[b];
+        if (lx <= 0) {                                             // empty utterance: logZ = LSE(start + end)
+            float z0 = 0.f;
+            for (int s = 0; s < p.S; ++s) z0 += p.start_lin[s] * p.end_lin[s];
+            zs = zb = z0 * pow2f(kScaleExp); ef = fb = kScaleExp;
+        }
+        p.den_zs[b] = zs; p.den_ez[b] = ef;
+        p.cost_alpha[b] = to_log(zs, ef, mxs);
+        p.cost_beta[b] = to_log(zb, fb, mxs);
+        if (!(zs > 0.f && zs < INFINITY)) p.redo[b] = 1;
+        if (!(zb > 0.f && zb < INFINITY)) p.redo[p.B + b] = 1;
+    }
+}
+
+// gamma_den[u][t][v] = u_v / sum_v u_v,  u_v = e'_t[v][u] * sum_{p: lab_p = v} Q_t[p][u] * BP_t[p][u]
+// (each frame normalises itself).  grid (T, 1, Bp / UL); a wave takes the labels wave, wave + 4, ...; the un-normalised
+// values go to the grad row first and are scaled by the same lanes afterwards.
+template <int UL>
+__global__ __launch_bounds__(kBatThreads) void crf_batch_grad_kernel(BatchParams p) {
+    constexpr int AL = 64 / UL;
+    __shared__ float wsum[kBatWaves][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ul = lane % UL, aj = lane / UL, u = blockIdx.z * UL + ul;
+    const int t = blockIdx.x, V = p.V, Bp = p.Bp;
+    const bool real = u < p.B;
+    const bool active = real && t < p.lx[u];
+    const float *Qt = p.Q + (size_t)t * p.P * Bp, *Bt = p.BP + (size_t)t * p.P * Bp;
+    const float *et = p.ept + (size_t)t * V * Bp;
+    float *row = real ? p.grad + ((size_t)u * p.T + t) * V : nullptr;
+    float part = 0.f;
+    for (int v = wave; v < V; v += kBatWaves) {
+        float acc = 0.f;
+        if (v <= p.max_label && active) {
+            const int p0 = p.g.lab_off[v], p1 = p.g.lab_off[v + 1];
+#pragma unroll 4
+            for (int q = p0 + aj; q < p1; q += AL) acc = fmaf(Qt[(size_t)q * Bp + u], Bt[(size_t)q * Bp + u], acc);
+            acc = arc_lane_sum<UL>(acc);                          // (every arc lane of the utterance holds the sum)
+        }
+        const float uv = active ? (et[(size_t)v * Bp + u] * pow2f(-kEpExp)) * acc : 0.f;
+        part += uv;
+        if (aj == 0 && real) row[v] = uv;                          // un-normalised; 0 past the utterance's length
+    }
+    wsum[wave][lane] = part;
+    __syncthreads();
+    const float nrm = wsum[0][lane] + wsum[1][lane] + wsum[2][lane] + wsum[3][lane];
+    const float inv = nrm > 0.f ? p.c_den / nrm : 0.f;
+    if (aj != 0 || !active) return;
+    for (int v = wave; v < V; v += kBatWaves) row[v] *= inv;       // the lane's own stores: program order
+}
+
+// =============================================================================================
 // ROBUST denominator (fallback, rare).  The fast recursions run in fp32 scaled per frame by a power of two and take
 // the emissions as e' = exp(logp - rowmax) * 2^64: an utterance in which, at some frame, EVERY live (state, label)
 // lies more than ~131 nats below the row maximum loses all its mass (logZ = -inf) where the reference's log-domain
@@ -2531,6 +2799,7 @@ struct WsLayout {
     int64_t xch_bytes;
     int64_t Rq, Rb;
     bool res, gv, fac;
+    bool bat; int UL; int64_t Bp, off_ept, off_Af, off_Zb, off_bsm;   // utterance-minor layout (large graphs)
     bool gv_robust;              // the robust fallback kernels keep their vectors in global memory too
     int64_t off_gvec, off_state, state_stride, gvec_stride;
 };
@@ -2560,6 +2829,13 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     int64_t o = 0;
     w.fac = use_factored(h, V);
     w.res = w.fac || use_resident(h, V);   // "res": register-resident kernels of either layout
+    // graphs that fit neither register-resident layout take the utterance-minor kernels (CRF_NO_BATCH=1: the streaming
+    // kernels instead; CRF_FORCE_BATCH=1: every graph, for tests)
+    const bool force_bat = getenv("CRF_FORCE_BATCH") && atoi(getenv("CRF_FORCE_BATCH"));
+    w.bat = h && h->dev.bat.ok && (force_bat || (!w.res && !(getenv("CRF_NO_BATCH") && atoi(getenv("CRF_NO_BATCH")))));
+    if (w.bat) w.res = w.fac = false;
+    w.UL = B > 32 ? 64 : B > 16 ? 32 : B > 8 ? 16 : 8;
+    w.Bp = (B + w.UL - 1) / w.UL * w.UL;
     // (rows are at least Pr wide: the robust fallback stores them in pair order, whatever layout the fast kernels use)
     w.Rq = h ? std::max<int64_t>(w.fac ? h->dev.fac.Rq : w.res ? h->dev.res.f.R : h->dev.Pr, h->dev.Pr) : 0;
     w.Rb = h ? std::max<int64_t>(w.fac ? h->dev.fac.Rbp : w.res ? h->dev.res.b.R : h->dev.Pr, h->dev.Pr) : 0;
@@ -2567,8 +2843,9 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_mx = o; o = al(o + B * T * 4);
     w.off_moff = o; o = al(o + B * T * 4);   // fused log_softmax only (crf_loss_fwd_bwd_logits)
     w.off_invs = o; o = al(o + B * T * 4);
-    w.off_Q = o; o = al(o + B * T * w.Rq * 4);
-    w.off_BP = o; o = al(o + B * T * w.Rb * 4);
+    const int64_t qb = w.bat ? T * (int64_t)h->dev.P * w.Bp : 0;   // utterance-minor rows [T][P][Bp]
+    w.off_Q = o; o = al(o + std::max(B * T * w.Rq, qb) * 4);
+    w.off_BP = o; o = al(o + std::max(B * T * w.Rb, qb) * 4);
     w.off_EQ = o; o = al(o + B * T * 4);
     w.off_EB = o; o = al(o + B * T * 4);
     w.off_CA = o; o = al(o + B * T * Sc * 8);
@@ -2580,7 +2857,11 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.xch_bytes = (w.res && !w.fac && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8) : 0;
     w.off_xch = o; o = al(o + w.xch_bytes + 256 + 8 * B);   // granules | error word, start counter | per-utterance progress of the two den recursions
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
-    w.gv = h && !w.res && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
+    w.off_ept = o; o = al(o + (w.bat ? T * V * w.Bp * 4 : 0));
+    w.off_Af = o; o = al(o + (w.bat ? 2 * (int64_t)h->dev.S * w.Bp * 4 : 0));
+    w.off_Zb = o; o = al(o + (w.bat ? 2 * (int64_t)h->dev.P * w.Bp * 4 : 0));
+    w.off_bsm = o; o = al(o + (w.bat ? 12 * w.Bp * 4 : 0));        // mxf[3], mxb[3], Ef, Fb, zs, zb
+    w.gv = h && !w.res && !w.bat && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
     w.gv_robust = h && robust_lds_bytes(h, (int)V, false) > 160 * 1024;
     w.gvec_stride = h ? 3 * (int64_t)rup64(h->dev.S) + 5 * (int64_t)h->dev.Pr : 0;
     w.off_gvec = o; o = al(o + ((w.gv || w.gv_robust) ? B * w.gvec_stride * 4 : 0));
@@ -2909,16 +3190,16 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     if (ctc && 2 * max_label_len + 1 > kCtcRegs * kCtcThreads) { set_error("label length > 2047 not supported by this build"); return CRF_ERR_UNSUPPORTED; }
     const WsLayout w = ws_layout(h, B, T, V, Sc);
     if (ws_bytes < w.total) { set_error("workspace too small: need " + std::to_string(w.total)); return CRF_ERR_WORKSPACE; }
-    const bool res = den && w.res, gv = den && w.gv, fac = den && w.fac;
+    const bool res = den && w.res, gv = den && w.gv, fac = den && w.fac, bat = den && w.bat;
     size_t lds_chain = 0;
-    if (den && !res) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0, gv), chain_lds_bytes(h, (int)V, Sc, 1, gv));
+    if (den && !res && !bat) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0, gv), chain_lds_bytes(h, (int)V, Sc, 1, gv));
     if (res && !fac) lds_chain = std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b));
     if (fac) lds_chain = std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1));
     if (ctc) lds_chain = std::max(lds_chain, chain_lds_bytes(h, (int)V, Sc, 2));
     const int gnc_all = den ? std::max(std::max(h->dev.NC, h->dev.res.NC), h->dev.fac.ok ? h->dev.fac.NC : 0) : 0;
     // the generic grad kernel stages the two rows of a frame in LDS when they fit, else gathers them from L2
-    const bool grad_stage = !den || ((size_t)rup64((int)w.Rq) + rup64((int)w.Rb) + rup64(gnc_all) + 2 * (size_t)rup64((int)V)) * 4 <= 150 * 1024;
-    const size_t lds_grad = ((den && grad_stage ? (size_t)rup64((int)w.Rq) + rup64((int)w.Rb) : 0) + rup64(gnc_all) + 2 * (size_t)rup64((int)V)) * sizeof(float);
+    const bool grad_stage = !den || bat || ((size_t)rup64((int)w.Rq) + rup64((int)w.Rb) + rup64(gnc_all) + 2 * (size_t)rup64((int)V)) * 4 <= 150 * 1024;
+    const size_t lds_grad = ((den && !bat && grad_stage ? (size_t)rup64((int)w.Rq) + rup64((int)w.Rb) : 0) + rup64(bat ? 0 : gnc_all) + 2 * (size_t)rup64((int)V)) * sizeof(float);
     if (lds_chain > 160 * 1024 || lds_grad > 160 * 1024) {
         set_error("graph too large for this build (states=" + std::to_string(h ? h->S : 0) + ")");
         return CRF_ERR_UNSUPPORTED;
@@ -3146,7 +3427,53 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         return r2;
     };
 
-    if (staged) {
+    if (bat) {
+        // Utterance-minor denominator (large graphs): one launch per frame on the caller's stream, forward step of
+        // frame j and backward step of frame T - j together; the numerator pair runs beside them on the side stream.
+        BatchParams bp{};
+        bp.g = h->dev.bat; bp.start_lin = h->dev.start_lin; bp.end_lin = h->dev.end_lin;
+        bp.S = h->dev.S; bp.P = h->dev.P; bp.B = (int)B; bp.Bp = (int)w.Bp; bp.T = (int)T; bp.V = (int)V; bp.max_label = h->dev.max_label;
+        bp.lx = lx; bp.ep = p.ep; bp.moff = p.moff;
+        bp.ept = (float *)(base + w.off_ept); bp.Af = (float *)(base + w.off_Af); bp.Zb = (float *)(base + w.off_Zb);
+        bp.Q = p.Q; bp.BP = p.BP;
+        unsigned *bsm = (unsigned *)(base + w.off_bsm);
+        bp.mxf = bsm; bp.mxb = bsm + 3 * w.Bp; bp.Ef = (int *)(bsm + 6 * w.Bp); bp.Fb = (int *)(bsm + 7 * w.Bp);
+        bp.zs = (float *)(bsm + 8 * w.Bp); bp.zb = (float *)(bsm + 9 * w.Bp);
+        bp.den_zs = p.den_zs; bp.cost_alpha = p.cost_alpha; bp.cost_beta = p.cost_beta; bp.den_ez = p.den_ez; bp.redo = p.redo;
+        bp.grad = grad; bp.c_den = c_den;
+        if (ctc) {
+            if ((rc = fork_side())) return rc;
+            if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
+        }
+        const unsigned ngrp = (unsigned)(w.Bp / w.UL);
+        const unsigned G = (unsigned)std::min<int64_t>(1024, ((int64_t)h->dev.S + kBatWaves - 1) / kBatWaves);
+        prof_mark(1, false, stream); prof_mark(2, false, stream);
+#define CRF_BAT_UL(KERNEL, GRID, ...)                                                                        \
+        switch (w.UL) {                                                                                       \
+            case 64: hipLaunchKernelGGL(KERNEL<64>, GRID, dim3(kBatThreads), 0, stream, __VA_ARGS__); break;  \
+            case 32: hipLaunchKernelGGL(KERNEL<32>, GRID, dim3(kBatThreads), 0, stream, __VA_ARGS__); break;  \
+            case 16: hipLaunchKernelGGL(KERNEL<16>, GRID, dim3(kBatThreads), 0, stream, __VA_ARGS__); break;  \
+            default: hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(kBatThreads), 0, stream, __VA_ARGS__); break;   \
+        }
+        CRF_BAT_UL(crf_batch_transpose_kernel, dim3((unsigned)((V + 63) / 64), (unsigned)T, ngrp), bp);
+        hipLaunchKernelGGL(crf_batch_init_kernel, dim3((unsigned)(((int64_t)h->dev.S * w.Bp + kBatThreads - 1) / kBatThreads)), dim3(kBatThreads), 0, stream, bp);
+        LAUNCH_CHECK("crf_batch_init_kernel");
+        for (int j = 0; j <= (int)T; ++j) {
+            bp.j = j;
+            CRF_BAT_UL(crf_batch_frame_kernel, dim3(G, 2, ngrp), bp);
+        }
+        LAUNCH_CHECK("crf_batch_frame_kernel");
+        CRF_BAT_UL(crf_batch_zsum_kernel, dim3((unsigned)((h->dev.S + 255) / 256), 1, ngrp), bp);
+        hipLaunchKernelGGL(crf_batch_cost_kernel, dim3((unsigned)B), dim3(kBatThreads), 0, stream, bp);
+        prof_mark(1, true, stream); prof_mark(2, true, stream);
+        prof_mark(5, false, stream);
+        CRF_BAT_UL(crf_batch_grad_kernel, dim3((unsigned)T, 1, ngrp), bp);
+#undef CRF_BAT_UL
+        LAUNCH_CHECK("crf_batch_grad_kernel");
+        if ((rc = join_side())) return rc;
+        if (ctc && (rc = launch_grad_ctc(2, stream))) return rc;
+        prof_mark(5, true, stream);
+    } else if (staged) {
         // caller's stream: the denominator pair.  Side stream, behind a short bounded start gate: numerator pair, its
         // grad half (writes -c_ctc * gamma_ctc), then the den half of the grad pass stage by stage (adds gamma_den).
         if ((rc = fork_side())) return rc;

@@ -329,6 +329,28 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     }
     std::vector<float> start_lin((size_t)S), end_lin((size_t)S);
     for (int64_t s = 0; s < S; ++s) { start_lin[s] = expf(start_w[s]); end_lin[s] = expf(end_w[s]); }
+    // 5. utterance-minor ("batch") tables: plain CSR, pairs in (label, destination) order = the temporary pair ids
+    std::vector<int2> b_farcs((size_t)A), b_stp((size_t)P), b_barcs((size_t)A);
+    std::vector<int> b_fpair_off((size_t)P + 1, 0), b_st_poff((size_t)S + 1, 0), b_bst_off((size_t)S + 1, 0), b_lab_off((size_t)max_label + 2, 0);
+    {
+        auto wbits = [](float x) { int b; memcpy(&b, &x, 4); return b; };
+        for (int tp = 0; tp < P; ++tp) b_st_poff[(size_t)tmp_dst[tp] + 1]++;
+        for (int64_t s = 0; s < S; ++s) b_st_poff[s + 1] += b_st_poff[s];
+        std::vector<int> fill(b_st_poff.begin(), b_st_poff.end() - 1), pos_of_tmp(P);
+        for (int tp = 0; tp < P; ++tp) { const int k = fill[tmp_dst[tp]]++; b_stp[k] = int2{tp, tmp_lab[tp]}; pos_of_tmp[tp] = k; }
+        for (int tp = 0; tp < P; ++tp) b_fpair_off[(size_t)pos_of_tmp[tp] + 1] = (int)frows[tp].size();
+        for (int k = 0; k < P; ++k) b_fpair_off[(size_t)k + 1] += b_fpair_off[k];
+        for (int tp = 0; tp < P; ++tp) {
+            int o = b_fpair_off[pos_of_tmp[tp]];
+            for (auto &a : frows[tp]) b_farcs[(size_t)o++] = int2{a.first, wbits(a.second)};
+        }
+        for (int64_t k = 0; k < A; ++k) b_bst_off[(size_t)src[k] + 1]++;
+        for (int64_t s = 0; s < S; ++s) b_bst_off[s + 1] += b_bst_off[s];
+        std::vector<int> bfill(b_bst_off.begin(), b_bst_off.end() - 1);
+        for (int64_t k = 0; k < A; ++k) b_barcs[(size_t)bfill[src[k]]++] = int2{arc_tmp_pair[(size_t)k], wbits(expf(w[k]))};
+        for (int tp = 0; tp < P; ++tp) b_lab_off[(size_t)tmp_lab[tp] + 1]++;
+        for (int v = 0; v <= max_label; ++v) b_lab_off[(size_t)v + 1] += b_lab_off[v];
+    }
 
     auto *h = new HostGraph();
     h->device = device; h->S = S; h->A = A; h->P = P;
@@ -375,6 +397,10 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
         if ((rc = upload(h, perm, &d.perm))) break;
         if ((rc = upload(h, chunk_off, &d.chunk_off))) break;
         if ((rc = upload(h, lab_chunk_off, &d.lab_chunk_off))) break;
+        if ((rc = upload(h, b_farcs, &d.bat.farcs)) || (rc = upload(h, b_fpair_off, &d.bat.fpair_off)) || (rc = upload(h, b_st_poff, &d.bat.st_poff)) ||
+            (rc = upload(h, b_stp, &d.bat.stp)) || (rc = upload(h, b_barcs, &d.bat.barcs)) || (rc = upload(h, b_bst_off, &d.bat.bst_off)) ||
+            (rc = upload(h, b_lab_off, &d.bat.lab_off))) break;
+        d.bat.ok = 1;
         if ((rc = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon))) break;
         if ((rc = build_factored(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin))) break;
     } while (0);

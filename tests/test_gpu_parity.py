@@ -27,7 +27,23 @@ def crf():
     return ctc_crf
 
 
-MODES = ["factored", "resident", "streaming"]
+MODES = ["factored", "resident", "streaming", "batch"]
+
+
+class _env:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update({k: str(v) for k, v in self.kw.items()})
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 class _mode:
@@ -39,9 +55,14 @@ class _mode:
         self.mode = mode
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("CRF_NO_RESIDENT", "CRF_NO_FACTORED")}
-        os.environ["CRF_NO_RESIDENT"] = "1" if self.mode == "streaming" else "0"
+        self.old = {k: os.environ.get(k) for k in ("CRF_NO_RESIDENT", "CRF_NO_FACTORED", "CRF_NO_BATCH")}
+        os.environ["CRF_NO_RESIDENT"] = "1" if self.mode in ("streaming", "batch") else "0"
         os.environ["CRF_NO_FACTORED"] = "0" if self.mode == "factored" else "1"
+        # "batch": the utterance-minor kernels (one launch per frame), what graphs that fit no register-resident layout
+        # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (CRF_NO_BATCH is read per call,
+        # so it stays set for the life of the test process's calls in this mode: see run_hip)
+        if self.mode in ("streaming", "batch"):
+            os.environ["CRF_NO_BATCH"] = "1" if self.mode == "streaming" else "0"
 
     def __exit__(self, *a):
         for k, v in self.old.items():
@@ -52,20 +73,20 @@ class _mode:
 
 
 def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mode="factored"):
-    with _mode(mode):
+    with _mode(mode):   # (CRF_NO_RESIDENT / CRF_NO_FACTORED are read when the graph is created, CRF_NO_BATCH per call)
         ctx = crf.CRFContext(den_lm, 0)
-    st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
-    if mode == "streaming":
-        assert st["res_K"] == 0 and st["fac"] == 0
-    if mode == "resident":
-        assert st["fac"] == 0
-    x = torch.tensor(logits, device="cuda:0", requires_grad=True)
-    crit = crf.CTC_CRF_LOSS(lamb=lamb, size_average=size_average)
-    loss = crit(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32),
-                torch.tensor(ly, dtype=torch.int32))
-    loss.backward()
-    out = float(loss.item()), x.grad.detach().cpu().numpy()
-    del ctx
+        st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+        if mode in ("streaming", "batch"):
+            assert st["res_K"] == 0 and st["fac"] == 0
+        if mode == "resident":
+            assert st["fac"] == 0
+        x = torch.tensor(logits, device="cuda:0", requires_grad=True)
+        crit = crf.CTC_CRF_LOSS(lamb=lamb, size_average=size_average)
+        loss = crit(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32),
+                    torch.tensor(ly, dtype=torch.int32))
+        loss.backward()
+        out = float(loss.item()), x.grad.detach().cpu().numpy()
+        del ctx
     return out
 
 
@@ -147,12 +168,12 @@ def test_fused_log_softmax(crf, tmp_path, mode, dtype):
     lab_t, lx_t, ly_t = (torch.tensor(a, dtype=torch.int32) for a in (labels, lx, ly))
     with _mode(mode):
         ctx = crf.CRFContext(fst, 0)
-    xf = raw.cuda().requires_grad_(True)
-    lf = crf.CTC_CRF_LOSS(lamb=0.1, fuse_log_softmax=True)(xf, lab_t, lx_t, ly_t)
-    lf.backward()
-    xu = raw.float().cuda().requires_grad_(True)
-    lu = crf.CTC_CRF_LOSS(lamb=0.1)(torch.log_softmax(xu, -1), lab_t, lx_t, ly_t)
-    lu.backward()
+        xf = raw.cuda().requires_grad_(True)
+        lf = crf.CTC_CRF_LOSS(lamb=0.1, fuse_log_softmax=True)(xf, lab_t, lx_t, ly_t)
+        lf.backward()
+        xu = raw.float().cuda().requires_grad_(True)
+        lu = crf.CTC_CRF_LOSS(lamb=0.1)(torch.log_softmax(xu, -1), lab_t, lx_t, ly_t)
+        lu.backward()
     assert xf.grad.dtype == raw.dtype
     assert abs(lf.item() - lu.item()) <= TOL * abs(lu.item())
     tol = TOL if dtype == "float32" else 1e-2                 # the fused gradient is rounded to the input's dtype at the end
@@ -310,22 +331,6 @@ def test_peaked_inputs(crf, tmp_path):
     assert rel_err(grad, ref["grad"]) <= TOL
 
 
-class _env:
-    def __init__(self, **kw):
-        self.kw = kw
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        os.environ.update({k: str(v) for k, v in self.kw.items()})
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 @pytest.mark.parametrize("mode", MODES)
 def test_robust_fallback_forced(crf, tmp_path, mode):
     """CRF_ROBUST=1: every utterance is redone by the robust (per-frame log-shifted) denominator kernels after the fast
@@ -338,9 +343,9 @@ def test_robust_fallback_forced(crf, tmp_path, mode):
         loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode=mode)
         with _mode(mode):
             ctx = crf.CRFContext(p, 0)
-        x = torch.tensor(logits, device="cuda:0")
-        _, gd, ex = crf._C.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, crf._C.graph_for(x.device), True)
-        del ctx
+            x = torch.tensor(logits, device="cuda:0")
+            _, gd, ex = crf._C.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, crf._C.graph_for(x.device), True)
+            del ctx
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
     den = oracle.den(fst_io.read_fst(p), logits, lx)
@@ -467,9 +472,9 @@ def test_config2_slice_vs_oracle(crf, default_graph, mode):
     core = crf._C
     with _mode(mode):
         ctx = crf.CRFContext(p, 0)
-    x = torch.tensor(logits, device="cuda:0")
-    _, gd, _ = core.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, core.graph_for(x.device), True)
-    _, gc, _ = core.loss_fwd_bwd(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
+        x = torch.tensor(logits, device="cuda:0")
+        _, gd, _ = core.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, core.graph_for(x.device), True)
+        _, gc, _ = core.loss_fwd_bwd(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
     gdo, _, _ = oracle.den(fst_io.read_fst(p), logits, lx)
     gco, _, _ = oracle.ctc(logits, labels, lx, ly)
     pe_d, pe_c = post_err(gd.cpu().numpy(), gdo), post_err(gc.cpu().numpy(), gco)
@@ -507,15 +512,18 @@ def test_full_size_invariants(crf, default_graph):
     del ctx
 
 
-def test_large_graph_global_vectors(crf, tmp_path):
-    """A den_lm whose state vectors exceed a CU's LDS (S = 20 001 states, ~200 k arcs): neither the
-    register-resident nor the LDS streaming kernels apply, the recursions keep their vectors in L2."""
+@pytest.mark.parametrize("path", ["batch", "streaming"])
+def test_large_graph_global_vectors(crf, tmp_path, path):
+    """A den_lm whose state vectors exceed a CU's LDS (S = 20 001 states, ~200 k arcs): no register-resident layout
+    applies.  Default: the utterance-minor kernels (state vectors [state][utterance] in global memory, one launch per
+    frame); CRF_NO_BATCH=1: the persistent streaming kernels with their vectors in L2."""
     from cat_amd.den_lm import synth_den_lm
     p = os.path.join(str(tmp_path), "big.fst")
     g = synth_den_lm(72, 10000, 8, seed=3, path=p)
     logits, labels, lx, ly = make_batch(g, 2, 40, 72, seed=9, ragged=True)
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
-    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
+    with _env(CRF_NO_BATCH=1 if path == "streaming" else 0):
+        loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
     st = crf._C.compile_graph_host_only(p)
     assert crf._C.graph_stats(st)["S"] == 20001
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])

@@ -26,6 +26,8 @@ pmc)
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o pmc -- $BENCH > $OUT/pmc_write_$TAG.log 2>&1; echo "pmc write rc=$?"
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq_$TAG -o pmc -- $BENCH > $OUT/pmc_sq_$TAG.log 2>&1; echo "pmc sq rc=$?" )
   find $OUT/pmc_*_$TAG -name "*kernel_trace.csv" -size +2M -delete ;;
+large)
+  bash tools/gpu_large.sh $TAG ;;
 points)
   bash tools/gpu_points.sh $TAG ;;
 esac; done
