@@ -133,12 +133,15 @@ struct FacDev {
 // ---------------------------------------------------------------------------------------------
 struct BatchDev {
     int ok;                  // 0: tables not built
+    // forward rows = destination states, in processing order (most arcs first); a row's arcs are contiguous
+    const int *frow_d;       // [S] state of the k-th row
+    const int4 *frow;        // [S] {first arc, arc end, first entry in stp, entry end}; ONE entering pair: {.., .., pair id, label | 1 << 30}
+    const int4 *stp;         // [P] {pair id, label, first arc, arc end}, grouped by destination state
     const int2 *farcs;       // [A] {source state, weight bits}: grouped by pair, the pairs of a destination state adjacent
-    const int *fpair_off;    // [P+1] arc range of the k-th entry of stp
-    const int *st_poff;      // [S+1] range in stp of the pairs entering state s
-    const int2 *stp;         // [P] {pair id, label}, grouped by destination state
+    // backward rows = source states, in processing order (most arcs first)
+    const int *brow_s;       // [S]
+    const int4 *brow;        // [S] {first arc, arc end, first entry in stp (pairs ENTERING the state), entry end}; one: as frow
     const int2 *barcs;       // [A] {pair id, weight bits}, grouped by source state
-    const int *bst_off;      // [S+1]
     const int *lab_off;      // [max_label+2] pair-id range of each label
 };
 

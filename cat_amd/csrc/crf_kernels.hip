@@ -1286,15 +1286,23 @@ __device__ __forceinline__ void res_chain_body(const ResParams &p, float *lds, c
     };
     // NOT unrolled by two for compile-time buffer offsets: the gathers add an SGPR base either way, and the
     // doubled loop body (2 x 30 KiB) did not fit the instruction cache next to the other direction's kernel
+    // (after frame 0: entries no row produces -- the start state -- still hold a_0 in buffer 0 and nothing rewrites
+    // them; cleared before the buffer is the source again, see fac_chain_body)
+    auto clear_start = [&](int i) __attribute__((always_inline)) {
+        if (DIR == 0 && i == 0) {
+            for (int s = tid; s < G; s += kResThreads) if (p.x_start[s] != 0.f) X[s] = 0.f;
+            sync_lds();
+        }
+    };
     if (K == 1) {
 #pragma clang loop unroll(disable)
-        for (int i = 0; i < lx; ++i) frame(std::integral_constant<int, 0>{}, i & 1, i);
+        for (int i = 0; i < lx; ++i) { frame(std::integral_constant<int, 0>{}, i & 1, i); clear_start(i); }
     } else if (same_l2) {
 #pragma clang loop unroll(disable)
-        for (int i = 0; i < lx; ++i) frame(std::integral_constant<int, 1>{}, i & 1, i);
+        for (int i = 0; i < lx; ++i) { frame(std::integral_constant<int, 1>{}, i & 1, i); clear_start(i); }
     } else {
 #pragma clang loop unroll(disable)
-        for (int i = 0; i < lx; ++i) frame(std::integral_constant<int, 2>{}, i & 1, i);
+        for (int i = 0; i < lx; ++i) { frame(std::integral_constant<int, 2>{}, i & 1, i); clear_start(i); }
     }
 
     if (DIR == 0) {
@@ -1685,7 +1693,17 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         CRF_TM(tm_on, tm_i + 4);
     };
 #pragma clang loop unroll(disable)
-    for (int i = i0; i < i1; ++i) frame(i & 1, i);
+    for (int i = i0; i < i1; ++i) {
+        frame(i & 1, i);
+        if (DIR == 0 && i == 0) {
+            // Entries no row produces (states nobody enters: the start state) still hold a_0 in the buffer frame 0 read
+            // from, and nothing rewrites them: clear them before that buffer becomes the source again (frame 2).  In
+            // an ordinary frame the stale start mass is ~2^-60 of the vector; once the vector underflows it would be
+            // ALL of it -- a finite, wrong logZ instead of the zero that sends the utterance to the robust kernels.
+            for (int s = tid; s < G; s += NTH) if (p.x_start[s] != 0.f) X[s] = 0.f;
+            sync_lds();
+        }
+    }
     if (i1 < lx) {                                           // not the last segment of this utterance: park the state
         const float *Xc = X + (i1 & 1) * Gp;
         for (int s = tid; s < G; s += NTH) state[s] = Xc[s];
@@ -2288,13 +2306,45 @@ __device__ __forceinline__ float arc_lane_max(float v) {
     return v;
 }
 
-// One frame of both recursions.  grid (G, 2 directions, Bp / UL utterance groups); every wave walks rows
-// wave_id, wave_id + total_waves, ...
+// sum over the arcs [a0, a1) of w * X[idx][u].  The wave fetches 64 arcs at a time (one coalesced 512-byte load), the arc
+// lanes of an utterance then walk them through lane broadcasts: the gathers of a chunk are independent loads, all in flight
+// together -- with the arc fetched inside the loop every gather waited for its own arc first (two dependent trips to L2 per
+// arc: 77 us per frame on the S = 16 k graph).
+template <int UL>
+__device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int a0, int a1, const float *__restrict__ X, int Bp, int u, int lane, int aj) {
+    constexpr int AL = 64 / UL;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int c = a0; c < a1; c += 64) {
+        const int n = min(64, a1 - c);
+        int2 arc = int2{0, 0};                                    // (lanes past the end: state 0, weight 0)
+        if (lane < n) arc = arcs[c + lane];
+        const int steps = (n + AL - 1) / AL;
+#pragma unroll 8
+        for (int i = 0; i < steps; i += 2) {
+            int s0, w0, s1, w1;
+            if (AL == 1) {
+                s0 = __builtin_amdgcn_readlane(arc.x, i); w0 = __builtin_amdgcn_readlane(arc.y, i);
+                s1 = __builtin_amdgcn_readlane(arc.x, min(i + 1, 63)); w1 = i + 1 < steps ? __builtin_amdgcn_readlane(arc.y, min(i + 1, 63)) : 0;
+            } else {
+                s0 = __shfl(arc.x, i * AL + aj); w0 = __shfl(arc.y, i * AL + aj);
+                const int l1 = min((i + 1) * AL + aj, 63);
+                s1 = __shfl(arc.x, l1); w1 = i + 1 < steps ? __shfl(arc.y, l1) : 0;
+            }
+            acc0 = fmaf(X[(size_t)s0 * Bp + u], __int_as_float(w0), acc0);
+            acc1 = fmaf(X[(size_t)s1 * Bp + u], __int_as_float(w1), acc1);
+        }
+    }
+    return arc_lane_sum<UL>(acc0 + acc1);
+}
+
+// One frame of both recursions.  grid (G, 2 directions, Bp / UL utterance groups); every wave walks the rows
+// wave_id, wave_id + total_waves, ... of the degree-sorted row list (about two rows per wave).
 template <int UL>
 __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParams p) {
     constexpr int AL = 64 / UL;
     __shared__ float wmax[kBatWaves][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ul = lane % UL, aj = lane / UL;
     const int u = blockIdx.z * UL + ul;
     const int dir = blockIdx.y, T = p.T, Bp = p.Bp;
@@ -2306,28 +2356,31 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
         const int t = p.j;
         if (t >= T) return;
         const bool active = t < lx;
-        const unsigned mb = p.mxf[(t % 3) * Bp + u];
-        const int k = rescale_exp(__uint_as_float(mb));
+        const int k = rescale_exp(__uint_as_float(p.mxf[(t % 3) * Bp + u]));
         const float sc = pow2f(k);
         const float *Ac = p.Af + (size_t)(t & 1) * p.S * Bp;
         float *An = p.Af + (size_t)((t + 1) & 1) * p.S * Bp;
         const float *et = p.ept + (size_t)t * p.V * Bp;
         float *Qt = p.Q + (size_t)t * p.P * Bp;
-        for (int d = row0; d < p.S; d += rstride) {
-            const int k0 = g.st_poff[d], k1 = g.st_poff[d + 1];
+        for (int r = row0; r < p.S; r += rstride) {
+            const int d = __builtin_amdgcn_readfirstlane(g.frow_d[r]);   // (the row is the wave's: everything about it is uniform)
+            int4 ds = g.frow[r];
+            ds.x = __builtin_amdgcn_readfirstlane(ds.x); ds.y = __builtin_amdgcn_readfirstlane(ds.y);
+            ds.z = __builtin_amdgcn_readfirstlane(ds.z); ds.w = __builtin_amdgcn_readfirstlane(ds.w);
             float acc = 0.f;
-            for (int kk = k0; kk < k1; ++kk) {
-                const int2 pl = g.stp[kk];
-                const int a0 = g.fpair_off[kk], a1 = g.fpair_off[kk + 1];
-                float q = 0.f;
-#pragma unroll 4
-                for (int a = a0 + aj; a < a1; a += AL) {
-                    const int2 arc = g.farcs[a];
-                    q = fmaf(Ac[(size_t)arc.x * Bp + u], __int_as_float(arc.y), q);
+            if (ds.w & 0x40000000) {                               // one pair enters the state
+                const float e = et[(size_t)(ds.w & 0xffff) * Bp + u];   // (requested before the arcs)
+                const float q = bat_row_sum<UL>(g.farcs, ds.x, ds.y, Ac, Bp, u, lane, aj) * sc;
+                if (aj == 0 && active) Qt[(size_t)ds.z * Bp + u] = q;
+                acc = e * q;
+            } else {
+                for (int kk = ds.z; kk < ds.w; ++kk) {
+                    int4 pl = g.stp[kk];
+                    pl.z = __builtin_amdgcn_readfirstlane(pl.z); pl.w = __builtin_amdgcn_readfirstlane(pl.w);
+                    const float q = bat_row_sum<UL>(g.farcs, pl.z, pl.w, Ac, Bp, u, lane, aj) * sc;
+                    if (aj == 0 && active) Qt[(size_t)pl.x * Bp + u] = q;
+                    acc = fmaf(et[(size_t)pl.y * Bp + u], q, acc);
                 }
-                q = arc_lane_sum<UL>(q) * sc;
-                if (aj == 0 && active) Qt[(size_t)pl.x * Bp + u] = q;
-                acc = fmaf(et[(size_t)pl.y * Bp + u], q, acc);
             }
             // an utterance that has ended keeps its last vector (its logZ is read after the last launch)
             const float an = active ? acc : Ac[(size_t)d * Bp + u];
@@ -2339,36 +2392,37 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
             p.mxf[((t + 2) % 3) * Bp + u] = 0u;                    // the slot the launch after next adds to
         }
     } else {
-        const int i = p.j - 1, t = T - 1 - i;                      // t = T (nothing active yet) ... 0
+        const int t = T - p.j;                                     // t = T (nothing active yet) ... 0
         const bool active = t < lx;                                // b_t of this utterance is computed
         const bool starts = t - 1 == lx - 1 && lx > 0;             // frame t-1 is its last frame: z_{lx-1} is set up
-        const unsigned mb = p.mxb[(p.j % 3) * Bp + u];
-        const int k = rescale_exp(__uint_as_float(mb));
+        const int k = rescale_exp(__uint_as_float(p.mxb[(p.j % 3) * Bp + u]));
         const float sc = pow2f(k);
         const float *Zc = p.Zb + (size_t)(p.j & 1) * p.P * Bp;
         float *Zn = p.Zb + (size_t)((p.j + 1) & 1) * p.P * Bp;
         const float *ep1 = t >= 1 ? p.ept + (size_t)(t - 1) * p.V * Bp : nullptr;
         float *BPt = t >= 1 ? p.BP + (size_t)(t - 1) * p.P * Bp : nullptr;
-        const unsigned long long any_active = __ballot(active);
-        for (int s = row0; s < p.S; s += rstride) {
-            float bv = 0.f;
-            if (any_active) {
-                const int a0 = g.bst_off[s], a1 = g.bst_off[s + 1];
-#pragma unroll 4
-                for (int a = a0 + aj; a < a1; a += AL) {
-                    const int2 arc = g.barcs[a];
-                    bv = fmaf(Zc[(size_t)arc.x * Bp + u], __int_as_float(arc.y), bv);
-                }
-                bv = arc_lane_sum<UL>(bv) * sc;
-            }
+        const bool any_active = __ballot(active) != 0ull;
+        for (int r = row0; r < p.S; r += rstride) {
+            const int s = __builtin_amdgcn_readfirstlane(g.brow_s[r]);
+            int4 ds = g.brow[r];
+            ds.x = __builtin_amdgcn_readfirstlane(ds.x); ds.y = __builtin_amdgcn_readfirstlane(ds.y);
+            ds.z = __builtin_amdgcn_readfirstlane(ds.z); ds.w = __builtin_amdgcn_readfirstlane(ds.w);
+            const bool one = (ds.w & 0x40000000) != 0;
+            float e1 = 0.f;
+            if (one && t >= 1) e1 = ep1[(size_t)(ds.w & 0xffff) * Bp + u];      // (requested before the arcs)
+            const float bv = any_active ? bat_row_sum<UL>(g.barcs, ds.x, ds.y, Zc, Bp, u, lane, aj) * sc : 0.f;
             if (t == 0) {
                 const float st = p.start_lin[s];
                 if (st != 0.f && active && aj == 0) atomicAdd(&p.zb[u], st * bv);
-            } else {
-                const float out = active ? bv : (starts ? p.end_lin[s] * pow2f(kScaleExp) : 0.f);
-                if (active || starts) {
-                    for (int kk = g.st_poff[s] + aj; kk < g.st_poff[s + 1]; kk += AL) {
-                        const int2 pl = g.stp[kk];
+            } else if (active || starts) {
+                const float out = active ? bv : p.end_lin[s] * pow2f(kScaleExp);
+                if (one) {
+                    const float z = e1 * out;
+                    if (aj == 0) { BPt[(size_t)ds.z * Bp + u] = out; Zn[(size_t)ds.z * Bp + u] = z; }
+                    mymax = fmaxf(mymax, z);
+                } else {
+                    for (int kk = ds.z + aj; kk < ds.w; kk += AL) {
+                        const int4 pl = g.stp[kk];
                         BPt[(size_t)pl.x * Bp + u] = out;
                         const float z = ep1[(size_t)pl.y * Bp + u] * out;
                         Zn[(size_t)pl.x * Bp + u] = z;
@@ -3446,7 +3500,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
         }
         const unsigned ngrp = (unsigned)(w.Bp / w.UL);
-        const unsigned G = (unsigned)std::min<int64_t>(1024, ((int64_t)h->dev.S + kBatWaves - 1) / kBatWaves);
+        const unsigned G = (unsigned)std::max<int64_t>(1, ((int64_t)h->dev.S + 2 * kBatWaves - 1) / (2 * kBatWaves));   // two rows per wave
         prof_mark(1, false, stream); prof_mark(2, false, stream);
 #define CRF_BAT_UL(KERNEL, GRID, ...)                                                                        \
         switch (w.UL) {                                                                                       \

@@ -329,29 +329,51 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     }
     std::vector<float> start_lin((size_t)S), end_lin((size_t)S);
     for (int64_t s = 0; s < S; ++s) { start_lin[s] = expf(start_w[s]); end_lin[s] = expf(end_w[s]); }
-    // 5. utterance-minor ("batch") tables: plain CSR, pairs in (label, destination) order = the temporary pair ids
-    std::vector<int2> b_farcs((size_t)A), b_stp((size_t)P), b_barcs((size_t)A);
-    std::vector<int> b_fpair_off((size_t)P + 1, 0), b_st_poff((size_t)S + 1, 0), b_bst_off((size_t)S + 1, 0), b_lab_off((size_t)max_label + 2, 0);
+    // 5. utterance-minor ("batch") tables: CSR with one descriptor per row, rows in processing order (most arcs first, so
+    //    the long rows of a launch start first); pairs in (label, destination) order = the temporary pair ids
+    std::vector<int2> b_farcs((size_t)A), b_barcs((size_t)A);
+    std::vector<int4> b_stp((size_t)P), b_frow((size_t)S), b_brow((size_t)S);
+    std::vector<int> b_frow_d((size_t)S), b_brow_s((size_t)S), b_lab_off((size_t)max_label + 2, 0);
     {
         auto wbits = [](float x) { int b; memcpy(&b, &x, 4); return b; };
-        for (int tp = 0; tp < P; ++tp) b_st_poff[(size_t)tmp_dst[tp] + 1]++;
-        for (int64_t s = 0; s < S; ++s) b_st_poff[s + 1] += b_st_poff[s];
-        std::vector<int> fill(b_st_poff.begin(), b_st_poff.end() - 1), pos_of_tmp(P);
-        for (int tp = 0; tp < P; ++tp) { const int k = fill[tmp_dst[tp]]++; b_stp[k] = int2{tp, tmp_lab[tp]}; pos_of_tmp[tp] = k; }
-        for (int tp = 0; tp < P; ++tp) b_fpair_off[(size_t)pos_of_tmp[tp] + 1] = (int)frows[tp].size();
-        for (int k = 0; k < P; ++k) b_fpair_off[(size_t)k + 1] += b_fpair_off[k];
-        for (int tp = 0; tp < P; ++tp) {
-            int o = b_fpair_off[pos_of_tmp[tp]];
+        std::vector<int> st_poff((size_t)S + 1, 0), bst_off((size_t)S + 1, 0);
+        for (int tp = 0; tp < P; ++tp) st_poff[(size_t)tmp_dst[tp] + 1]++;
+        for (int64_t s = 0; s < S; ++s) st_poff[s + 1] += st_poff[s];
+        std::vector<int> fill(st_poff.begin(), st_poff.end() - 1), tmp_at((size_t)P);
+        for (int tp = 0; tp < P; ++tp) tmp_at[(size_t)fill[tmp_dst[tp]]++] = tp;       // stp position -> temporary pair id
+        int o = 0;
+        for (int k = 0; k < P; ++k) {
+            const int tp = tmp_at[k];
+            b_stp[k] = int4{tp, tmp_lab[tp], o, o + (int)frows[tp].size()};
             for (auto &a : frows[tp]) b_farcs[(size_t)o++] = int2{a.first, wbits(a.second)};
         }
-        for (int64_t k = 0; k < A; ++k) b_bst_off[(size_t)src[k] + 1]++;
-        for (int64_t s = 0; s < S; ++s) b_bst_off[s + 1] += b_bst_off[s];
-        std::vector<int> bfill(b_bst_off.begin(), b_bst_off.end() - 1);
+        for (int64_t k = 0; k < A; ++k) bst_off[(size_t)src[k] + 1]++;
+        for (int64_t s = 0; s < S; ++s) bst_off[s + 1] += bst_off[s];
+        std::vector<int> bfill(bst_off.begin(), bst_off.end() - 1);
         for (int64_t k = 0; k < A; ++k) b_barcs[(size_t)bfill[src[k]]++] = int2{arc_tmp_pair[(size_t)k], wbits(expf(w[k]))};
+        std::vector<int> ord((size_t)S);
+        std::iota(ord.begin(), ord.end(), 0);
+        auto fdeg = [&](int s) { return st_poff[(size_t)s + 1] > st_poff[s] ? b_stp[(size_t)st_poff[(size_t)s + 1] - 1].w - b_stp[(size_t)st_poff[s]].z : 0; };
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return fdeg(x) > fdeg(y); });
+        for (int64_t r = 0; r < S; ++r) {
+            const int s0 = ord[(size_t)r], k0 = st_poff[s0], k1 = st_poff[(size_t)s0 + 1];
+            b_frow_d[(size_t)r] = s0;
+            // one entering pair (every state of a T o LM graph): pair id and label sit in the descriptor itself
+            b_frow[(size_t)r] = k1 - k0 == 1 ? int4{b_stp[k0].z, b_stp[k0].w, b_stp[k0].x, b_stp[k0].y | 0x40000000}
+                              : k1 > k0 ? int4{b_stp[k0].z, b_stp[(size_t)k1 - 1].w, k0, k1} : int4{0, 0, 0, 0};
+        }
+        std::iota(ord.begin(), ord.end(), 0);
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return bst_off[(size_t)x + 1] - bst_off[x] > bst_off[(size_t)y + 1] - bst_off[y]; });
+        for (int64_t r = 0; r < S; ++r) {
+            const int s0 = ord[(size_t)r];
+            b_brow_s[(size_t)r] = s0;
+            const int k0 = st_poff[s0], k1 = st_poff[(size_t)s0 + 1];
+            b_brow[(size_t)r] = k1 - k0 == 1 ? int4{bst_off[s0], bst_off[(size_t)s0 + 1], b_stp[k0].x, b_stp[k0].y | 0x40000000}
+                              : k1 > k0 ? int4{bst_off[s0], bst_off[(size_t)s0 + 1], k0, k1} : int4{bst_off[s0], bst_off[(size_t)s0 + 1], 0, 0};
+        }
         for (int tp = 0; tp < P; ++tp) b_lab_off[(size_t)tmp_lab[tp] + 1]++;
         for (int v = 0; v <= max_label; ++v) b_lab_off[(size_t)v + 1] += b_lab_off[v];
     }
-
     auto *h = new HostGraph();
     h->device = device; h->S = S; h->A = A; h->P = P;
     h->fwd_padded_arcs = fe.padded_arcs; h->bwd_padded_arcs = be.padded_arcs;
@@ -397,9 +419,9 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
         if ((rc = upload(h, perm, &d.perm))) break;
         if ((rc = upload(h, chunk_off, &d.chunk_off))) break;
         if ((rc = upload(h, lab_chunk_off, &d.lab_chunk_off))) break;
-        if ((rc = upload(h, b_farcs, &d.bat.farcs)) || (rc = upload(h, b_fpair_off, &d.bat.fpair_off)) || (rc = upload(h, b_st_poff, &d.bat.st_poff)) ||
-            (rc = upload(h, b_stp, &d.bat.stp)) || (rc = upload(h, b_barcs, &d.bat.barcs)) || (rc = upload(h, b_bst_off, &d.bat.bst_off)) ||
-            (rc = upload(h, b_lab_off, &d.bat.lab_off))) break;
+        if ((rc = upload(h, b_farcs, &d.bat.farcs)) || (rc = upload(h, b_frow_d, &d.bat.frow_d)) || (rc = upload(h, b_frow, &d.bat.frow)) ||
+            (rc = upload(h, b_stp, &d.bat.stp)) || (rc = upload(h, b_barcs, &d.bat.barcs)) || (rc = upload(h, b_brow_s, &d.bat.brow_s)) ||
+            (rc = upload(h, b_brow, &d.bat.brow)) || (rc = upload(h, b_lab_off, &d.bat.lab_off))) break;
         d.bat.ok = 1;
         if ((rc = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon))) break;
         if ((rc = build_factored(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin))) break;
