@@ -2225,25 +2225,30 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
 // BatchDev).  The reference runs ANY graph with one launch per frame and one block per utterance, re-reading every arc
 // for every utterance (den_calculate.cu:75-103, 189-227, 443-476); the streaming kernels above do the same from one
 // persistent workgroup per utterance.  Here the batch is the minor dimension of everything:
-//     a_t  [state][u]     z_t [pair][u]     Q_t, BP_t [pair][u]     e'_t [label][u]
-// a wave takes one row (a destination state forward, a source state backward) with the utterances in its lanes (UL
+//     a_t  [group][state][ul]     z_t [group][pair][ul]     Q_t, BP_t [group][pair][ul]     e'_t [group][label][ul]
+// (utterance u = group * UL + ul; UL utterances = one 32..256-byte segment per entry, chosen so that ONE group's state
+// vector stays in an XCD's 4 MiB L2: ws_layout).  A wave takes one row (a destination state forward, a source state backward) with the utterances in its lanes (UL
 // utterances x 64/UL arcs of the row side by side), so an arc is fetched ONCE per frame for the whole batch and every
 // gather of a state-vector entry is one contiguous UL*4-byte segment.  One launch per frame -- the kernel boundary is
 // the grid barrier and makes the vectors visible across XCDs -- with the forward step of frame j and the backward step
-// of frame T-j in the same launch.  Scaling: per utterance and frame an exact power of two from the maximum of the
+// of frame T-j in the same launch.  XCD placement (speed only): the per-XCD L2s do not share, and with every XCD
+// gathering from every group's vectors of both directions (8.4 MB at S = 16 k, B = 64) nearly every gather missed L2
+// (measured 93 us per launch = 3 TB/s of fabric reads).  A (group, direction) "combo" therefore belongs to 8 / #combos
+// XCDs (block b runs on XCD b % 8): an XCD gathers from ONE vector that fits its L2 and streams its share of the arcs.  Scaling: per utterance and frame an exact power of two from the maximum of the
 // vector (atomic max per utterance, three slots in rotation), integer exponents carried per utterance.
 // Backward frames are aligned at the END of the padded batch (iteration i handles frame T-1-i of every utterance); an
 // utterance joins when the iteration reaches its last frame.
 // =============================================================================================
 struct BatchParams {
     BatchDev g;
+    StreamDev st;                  // arc streams for AL = 64 / UL lane groups
     const float *start_lin, *end_lin;
-    int S, P, B, Bp, T, V, max_label;
+    int S, P, B, Bp, T, V, max_label, ngrp;
     const int *lx;
     const float *ep, *moff;        // [B][T][V] e' (prep kernel), [B][T] log-likelihood offset per frame
-    float *ept;                    // [T][V][Bp] e' transposed
-    float *Af, *Zb;                // [2][S][Bp], [2][P][Bp]
-    float *Q, *BP;                 // [T][P][Bp]
+    float *ept;                    // [T][grp][V][UL] e' transposed
+    float *Af, *Zb;                // [2][grp][S][UL], [2][grp][P][UL]
+    float *Q, *BP;                 // [T][grp][P][UL]
     unsigned *mxf, *mxb;           // [3][Bp] maxima of the vectors (float bits; the values are non-negative)
     int *Ef, *Fb;                  // [Bp] running exponents
     float *zs, *zb;                // [Bp] scaled partition sums
@@ -2252,10 +2257,11 @@ struct BatchParams {
     float *grad;                   // [B][T][V]
     float c_den;
     int j;                         // launch number: forward frame j, backward frame T - j
+    int prefetch;                  // warm the XCD's L2 with the gathered vector at the start of every launch
 };
 constexpr int kBatThreads = 256, kBatWaves = kBatThreads / kWave;
 
-// ep [B][T][V] -> ept [T][V][Bp] through a 64 x UL tile in LDS.  grid (ceil(V / 64), T, Bp / UL)
+// ep [B][T][V] -> ept [T][grp][V][UL] through a 64 x UL tile in LDS.  grid (ceil(V / 64), T, Bp / UL)
 template <int UL>
 __global__ __launch_bounds__(kBatThreads) void crf_batch_transpose_kernel(BatchParams p) {
     __shared__ float tile[UL][65];
@@ -2268,14 +2274,15 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_transpose_kernel(BatchP
     __syncthreads();
     for (int i = tid; i < UL * 64; i += kBatThreads) {
         const int v = i / UL, u = i % UL;
-        if (v0 + v < p.V) p.ept[((int64_t)t * p.V + v0 + v) * p.Bp + u0 + u] = tile[u][v];
+        if (v0 + v < p.V) p.ept[(((int64_t)t * p.ngrp + blockIdx.z) * p.V + v0 + v) * UL + u] = tile[u][v];
     }
 }
 
 // a_0, the slots, the exponents.  grid: enough blocks for S * Bp elements
 __global__ __launch_bounds__(kBatThreads) void crf_batch_init_kernel(BatchParams p) {
     const int64_t i = (int64_t)blockIdx.x * kBatThreads + threadIdx.x;
-    if (i < (int64_t)p.S * p.Bp) p.Af[i] = p.start_lin[i / p.Bp] * pow2f(kScaleExp);
+    const int UL = p.Bp / p.ngrp;
+    if (i < (int64_t)p.S * p.Bp) p.Af[i] = p.start_lin[(i / UL) % p.S] * pow2f(kScaleExp);
     if (blockIdx.x == 0) {
         float m = 0.f;
         for (int s = threadIdx.x; s < p.S; s += kBatThreads) m = fmaxf(m, p.start_lin[s]);
@@ -2311,7 +2318,7 @@ __device__ __forceinline__ float arc_lane_max(float v) {
 // together -- with the arc fetched inside the loop every gather waited for its own arc first (two dependent trips to L2 per
 // arc: 77 us per frame on the S = 16 k graph).
 template <int UL>
-__device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int a0, int a1, const float *__restrict__ X, int Bp, int u, int lane, int aj) {
+__device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int a0, int a1, const float *__restrict__ X, int ul, int lane, int aj) {
     constexpr int AL = 64 / UL;
     float acc0 = 0.f, acc1 = 0.f;
     for (int c = a0; c < a1; c += 64) {
@@ -2330,87 +2337,236 @@ __device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int 
                 const int l1 = min((i + 1) * AL + aj, 63);
                 s1 = __shfl(arc.x, l1); w1 = i + 1 < steps ? __shfl(arc.y, l1) : 0;
             }
-            acc0 = fmaf(X[(size_t)s0 * Bp + u], __int_as_float(w0), acc0);
-            acc1 = fmaf(X[(size_t)s1 * Bp + u], __int_as_float(w1), acc1);
+            acc0 = fmaf(X[(size_t)s0 * UL + ul], __int_as_float(w0), acc0);
+            acc1 = fmaf(X[(size_t)s1 * UL + ul], __int_as_float(w1), acc1);
         }
     }
     return arc_lane_sum<UL>(acc0 + acc1);
 }
 
-// One frame of both recursions.  grid (G, 2 directions, Bp / UL utterance groups); every wave walks the rows
-// wave_id, wave_id + total_waves, ... of the degree-sorted row list (about two rows per wave).
+// The XCD's L2 starts every launch without the vector the launch gathers from (other XCDs wrote half of it; the kernel
+// boundary dropped the rest), and a first touch is a trip to the Infinity Cache: ~1 us at the head of an in-order queue of
+// 16 gathers.  Every wave therefore touches its share of the vector's lines first -- one load per lane, asked for before
+// the first gather; the value is looked at once, at the end of the kernel.
+__device__ __forceinline__ float bat_touch(const float *X, int64_t bytes, int w0, int NW, int lane) {
+    float sink = 0.f;
+    for (int64_t o = ((int64_t)w0 * 64 + lane) * 128; o < bytes; o += (int64_t)NW * 64 * 128) sink += *(const float *)((const char *)X + o);
+    return sink;
+}
+
+// A wave's TASK of an arc stream (crf_internal.h: StreamDirDev): lane group aj walks row aj of every bundle, utterance ul in
+// the lane; X = the gathered vector of this utterance group ([entry][UL]).  Everything but the gathers reaches the wave
+// through its slice of LDS: the records (2 KB chunks = kStreamChunk / AL batches; the next chunk's loads are the OLDEST
+// entries of the memory queue while a chunk is worked on), the row descriptors of the task's (at most kStreamBundles)
+// bundles and each lane's emission for every bundle (loaded up front, older than every gather).  So the memory queue holds
+// the gathers -- kStreamDepth batches of kStreamBatch in flight, consumed in order behind partial vmcnt waits -- and a
+// row's stores; a wait for something just requested happens nowhere.  epi(acc, m, e) is called at every bundle end with
+// the row's descriptor {state, pair, label} and emission et[label].
+constexpr int kStreamBatch = 4, kStreamDepth = 4, kStreamChunk = 64;    // steps per batch; batches in flight; batches * AL per 2 KB chunk
+constexpr int kStreamBundles = 16;                                       // bundles per task at most (fst_graph.cpp: build_stream_dir)
+constexpr int kStreamRecB = kStreamChunk * 32;                           // bytes of a chunk of records
+constexpr int kStreamLds = kStreamRecB + kStreamBundles * 64 * 4 + kStreamBundles * 8 * 16;   // per wave: records | emissions | descriptors (8 KB: four workgroups per CU)
+template <int UL, typename Epi>
+__device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, const float *__restrict__ X, const float *__restrict__ et,
+                                           int ul, int aj, int lane, char *ldsw, Epi &&epi) {
+    constexpr int AL = 64 / UL, CB = kStreamChunk / AL, D = kStreamDepth;
+    static_assert(kStreamBatch == 4 && D == 4, "bat_stream is written for batches of 4 steps, 4 batches deep");
+    float *elds = (float *)(ldsw + kStreamRecB);                           // [bundle][lane]
+    int4 *mlds = (int4 *)(ldsw + kStreamRecB + kStreamBundles * 64 * 4);   // [bundle][AL]
+    const int4 tk = sd.tasks[task];
+    const int b0 = __builtin_amdgcn_readfirstlane(tk.x), nb = __builtin_amdgcn_readfirstlane(tk.y);
+    const int bund0 = __builtin_amdgcn_readfirstlane(tk.z), nbund = __builtin_amdgcn_readfirstlane(tk.w);
+    const int4 *gsrc = (const int4 *)sd.recs + (size_t)b0 * AL * 2 + lane;   // a chunk = 128 int4: two per lane (the stream is padded)
+    int4 st0 = gsrc[0], st1 = gsrc[64];
+    gsrc += 128;
+    {   // descriptors -> LDS, then every bundle's emission for this lane (requested together; written to LDS further down)
+        const int4 *mp = sd.meta + (size_t)bund0 * AL;
+        constexpr int NM = (kStreamBundles * AL + 63) / 64;
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+            const int i = q * 64 + lane;
+            if (i < nbund * AL) mlds[i] = mp[i];
+        }
+    }
+    float ev[kStreamBundles];
+#pragma unroll
+    for (int i = 0; i < kStreamBundles; ++i) ev[i] = i < nbund ? et[(size_t)mlds[i * AL + aj].z * UL + ul] : 0.f;
+    const char *Xc = (const char *)X + ul * 4;
+    float acc = 0.f;
+    float x[D][4], w[D][4];
+    unsigned fl[D];
+    int bund = 0;
+    for (int c0 = 0; c0 < nb; c0 += CB) {
+        const int nbc = min(CB, nb - c0);
+        *(int4 *)(ldsw + lane * 16) = st0; *(int4 *)(ldsw + (64 + lane) * 16) = st1;
+        if (c0 + CB < nb) {                                        // next chunk: in flight behind everything this chunk asks for
+            st0 = gsrc[0]; st1 = gsrc[64];
+            gsrc += 128;
+        }
+        auto issue = [&](const int j, const int b) __attribute__((always_inline)) {   // gathers of batch b of the chunk into slot j
+            const int4 *lp = (const int4 *)(ldsw + (b * AL + aj) * 32);
+            const int4 r0 = lp[0], r1 = lp[1];
+            fl[j] = (unsigned)__builtin_amdgcn_readfirstlane(r0.x) >> 24;
+            x[j][0] = *(const float *)(Xc + (size_t)(((unsigned)r0.x & 0xffffffu) * (unsigned)(UL * 4)));
+            x[j][1] = *(const float *)(Xc + (size_t)(((unsigned)r0.z & 0xffffffu) * (unsigned)(UL * 4)));
+            x[j][2] = *(const float *)(Xc + (size_t)(((unsigned)r1.x & 0xffffffu) * (unsigned)(UL * 4)));
+            x[j][3] = *(const float *)(Xc + (size_t)(((unsigned)r1.z & 0xffffffu) * (unsigned)(UL * 4)));
+            w[j][0] = __int_as_float(r0.y); w[j][1] = __int_as_float(r0.w); w[j][2] = __int_as_float(r1.y); w[j][3] = __int_as_float(r1.w);
+        };
+        auto consume = [&](const int j) __attribute__((always_inline)) {
+            acc = fmaf(x[j][0], w[j][0], acc); acc = fmaf(x[j][1], w[j][1], acc);
+            acc = fmaf(x[j][2], w[j][2], acc); acc = fmaf(x[j][3], w[j][3], acc);
+            if (fl[j] & 1u) {                                      // (uniform) the rows of the bundle end with this batch
+                epi(acc, mlds[bund * AL + aj], elds[bund * 64 + lane]);
+                acc = 0.f;
+                ++bund;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j)
+            if (j < nbc) issue(j, j);
+        if (c0 == 0) {                                             // (the emissions are older than the gathers just issued)
+#pragma unroll
+            for (int i = 0; i < kStreamBundles; ++i) elds[i * 64 + lane] = ev[i];
+        }
+        int b = 0;
+        for (; b + 2 * D - 1 <= nbc; b += D) {                    // steady state: no conditions around the loads
+#pragma unroll
+            for (int j = 0; j < D; ++j) { issue((j + D - 1) % D, b + j + D - 1); consume(j); }
+        }
+        for (; b < nbc; b += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                if (b + j + D - 1 < nbc) issue((j + D - 1) % D, b + j + D - 1);
+                if (b + j < nbc) consume(j);
+            }
+        }
+    }
+}
+
+// One frame of both recursions.  1-D grid of 8 * nslot workgroups; block b sits on XCD b % 8 (observed; a matter of speed
+// only) and works for ONE combo = (utterance group, direction):
+//   #combos <  8: XCD x serves combo x % #combos together with the other XCDs of that residue, the combo's workgroups
+//                 ("chunks") dealt round-robin among them;
+//   #combos >= 8: XCD x serves the combos x, x + 8, ..., its slots dealt round-robin among them.
+// The waves of a combo take the tasks of its arc stream (rows with one entering pair: all of a T o LM graph) and then the
+// remaining rows one at a time (bat_row_sum).
 template <int UL>
 __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParams p) {
     constexpr int AL = 64 / UL;
     __shared__ float wmax[kBatWaves][64];
+    __shared__ __attribute__((aligned(16))) char stage[kBatWaves][kStreamLds];   // bat_stream: records, emissions, descriptors of a wave's task
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char *ldsw = stage[wave];
     const int ul = lane % UL, aj = lane / UL;
-    const int u = blockIdx.z * UL + ul;
-    const int dir = blockIdx.y, T = p.T, Bp = p.Bp;
+    const int T = p.T, S = p.S, P = p.P;
+    int combo, chunk, nchunk;
+    {
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3, ncombo = 2 * p.ngrp;
+        if (ncombo >= 8) {
+            const int ncx = (ncombo - x + 7) >> 3, k = slot % ncx;
+            combo = x + 8 * k; chunk = slot / ncx; nchunk = (nslot - k + ncx - 1) / ncx;
+        } else {
+            combo = x % ncombo;
+            const int k = x / ncombo, nk = (8 - combo + ncombo - 1) / ncombo;
+            chunk = slot * nk + k; nchunk = nslot * nk;
+        }
+    }
+    const int dir = combo & 1, grp = combo >> 1;
+    const int u = grp * UL + ul;
     const int lx = u < p.B ? p.lx[u] : 0;
-    const int row0 = blockIdx.x * kBatWaves + wave, rstride = gridDim.x * kBatWaves;
+    const int w0 = chunk * kBatWaves + wave, NW = nchunk * kBatWaves;   // this wave among the waves of its combo
+    const bool lead = chunk == 0 && wave == 0 && aj == 0;          // one writer per utterance for the scalars
     const BatchDev &g = p.g;
-    float mymax = 0.f;
+    const size_t gS = (size_t)grp * S * UL, gP = (size_t)grp * P * UL, gV = (size_t)grp * p.V * UL;
+    const size_t Sall = (size_t)S * p.Bp, Pall = (size_t)P * p.Bp, Vall = (size_t)p.V * p.Bp;
+    float mymax = 0.f, sink = 0.f;
     if (dir == 0) {
         const int t = p.j;
         if (t >= T) return;
         const bool active = t < lx;
-        const int k = rescale_exp(__uint_as_float(p.mxf[(t % 3) * Bp + u]));
+        const int k = rescale_exp(__uint_as_float(p.mxf[(t % 3) * p.Bp + u]));
         const float sc = pow2f(k);
-        const float *Ac = p.Af + (size_t)(t & 1) * p.S * Bp;
-        float *An = p.Af + (size_t)((t + 1) & 1) * p.S * Bp;
-        const float *et = p.ept + (size_t)t * p.V * Bp;
-        float *Qt = p.Q + (size_t)t * p.P * Bp;
-        for (int r = row0; r < p.S; r += rstride) {
+        const float *Ac = p.Af + (size_t)(t & 1) * Sall + gS;
+        float *An = p.Af + (size_t)((t + 1) & 1) * Sall + gS;
+        const float *et = p.ept + (size_t)t * Vall + gV;
+        float *Qt = p.Q + (size_t)t * Pall + gP;
+        if (p.prefetch) sink = bat_touch(Ac, (int64_t)S * UL * 4, w0, NW, lane);
+        for (int task = w0; task < p.st.f.ntasks; task += NW)
+            bat_stream<UL>(p.st.f, task, Ac, et, ul, aj, lane, ldsw, [&](float acc, const int4 &m, float e) __attribute__((always_inline)) {
+                if (m.x < 0) return;                               // padding row of the last bundle
+                if (!active) return;                               // an utterance that has ended keeps a_lx where it is: nobody writes
+                const float q = acc * sc, an = e * q;                //   that buffer for it again (crf_batch_zsum_kernel reads it there)
+                Qt[(size_t)m.y * UL + ul] = q;
+                An[(size_t)m.x * UL + ul] = an;
+                mymax = fmaxf(mymax, an);
+            });
+        for (int i = w0; i < p.st.f.nrest; i += NW) {
+            const int r = __builtin_amdgcn_readfirstlane(p.st.f.rest[i]);
             const int d = __builtin_amdgcn_readfirstlane(g.frow_d[r]);   // (the row is the wave's: everything about it is uniform)
             int4 ds = g.frow[r];
             ds.x = __builtin_amdgcn_readfirstlane(ds.x); ds.y = __builtin_amdgcn_readfirstlane(ds.y);
             ds.z = __builtin_amdgcn_readfirstlane(ds.z); ds.w = __builtin_amdgcn_readfirstlane(ds.w);
             float acc = 0.f;
             if (ds.w & 0x40000000) {                               // one pair enters the state
-                const float e = et[(size_t)(ds.w & 0xffff) * Bp + u];   // (requested before the arcs)
-                const float q = bat_row_sum<UL>(g.farcs, ds.x, ds.y, Ac, Bp, u, lane, aj) * sc;
-                if (aj == 0 && active) Qt[(size_t)ds.z * Bp + u] = q;
+                const float e = et[(size_t)(ds.w & 0xffff) * UL + ul];   // (requested before the arcs)
+                const float q = bat_row_sum<UL>(g.farcs, ds.x, ds.y, Ac, ul, lane, aj) * sc;
+                if (aj == 0 && active) Qt[(size_t)ds.z * UL + ul] = q;
                 acc = e * q;
             } else {
                 for (int kk = ds.z; kk < ds.w; ++kk) {
                     int4 pl = g.stp[kk];
                     pl.z = __builtin_amdgcn_readfirstlane(pl.z); pl.w = __builtin_amdgcn_readfirstlane(pl.w);
-                    const float q = bat_row_sum<UL>(g.farcs, pl.z, pl.w, Ac, Bp, u, lane, aj) * sc;
-                    if (aj == 0 && active) Qt[(size_t)pl.x * Bp + u] = q;
-                    acc = fmaf(et[(size_t)pl.y * Bp + u], q, acc);
+                    const float q = bat_row_sum<UL>(g.farcs, pl.z, pl.w, Ac, ul, lane, aj) * sc;
+                    if (aj == 0 && active) Qt[(size_t)pl.x * UL + ul] = q;
+                    acc = fmaf(et[(size_t)pl.y * UL + ul], q, acc);
                 }
             }
-            // an utterance that has ended keeps its last vector (its logZ is read after the last launch)
-            const float an = active ? acc : Ac[(size_t)d * Bp + u];
-            if (aj == 0) An[(size_t)d * Bp + u] = an;
-            if (active) mymax = fmaxf(mymax, an);
+            if (aj == 0 && active) An[(size_t)d * UL + ul] = acc;
+            if (active) mymax = fmaxf(mymax, acc);
         }
-        if (blockIdx.x == 0 && wave == 0 && aj == 0) {
+        if (lead) {
             if (active) p.Ef[u] += k + kEpExp;                    // exponent of a_{t+1}
-            p.mxf[((t + 2) % 3) * Bp + u] = 0u;                    // the slot the launch after next adds to
+            p.mxf[((t + 2) % 3) * p.Bp + u] = 0u;                  // the slot the launch after next adds to
         }
     } else {
         const int t = T - p.j;                                     // t = T (nothing active yet) ... 0
         const bool active = t < lx;                                // b_t of this utterance is computed
         const bool starts = t - 1 == lx - 1 && lx > 0;             // frame t-1 is its last frame: z_{lx-1} is set up
-        const int k = rescale_exp(__uint_as_float(p.mxb[(p.j % 3) * Bp + u]));
+        const int k = rescale_exp(__uint_as_float(p.mxb[(p.j % 3) * p.Bp + u]));
         const float sc = pow2f(k);
-        const float *Zc = p.Zb + (size_t)(p.j & 1) * p.P * Bp;
-        float *Zn = p.Zb + (size_t)((p.j + 1) & 1) * p.P * Bp;
-        const float *ep1 = t >= 1 ? p.ept + (size_t)(t - 1) * p.V * Bp : nullptr;
-        float *BPt = t >= 1 ? p.BP + (size_t)(t - 1) * p.P * Bp : nullptr;
+        const float *Zc = p.Zb + (size_t)(p.j & 1) * Pall + gP;
+        float *Zn = p.Zb + (size_t)((p.j + 1) & 1) * Pall + gP;
+        const float *ep1 = p.ept + (size_t)(t >= 1 ? t - 1 : 0) * Vall + gV;   // (t = 0: read, not used)
+        float *BPt = t >= 1 ? p.BP + (size_t)(t - 1) * Pall + gP : nullptr;
         const bool any_active = __ballot(active) != 0ull;
-        for (int r = row0; r < p.S; r += rstride) {
+        if (p.prefetch && any_active) sink = bat_touch(Zc, (int64_t)P * UL * 4, w0, NW, lane);
+        if (any_active || __ballot(starts) != 0ull)
+            for (int task = w0; task < p.st.b.ntasks; task += NW)
+                bat_stream<UL>(p.st.b, task, Zc, ep1, ul, aj, lane, ldsw, [&](float acc, const int4 &m, float e) __attribute__((always_inline)) {
+                    if (m.x < 0) return;
+                    const float bv = acc * sc;
+                    if (t == 0) {
+                        const float st = p.start_lin[m.x];
+                        if (st != 0.f && active) atomicAdd(&p.zb[u], st * bv);
+                    } else if (active || starts) {
+                        const float out = active ? bv : p.end_lin[m.x] * pow2f(kScaleExp);
+                        const float z = e * out;
+                        BPt[(size_t)m.y * UL + ul] = out; Zn[(size_t)m.y * UL + ul] = z;
+                        mymax = fmaxf(mymax, z);
+                    }
+                });
+        for (int i = w0; i < p.st.b.nrest; i += NW) {
+            const int r = __builtin_amdgcn_readfirstlane(p.st.b.rest[i]);
             const int s = __builtin_amdgcn_readfirstlane(g.brow_s[r]);
             int4 ds = g.brow[r];
             ds.x = __builtin_amdgcn_readfirstlane(ds.x); ds.y = __builtin_amdgcn_readfirstlane(ds.y);
             ds.z = __builtin_amdgcn_readfirstlane(ds.z); ds.w = __builtin_amdgcn_readfirstlane(ds.w);
             const bool one = (ds.w & 0x40000000) != 0;
             float e1 = 0.f;
-            if (one && t >= 1) e1 = ep1[(size_t)(ds.w & 0xffff) * Bp + u];      // (requested before the arcs)
-            const float bv = any_active ? bat_row_sum<UL>(g.barcs, ds.x, ds.y, Zc, Bp, u, lane, aj) * sc : 0.f;
+            if (one && t >= 1) e1 = ep1[(size_t)(ds.w & 0xffff) * UL + ul];      // (requested before the arcs)
+            const float bv = any_active ? bat_row_sum<UL>(g.barcs, ds.x, ds.y, Zc, ul, lane, aj) * sc : 0.f;
             if (t == 0) {
                 const float st = p.start_lin[s];
                 if (st != 0.f && active && aj == 0) atomicAdd(&p.zb[u], st * bv);
@@ -2418,23 +2574,23 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
                 const float out = active ? bv : p.end_lin[s] * pow2f(kScaleExp);
                 if (one) {
                     const float z = e1 * out;
-                    if (aj == 0) { BPt[(size_t)ds.z * Bp + u] = out; Zn[(size_t)ds.z * Bp + u] = z; }
+                    if (aj == 0) { BPt[(size_t)ds.z * UL + ul] = out; Zn[(size_t)ds.z * UL + ul] = z; }
                     mymax = fmaxf(mymax, z);
                 } else {
                     for (int kk = ds.z + aj; kk < ds.w; kk += AL) {
                         const int4 pl = g.stp[kk];
-                        BPt[(size_t)pl.x * Bp + u] = out;
-                        const float z = ep1[(size_t)pl.y * Bp + u] * out;
-                        Zn[(size_t)pl.x * Bp + u] = z;
+                        BPt[(size_t)pl.x * UL + ul] = out;
+                        const float z = ep1[(size_t)pl.y * UL + ul] * out;
+                        Zn[(size_t)pl.x * UL + ul] = z;
                         mymax = fmaxf(mymax, z);
                     }
                 }
             }
         }
-        if (blockIdx.x == 0 && wave == 0 && aj == 0) {
+        if (lead) {
             if (starts) p.Fb[u] = kScaleExp;
             else if (active) p.Fb[u] += k + kEpExp;
-            p.mxb[((p.j + 2) % 3) * Bp + u] = 0u;
+            p.mxb[((p.j + 2) % 3) * p.Bp + u] = 0u;
         }
     }
     // maximum of the vector this launch wrote, per utterance: lanes -> waves -> one atomic per utterance and workgroup
@@ -2443,9 +2599,10 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
     __syncthreads();
     if (wave == 0 && aj == 0) {
         const float m = fmaxf(fmaxf(wmax[0][lane], wmax[1][lane]), fmaxf(wmax[2][lane], wmax[3][lane]));
-        unsigned *slot = (dir == 0 ? p.mxf : p.mxb) + ((p.j + 1) % 3) * Bp + u;
+        unsigned *slot = (dir == 0 ? p.mxf : p.mxb) + ((p.j + 1) % 3) * p.Bp + u;
         if (m > 0.f) atomicMax(slot, __float_as_uint(m));
     }
+    if (sink == 1.0e-37f) wmax[0][0] = sink;                        // (bat_touch: keeps its loads)
 }
 
 // zs[u] = sum_s a_{lx}[s][u] * end[s].  grid (ceil(S / (4 * 64)), 1, Bp / UL): a wave sums 64 states
@@ -2454,10 +2611,11 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_zsum_kernel(BatchParams
     constexpr int AL = 64 / UL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ul = lane % UL, aj = lane / UL, u = blockIdx.z * UL + ul;
-    const float *Af = p.Af + (size_t)(p.T & 1) * p.S * p.Bp;
+    const int lxu = u < p.B ? p.lx[u] : 0;                         // a_lx sits in the buffer frame lx - 1 wrote: parity lx & 1
+    const float *Af = p.Af + (size_t)(lxu & 1) * p.S * p.Bp + (size_t)blockIdx.z * p.S * UL;
     const int s0 = (blockIdx.x * kBatWaves + wave) * 64;
     float acc = 0.f;
-    for (int s = s0 + aj; s < min(s0 + 64, p.S); s += AL) acc = fmaf(Af[(size_t)s * p.Bp + u], p.end_lin[s], acc);
+    for (int s = s0 + aj; s < min(s0 + 64, p.S); s += AL) acc = fmaf(Af[(size_t)s * UL + ul], p.end_lin[s], acc);
     acc = arc_lane_sum<UL>(acc);
     if (aj == 0 && acc != 0.f) atomicAdd(&p.zs[u], acc);
 }
@@ -2500,8 +2658,8 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_grad_kernel(BatchParams
     const int t = blockIdx.x, V = p.V, Bp = p.Bp;
     const bool real = u < p.B;
     const bool active = real && t < p.lx[u];
-    const float *Qt = p.Q + (size_t)t * p.P * Bp, *Bt = p.BP + (size_t)t * p.P * Bp;
-    const float *et = p.ept + (size_t)t * V * Bp;
+    const float *Qt = p.Q + (size_t)t * p.P * Bp + (size_t)blockIdx.z * p.P * UL, *Bt = p.BP + (size_t)t * p.P * Bp + (size_t)blockIdx.z * p.P * UL;
+    const float *et = p.ept + (size_t)t * V * Bp + (size_t)blockIdx.z * V * UL;
     float *row = real ? p.grad + ((size_t)u * p.T + t) * V : nullptr;
     float part = 0.f;
     for (int v = wave; v < V; v += kBatWaves) {
@@ -2509,10 +2667,10 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_grad_kernel(BatchParams
         if (v <= p.max_label && active) {
             const int p0 = p.g.lab_off[v], p1 = p.g.lab_off[v + 1];
 #pragma unroll 4
-            for (int q = p0 + aj; q < p1; q += AL) acc = fmaf(Qt[(size_t)q * Bp + u], Bt[(size_t)q * Bp + u], acc);
+            for (int q = p0 + aj; q < p1; q += AL) acc = fmaf(Qt[(size_t)q * UL + ul], Bt[(size_t)q * UL + ul], acc);
             acc = arc_lane_sum<UL>(acc);                          // (every arc lane of the utterance holds the sum)
         }
-        const float uv = active ? (et[(size_t)v * Bp + u] * pow2f(-kEpExp)) * acc : 0.f;
+        const float uv = active ? (et[(size_t)v * UL + ul] * pow2f(-kEpExp)) * acc : 0.f;
         part += uv;
         if (aj == 0 && real) row[v] = uv;                          // un-normalised; 0 past the utterance's length
     }
@@ -2888,7 +3046,11 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     const bool force_bat = getenv("CRF_FORCE_BATCH") && atoi(getenv("CRF_FORCE_BATCH"));
     w.bat = h && h->dev.bat.ok && (force_bat || (!w.res && !(getenv("CRF_NO_BATCH") && atoi(getenv("CRF_NO_BATCH")))));
     if (w.bat) w.res = w.fac = false;
+    // utterances per group: as wide as the batch allows (an arc is fetched once per group), but one group's state vector
+    // [S][UL] has to stay in an XCD's 4 MiB L2 next to the arc stream: at most ~2.25 MB (CRF_BAT_UL overrides, for sweeps)
     w.UL = B > 32 ? 64 : B > 16 ? 32 : B > 8 ? 16 : 8;
+    if (h) while (w.UL > 8 && std::max<int64_t>(h->dev.S, h->dev.P) * w.UL * 4 > (int64_t)(2.25 * 1024 * 1024)) w.UL >>= 1;
+    if (const char *e = getenv("CRF_BAT_UL")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) w.UL = v; }
     w.Bp = (B + w.UL - 1) / w.UL * w.UL;
     // (rows are at least Pr wide: the robust fallback stores them in pair order, whatever layout the fast kernels use)
     w.Rq = h ? std::max<int64_t>(w.fac ? h->dev.fac.Rq : w.res ? h->dev.res.f.R : h->dev.Pr, h->dev.Pr) : 0;
@@ -3500,7 +3662,28 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
         }
         const unsigned ngrp = (unsigned)(w.Bp / w.UL);
-        const unsigned G = (unsigned)std::max<int64_t>(1, ((int64_t)h->dev.S + 2 * kBatWaves - 1) / (2 * kBatWaves));   // two rows per wave
+        bp.ngrp = (int)ngrp;
+        // one task per wave, ONE round of workgroups (a second round with a fraction of the device doubled the launch):
+        // the tasks wanted per direction follow from the occupancy the runtime reports, shared by the combos
+        const int64_t ncombo = 2 * (int64_t)ngrp;
+        int wg_cu = 0;
+        {
+            const void *fn = w.UL == 64 ? (const void *)crf_batch_frame_kernel<64> : w.UL == 32 ? (const void *)crf_batch_frame_kernel<32>
+                           : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16> : (const void *)crf_batch_frame_kernel<8>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, fn, kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = 3; }
+        }
+        const int want = (int)std::max<int64_t>(16, (int64_t)ncu_dev * wg_cu * kBatWaves * 15 / 16 / ncombo);
+        const StreamDev *sdv = nullptr;
+        if ((rc = ensure_stream_tables(g->h, 64 / w.UL, want, &sdv))) return rc;
+        bp.st = *sdv;
+        static const bool bat_prefetch = !(getenv("CRF_BAT_PREFETCH") && !atoi(getenv("CRF_BAT_PREFETCH")));
+        bp.prefetch = bat_prefetch ? 1 : 0;
+        // 8 * nslot workgroups (block b -> XCD b % 8, slot b / 8): every combo gets at least one wave per task of its arc
+        // stream (crf_batch_frame_kernel: a combo has nslot * nk or about nslot / ncx workgroups)
+        const int64_t tasks_max = std::max({(int64_t)sdv->f.ntasks, (int64_t)sdv->b.ntasks, (int64_t)1});
+        const int64_t wg_combo = (tasks_max + kBatWaves - 1) / kBatWaves + ((sdv->f.nrest > 64 || sdv->b.nrest > 64) ? (std::max(sdv->f.nrest, sdv->b.nrest) + 4 * kBatWaves - 1) / (4 * kBatWaves) : 0);
+        const unsigned nslot = (unsigned)(ncombo < 8 ? (wg_combo + (8 / ncombo) - 1) / (8 / ncombo) : wg_combo * ((ncombo + 7) / 8));
+        const unsigned G = 8 * nslot;
         prof_mark(1, false, stream); prof_mark(2, false, stream);
 #define CRF_BAT_UL(KERNEL, GRID, ...)                                                                        \
         switch (w.UL) {                                                                                       \
@@ -3514,7 +3697,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         LAUNCH_CHECK("crf_batch_init_kernel");
         for (int j = 0; j <= (int)T; ++j) {
             bp.j = j;
-            CRF_BAT_UL(crf_batch_frame_kernel, dim3(G, 2, ngrp), bp);
+            CRF_BAT_UL(crf_batch_frame_kernel, dim3(G), bp);
         }
         LAUNCH_CHECK("crf_batch_frame_kernel");
         CRF_BAT_UL(crf_batch_zsum_kernel, dim3((unsigned)((h->dev.S + 255) / 256), 1, ngrp), bp);

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <numeric>
 
 #include "../../include/ctc_crf_hip.h"
@@ -236,6 +237,68 @@ int upload(HostGraph *h, const std::vector<T> &v, const T **out) {
     return CRF_OK;
 }
 
+// One direction's arc stream (crf_internal.h: StreamDirDev).  rows / row_st / arcs: the BatchDev tables of that direction.
+static int build_stream_dir(HostGraph *h, int AL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
+                            const std::vector<int2> &arcs, StreamDirDev *out) {
+    constexpr int kB = 4;                                 // steps per batch (crf_kernels.hip: kStreamBatch)
+    std::vector<int> simple, rest;
+    for (int r = 0; r < (int)rows.size(); ++r) {
+        const int4 &d = rows[(size_t)r];
+        if ((d.w & 0x40000000) && d.y > d.x) simple.push_back(r); else rest.push_back(r);   // (rows are most-arcs-first already)
+    }
+    std::vector<int4> tasks, meta;
+    std::vector<int2> recs;
+    const int nbund = ((int)simple.size() + AL - 1) / AL;
+    int task_b0 = 0, task_batch0 = 0, task_steps_now = 0;
+    auto close_task = [&](int b1) {
+        if (b1 == task_b0) return;
+        const int nbat = (int)(recs.size() / ((size_t)AL * kB)) - task_batch0;
+        tasks.push_back(int4{task_batch0, nbat, task_b0, b1 - task_b0});
+        task_b0 = b1; task_batch0 += nbat; task_steps_now = 0;
+    };
+    for (int b = 0; b < nbund; ++b) {
+        int len = 0;
+        for (int aj = 0; aj < AL; ++aj) {
+            const int i = b * AL + aj;
+            if (i < (int)simple.size()) len = std::max(len, rows[(size_t)simple[(size_t)i]].y - rows[(size_t)simple[(size_t)i]].x);
+        }
+        const int nbat = (len + kB - 1) / kB;             // every row of the bundle padded to whole batches
+        if (task_steps_now > 0 && (task_steps_now + nbat * kB > task_steps || b - task_b0 >= 16)) close_task(b);   // (16: kStreamBundles)
+        int n[8] = {0}, a0[8] = {0};
+        for (int aj = 0; aj < AL; ++aj) {
+            const int i = b * AL + aj;
+            int4 m{-1, 0, 0, 0};
+            if (i < (int)simple.size()) {
+                const int r = simple[(size_t)i];
+                const int4 &d = rows[(size_t)r];
+                m = int4{row_st[(size_t)r], d.z, d.w & 0xffff, 0};
+                n[aj] = d.y - d.x; a0[aj] = d.x;
+            }
+            meta.push_back(m);
+        }
+        for (int bt = 0; bt < nbat; ++bt)
+            for (int aj = 0; aj < AL; ++aj)
+                for (int k = 0; k < kB; ++k) {
+                    const int st = bt * kB + k;
+                    int2 rcd{0, 0};
+                    if (st < n[aj]) {
+                        rcd = arcs[(size_t)a0[aj] + st];
+                        if (rcd.x < 0 || rcd.x >= (1 << 24)) { set_error("arc stream: index does not fit 24 bits"); return CRF_ERR_ARG; }
+                    }
+                    if (k == 0 && bt == nbat - 1) rcd.x |= 1 << 24;   // the bundle ends with this batch
+                    recs.push_back(rcd);
+                }
+        task_steps_now += nbat * kB;
+    }
+    close_task(nbund);
+    for (int k = 0; k < 3 * AL; ++k) meta.push_back(int4{-1, 0, 0, 0});   // the kernels read descriptors up to three bundles ahead
+    for (int k = 0; k < 256; ++k) recs.push_back(int2{0, 0});             // ... and stage whole 2 KB chunks
+    out->ntasks = (int)tasks.size(); out->nrest = (int)rest.size();
+    int rc;
+    if ((rc = upload(h, tasks, &out->tasks)) || (rc = upload(h, recs, &out->recs)) || (rc = upload(h, meta, &out->meta)) || (rc = upload(h, rest, &out->rest))) return rc;
+    return CRF_OK;
+}
+
 int upload_ell(HostGraph *h, const EllHost &e, EllDev *d) {
     int rc;
     if ((rc = upload(h, e.arcs, &d->arcs))) return rc;
@@ -248,6 +311,35 @@ int upload_ell(HostGraph *h, const EllHost &e, EllDev *d) {
 }
 
 }  // namespace
+
+int ensure_stream_tables(HostGraph *h, int AL, int want, const StreamDev **out) {
+    static std::mutex mu;
+    if (!h || !(AL == 1 || AL == 2 || AL == 4 || AL == 8) || want < 1 || !h->dev.bat.ok) { set_error("ensure_stream_tables: bad arguments"); return CRF_ERR_ARG; }
+    std::lock_guard<std::mutex> lock(mu);
+    for (StreamDev *sd : h->streams)
+        if (sd->AL == AL && sd->want == want) { *out = sd; return CRF_OK; }
+    // steps per task: the longer direction's steps (rows padded to whole batches of 4) over the tasks wanted; CRF_BAT_TASK overrides
+    auto steps_of = [&](const std::vector<int4> &rows) {
+        int64_t n = 0;
+        for (const int4 &d : rows) if ((d.w & 0x40000000) && d.y > d.x) n += (d.y - d.x + 3) / 4 * 4;
+        return (n + AL - 1) / AL;                         // (rows of a bundle have about the same length)
+    };
+    const int64_t steps = std::max(steps_of(h->hb_frow), steps_of(h->hb_brow));
+    int task_steps = (int)std::min<int64_t>(4096, std::max<int64_t>(64, ((steps + want - 1) / want + 3) / 4 * 4));
+    if (getenv("CRF_BAT_TASK")) task_steps = std::max(8, atoi(getenv("CRF_BAT_TASK")));
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(h->device) != hipSuccess) { set_error("ensure_stream_tables: cannot select the graph's device"); return CRF_ERR_HIP; }
+    auto *sd = new StreamDev();
+    int rc = build_stream_dir(h, AL, task_steps, h->hb_frow, h->hb_frow_d, h->hb_farcs, &sd->f);
+    if (!rc) rc = build_stream_dir(h, AL, task_steps, h->hb_brow, h->hb_brow_s, h->hb_barcs, &sd->b);
+    (void)hipSetDevice(prev);
+    if (rc) { delete sd; return rc; }
+    sd->AL = AL; sd->want = want; sd->ok = 1;
+    h->streams.push_back(sd);
+    *out = sd;
+    return CRF_OK;
+}
+
 
 int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, const int32_t *lab,
                   const float *w, const float *start_w, const float *end_w, int device, HostGraph **out) {
@@ -423,6 +515,8 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
             (rc = upload(h, b_stp, &d.bat.stp)) || (rc = upload(h, b_barcs, &d.bat.barcs)) || (rc = upload(h, b_brow_s, &d.bat.brow_s)) ||
             (rc = upload(h, b_brow, &d.bat.brow)) || (rc = upload(h, b_lab_off, &d.bat.lab_off))) break;
         d.bat.ok = 1;
+        h->hb_farcs = std::move(b_farcs); h->hb_barcs = std::move(b_barcs); h->hb_frow = std::move(b_frow); h->hb_brow = std::move(b_brow);
+        h->hb_frow_d = std::move(b_frow_d); h->hb_brow_s = std::move(b_brow_s);
         if ((rc = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon))) break;
         if ((rc = build_factored(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin))) break;
     } while (0);
@@ -469,6 +563,7 @@ void crf_graph_destroy(crf_graph *g) {
         bool sw = hipGetDevice(&prev) == hipSuccess && hipSetDevice(g->h->device) == hipSuccess;
         for (void *p : g->h->allocs) (void)hipFree(p);
         if (sw) (void)hipSetDevice(prev);
+        for (crf::StreamDev *sd : g->h->streams) delete sd;
         delete g->h;
     }
     delete g;
