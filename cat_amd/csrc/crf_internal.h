@@ -145,16 +145,17 @@ struct BatchDev {
     const int *lab_off;      // [max_label+2] pair-id range of each label
 };
 
-// Arc STREAMS of the utterance-minor kernels (built on first use for AL = 64 / UL lane groups, ensure_stream_tables):
-// the rows with exactly one entering pair (every state of a T o LM graph), most arcs first, in BUNDLES of AL rows -- lane
-// group aj of a wave walks row aj of the bundle, all AL rows padded with null records to the same whole number of
-// BATCHES of 4 steps.  A wave's TASK is a run of whole bundles (~task_steps steps); its records are one contiguous stream
-//   [batch][AL lane groups][4 records {index | flags, weight bits}]        (bit 24 of a batch's first record: the bundle ends)
-// which the wave copies to LDS 2 KB at a time: nothing in its memory queue but the gathers of the state vector, four
-// batches deep, and -- at bundle ends -- a row's stores and the descriptor / emission of a row three / two bundles ahead.
+// Arc STREAMS of the utterance-minor kernels (built on first use for UL utterances per group, ensure_stream_tables).  A
+// lane takes FOUR utterances (one 16-byte gather), UL / 4 lanes a row, so a wave walks AL = 256 / UL rows side by side:
+// the rows with exactly one entering pair (every state of a T o LM graph), most arcs first, in BUNDLES of AL rows, all AL
+// rows padded with null records to the same whole number of BATCHES of 4 steps.  A wave's TASK is a run of whole bundles
+// (at most 8); its records are one contiguous stream
+//   [batch][AL lane groups][4 records {entry * UL | flag, weight bits}]     (bit 31 of a batch's first record: the bundle ends)
+// which the wave copies to LDS 4 KB at a time, one chunk ahead: its memory queue holds the gathers of the state vector --
+// D batches deep -- and, at bundle ends, a row's stores and the emissions of the bundle after the next.
 struct StreamDirDev {
     const int4 *tasks;       // [ntasks] {first batch, batches, first bundle, bundles}
-    const int2 *recs;        // [batches][AL][4] (+ 2 KB of padding)
+    const int2 *recs;        // [batches][AL][4] (+ 8 KB of padding)
     const int4 *meta;        // [bundles][AL] {state (-1: padding row), pair id, label, 0}
     const int *rest;         // [nrest] rows (indices into BatchDev::frow / brow) that are not in the stream
     int ntasks, nrest;
@@ -225,9 +226,9 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                    const std::vector<std::vector<std::pair<int, float>>> &in_arcs_of_pair,
                    const std::vector<std::vector<std::pair<int, float>>> &out_arcs_of_state,
                    const std::vector<float> &start_lin, const std::vector<float> &end_lin);
-// Arc streams for AL lane groups (1, 2, 4 or 8) cut into about `want` tasks per direction, built and uploaded on first use
-// (thread-safe; a graph keeps every variant it has been asked for).
-int ensure_stream_tables(HostGraph *h, int AL, int want, const StreamDev **out);
+// Arc streams for UL (8, 16, 32 or 64) utterances per group cut into about `want` tasks per direction, built and uploaded
+// on first use (thread-safe; a graph keeps every variant it has been asked for).
+int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out);
 int read_fst_file(const char *path, int64_t *S, std::vector<int32_t> *src, std::vector<int32_t> *dst,
                   std::vector<int32_t> *lab, std::vector<float> *w, std::vector<float> *start_w,
                   std::vector<float> *end_w);

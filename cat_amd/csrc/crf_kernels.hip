@@ -2257,7 +2257,6 @@ struct BatchParams {
     float *grad;                   // [B][T][V]
     float c_den;
     int j;                         // launch number: forward frame j, backward frame T - j
-    int prefetch;                  // warm the XCD's L2 with the gathered vector at the start of every launch
 };
 constexpr int kBatThreads = 256, kBatWaves = kBatThreads / kWave;
 
@@ -2344,104 +2343,122 @@ __device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int 
     return arc_lane_sum<UL>(acc0 + acc1);
 }
 
-// The XCD's L2 starts every launch without the vector the launch gathers from (other XCDs wrote half of it; the kernel
-// boundary dropped the rest), and a first touch is a trip to the Infinity Cache: ~1 us at the head of an in-order queue of
-// 16 gathers.  Every wave therefore touches its share of the vector's lines first -- one load per lane, asked for before
-// the first gather; the value is looked at once, at the end of the kernel.
-__device__ __forceinline__ float bat_touch(const float *X, int64_t bytes, int w0, int NW, int lane) {
-    float sink = 0.f;
-    for (int64_t o = ((int64_t)w0 * 64 + lane) * 128; o < bytes; o += (int64_t)NW * 64 * 128) sink += *(const float *)((const char *)X + o);
-    return sink;
-}
-
-// A wave's TASK of an arc stream (crf_internal.h: StreamDirDev): lane group aj walks row aj of every bundle, utterance ul in
-// the lane; X = the gathered vector of this utterance group ([entry][UL]).  Everything but the gathers reaches the wave
-// through its slice of LDS: the records (2 KB chunks = kStreamChunk / AL batches; the next chunk's loads are the OLDEST
-// entries of the memory queue while a chunk is worked on), the row descriptors of the task's (at most kStreamBundles)
-// bundles and each lane's emission for every bundle (loaded up front, older than every gather).  So the memory queue holds
-// the gathers -- kStreamDepth batches of kStreamBatch in flight, consumed in order behind partial vmcnt waits -- and a
-// row's stores; a wait for something just requested happens nowhere.  epi(acc, m, e) is called at every bundle end with
-// the row's descriptor {state, pair, label} and emission et[label].
-constexpr int kStreamBatch = 4, kStreamDepth = 4, kStreamChunk = 64;    // steps per batch; batches in flight; batches * AL per 2 KB chunk
-constexpr int kStreamBundles = 16;                                       // bundles per task at most (fst_graph.cpp: build_stream_dir)
-constexpr int kStreamRecB = kStreamChunk * 32;                           // bytes of a chunk of records
-constexpr int kStreamLds = kStreamRecB + kStreamBundles * 64 * 4 + kStreamBundles * 8 * 16;   // per wave: records | emissions | descriptors (8 KB: four workgroups per CU)
-template <int UL, typename Epi>
+// A wave's TASK of an arc stream (crf_internal.h: StreamDirDev).  A lane takes FOUR utterances (uq: which four of the
+// group's UL) -- one 16-byte gather per arc and lane, LG = UL / 4 lanes a row -- and lane group aj walks row aj of every
+// bundle: measured with one utterance per lane, the frame kernel was bound by the NUMBER of memory instructions a CU can
+// take (~9 cycles each; with every gather hitting the same cached lines it was no faster), not by what they fetched.
+// X = the gathered vector of this utterance group ([entry][UL]).  Everything but the gathers reaches the wave through its
+// slice of LDS: the records (two 4 KB halves, kStreamChunk / AL batches each, staged one chunk ahead: the loads of the chunk
+// after the next are the OLDEST entries of the memory queue), the row descriptors of the task's (at most kStreamBundles)
+// bundles, and a ring of two emission rows filled from a register set loaded one bundle earlier.  So the memory queue holds
+// the gathers -- D batches of kStreamBatch in flight, consumed in order behind partial vmcnt waits -- and a row's stores;
+// a wait for something just requested happens nowhere.  epi(acc, m, e) is called at every bundle end with the row's
+// descriptor {state, pair, label} and the four utterances' emissions et[label].
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kStreamBatch = 4, kStreamChunk = 128;   // steps per batch; batches * AL per 4 KB chunk (batches in flight: template parameter D)
+constexpr int kStreamBundles = 8;                     // bundles per task at most (fst_graph.cpp: build_stream_dir)
+constexpr int kStreamRecB = kStreamChunk * 32;        // bytes of a chunk of records
+constexpr int kStreamLds = 2 * kStreamRecB + 2 * 64 * 16 + kStreamBundles * 32 * 16;   // per wave: records (2 halves) | emission ring | descriptors
+template <int UL, int D, typename Epi>
 __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, const float *__restrict__ X, const float *__restrict__ et,
-                                           int ul, int aj, int lane, char *ldsw, Epi &&epi) {
-    constexpr int AL = 64 / UL, CB = kStreamChunk / AL, D = kStreamDepth;
-    static_assert(kStreamBatch == 4 && D == 4, "bat_stream is written for batches of 4 steps, 4 batches deep");
-    float *elds = (float *)(ldsw + kStreamRecB);                           // [bundle][lane]
-    int4 *mlds = (int4 *)(ldsw + kStreamRecB + kStreamBundles * 64 * 4);   // [bundle][AL]
+                                           int uq, int aj, int lane, char *ldsw, int tmi, Epi &&epi) {
+    constexpr int LG = UL / 4, AL = 64 / LG, CB = kStreamChunk / AL;
+    static_assert(kStreamBatch == 4 && CB % D == 0 && CB >= D, "a chunk holds a whole number of pipeline rounds");
+    f32x4 *elds = (f32x4 *)(ldsw + 2 * kStreamRecB);               // [2][lane]
+    int4 *mlds = (int4 *)(ldsw + 2 * kStreamRecB + 2 * 64 * 16);   // [bundle][AL]
     const int4 tk = sd.tasks[task];
     const int b0 = __builtin_amdgcn_readfirstlane(tk.x), nb = __builtin_amdgcn_readfirstlane(tk.y);
     const int bund0 = __builtin_amdgcn_readfirstlane(tk.z), nbund = __builtin_amdgcn_readfirstlane(tk.w);
-    const int4 *gsrc = (const int4 *)sd.recs + (size_t)b0 * AL * 2 + lane;   // a chunk = 128 int4: two per lane (the stream is padded)
-    int4 st0 = gsrc[0], st1 = gsrc[64];
-    gsrc += 128;
-    {   // descriptors -> LDS, then every bundle's emission for this lane (requested together; written to LDS further down)
+    CRF_TM(tmi >= 0, tmi + 2);
+    const int4 *gsrc = (const int4 *)sd.recs + (size_t)b0 * AL * 2 + lane;   // a chunk = 256 int4: four per lane (the stream is padded)
+    {   // chunk 0 -> LDS half 0 (the only wait for something just requested: once per task)
+        const int4 s0 = gsrc[0], s1 = gsrc[64], s2 = gsrc[128], s3 = gsrc[192];
         const int4 *mp = sd.meta + (size_t)bund0 * AL;
         constexpr int NM = (kStreamBundles * AL + 63) / 64;
+        int4 mm[NM];
 #pragma unroll
-        for (int q = 0; q < NM; ++q) {
-            const int i = q * 64 + lane;
-            if (i < nbund * AL) mlds[i] = mp[i];
-        }
+        for (int q = 0; q < NM; ++q) mm[q] = (q * 64 + lane < nbund * AL) ? mp[q * 64 + lane] : int4{-1, 0, 0, 0};
+        *(int4 *)(ldsw + lane * 16) = s0; *(int4 *)(ldsw + (64 + lane) * 16) = s1;
+        *(int4 *)(ldsw + (128 + lane) * 16) = s2; *(int4 *)(ldsw + (192 + lane) * 16) = s3;
+#pragma unroll
+        for (int q = 0; q < NM; ++q) mlds[q * 64 + lane] = mm[q];
     }
-    float ev[kStreamBundles];
-#pragma unroll
-    for (int i = 0; i < kStreamBundles; ++i) ev[i] = i < nbund ? et[(size_t)mlds[i * AL + aj].z * UL + ul] : 0.f;
-    const char *Xc = (const char *)X + ul * 4;
-    float acc = 0.f;
-    float x[D][4], w[D][4];
+    CRF_TM(tmi >= 0, tmi + 3);
+    int4 st0 = gsrc[256], st1 = gsrc[320], st2 = gsrc[384], st3 = gsrc[448];   // chunk 1 (padding if there is none)
+    gsrc += 512;
+    const f32x4 *et4 = (const f32x4 *)et + uq;                     // et[label * UL + 4 uq ..]
+    // emissions of bundles 0 and 1 -> ring (written once the first gathers are out), bundle 2 -> eA
+    const f32x4 ei0 = et4[(size_t)mlds[aj].z * LG];
+    const f32x4 ei1 = et4[(size_t)mlds[(nbund > 1 ? AL : 0) + aj].z * LG];
+    f32x4 eA = et4[(size_t)mlds[(nbund > 2 ? 2 * AL : 0) + aj].z * LG];
+    const unsigned uq16 = (unsigned)uq * 16u;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 x[D][4];
+    float w[D][4];
     unsigned fl[D];
     int bund = 0;
-    for (int c0 = 0; c0 < nb; c0 += CB) {
-        const int nbc = min(CB, nb - c0);
-        *(int4 *)(ldsw + lane * 16) = st0; *(int4 *)(ldsw + (64 + lane) * 16) = st1;
-        if (c0 + CB < nb) {                                        // next chunk: in flight behind everything this chunk asks for
-            st0 = gsrc[0]; st1 = gsrc[64];
-            gsrc += 128;
+    auto issue = [&](const int j, const int b) __attribute__((always_inline)) {   // gathers of batch b of the task into slot j
+        const int4 *lp = (const int4 *)(ldsw + (((b % (2 * CB)) * AL + aj) * 32));
+        int4 r0 = lp[0], r1 = lp[1];
+#if defined(CRF_BAT_DBG) && CRF_BAT_DBG == 2
+        r0.x &= 0x80000000; r0.z = 0; r1.x = 0; r1.z = 0;   // timing experiment: every gather reads entry 0
+#endif
+#if defined(CRF_BAT_DBG) && CRF_BAT_DBG == 3
+        r0.x &= 0x800fffff; r0.z &= 0xfffff; r1.x &= 0xfffff; r1.z &= 0xfffff;   // timing experiment: gathers confined to 4 MB / 64 = the first 1/8 .. 1/2 of the vector
+#endif
+        // (a record's index is entry * UL with the flag in bit 31: the shift to bytes drops the flag -- one VALU per gather --
+        // and the address is a 32-bit offset to a uniform base)
+        fl[j] = (unsigned)__builtin_amdgcn_readfirstlane(r0.x) >> 31;
+        x[j][0] = *(const f32x4 *)((const char *)X + (((unsigned)r0.x << 2) + uq16));
+        x[j][1] = *(const f32x4 *)((const char *)X + (((unsigned)r0.z << 2) + uq16));
+        x[j][2] = *(const f32x4 *)((const char *)X + (((unsigned)r1.x << 2) + uq16));
+        x[j][3] = *(const f32x4 *)((const char *)X + (((unsigned)r1.z << 2) + uq16));
+        w[j][0] = __int_as_float(r0.y); w[j][1] = __int_as_float(r0.w); w[j][2] = __int_as_float(r1.y); w[j][3] = __int_as_float(r1.w);
+    };
+    auto consume = [&](const int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __builtin_elementwise_fma(x[j][k], (f32x4){w[j][k], w[j][k], w[j][k], w[j][k]}, acc);
+        if (fl[j] & 1u) {                                          // (uniform) the rows of the bundle end with this batch
+            const f32x4 e = elds[(bund & 1) * 64 + lane];
+            epi(acc, mlds[bund * AL + aj], e);
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            elds[(bund & 1) * 64 + lane] = eA;                     // emissions of bundle + 2 (asked for one bundle ago)
+            if (bund + 3 < nbund) eA = et4[(size_t)mlds[(bund + 3) * AL + aj].z * LG];
+            ++bund;
         }
-        auto issue = [&](const int j, const int b) __attribute__((always_inline)) {   // gathers of batch b of the chunk into slot j
-            const int4 *lp = (const int4 *)(ldsw + (b * AL + aj) * 32);
-            const int4 r0 = lp[0], r1 = lp[1];
-            fl[j] = (unsigned)__builtin_amdgcn_readfirstlane(r0.x) >> 24;
-            x[j][0] = *(const float *)(Xc + (size_t)(((unsigned)r0.x & 0xffffffu) * (unsigned)(UL * 4)));
-            x[j][1] = *(const float *)(Xc + (size_t)(((unsigned)r0.z & 0xffffffu) * (unsigned)(UL * 4)));
-            x[j][2] = *(const float *)(Xc + (size_t)(((unsigned)r1.x & 0xffffffu) * (unsigned)(UL * 4)));
-            x[j][3] = *(const float *)(Xc + (size_t)(((unsigned)r1.z & 0xffffffu) * (unsigned)(UL * 4)));
-            w[j][0] = __int_as_float(r0.y); w[j][1] = __int_as_float(r0.w); w[j][2] = __int_as_float(r1.y); w[j][3] = __int_as_float(r1.w);
-        };
-        auto consume = [&](const int j) __attribute__((always_inline)) {
-            acc = fmaf(x[j][0], w[j][0], acc); acc = fmaf(x[j][1], w[j][1], acc);
-            acc = fmaf(x[j][2], w[j][2], acc); acc = fmaf(x[j][3], w[j][3], acc);
-            if (fl[j] & 1u) {                                      // (uniform) the rows of the bundle end with this batch
-                epi(acc, mlds[bund * AL + aj], elds[bund * 64 + lane]);
-                acc = 0.f;
-                ++bund;
-            }
-        };
-#pragma unroll
-        for (int j = 0; j < D - 1; ++j)
-            if (j < nbc) issue(j, j);
-        if (c0 == 0) {                                             // (the emissions are older than the gathers just issued)
-#pragma unroll
-            for (int i = 0; i < kStreamBundles; ++i) elds[i * 64 + lane] = ev[i];
+    };
+    auto stage = [&](const int c) __attribute__((always_inline)) {   // entering chunk c: chunk c + 1 -> the other half, ask for chunk c + 2
+        if ((c + 1) * CB < nb) {
+            char *h = ldsw + ((c + 1) & 1) * kStreamRecB;
+            *(int4 *)(h + lane * 16) = st0; *(int4 *)(h + (64 + lane) * 16) = st1;
+            *(int4 *)(h + (128 + lane) * 16) = st2; *(int4 *)(h + (192 + lane) * 16) = st3;
+            if ((c + 2) * CB < nb) { st0 = gsrc[0]; st1 = gsrc[64]; st2 = gsrc[128]; st3 = gsrc[192]; gsrc += 256; }
         }
-        int b = 0;
-        for (; b + 2 * D - 1 <= nbc; b += D) {                    // steady state: no conditions around the loads
+    };
+    stage(0);
 #pragma unroll
-            for (int j = 0; j < D; ++j) { issue((j + D - 1) % D, b + j + D - 1); consume(j); }
-        }
-        for (; b < nbc; b += D) {
+    for (int j = 0; j < D - 1; ++j)
+        if (j < nb) issue(j, j);
+    elds[lane] = ei0; elds[64 + lane] = ei1;                       // (older than the gathers just issued)
+    CRF_TM(tmi >= 0, tmi + 4);
+#ifdef CRF_TIMING
+    if (tmi >= 0 && lane == 0) { g_tm[tmi + 8] = (unsigned long long)nb; g_tm[tmi + 9] = (unsigned long long)nbund; }
+#endif
+    int b = 0;
+    for (; b + 2 * D - 1 <= nb; b += D) {                          // steady state: no conditions around the loads
+        if (b > 0 && b % CB == 0) stage(b / CB);
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                if (b + j + D - 1 < nbc) issue((j + D - 1) % D, b + j + D - 1);
-                if (b + j < nbc) consume(j);
-            }
+        for (int j = 0; j < D; ++j) { issue((j + D - 1) % D, b + j + D - 1); consume(j); }
+    }
+    for (; b < nb; b += D) {
+        if (b > 0 && b % CB == 0) stage(b / CB);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (b + j + D - 1 < nb) issue((j + D - 1) % D, b + j + D - 1);
+            if (b + j < nb) consume(j);
         }
     }
+    CRF_TM(tmi >= 0, tmi + 5);
 }
 
 // One frame of both recursions.  1-D grid of 8 * nslot workgroups; block b sits on XCD b % 8 (observed; a matter of speed
@@ -2450,16 +2467,21 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, con
 //                 ("chunks") dealt round-robin among them;
 //   #combos >= 8: XCD x serves the combos x, x + 8, ..., its slots dealt round-robin among them.
 // The waves of a combo take the tasks of its arc stream (rows with one entering pair: all of a T o LM graph) and then the
-// remaining rows one at a time (bat_row_sum).
-template <int UL>
+// remaining rows one at a time (bat_row_sum: one utterance per lane, 64 / UL arcs of the row side by side).
+template <int UL, int D>
 __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParams p) {
-    constexpr int AL = 64 / UL;
-    __shared__ float wmax[kBatWaves][64];
-    __shared__ __attribute__((aligned(16))) char stage[kBatWaves][kStreamLds];   // bat_stream: records, emissions, descriptors of a wave's task
+    constexpr int ALR = 64 / UL;                                   // rest rows: arc lanes per utterance
+    constexpr int LG = UL / 4, AL = 64 / LG;                       // stream: lanes per row, rows side by side
+    __shared__ unsigned umax[UL];                                  // maximum of the vector this workgroup wrote, per utterance (float bits)
+    __shared__ __attribute__((aligned(16))) char stage[kBatWaves][kStreamLds];   // bat_stream: records, emission ring, descriptors of a wave's task
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (timing build: launch 700, four workgroups of the first XCD x their four waves, 16 stamps each from g_tm[14000])
+    const int tmi = (p.j == 700 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) % 24 == 0 && (blockIdx.x >> 3) < 96) ? 14000 + (((blockIdx.x >> 3) / 24) * 4 + wave) * 16 : -1;
+    CRF_TM(tmi >= 0, tmi + 0);
     char *ldsw = stage[wave];
-    const int ul = lane % UL, aj = lane / UL;
+    const int ul = lane % UL, aj = lane / UL;                      // rest rows and the per-utterance scalars: utterance ul of the group
+    const int uq = lane % LG, sj = lane / LG;                      // stream: utterances 4 uq .. 4 uq + 3, row sj of the bundle
     const int T = p.T, S = p.S, P = p.P;
     int combo, chunk, nchunk;
     {
@@ -2476,31 +2498,52 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
     const int dir = combo & 1, grp = combo >> 1;
     const int u = grp * UL + ul;
     const int lx = u < p.B ? p.lx[u] : 0;
+    const int u4 = grp * UL + 4 * uq;                              // first of the lane's four utterances (stream)
+    int lx4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lx4[c] = u4 + c < p.B ? p.lx[u4 + c] : 0;
     const int w0 = chunk * kBatWaves + wave, NW = nchunk * kBatWaves;   // this wave among the waves of its combo
     const bool lead = chunk == 0 && wave == 0 && aj == 0;          // one writer per utterance for the scalars
     const BatchDev &g = p.g;
     const size_t gS = (size_t)grp * S * UL, gP = (size_t)grp * P * UL, gV = (size_t)grp * p.V * UL;
     const size_t Sall = (size_t)S * p.Bp, Pall = (size_t)P * p.Bp, Vall = (size_t)p.V * p.Bp;
-    float mymax = 0.f, sink = 0.f;
+    if (tid < UL) umax[tid] = 0u;
+    __syncthreads();
+    CRF_TM(tmi >= 0 && lx4[0] + lx4[1] + lx4[2] + lx4[3] + lx >= 0, tmi + 1);   // (the scalar loads have landed)
+    float mymax = 0.f;                                             // rest rows: utterance ul
+    f32x4 mymax4 = {0.f, 0.f, 0.f, 0.f};                           // stream: the lane's four utterances
+#if defined(CRF_BAT_DBG) && CRF_BAT_DBG == 1
+    if (p.j >= 0) return;   // timing experiment: the launch and nothing else
+#endif
     if (dir == 0) {
         const int t = p.j;
         if (t >= T) return;
         const bool active = t < lx;
         const int k = rescale_exp(__uint_as_float(p.mxf[(t % 3) * p.Bp + u]));
         const float sc = pow2f(k);
+        f32x4 sc4;
+        bool act4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sc4[c] = pow2f(rescale_exp(__uint_as_float(p.mxf[(t % 3) * p.Bp + u4 + c]))); act4[c] = t < lx4[c]; }
+        const bool all4 = act4[0] && act4[1] && act4[2] && act4[3];
         const float *Ac = p.Af + (size_t)(t & 1) * Sall + gS;
         float *An = p.Af + (size_t)((t + 1) & 1) * Sall + gS;
         const float *et = p.ept + (size_t)t * Vall + gV;
         float *Qt = p.Q + (size_t)t * Pall + gP;
-        if (p.prefetch) sink = bat_touch(Ac, (int64_t)S * UL * 4, w0, NW, lane);
         for (int task = w0; task < p.st.f.ntasks; task += NW)
-            bat_stream<UL>(p.st.f, task, Ac, et, ul, aj, lane, ldsw, [&](float acc, const int4 &m, float e) __attribute__((always_inline)) {
+            bat_stream<UL, D>(p.st.f, task, Ac, et, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 &m, const f32x4 &e) __attribute__((always_inline)) {
                 if (m.x < 0) return;                               // padding row of the last bundle
-                if (!active) return;                               // an utterance that has ended keeps a_lx where it is: nobody writes
-                const float q = acc * sc, an = e * q;                //   that buffer for it again (crf_batch_zsum_kernel reads it there)
-                Qt[(size_t)m.y * UL + ul] = q;
-                An[(size_t)m.x * UL + ul] = an;
-                mymax = fmaxf(mymax, an);
+                // an utterance that has ended keeps a_lx where it is: nobody writes that buffer for it again
+                // (crf_batch_zsum_kernel reads it there)
+                const f32x4 q = acc * sc4, an = e * q;
+                float *qp = Qt + (size_t)m.y * UL + 4 * uq, *ap = An + (size_t)m.x * UL + 4 * uq;
+                if (all4) { *(f32x4 *)qp = q; *(f32x4 *)ap = an; }
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (act4[c]) { qp[c] = q[c]; ap[c] = an[c]; }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (act4[c]) mymax4[c] = fmaxf(mymax4[c], an[c]);
             });
         for (int i = w0; i < p.st.f.nrest; i += NW) {
             const int r = __builtin_amdgcn_readfirstlane(p.st.f.rest[i]);
@@ -2536,25 +2579,46 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
         const bool starts = t - 1 == lx - 1 && lx > 0;             // frame t-1 is its last frame: z_{lx-1} is set up
         const int k = rescale_exp(__uint_as_float(p.mxb[(p.j % 3) * p.Bp + u]));
         const float sc = pow2f(k);
+        f32x4 sc4;
+        bool act4[4], st4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            sc4[c] = pow2f(rescale_exp(__uint_as_float(p.mxb[(p.j % 3) * p.Bp + u4 + c])));
+            act4[c] = t < lx4[c]; st4[c] = t == lx4[c] && lx4[c] > 0;
+        }
+        const bool all4 = act4[0] && act4[1] && act4[2] && act4[3];
         const float *Zc = p.Zb + (size_t)(p.j & 1) * Pall + gP;
         float *Zn = p.Zb + (size_t)((p.j + 1) & 1) * Pall + gP;
         const float *ep1 = p.ept + (size_t)(t >= 1 ? t - 1 : 0) * Vall + gV;   // (t = 0: read, not used)
         float *BPt = t >= 1 ? p.BP + (size_t)(t - 1) * Pall + gP : nullptr;
         const bool any_active = __ballot(active) != 0ull;
-        if (p.prefetch && any_active) sink = bat_touch(Zc, (int64_t)P * UL * 4, w0, NW, lane);
         if (any_active || __ballot(starts) != 0ull)
             for (int task = w0; task < p.st.b.ntasks; task += NW)
-                bat_stream<UL>(p.st.b, task, Zc, ep1, ul, aj, lane, ldsw, [&](float acc, const int4 &m, float e) __attribute__((always_inline)) {
+                bat_stream<UL, D>(p.st.b, task, Zc, ep1, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 &m, const f32x4 &e) __attribute__((always_inline)) {
                     if (m.x < 0) return;
-                    const float bv = acc * sc;
+                    const f32x4 bv = acc * sc4;
                     if (t == 0) {
                         const float st = p.start_lin[m.x];
-                        if (st != 0.f && active) atomicAdd(&p.zb[u], st * bv);
-                    } else if (active || starts) {
-                        const float out = active ? bv : p.end_lin[m.x] * pow2f(kScaleExp);
-                        const float z = e * out;
-                        BPt[(size_t)m.y * UL + ul] = out; Zn[(size_t)m.y * UL + ul] = z;
-                        mymax = fmaxf(mymax, z);
+                        if (st != 0.f) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) if (act4[c]) atomicAdd(&p.zb[u4 + c], st * bv[c]);
+                        }
+                        return;
+                    }
+                    float *bp = BPt + (size_t)m.y * UL + 4 * uq, *zp = Zn + (size_t)m.y * UL + 4 * uq;
+                    if (all4) {
+                        const f32x4 z = e * bv;
+                        *(f32x4 *)bp = bv; *(f32x4 *)zp = z;
+                        mymax4 = __builtin_elementwise_max(mymax4, z);
+                    } else {
+                        const float eend = p.end_lin[m.x] * pow2f(kScaleExp);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (act4[c] || st4[c]) {
+                                const float out = act4[c] ? bv[c] : eend, z = e[c] * out;
+                                bp[c] = out; zp[c] = z;
+                                mymax4[c] = fmaxf(mymax4[c], z);
+                            }
                     }
                 });
         for (int i = w0; i < p.st.b.nrest; i += NW) {
@@ -2577,7 +2641,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
                     if (aj == 0) { BPt[(size_t)ds.z * UL + ul] = out; Zn[(size_t)ds.z * UL + ul] = z; }
                     mymax = fmaxf(mymax, z);
                 } else {
-                    for (int kk = ds.z + aj; kk < ds.w; kk += AL) {
+                    for (int kk = ds.z + aj; kk < ds.w; kk += ALR) {
                         const int4 pl = g.stp[kk];
                         BPt[(size_t)pl.x * UL + ul] = out;
                         const float z = ep1[(size_t)pl.y * UL + ul] * out;
@@ -2593,16 +2657,18 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
             p.mxb[((p.j + 2) % 3) * p.Bp + u] = 0u;
         }
     }
-    // maximum of the vector this launch wrote, per utterance: lanes -> waves -> one atomic per utterance and workgroup
-    mymax = arc_lane_max<UL>(mymax);
-    wmax[wave][lane] = mymax;
+    // maximum of the vector this launch wrote, per utterance: lanes -> LDS (the values are non-negative: their bits order
+    // like unsigned integers) -> one atomic per utterance and workgroup
+    if (mymax > 0.f) atomicMax(&umax[ul], __float_as_uint(mymax));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (mymax4[c] > 0.f) atomicMax(&umax[4 * uq + c], __float_as_uint(mymax4[c]));
     __syncthreads();
-    if (wave == 0 && aj == 0) {
-        const float m = fmaxf(fmaxf(wmax[0][lane], wmax[1][lane]), fmaxf(wmax[2][lane], wmax[3][lane]));
-        unsigned *slot = (dir == 0 ? p.mxf : p.mxb) + ((p.j + 1) % 3) * p.Bp + u;
-        if (m > 0.f) atomicMax(slot, __float_as_uint(m));
+    if (tid < UL) {
+        const unsigned m = umax[tid];
+        unsigned *slot = (dir == 0 ? p.mxf : p.mxb) + ((p.j + 1) % 3) * p.Bp + grp * UL + tid;
+        if (m != 0u) atomicMax(slot, m);
     }
-    if (sink == 1.0e-37f) wmax[0][0] = sink;                        // (bat_touch: keeps its loads)
+    CRF_TM(tmi >= 0, tmi + 6);
 }
 
 // zs[u] = sum_s a_{lx}[s][u] * end[s].  grid (ceil(S / (4 * 64)), 1, Bp / UL): a wave sums 64 states
@@ -3666,18 +3732,19 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // one task per wave, ONE round of workgroups (a second round with a fraction of the device doubled the launch):
         // the tasks wanted per direction follow from the occupancy the runtime reports, shared by the combos
         const int64_t ncombo = 2 * (int64_t)ngrp;
+        static const bool deep = getenv("CRF_BAT_DEPTH") && atoi(getenv("CRF_BAT_DEPTH")) == 2;   // ("deep": the other depth) batches of 16-byte gathers in flight per wave: 4, or 2
         int wg_cu = 0;
         {
-            const void *fn = w.UL == 64 ? (const void *)crf_batch_frame_kernel<64> : w.UL == 32 ? (const void *)crf_batch_frame_kernel<32>
-                           : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16> : (const void *)crf_batch_frame_kernel<8>;
+            const void *fn = deep ? (w.UL == 64 ? (const void *)crf_batch_frame_kernel<64, 2> : w.UL == 32 ? (const void *)crf_batch_frame_kernel<32, 2>
+                                     : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16, 2> : (const void *)crf_batch_frame_kernel<8, 2>)
+                                  : (w.UL == 64 ? (const void *)crf_batch_frame_kernel<64, 4> : w.UL == 32 ? (const void *)crf_batch_frame_kernel<32, 4>
+                                     : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16, 4> : (const void *)crf_batch_frame_kernel<8, 4>);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, fn, kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = 3; }
         }
         const int want = (int)std::max<int64_t>(16, (int64_t)ncu_dev * wg_cu * kBatWaves * 15 / 16 / ncombo);
         const StreamDev *sdv = nullptr;
-        if ((rc = ensure_stream_tables(g->h, 64 / w.UL, want, &sdv))) return rc;
+        if ((rc = ensure_stream_tables(g->h, w.UL, want, &sdv))) return rc;
         bp.st = *sdv;
-        static const bool bat_prefetch = !(getenv("CRF_BAT_PREFETCH") && !atoi(getenv("CRF_BAT_PREFETCH")));
-        bp.prefetch = bat_prefetch ? 1 : 0;
         // 8 * nslot workgroups (block b -> XCD b % 8, slot b / 8): every combo gets at least one wave per task of its arc
         // stream (crf_batch_frame_kernel: a combo has nslot * nk or about nslot / ncx workgroups)
         const int64_t tasks_max = std::max({(int64_t)sdv->f.ntasks, (int64_t)sdv->b.ntasks, (int64_t)1});
@@ -3697,7 +3764,21 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         LAUNCH_CHECK("crf_batch_init_kernel");
         for (int j = 0; j <= (int)T; ++j) {
             bp.j = j;
-            CRF_BAT_UL(crf_batch_frame_kernel, dim3(G), bp);
+            if (deep) {
+                switch (w.UL) {
+                    case 64: hipLaunchKernelGGL((crf_batch_frame_kernel<64, 2>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                    case 32: hipLaunchKernelGGL((crf_batch_frame_kernel<32, 2>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                    case 16: hipLaunchKernelGGL((crf_batch_frame_kernel<16, 2>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                    default: hipLaunchKernelGGL((crf_batch_frame_kernel<8, 2>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                }
+            } else {
+                switch (w.UL) {
+                    case 64: hipLaunchKernelGGL((crf_batch_frame_kernel<64, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                    case 32: hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                    case 16: hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                    default: hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                }
+            }
         }
         LAUNCH_CHECK("crf_batch_frame_kernel");
         CRF_BAT_UL(crf_batch_zsum_kernel, dim3((unsigned)((h->dev.S + 255) / 256), 1, ngrp), bp);

@@ -238,7 +238,7 @@ int upload(HostGraph *h, const std::vector<T> &v, const T **out) {
 }
 
 // One direction's arc stream (crf_internal.h: StreamDirDev).  rows / row_st / arcs: the BatchDev tables of that direction.
-static int build_stream_dir(HostGraph *h, int AL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
+static int build_stream_dir(HostGraph *h, int AL, int UL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
                             const std::vector<int2> &arcs, StreamDirDev *out) {
     constexpr int kB = 4;                                 // steps per batch (crf_kernels.hip: kStreamBatch)
     std::vector<int> simple, rest;
@@ -263,8 +263,8 @@ static int build_stream_dir(HostGraph *h, int AL, int task_steps, const std::vec
             if (i < (int)simple.size()) len = std::max(len, rows[(size_t)simple[(size_t)i]].y - rows[(size_t)simple[(size_t)i]].x);
         }
         const int nbat = (len + kB - 1) / kB;             // every row of the bundle padded to whole batches
-        if (task_steps_now > 0 && (task_steps_now + nbat * kB > task_steps || b - task_b0 >= 16)) close_task(b);   // (16: kStreamBundles)
-        int n[8] = {0}, a0[8] = {0};
+        if (task_steps_now > 0 && (task_steps_now + nbat * kB > task_steps || b - task_b0 >= 8)) close_task(b);   // (8: kStreamBundles)
+        int n[32] = {0}, a0[32] = {0};
         for (int aj = 0; aj < AL; ++aj) {
             const int i = b * AL + aj;
             int4 m{-1, 0, 0, 0};
@@ -283,16 +283,17 @@ static int build_stream_dir(HostGraph *h, int AL, int task_steps, const std::vec
                     int2 rcd{0, 0};
                     if (st < n[aj]) {
                         rcd = arcs[(size_t)a0[aj] + st];
-                        if (rcd.x < 0 || rcd.x >= (1 << 24)) { set_error("arc stream: index does not fit 24 bits"); return CRF_ERR_ARG; }
+                        // the kernels want entry * UL (UL utterances per entry), below 2^29 so that the byte offset fits 31 bits
+                        if (rcd.x < 0 || (int64_t)rcd.x * UL >= (1ll << 29)) { set_error("arc stream: index does not fit"); return CRF_ERR_ARG; }
+                        rcd.x *= UL;
                     }
-                    if (k == 0 && bt == nbat - 1) rcd.x |= 1 << 24;   // the bundle ends with this batch
+                    if (k == 0 && bt == nbat - 1) rcd.x |= (int)0x80000000u;   // the bundle ends with this batch
                     recs.push_back(rcd);
                 }
         task_steps_now += nbat * kB;
     }
     close_task(nbund);
-    for (int k = 0; k < 3 * AL; ++k) meta.push_back(int4{-1, 0, 0, 0});   // the kernels read descriptors up to three bundles ahead
-    for (int k = 0; k < 256; ++k) recs.push_back(int2{0, 0});             // ... and stage whole 2 KB chunks
+    for (int k = 0; k < 1024; ++k) recs.push_back(int2{0, 0});            // the kernels stage whole 4 KB chunks, one chunk ahead
     out->ntasks = (int)tasks.size(); out->nrest = (int)rest.size();
     int rc;
     if ((rc = upload(h, tasks, &out->tasks)) || (rc = upload(h, recs, &out->recs)) || (rc = upload(h, meta, &out->meta)) || (rc = upload(h, rest, &out->rest))) return rc;
@@ -312,9 +313,10 @@ int upload_ell(HostGraph *h, const EllHost &e, EllDev *d) {
 
 }  // namespace
 
-int ensure_stream_tables(HostGraph *h, int AL, int want, const StreamDev **out) {
+int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) {
+    const int AL = 256 / std::max(UL, 1);                 // lane groups: a lane takes 4 utterances, UL / 4 lanes a row
     static std::mutex mu;
-    if (!h || !(AL == 1 || AL == 2 || AL == 4 || AL == 8) || want < 1 || !h->dev.bat.ok) { set_error("ensure_stream_tables: bad arguments"); return CRF_ERR_ARG; }
+    if (!h || !(UL == 8 || UL == 16 || UL == 32 || UL == 64) || want < 1 || !h->dev.bat.ok) { set_error("ensure_stream_tables: bad arguments"); return CRF_ERR_ARG; }
     std::lock_guard<std::mutex> lock(mu);
     for (StreamDev *sd : h->streams)
         if (sd->AL == AL && sd->want == want) { *out = sd; return CRF_OK; }
@@ -330,8 +332,8 @@ int ensure_stream_tables(HostGraph *h, int AL, int want, const StreamDev **out) 
     int prev = 0;
     if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(h->device) != hipSuccess) { set_error("ensure_stream_tables: cannot select the graph's device"); return CRF_ERR_HIP; }
     auto *sd = new StreamDev();
-    int rc = build_stream_dir(h, AL, task_steps, h->hb_frow, h->hb_frow_d, h->hb_farcs, &sd->f);
-    if (!rc) rc = build_stream_dir(h, AL, task_steps, h->hb_brow, h->hb_brow_s, h->hb_barcs, &sd->b);
+    int rc = build_stream_dir(h, AL, UL, task_steps, h->hb_frow, h->hb_frow_d, h->hb_farcs, &sd->f);
+    if (!rc) rc = build_stream_dir(h, AL, UL, task_steps, h->hb_brow, h->hb_brow_s, h->hb_barcs, &sd->b);
     (void)hipSetDevice(prev);
     if (rc) { delete sd; return rc; }
     sd->AL = AL; sd->want = want; sd->ok = 1;
