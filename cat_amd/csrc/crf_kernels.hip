@@ -3732,14 +3732,11 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // one task per wave, ONE round of workgroups (a second round with a fraction of the device doubled the launch):
         // the tasks wanted per direction follow from the occupancy the runtime reports, shared by the combos
         const int64_t ncombo = 2 * (int64_t)ngrp;
-        static const bool deep = getenv("CRF_BAT_DEPTH") && atoi(getenv("CRF_BAT_DEPTH")) == 2;   // ("deep": the other depth) batches of 16-byte gathers in flight per wave: 4, or 2
         int wg_cu = 0;
         {
-            const void *fn = deep ? (w.UL == 64 ? (const void *)crf_batch_frame_kernel<64, 2> : w.UL == 32 ? (const void *)crf_batch_frame_kernel<32, 2>
-                                     : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16, 2> : (const void *)crf_batch_frame_kernel<8, 2>)
-                                  : (w.UL == 64 ? (const void *)crf_batch_frame_kernel<64, 4> : w.UL == 32 ? (const void *)crf_batch_frame_kernel<32, 4>
-                                     : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16, 4> : (const void *)crf_batch_frame_kernel<8, 4>);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, fn, kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = 3; }
+            const void *fn = w.UL == 64 ? (const void *)crf_batch_frame_kernel<64, 4> : w.UL == 32 ? (const void *)crf_batch_frame_kernel<32, 4>
+                           : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16, 4> : (const void *)crf_batch_frame_kernel<8, 4>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, fn, kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = 2; }
         }
         const int want = (int)std::max<int64_t>(16, (int64_t)ncu_dev * wg_cu * kBatWaves * 15 / 16 / ncombo);
         const StreamDev *sdv = nullptr;
@@ -3764,20 +3761,11 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         LAUNCH_CHECK("crf_batch_init_kernel");
         for (int j = 0; j <= (int)T; ++j) {
             bp.j = j;
-            if (deep) {
-                switch (w.UL) {
-                    case 64: hipLaunchKernelGGL((crf_batch_frame_kernel<64, 2>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                    case 32: hipLaunchKernelGGL((crf_batch_frame_kernel<32, 2>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                    case 16: hipLaunchKernelGGL((crf_batch_frame_kernel<16, 2>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                    default: hipLaunchKernelGGL((crf_batch_frame_kernel<8, 2>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                }
-            } else {
-                switch (w.UL) {
-                    case 64: hipLaunchKernelGGL((crf_batch_frame_kernel<64, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                    case 32: hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                    case 16: hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                    default: hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                }
+            switch (w.UL) {   // (4: batches of gathers in flight per wave; 2 measured 6 % slower, 8 needs more registers than a wave has)
+                case 64: hipLaunchKernelGGL((crf_batch_frame_kernel<64, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                case 32: hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                case 16: hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                default: hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
             }
         }
         LAUNCH_CHECK("crf_batch_frame_kernel");

@@ -152,11 +152,12 @@ def test_synth_vs_oracle_ragged(crf, tmp_path, seed, B, T, vocab, hist, fan, mod
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
-@pytest.mark.parametrize("B,ul", [(20, 8), (41, 8), (40, 16), (70, 32), (70, 64)])
+@pytest.mark.parametrize("B,ul", [(20, 8), (41, 8), (33, 8), (64, 16), (40, 16), (70, 32), (70, 64)])
 def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
     """Utterance-minor kernels with several utterance groups: 3 groups (6 combos on 8 XCDs, uneven), 6 groups (12 combos:
     two per XCD on four of them), 3 / 3 / 2 groups of 16 / 32 / 64 with padding utterances in the last one -- the
-    (group, direction) -> XCD / row-chunk decode of crf_batch_frame_kernel and the group-major vectors."""
+    (group, direction) -> XCD / row-chunk decode of crf_batch_frame_kernel (fewer, exactly and more than eight combos: B=41:
+    12, B=33: 10, B=64 / UL=16: 8) and the group-major vectors."""
     g, p = small_synth(tmp_path, 12, 40, 6, 5)
     logits, labels, lx, ly = make_batch(g, B, 31, 12, seed=B, ragged=True)
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
