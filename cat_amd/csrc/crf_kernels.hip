@@ -1288,22 +1288,23 @@ __device__ __forceinline__ void res_chain_body(const ResParams &p, float *lds, c
     // doubled loop body (2 x 30 KiB) did not fit the instruction cache next to the other direction's kernel
     // (after frame 0: entries no row produces -- the start state -- still hold a_0 in buffer 0 and nothing rewrites
     // them; cleared before the buffer is the source again, see fac_chain_body)
-    auto clear_start = [&](int i) __attribute__((always_inline)) {
-        if (DIR == 0 && i == 0) {
-            for (int s = tid; s < G; s += kResThreads) if (p.x_start[s] != 0.f) X[s] = 0.f;
-            sync_lds();
+    // (between two runs of the one frame loop -- frame 0 alone, then the rest: inside the loop body it cost 2.6 % of the step)
+    auto run = [&](auto xmode) __attribute__((always_inline)) {
+        int i = 0;
+#pragma clang loop unroll(disable)
+        for (int seg = 0; seg < 2; ++seg) {
+            const int iend = (DIR == 0 && seg == 0) ? min(lx, 1) : lx;
+#pragma clang loop unroll(disable)
+            for (; i < iend; ++i) frame(xmode, i & 1, i);
+            if (DIR == 0 && seg == 0 && lx > 0) {
+                for (int s = tid; s < G; s += kResThreads) if (p.x_start[s] != 0.f) X[s] = 0.f;
+                sync_lds();
+            }
         }
     };
-    if (K == 1) {
-#pragma clang loop unroll(disable)
-        for (int i = 0; i < lx; ++i) { frame(std::integral_constant<int, 0>{}, i & 1, i); clear_start(i); }
-    } else if (same_l2) {
-#pragma clang loop unroll(disable)
-        for (int i = 0; i < lx; ++i) { frame(std::integral_constant<int, 1>{}, i & 1, i); clear_start(i); }
-    } else {
-#pragma clang loop unroll(disable)
-        for (int i = 0; i < lx; ++i) { frame(std::integral_constant<int, 2>{}, i & 1, i); clear_start(i); }
-    }
+    if (K == 1) run(std::integral_constant<int, 0>{});
+    else if (same_l2) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
 
     if (DIR == 0) {
         if (k == 0) {
@@ -1692,14 +1693,18 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         sync_lds();
         CRF_TM(tm_on, tm_i + 4);
     };
+    // Entries no row produces (states nobody enters: the start state) still hold a_0 in the buffer frame 0 read from, and
+    // nothing rewrites them: they are cleared before that buffer becomes the source again (frame 2).  In an ordinary frame
+    // the stale start mass is ~2^-60 of the vector; once the vector underflows it would be ALL of it -- a finite, wrong
+    // logZ instead of the zero that sends the utterance to the robust kernels.  The clearing sits BETWEEN two runs of the
+    // one frame loop (frame 0 alone, then the rest): inside the loop body it cost 2.6 % of the step (measured).
+    int i = i0;
 #pragma clang loop unroll(disable)
-    for (int i = i0; i < i1; ++i) {
-        frame(i & 1, i);
-        if (DIR == 0 && i == 0) {
-            // Entries no row produces (states nobody enters: the start state) still hold a_0 in the buffer frame 0 read
-            // from, and nothing rewrites them: clear them before that buffer becomes the source again (frame 2).  In
-            // an ordinary frame the stale start mass is ~2^-60 of the vector; once the vector underflows it would be
-            // ALL of it -- a finite, wrong logZ instead of the zero that sends the utterance to the robust kernels.
+    for (int seg = 0; seg < 2; ++seg) {
+        const int iend = (DIR == 0 && seg == 0) ? min(i1, 1) : i1;
+#pragma clang loop unroll(disable)
+        for (; i < iend; ++i) frame(i & 1, i);
+        if (DIR == 0 && seg == 0 && i0 == 0 && i1 > 0) {
             for (int s = tid; s < G; s += NTH) if (p.x_start[s] != 0.f) X[s] = 0.f;
             sync_lds();
         }
