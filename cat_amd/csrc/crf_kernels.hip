@@ -713,8 +713,8 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         const double *Ac = A + ((t - 1) & 1) * Sxp;
         double *An = A + (t & 1) * Sxp;
         double em[NR];
-        const bool tm_on = b == 3 && t >= 100 && t < 228 && wave == 0;
-        const int tm_i = 14336 + (t - 100) * 8;
+        [[maybe_unused]] const bool tm_on = b == 3 && t >= 100 && t < 228 && wave == 0;
+        [[maybe_unused]] const int tm_i = 14336 + (t - 100) * 8;
         CRF_TM(tm_on, tm_i + 0);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -1174,8 +1174,8 @@ __device__ __forceinline__ void res_chain_body(const ResParams &p, float *lds, c
         constexpr int mode = decltype(MODE)::value;
         const int t = DIR == 0 ? i : lx - 1 - i;                     // frame whose emissions are consumed
         const bool produce = DIR == 0 || t > 0;                      // a next vector exists
-        const bool tm_on = b == p.b0 + 3 && i >= 100 && i < 228 && wave == 0;
-        const int tm_i = (DIR * 4 + k) * 1024 + (i - 100) * 8;
+        [[maybe_unused]] const bool tm_on = b == p.b0 + 3 && i >= 100 && i < 228 && wave == 0;
+        [[maybe_unused]] const int tm_i = (DIR * 4 + k) * 1024 + (i - 100) * 8;
         CRF_TM(tm_on, tm_i + 0);
 #ifdef CRF_TIMING
         if (b == p.b0 + 3 && i >= 150 && i < 158 && wave == 0) CRF_TM(true, 12288 + 1024 + (DIR * 4 + k) * 8 + (i - 150));  // frame start
@@ -1516,8 +1516,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     auto frame = [&](const int par, int i) __attribute__((always_inline)) {
         const int t = DIR == 0 ? i : lx - 1 - i;
         if (FLAG && i == next_bound) publish_stage();
-        const bool tm_on = b == 3 && i >= 100 && i < 228 && wave == 0;
-        const int tm_i = (DIR * 4) * 1024 + (i - 100) * 8;
+        [[maybe_unused]] const bool tm_on = b == 3 && i >= 100 && i < 228 && wave == 0;
+        [[maybe_unused]] const int tm_i = (DIR * 4) * 1024 + (i - 100) * 8;
         CRF_TM(tm_on, tm_i + 0);
 #ifdef CRF_TIMING
         if (b == 3 && i >= 150 && i < 158 && wave == 0) CRF_TM(true, 12288 + 1024 + (DIR * 4) * 8 + (i - 150));  // frame start
@@ -2023,7 +2023,7 @@ __global__ __launch_bounds__(NT, (NCPT == 1 && EPR == 1 && NT == kGDThreads) ? C
         for (int q = 0; q < EPR; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
     }
     sync_lds();
-    const bool tm_on = blockIdx.x == 40 && blockIdx.y == 3 && tid < 64;
+    [[maybe_unused]] const bool tm_on = blockIdx.x == 40 && blockIdx.y == 3 && tid < 64;
     for (int t = t0; t < tl; ++t) {
         CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
         float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
@@ -2476,7 +2476,7 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, con
 template <int UL, int D>
 __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParams p) {
     constexpr int ALR = 64 / UL;                                   // rest rows: arc lanes per utterance
-    constexpr int LG = UL / 4, AL = 64 / LG;                       // stream: lanes per row, rows side by side
+    constexpr int LG = UL / 4;                                     // stream: lanes per row (64 / LG rows side by side)
     __shared__ unsigned umax[UL];                                  // maximum of the vector this workgroup wrote, per utterance (float bits)
     __shared__ __attribute__((aligned(16))) char stage[kBatWaves][kStreamLds];   // bat_stream: records, emission ring, descriptors of a wave's task
     const int tid = threadIdx.x, lane = tid & 63;

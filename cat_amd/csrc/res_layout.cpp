@@ -1128,7 +1128,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (bx_idx.empty()) { bx_idx.push_back(zsink); bx_w.push_back(0.f); }
     pack_arcs(bsub, bslices, &bo, 4, *gm, bdup ? 2 * Rb : 0, bdup);
     const int noLab = -1;
-    std::vector<int4> brow_meta(Rb, int4{(zsink * 4) | ((zsink * 4) << 16), 0, 0, (noLab & 0xffff) | (noLab << 16)});
+    std::vector<int4> brow_meta(Rb, int4{(zsink * 4) | ((zsink * 4) << 16), 0, 0, (noLab & 0xffff) | (int)((unsigned)noLab << 16)});
     std::vector<float> brow_start((size_t)2 * Rb, 0.f), brow_end((size_t)2 * Rb, 0.f), z_end(Gb, 0.f);
     std::vector<int> z_lab(Gb, -1);
     for (int rid = 0; rid < Rb; ++rid) {

@@ -629,13 +629,15 @@ def _ref_den(p, logits, lx):
     return out
 
 
-def test_denominator_vs_reference_kernels(crf, tmp_path):
+@pytest.mark.parametrize("hist,fan,B,T,tol_ref", [(256, 16, 4, 120, 2e-2), (2048, 24, 3, 500, 1e-1)])
+def test_denominator_vs_reference_kernels(crf, tmp_path, hist, fan, B, T, tol_ref):
     """gpu_den of this repo vs the REFERENCE'S OWN CUDA kernels built for gfx950 (oracle/Makefile `ref`),
     both judged against the fp64 oracle: the reference's fp32 log-domain arithmetic drifts with T
-    (each alpha is rounded at ulp(|alpha|) ~ 3e-5 per frame), so it is held to 2e-2 and ours to 1e-4;
-    ours must be the closer of the two."""
-    g, p = small_synth(tmp_path, 72, 256, 16, 4)
-    logits, _, lx, _ = make_batch(g, 4, 120, 72, seed=4, ragged=True)
+    (each alpha is rounded at ulp(|alpha|) ~ 3e-5 per frame), so its GRADIENT is held to 2e-2 at T = 120 and 1e-1 at
+    T = 500 on the benchmark's graph (S = 4097), ours to 1e-4, and ours must be the closer of the two; logZ -- what
+    "within 1e-4 of the reference build" can be demonstrated on directly -- agrees to 1e-4 all three ways."""
+    g, p = small_synth(tmp_path, 72, hist, fan, 4 if hist == 256 else 0)
+    logits, _, lx, _ = make_batch(g, B, T, 72, seed=4, ragged=True)
     gref, cref = _ref_den(p, logits, lx)
     gor, cor, _ = oracle.den(fst_io.read_fst(p), logits, lx)
     core = crf._C
@@ -644,10 +646,11 @@ def test_denominator_vs_reference_kernels(crf, tmp_path):
     _, gd, ex = core.loss_fwd_bwd(x, None, torch.tensor(lx), None, 1.0, 0.0, core.graph_for(x.device), True)
     ours, cours = gd.cpu().numpy(), ex["costs_alpha"].cpu().numpy()
     e_ref, e_ours = rel_err(gref, gor), rel_err(ours, gor)
-    print(f"reference kernels vs fp64 oracle: {e_ref:.2e}; this repo vs fp64 oracle: {e_ours:.2e}")
-    assert np.allclose(cref, cor, rtol=1e-4) and np.allclose(cours, cor, rtol=TOL)
-    assert e_ref <= 2e-2 and e_ours <= TOL and e_ours <= e_ref
-    assert rel_err(ours, gref) <= 2e-2
+    print(f"S={g['S']} T={T}: reference kernels vs fp64 oracle: {e_ref:.2e}; this repo vs fp64 oracle: {e_ours:.2e}; "
+          f"logZ: reference {np.abs(cref / cor - 1).max():.1e}, ours {np.abs(cours / cor - 1).max():.1e}, ours vs reference {np.abs(cours / cref - 1).max():.1e}")
+    assert np.allclose(cref, cor, rtol=1e-4) and np.allclose(cours, cor, rtol=TOL) and np.allclose(cours, cref, rtol=1e-4)
+    assert e_ref <= tol_ref and e_ours <= TOL and e_ours <= e_ref
+    assert rel_err(ours, gref) <= tol_ref
     del ctx
 
 

@@ -22,6 +22,6 @@ run B16 --B 16
 run C2 --B 32 --T 500
 run T3000 --T 3000 --steps 10
 run small --histories 256 --fanout 16
-run large --histories 8192 --fanout 32 --steps 3 --warmup 1
+run B256 --B 256 --steps 5
 # estimated n-gram den_lm graphs (cat_amd.den_lm.prep_den_lm on a synthetic corpus): in-degree profile of a real LM
 for a in "4000 250" "12000 800" "40000 2000"; do timeout 600 python tools/bench_fst.py $a 2>/dev/null | tail -3; done | tee $OUT/pt_${TAG}_estimated.txt
