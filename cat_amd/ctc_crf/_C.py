@@ -6,6 +6,7 @@ and every call goes through the C ABI of include/ctc_crf_hip.h.
 """
 import ctypes
 import os
+import threading
 from typing import Dict, Optional
 
 import torch
@@ -167,7 +168,7 @@ class _PinnedRing:
     GPU idle for ~0.15 ms between two calls while the copy engine started (rocprofv3 timeline), and a copy
     stream of its own would be the process's fifth stream -- HIP maps streams onto four hardware queues, two of
     the loss's own side streams then share one and the numerator recursions run one after the other.
-    A slot is reused only after the event of its last copy has completed."""
+    A slot is reused only after the event of its last copy has completed; host threads take slots under a lock."""
 
     SLOTS = 8
 
@@ -175,8 +176,13 @@ class _PinnedRing:
         self.buf = [None] * self.SLOTS
         self.ev = [None] * self.SLOTS
         self.i = 0
+        self.lock = threading.Lock()
 
     def stage(self, src: torch.Tensor, dev: torch.device) -> torch.Tensor:
+        with self.lock:
+            return self._stage(src, dev)
+
+    def _stage(self, src: torch.Tensor, dev: torch.device) -> torch.Tensor:
         k = self.i
         self.i = (k + 1) % self.SLOTS
         n = src.numel()
@@ -204,7 +210,7 @@ def _h2d_async(src: torch.Tensor, dev: torch.device) -> torch.Tensor:
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ring = _RINGS.get(key)
     if ring is None:
-        ring = _RINGS[key] = _PinnedRing()
+        ring = _RINGS.setdefault(key, _PinnedRing())
     return ring.stage(src, dev)
 
 

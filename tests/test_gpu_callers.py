@@ -174,3 +174,58 @@ def test_trainer_call_sequence_vs_oracle(crf, tmp_path, kind):
     loss16.backward()
     assert abs(loss16.item() - ref_loss) <= 3e-2 * abs(ref_loss)
     assert all(torch.isfinite(pg.grad).all() for pg in enc_gpu.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [False, True])
+def test_concurrent_caller_streams(crf, tmp_path, threads):
+    """Two callers on one device that are NOT ordered on one stream -- two torch streams driven from one host thread, and two
+    host threads with a stream each -- each issuing a run of loss calls with its own inputs.  Every call owns a context per
+    (device, caller stream): counters, events and the side stream of one caller never meet the other's (round 1 had ONE
+    context per device: a second caller's prep kernel could clear the stage counters the first caller's grad launches were
+    waiting on).  Every result must equal the one the same inputs give alone (up to the summation order of the numerator's
+    LDS float atomics: 1e-6 of the largest gradient entry)."""
+    import threading
+    g, fst = small_synth(tmp_path, 72, 256, 16, 9)
+    core = crf._C
+    ctx = crf.CRFContext(fst, 0)
+    gh = core.graph_for(torch.device("cuda", 0))
+    assert core.graph_stats(gh)["fac"] == 1                       # the staged schedule (stream-level waits on per-context counters)
+    B, T, V, lamb = 8, 300, 72, 0.1
+    data = [make_batch(g, B, T, V, seed=s, ragged=True) for s in (21, 22)]
+    dev = [(torch.tensor(lg, device="cuda:0"), torch.tensor(lab), torch.tensor(lx), torch.tensor(ly)) for lg, lab, lx, ly in data]
+
+    def call(i):
+        x, lab, lx, ly = dev[i]
+        loss, grad, _ = core.loss_fwd_bwd(x, lab, lx, ly, 1.0 / B, (1 + lamb) / B, gh, True)
+        return loss, grad
+
+    alone = [call(0), call(1)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+
+    def run(i, reps):
+        with torch.cuda.stream(streams[i]):
+            for _ in range(reps):
+                outs[i].append(call(i))
+
+    if threads:
+        th = [threading.Thread(target=run, args=(i, 12)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    else:
+        for _ in range(12):                                         # interleaved enqueueing from one thread
+            run(0, 1)
+            run(1, 1)
+    torch.cuda.synchronize()
+    for i in range(2):
+        l0, g0 = alone[i]
+        assert len(outs[i]) == 12
+        for loss, grad in outs[i]:
+            assert torch.isfinite(loss).all()
+            assert abs(loss.item() - l0.item()) <= 1e-6 * abs(l0.item()), (i, loss.item(), l0.item())
+            assert (grad - g0).abs().max().item() <= 1e-6 * g0.abs().max().item()
+    del ctx
