@@ -199,6 +199,7 @@ struct HostGraph {
     // statistics for diagnostics / DESIGN.md
     int64_t fwd_padded_arcs = 0, bwd_padded_arcs = 0, fwd_conflicts = 0, bwd_conflicts = 0;
     int max_in_deg = 0, max_out_deg = 0;
+    int regauged = 0;            // the weights were re-gauged (fst_graph.cpp: regauge_pushed)
     ResBuildStats res_stats;
     FacBuildStats fac_stats;
     // host copies of the utterance-minor tables (BatchDev) and the arc streams derived from them per lane-group count

@@ -343,8 +343,86 @@ int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) 
 }
 
 
+// RE-GAUGING of weight-pushed graphs.  A den_lm is CTC topology o LM: the two states (g, blank) and (g, token) of an LM
+// history feed the same rows with the same weights, which is what the factored layout lives on (res_layout.cpp:
+// build_factored).  A tool that PUSHES weights (w' = w + V(dst) - V(src), final' = final - V, V(start) = 0: every path
+// weight unchanged) destroys the equality -- the two weights into a row then differ by the constant V(token state) -
+// V(blank state).  Path weights are invariant under ANY such potential, so the compiler may choose its own: states that
+// share >= 2 rows with a CONSTANT log-weight difference d get potentials that make the weights equal again (g[s2] = -d;
+// w~ = w + g[dst] - g[src], start~ = start + g, end~ = end - g), and the now-equal weights are snapped to the same bits.
+// Nothing happens to graphs that need nothing (all differences zero).  Returns true when the weights were changed.
+static bool regauge_pushed(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, const int32_t *lab,
+                           std::vector<float> &w, std::vector<float> &start_w, std::vector<float> &end_w) {
+    if (getenv("CRF_NO_REGAUGE") && atoi(getenv("CRF_NO_REGAUGE"))) return false;
+    std::map<std::pair<int, int>, std::vector<int>> rows;           // (label, dst) -> arcs
+    for (int64_t k = 0; k < A; ++k) rows[{(int)lab[k], (int)dst[k]}].push_back((int)k);
+    struct Obs { uint64_t key; double d; };
+    std::vector<Obs> obs;
+    for (auto &kv : rows) {
+        const std::vector<int> &a = kv.second;
+        if (a.size() < 2 || a.size() > 512) continue;   // (quadratic in the row length)
+        for (size_t u = 0; u < a.size(); ++u)
+            for (size_t v = u + 1; v < a.size(); ++v) {
+                int s1 = src[a[u]], s2 = src[a[v]];
+                double d = (double)w[(size_t)a[u]] - (double)w[(size_t)a[v]];
+                if (s1 == s2 || !std::isfinite(d)) continue;
+                if (s1 > s2) { std::swap(s1, s2); d = -d; }
+                obs.push_back({(uint64_t)s1 << 32 | (unsigned)s2, d});
+            }
+    }
+    std::sort(obs.begin(), obs.end(), [](const Obs &x, const Obs &y) { return x.key < y.key || (x.key == y.key && x.d < y.d); });
+    struct Cand { uint64_t key; int n; double d; };
+    std::vector<Cand> cand;
+    for (size_t i = 0; i < obs.size();) {
+        size_t j = i;
+        while (j < obs.size() && obs[j].key == obs[i].key) ++j;
+        // the difference MOST of the common rows agree on (a pair may also meet in a row where its weights have nothing to
+        // do with each other: the self-loop of (g, token) beside the arc from (g, blank) when the history maps to itself)
+        size_t best_a = i, best_n = 0;
+        for (size_t a = i, b = i; a < j; ++a) {
+            while (b < j && obs[b].d - obs[a].d <= 1e-4) ++b;
+            if (b - a > best_n) { best_n = b - a; best_a = a; }
+        }
+        if (best_n >= 2) {
+            double sum = 0.0;
+            for (size_t a = best_a; a < best_a + best_n; ++a) sum += obs[a].d;
+            cand.push_back({obs[i].key, (int)best_n, sum / (double)best_n});
+        }
+        i = j;
+    }
+    std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.n > y.n; });
+    std::vector<int> mate((size_t)S, -1);
+    std::vector<double> g((size_t)S, 0.0);
+    int64_t moved = 0, matched = 0;
+    for (const Cand &c : cand) {
+        const int s1 = (int)(c.key >> 32), s2 = (int)(c.key & 0xffffffffu);
+        if (mate[s1] >= 0 || mate[s2] >= 0) continue;
+        mate[s1] = s2; mate[s2] = s1;
+        g[s2] = -c.d;                                     // w(s1 -> d) - g[s1] == w(s2 -> d) - g[s2], g[s1] = 0
+        ++matched;
+        if (std::fabs(c.d) > 1e-6) ++moved;
+    }
+    if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE")))
+        fprintf(stderr, "[regauge] %lld candidate pairs, %lld matched, %lld with a non-zero difference (S = %lld)\n", (long long)cand.size(), (long long)matched, (long long)moved, (long long)S);
+    if (moved * 8 < S) return false;                       // not a pushed T o LM graph (or nothing to undo)
+    for (int64_t k = 0; k < A; ++k) w[(size_t)k] = (float)((double)w[(size_t)k] + g[dst[k]] - g[src[k]]);
+    for (int64_t s = 0; s < S; ++s) {
+        if (std::isfinite(start_w[(size_t)s])) start_w[(size_t)s] = (float)((double)start_w[(size_t)s] + g[s]);
+        if (std::isfinite(end_w[(size_t)s])) end_w[(size_t)s] = (float)((double)end_w[(size_t)s] - g[s]);
+    }
+    for (auto &kv : rows) {                                // snap the weights of mates in a common row to the same bits
+        const std::vector<int> &a = kv.second;
+        if (a.size() < 2 || a.size() > 512) continue;   // (quadratic in the row length)
+        for (size_t u = 0; u < a.size(); ++u)
+            for (size_t v = u + 1; v < a.size(); ++v)
+                if (mate[src[a[u]]] == src[a[v]] && std::fabs((double)w[(size_t)a[u]] - (double)w[(size_t)a[v]]) <= 2e-4)
+                    w[(size_t)a[v]] = w[(size_t)a[u]];
+    }
+    return true;
+}
+
 int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, const int32_t *lab,
-                  const float *w, const float *start_w, const float *end_w, int device, HostGraph **out) {
+                  const float *w_in, const float *start_in, const float *end_in, int device, HostGraph **out) {
     if (S <= 0 || S > INT32_MAX / 4 || A < 0 || A > INT32_MAX / 4) { set_error("graph size out of range"); return CRF_ERR_UNSUPPORTED; }
     int max_label = 0;
     for (int64_t k = 0; k < A; ++k) {
@@ -352,6 +430,10 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
         if (lab[k] < 0) { set_error("negative label (epsilon ilabel) on an arc"); return CRF_ERR_FORMAT; }
         max_label = std::max(max_label, (int)lab[k]);
     }
+    // the compiler's own potentials for weight-pushed graphs (regauge_pushed): every table below is built from these weights
+    std::vector<float> w_v(w_in, w_in + A), start_v(start_in, start_in + S), end_v(end_in, end_in + S);
+    const bool regauged = regauge_pushed(S, A, src, dst, lab, w_v, start_v, end_v);
+    const float *w = w_v.data(), *start_w = start_v.data(), *end_w = end_v.data();
     // 1. pairs = distinct (dst, label)
     std::map<std::pair<int, int>, int> pair_id;  // (label, dst) -> temp id, ordered => deterministic
     for (int64_t k = 0; k < A; ++k) pair_id.emplace(std::make_pair((int)lab[k], (int)dst[k]), 0);
@@ -469,7 +551,7 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
         for (int v = 0; v <= max_label; ++v) b_lab_off[(size_t)v + 1] += b_lab_off[v];
     }
     auto *h = new HostGraph();
-    h->device = device; h->S = S; h->A = A; h->P = P;
+    h->device = device; h->S = S; h->A = A; h->P = P; h->regauged = regauged ? 1 : 0;
     h->fwd_padded_arcs = fe.padded_arcs; h->bwd_padded_arcs = be.padded_arcs;
     h->fwd_conflicts = fe.conflict_cycles; h->bwd_conflicts = be.conflict_cycles;
     for (auto &r : frows) h->max_in_deg = std::max(h->max_in_deg, (int)r.size());
@@ -587,7 +669,7 @@ int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
                            h->fwd_conflicts, h->bwd_conflicts, (int64_t)h->max_in_deg * 100000 + h->max_out_deg,
                            h->res_stats.K, h->res_stats.slots_f, h->res_stats.slots_b, h->res_stats.conflicts_f,
                            h->res_stats.conflicts_b, (int64_t)h->dev.res.f.R * 100000 + h->dev.res.b.R,
-                           h->fac_stats.ok, h->fac_stats.matched, h->fac_stats.solo, h->fac_stats.tail,
+                           h->fac_stats.ok, h->fac_stats.matched, (int64_t)h->regauged, h->fac_stats.tail,
                            h->fac_stats.slots_f, h->fac_stats.slots_b, h->fac_stats.fused,
                            h->fac_stats.Gf * 100000 + h->fac_stats.Gb};
     for (int i = 0; i < n && i < 24; ++i) out[i] = v[i];

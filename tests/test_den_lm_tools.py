@@ -114,9 +114,9 @@ def test_cli_and_bad_input(tmp_path):
 def test_factoring_survives_openfst_style_rewrites(tmp_path):
     """den_lm files come out of ``fstcompose | fstdeterminizestar --use-log=true`` (cat/utils/tool/prep_den_lm.sh:48-49):
     state numbers and arc order are whatever those tools leave.  The graph compiler must find the T o LM structure
-    (factored layout: one CU per recursion) under ANY numbering and arc order; a weight-pushed graph (potentials moved
-    along the arcs -- determinizestar does not do this to an input-deterministic graph, but other OpenFst tools would)
-    is still compiled, into the generic layout.  Host-only compile: no GPU needed."""
+    (factored layout: one CU per recursion) under ANY numbering and arc order, and in a weight-pushed graph too (potentials
+    moved along the arcs -- determinizestar does not do this to an input-deterministic graph, but other OpenFst tools
+    would): fst_graph.cpp regauge_pushed.  Host-only compile: no GPU needed."""
     from cat_amd.ctc_crf import _C
     from tests.util import transform_graph
 
@@ -136,10 +136,21 @@ def test_factoring_survives_openfst_style_rewrites(tmp_path):
         s = stats(q)
         assert s["fac"] == 1 and s["fac_matched_pairs"] == base["fac_matched_pairs"]
         assert s["fac_fwd_slots"] == base["fac_fwd_slots"] and s["fac_bwd_slots"] == base["fac_bwd_slots"]
+    # a weight-pushed graph: the compiler re-gauges it (its own potentials undo the constant log-weight difference between
+    # the two states of a history) and the factored layout is back, same size; CRF_NO_REGAUGE=1: generic layout
     q = str(tmp_path / "pushed.fst")
     transform_graph(g, q, seed=5, renumber=True, reorder=True, push=True)
     s = stats(q)
-    assert s["S"] == base["S"] and s["A"] == base["A"] and (s["fac"] == 1 or s["res_K"] >= 1)
+    assert s["S"] == base["S"] and s["A"] == base["A"]
+    assert s["regauged"] == 1 and s["fac"] == 1 and s["fac_matched_pairs"] == base["fac_matched_pairs"]
+    assert s["fac_fwd_slots"] == base["fac_fwd_slots"] and s["fac_bwd_slots"] == base["fac_bwd_slots"]
+    assert base["regauged"] == 0
+    os.environ["CRF_NO_REGAUGE"] = "1"
+    try:
+        s = stats(q)
+    finally:
+        del os.environ["CRF_NO_REGAUGE"]
+    assert s["regauged"] == 0 and (s["fac"] == 0 or s["fac_matched_pairs"] < base["fac_matched_pairs"]) and (s["fac"] == 1 or s["res_K"] >= 1)
 
 
 def test_reference_fixture_layout(golden_dir):

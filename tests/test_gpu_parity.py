@@ -248,8 +248,8 @@ def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
 def test_rewritten_den_lm_vs_oracle(crf, tmp_path, push):
     """A den_lm as OpenFst tools leave it (cat/utils/tool/prep_den_lm.sh:48-49): states re-numbered, arcs of a state in
     another order, optionally weights pushed along the arcs.  Same loss and gradient as the ORIGINAL graph's oracle (the
-    rewrites preserve every path weight; pushing only up to fp32 rounding of the new weights), and the re-numbered
-    graph keeps the factored layout."""
+    rewrites preserve every path weight; pushing only up to fp32 rounding of the new weights), and the rewritten graph
+    keeps the factored layout (a pushed one after the compiler has re-gauged it, fst_graph.cpp regauge_pushed)."""
     from tests.util import transform_graph
     g, p = small_synth(tmp_path, 24, 96, 8, 13)
     q = os.path.join(str(tmp_path), "rewritten.fst")
@@ -260,11 +260,11 @@ def test_rewritten_den_lm_vs_oracle(crf, tmp_path, push):
     ref = oracle.ctc_crf(g2, logits, labels, lx, ly, lamb=0.1)
     assert abs(ref["loss"] - ref0["loss"]) <= (1e-4 if push else 1e-6) * abs(ref0["loss"])   # the rewrite itself
     loss, grad = run_hip(crf, q, logits, labels, lx, ly, lamb=0.1)
-    if not push:
-        with _mode("factored"):
-            ctx = crf.CRFContext(q, 0)
-        assert crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))["fac"] == 1
-        del ctx
+    with _mode("factored"):
+        ctx = crf.CRFContext(q, 0)
+    st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+    assert st["fac"] == 1 and st["regauged"] == (1 if push else 0)   # (pushed: the compiler's own potentials bring the structure back)
+    del ctx
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
 
