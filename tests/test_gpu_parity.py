@@ -123,20 +123,25 @@ def test_fixture_costs_and_gpu_den_gpu_ctc(crf, golden_dir):
     del ctx
 
 
-def test_random_golden(crf, golden_dir):
+@pytest.mark.parametrize("force_batch", [0, 1])
+def test_random_golden(crf, golden_dir, force_batch):
+    """Random tiny GENERAL graphs (states entered with several labels, states nobody enters) against the brute-force
+    enumerator's values; force_batch: the same through the utterance-minor kernels, whose arc streams take only the rows
+    with one entering pair -- these graphs exercise the per-row path for the others inside the same launches."""
     cases = json.load(open(os.path.join(golden_dir, "kat_random.json")))
     core = crf._C
-    for c in cases:
-        ctx = crf.CRFContext(os.path.join(golden_dir, c["fst"]), 0)
-        lg = torch.tensor(np.array(c["logits"], dtype=np.float32)[None], device="cuda:0")
-        T = lg.shape[1]
-        gd = torch.zeros_like(lg)
-        ca, cb = torch.zeros(1, device="cuda:0"), torch.zeros(1, device="cuda:0")
-        core.gpu_den(lg, gd, torch.tensor([T], dtype=torch.int32).cuda(), ca, cb)
-        assert abs(ca.item() - c["logZ_den"]) <= TOL * max(1.0, abs(c["logZ_den"])), c["fst"]
-        assert abs(cb.item() - c["logZ_den"]) <= TOL * max(1.0, abs(c["logZ_den"])), c["fst"]
-        assert rel_err(gd[0].cpu().numpy(), np.array(c["gamma_den"])) <= TOL, c["fst"]
-        del ctx
+    with _env(CRF_FORCE_BATCH=force_batch):
+        for c in cases:
+            ctx = crf.CRFContext(os.path.join(golden_dir, c["fst"]), 0)
+            lg = torch.tensor(np.array(c["logits"], dtype=np.float32)[None], device="cuda:0")
+            T = lg.shape[1]
+            gd = torch.zeros_like(lg)
+            ca, cb = torch.zeros(1, device="cuda:0"), torch.zeros(1, device="cuda:0")
+            core.gpu_den(lg, gd, torch.tensor([T], dtype=torch.int32).cuda(), ca, cb)
+            assert abs(ca.item() - c["logZ_den"]) <= TOL * max(1.0, abs(c["logZ_den"])), c["fst"]
+            assert abs(cb.item() - c["logZ_den"]) <= TOL * max(1.0, abs(c["logZ_den"])), c["fst"]
+            assert rel_err(gd[0].cpu().numpy(), np.array(c["gamma_den"])) <= TOL, c["fst"]
+            del ctx
 
 
 @pytest.mark.parametrize("mode", MODES)
