@@ -1051,7 +1051,9 @@ struct ResParams {
 // LDS map of the resident kernels: the two state-vector buffers sit at byte offsets 0 and kResXB; a gather
 // is `ds_read_b32 v, (buffer base SGPR + 16-bit offset from the packed arc word)` -- one VALU (an SDWA add)
 // per arc besides the FMA.
-constexpr int kResXB = 32768;                 // bytes per state-vector buffer  -> gather vector <= 8192 entries
+constexpr int kResXB = 65536;                 // bytes per state-vector buffer  -> gather vector <= 16384 entries (16-bit byte offsets);
+                                              // 32 KiB until round 2: graphs of 8 k - 16 k states fell to the utterance-minor kernels (27 ms
+                                              // instead of ~14 at S = 8193 / A = 208 k)
 constexpr int kResGmax = kResXB / 4;
 
 template <int DIR>
@@ -3427,6 +3429,12 @@ extern "C" {
 int64_t crf_workspace_bytes(const crf_graph *g, int64_t B, int64_t T, int64_t V, int64_t max_label_len) {
     const int64_t Sc = rup64((int)(2 * max_label_len + 1));
     return ws_layout(g ? g->h : nullptr, B, T, V, Sc).total;
+}
+
+int crf_den_kernels(const crf_graph *g, int64_t B, int64_t T, int64_t V) {
+    if (!g || !g->h) { set_error("null graph"); return -1; }
+    const WsLayout w = ws_layout(g->h, B, T, V, 64);
+    return w.bat ? 3 : w.fac ? 2 : w.res ? 1 : 0;
 }
 
 static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dtype, const int32_t *labels, const int32_t *lab_off,

@@ -35,6 +35,8 @@ _lib.crf_graph_stats.argtypes = [_vp, ctypes.POINTER(_i64), ctypes.c_int]
 _lib.crf_graph_stats.restype = ctypes.c_int
 _lib.crf_workspace_bytes.argtypes = [_vp, _i64, _i64, _i64, _i64]
 _lib.crf_workspace_bytes.restype = _i64
+_lib.crf_den_kernels.argtypes = [_vp, _i64, _i64, _i64]
+_lib.crf_den_kernels.restype = ctypes.c_int
 _lib.crf_loss_fwd_bwd.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _f32,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]
 _lib.crf_loss_fwd_bwd.restype = ctypes.c_int
@@ -54,7 +56,7 @@ _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
-    "crf_workspace_bytes", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
+    "crf_workspace_bytes", "crf_den_kernels", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
     "crf_last_error", "crf_version",
 )
 
@@ -104,6 +106,14 @@ def graph_stats(handle: int):
     d["res_fwd_rows"], d["res_bwd_rows"] = d["res_rows"] // 100000, d.pop("res_rows") % 100000
     d["fac_Gf"], d["fac_Gb"] = d["fac_G"] // 100000, d.pop("fac_G") % 100000
     return d
+
+
+def den_kernels(handle: int, B: int, T: int, V: int) -> str:
+    """Which denominator kernels a call of this shape takes (include/ctc_crf_hip.h crf_den_kernels)."""
+    k = _lib.crf_den_kernels(_vp(handle), B, T, V)
+    if k < 0:
+        _check(1)
+    return ("streaming", "resident", "factored", "batch")[k]
 
 
 def timing_read(n: int = 16384):

@@ -68,7 +68,7 @@ int crf_graph_dims(const crf_graph *g, int64_t *num_states, int64_t *num_arcs, i
  * (0 = graph too large, streaming kernels are used), forward / backward arc slots incl. padding,
  * forward / backward extra LDS cycles (busiest bank per half-wave gather), forward_rows*100000 + backward_rows;
  * out[16..23] = factored layout (one CU per recursion, T o LM structure): available (0/1), matched state pairs,
- * solo slots, single-gather (tail) rows, forward / backward arc slots, fused backward rows, Gf*100000 + Gb.
+ * weights re-gauged (0/1), single-gather (tail) rows, forward / backward arc slots, fused backward rows, Gf*100000 + Gb.
  * A graph created with device < 0 is compiled on the host
  * only (no GPU needed) and can be used with crf_graph_dims / crf_graph_stats / crf_graph_destroy. */
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n);
@@ -77,6 +77,11 @@ int crf_graph_stats(const crf_graph *g, int64_t *out, int n);
  * (binding.cpp:77-79): bytes of device scratch crf_loss_fwd_bwd needs.  `g` may be NULL when
  * c_den == 0 (plain CTC).  `max_label_len` >= max(ly). */
 int64_t crf_workspace_bytes(const crf_graph *g, int64_t B, int64_t T, int64_t V, int64_t max_label_len);
+
+/* Which denominator kernels a call of this shape takes (no reference counterpart: the reference has one set of kernels,
+ * den_calculate.cu:63-261, for every graph): 0 streaming, 1 generic register-resident (K CUs per recursion),
+ * 2 factored register-resident, 3 utterance-minor; < 0 on error.  Diagnostics / bench labels. */
+int crf_den_kernels(const crf_graph *g, int64_t B, int64_t T, int64_t V);
 
 /* The hot path.  Replaces, in one call and with no host synchronisation:
  *   gpu_ctc  (binding.cpp:86-117  -> compute_ctc_loss, ctc_entrypoint.cu:29-60)

@@ -553,6 +553,25 @@ def test_large_graph_global_vectors(crf, tmp_path, path):
     assert rel_err(grad, ref["grad"]) <= TOL
 
 
+def test_resident_layout_beyond_8k_states(crf, tmp_path):
+    """A graph with 8 k < S <= 16 k states on the generic register-resident layout (K CUs per recursion exchanging the state
+    vector every frame): its gather vector needs the 64 KiB state-vector buffers (16-bit LDS byte offsets: <= 16 384 entries)."""
+    g, p = small_synth(tmp_path, 72, 4500, 8, 2)
+    assert 8192 < g["S"] <= 16384
+    B, T, V = 3, 40, 72
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=2, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    with _mode("resident"):
+        ctx = crf.CRFContext(p, 0)
+        h = crf._C.graph_for(torch.device("cuda", 0))
+        st = crf._C.graph_stats(h)
+        assert st["res_K"] >= 1 and crf._C.den_kernels(h, B, T, V) == "resident", st
+        del ctx
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode="resident")
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
 def test_large_vocab(crf, tmp_path):
     """V = 5000 output units (BASELINE config #5's vocabulary) on a small BPE-like graph."""
     from cat_amd.den_lm import synth_den_lm
