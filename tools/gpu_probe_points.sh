@@ -1,3 +1,6 @@
+#!/bin/bash
+# tools/gpu_probe_points.sh -- probe points around the limits: a graph just above the factored capacity, larger vocabularies, short
+# utterances, a batch between 64 and 128 per GPU (one JSON each under gpurun_out/pr_*.json)
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 run() { name=$1; shift; timeout 300 python bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > $OUT/pr_$name.json 2> $OUT/pr_$name.err
   python - <<PY
