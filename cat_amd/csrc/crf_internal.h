@@ -230,6 +230,8 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // Arc streams for UL (8, 16, 32 or 64) utterances per group cut into about `want` tasks per direction, built and uploaded
 // on first use (thread-safe; a graph keeps every variant it has been asked for).
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out);
+// Host-side construction + self-check of the arc streams (tests; works on host-only graphs).
+int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4);
 int read_fst_file(const char *path, int64_t *S, std::vector<int32_t> *src, std::vector<int32_t> *dst,
                   std::vector<int32_t> *lab, std::vector<float> *w, std::vector<float> *start_w,
                   std::vector<float> *end_w);

@@ -238,8 +238,9 @@ int upload(HostGraph *h, const std::vector<T> &v, const T **out) {
 }
 
 // One direction's arc stream (crf_internal.h: StreamDirDev).  rows / row_st / arcs: the BatchDev tables of that direction.
-static int build_stream_dir(HostGraph *h, int AL, int UL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
-                            const std::vector<int2> &arcs, StreamDirDev *out) {
+struct StreamHost { std::vector<int4> tasks, meta; std::vector<int2> recs; std::vector<int> rest; };
+static int build_stream_host(int AL, int UL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
+                             const std::vector<int2> &arcs, StreamHost *sh) {
     constexpr int kB = 4;                                 // steps per batch (crf_kernels.hip: kStreamBatch)
     std::vector<int> simple, rest;
     for (int r = 0; r < (int)rows.size(); ++r) {
@@ -294,9 +295,84 @@ static int build_stream_dir(HostGraph *h, int AL, int UL, int task_steps, const 
     }
     close_task(nbund);
     for (int k = 0; k < 1024; ++k) recs.push_back(int2{0, 0});            // the kernels stage whole 4 KB chunks, one chunk ahead
-    out->ntasks = (int)tasks.size(); out->nrest = (int)rest.size();
+    sh->tasks = std::move(tasks); sh->meta = std::move(meta); sh->recs = std::move(recs); sh->rest = std::move(rest);
+    return CRF_OK;
+}
+
+static int build_stream_dir(HostGraph *h, int AL, int UL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
+                            const std::vector<int2> &arcs, StreamDirDev *out) {
+    StreamHost sh;
     int rc;
-    if ((rc = upload(h, tasks, &out->tasks)) || (rc = upload(h, recs, &out->recs)) || (rc = upload(h, meta, &out->meta)) || (rc = upload(h, rest, &out->rest))) return rc;
+    if ((rc = build_stream_host(AL, UL, task_steps, rows, row_st, arcs, &sh))) return rc;
+    out->ntasks = (int)sh.tasks.size(); out->nrest = (int)sh.rest.size();
+    if ((rc = upload(h, sh.tasks, &out->tasks)) || (rc = upload(h, sh.recs, &out->recs)) || (rc = upload(h, sh.meta, &out->meta)) || (rc = upload(h, sh.rest, &out->rest))) return rc;
+    return CRF_OK;
+}
+
+// Host-side check of the arc streams (tests; no GPU): every row with one entering pair and at least one arc is in exactly one
+// bundle of exactly one task, its records are its arcs (index * UL, weight bits) in order followed by null records, the
+// end-of-bundle flag sits in the first record of the bundle's last batch for every lane group and nowhere else, a task has
+// at most 8 bundles, every other row is in `rest`.  out: {tasks, rest rows, steps, arc records that are not padding}.
+static int check_stream_host(int AL, int UL, const StreamHost &sh, const std::vector<int4> &rows, const std::vector<int> &row_st,
+                             const std::vector<int2> &arcs, int64_t *out) {
+    constexpr int kB = 4;
+    auto fail = [&](const char *why) { set_error(std::string("arc stream check: ") + why); return CRF_ERR_ARG; };
+    std::vector<int> row_of_state_pair;                   // rows are identified by (state, pair id)
+    std::vector<char> seen(rows.size(), 0);
+    std::map<std::pair<int, int>, int> row_at;
+    for (int r = 0; r < (int)rows.size(); ++r) if ((rows[(size_t)r].w & 0x40000000) && rows[(size_t)r].y > rows[(size_t)r].x) row_at[{row_st[(size_t)r], rows[(size_t)r].z}] = r;
+    int64_t steps = 0, real = 0;
+    int next_bundle = 0;
+    for (const int4 &t : sh.tasks) {
+        if (t.w < 1 || t.w > 8) return fail("a task has no or more than 8 bundles");
+        if (t.z != next_bundle) return fail("the tasks do not cover the bundles in order");
+        next_bundle += t.w;
+        int batch = t.x;
+        for (int b = 0; b < t.w; ++b) {
+            // length of this bundle: up to the batch that carries the flag
+            int nbat = 0;
+            for (;;) {
+                if (batch + nbat >= t.x + t.y) return fail("a bundle runs past its task");
+                const int2 first = sh.recs[((size_t)(batch + nbat) * AL + 0) * kB];
+                ++nbat;
+                if (first.x < 0) break;
+            }
+            for (int aj = 0; aj < AL; ++aj) {
+                const int4 m = sh.meta[(size_t)(t.z + b) * AL + aj];
+                int n = 0, a0 = 0;
+                if (m.x >= 0) {
+                    auto it = row_at.find({m.x, m.y});
+                    if (it == row_at.end()) return fail("a descriptor names a row that is not a stream row");
+                    const int r = it->second;
+                    if (seen[(size_t)r]) return fail("a row appears twice");
+                    seen[(size_t)r] = 1;
+                    if ((rows[(size_t)r].w & 0xffff) != m.z) return fail("label of a descriptor");
+                    n = rows[(size_t)r].y - rows[(size_t)r].x; a0 = rows[(size_t)r].x;
+                    if (n > nbat * kB) return fail("a row is longer than its bundle");
+                }
+                for (int st = 0; st < nbat * kB; ++st) {
+                    const int2 rc = sh.recs[((size_t)(batch + st / kB) * AL + aj) * kB + st % kB];
+                    const bool flag = rc.x < 0, want_flag = st == (nbat - 1) * kB;
+                    if (flag != want_flag) return fail("end-of-bundle flag");
+                    const int idx = rc.x & 0x7fffffff;
+                    if (st < n) {
+                        if (idx != arcs[(size_t)a0 + st].x * UL || rc.y != arcs[(size_t)a0 + st].y) return fail("a record is not its arc");
+                        ++real;
+                    } else if (idx != 0 || rc.y != 0) return fail("padding record is not null");
+                }
+            }
+            batch += nbat; steps += (int64_t)nbat * kB;
+        }
+        if (batch != t.x + t.y) return fail("batches of a task");
+    }
+    int64_t nrest = 0;
+    std::vector<char> in_rest(rows.size(), 0);
+    for (int r : sh.rest) { if (r < 0 || r >= (int)rows.size() || in_rest[(size_t)r]) return fail("rest list"); in_rest[(size_t)r] = 1; ++nrest; }
+    for (int r = 0; r < (int)rows.size(); ++r) {
+        const bool simple = (rows[(size_t)r].w & 0x40000000) && rows[(size_t)r].y > rows[(size_t)r].x;
+        if (simple != (seen[(size_t)r] != 0) || simple == (in_rest[(size_t)r] != 0)) return fail("a row is in neither or both of stream and rest");
+    }
+    out[0] += (int64_t)sh.tasks.size(); out[1] += nrest; out[2] += steps; out[3] += real;
     return CRF_OK;
 }
 
@@ -313,14 +389,8 @@ int upload_ell(HostGraph *h, const EllHost &e, EllDev *d) {
 
 }  // namespace
 
-int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) {
-    const int AL = 256 / std::max(UL, 1);                 // lane groups: a lane takes 4 utterances, UL / 4 lanes a row
-    static std::mutex mu;
-    if (!h || !(UL == 8 || UL == 16 || UL == 32 || UL == 64) || want < 1 || !h->dev.bat.ok) { set_error("ensure_stream_tables: bad arguments"); return CRF_ERR_ARG; }
-    std::lock_guard<std::mutex> lock(mu);
-    for (StreamDev *sd : h->streams)
-        if (sd->AL == AL && sd->want == want) { *out = sd; return CRF_OK; }
-    // steps per task: the longer direction's steps (rows padded to whole batches of 4) over the tasks wanted; CRF_BAT_TASK overrides
+// steps per task: the longer direction's steps (rows padded to whole batches of 4) over the tasks wanted; CRF_BAT_TASK overrides
+static int stream_task_steps(const HostGraph *h, int AL, int want) {
     auto steps_of = [&](const std::vector<int4> &rows) {
         int64_t n = 0;
         for (const int4 &d : rows) if ((d.w & 0x40000000) && d.y > d.x) n += (d.y - d.x + 3) / 4 * 4;
@@ -329,6 +399,34 @@ int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) 
     const int64_t steps = std::max(steps_of(h->hb_frow), steps_of(h->hb_brow));
     int task_steps = (int)std::min<int64_t>(4096, std::max<int64_t>(64, ((steps + want - 1) / want + 3) / 4 * 4));
     if (getenv("CRF_BAT_TASK")) task_steps = std::max(8, atoi(getenv("CRF_BAT_TASK")));
+    return task_steps;
+}
+
+// Builds the arc streams of both directions on the host and checks them (check_stream_host); no device needed.
+int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4) {
+    if (!h || !(UL == 8 || UL == 16 || UL == 32 || UL == 64) || want < 1 || !out4) { set_error("debug_check_streams: bad arguments"); return CRF_ERR_ARG; }
+    const int AL = 256 / UL, task_steps = stream_task_steps(h, AL, want);
+    for (int i = 0; i < 4; ++i) out4[i] = 0;
+    for (int dir = 0; dir < 2; ++dir) {
+        const std::vector<int4> &rows = dir == 0 ? h->hb_frow : h->hb_brow;
+        const std::vector<int> &st = dir == 0 ? h->hb_frow_d : h->hb_brow_s;
+        const std::vector<int2> &arcs = dir == 0 ? h->hb_farcs : h->hb_barcs;
+        StreamHost sh;
+        int rc = build_stream_host(AL, UL, task_steps, rows, st, arcs, &sh);
+        if (!rc) rc = check_stream_host(AL, UL, sh, rows, st, arcs, out4);
+        if (rc) return rc;
+    }
+    return CRF_OK;
+}
+
+int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) {
+    const int AL = 256 / std::max(UL, 1);                 // lane groups: a lane takes 4 utterances, UL / 4 lanes a row
+    static std::mutex mu;
+    if (!h || !(UL == 8 || UL == 16 || UL == 32 || UL == 64) || want < 1 || !h->dev.bat.ok) { set_error("ensure_stream_tables: bad arguments"); return CRF_ERR_ARG; }
+    std::lock_guard<std::mutex> lock(mu);
+    for (StreamDev *sd : h->streams)
+        if (sd->AL == AL && sd->want == want) { *out = sd; return CRF_OK; }
+    const int task_steps = stream_task_steps(h, AL, want);
     int prev = 0;
     if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(h->device) != hipSuccess) { set_error("ensure_stream_tables: cannot select the graph's device"); return CRF_ERR_HIP; }
     auto *sd = new StreamDev();
@@ -564,6 +662,8 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     GraphDev &d0 = h->dev;
     d0.S = (int)S; d0.A = (int)A; d0.P = P; d0.Pr = Pr; d0.Sr = Sr; d0.max_label = max_label;
     d0.NC = (int)chunk_off.size() - 1;
+    h->hb_farcs = b_farcs; h->hb_barcs = b_barcs; h->hb_frow = b_frow; h->hb_brow = b_brow;   // (kept: arc streams are cut from them on first use)
+    h->hb_frow_d = b_frow_d; h->hb_brow_s = b_brow_s;
     if (device < 0) {  // host-only compile (diagnostics / CPU tests): tables are built, nothing is uploaded
         h->device = -1;
         int rcr = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon);
@@ -599,8 +699,6 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
             (rc = upload(h, b_stp, &d.bat.stp)) || (rc = upload(h, b_barcs, &d.bat.barcs)) || (rc = upload(h, b_brow_s, &d.bat.brow_s)) ||
             (rc = upload(h, b_brow, &d.bat.brow)) || (rc = upload(h, b_lab_off, &d.bat.lab_off))) break;
         d.bat.ok = 1;
-        h->hb_farcs = std::move(b_farcs); h->hb_barcs = std::move(b_barcs); h->hb_frow = std::move(b_frow); h->hb_brow = std::move(b_brow);
-        h->hb_frow_d = std::move(b_frow_d); h->hb_brow_s = std::move(b_brow_s);
         if ((rc = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon))) break;
         if ((rc = build_factored(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin))) break;
     } while (0);
@@ -674,6 +772,11 @@ int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
                            h->fac_stats.Gf * 100000 + h->fac_stats.Gb};
     for (int i = 0; i < n && i < 24; ++i) out[i] = v[i];
     return CRF_OK;
+}
+
+int crf_debug_stream_check(const crf_graph *g, int UL, int want, int64_t *out4) {
+    if (!g || !g->h) { crf::set_error("null graph"); return CRF_ERR_ARG; }
+    return crf::debug_check_streams(g->h, UL, want, out4);
 }
 
 const char *crf_last_error(void) { return crf::last_error_cstr(); }

@@ -83,6 +83,12 @@ int64_t crf_workspace_bytes(const crf_graph *g, int64_t B, int64_t T, int64_t V,
  * 2 factored register-resident, 3 utterance-minor; < 0 on error.  Diagnostics / bench labels. */
 int crf_den_kernels(const crf_graph *g, int64_t B, int64_t T, int64_t V);
 
+/* Test aid (no reference counterpart): builds the arc streams of the utterance-minor kernels for UL utterances per group and
+ * about `want` tasks per direction ON THE HOST and checks them against the graph's row tables (every row once, records = arcs,
+ * flags, task limits); works on host-only graphs.  out4 = {tasks, rows outside the streams, steps, arc records}, both
+ * directions summed. */
+int crf_debug_stream_check(const crf_graph *g, int UL, int want, int64_t *out4);
+
 /* The hot path.  Replaces, in one call and with no host synchronisation:
  *   gpu_ctc  (binding.cpp:86-117  -> compute_ctc_loss, ctc_entrypoint.cu:29-60)
  *   gpu_den  (binding.cpp:65-84   -> compute_alpha + compute_beta_and_grad, den_calculate.cu:427-481)

@@ -161,3 +161,51 @@ def test_reference_fixture_layout(golden_dir):
     s = _C.graph_stats(h)
     _C._lib.crf_graph_destroy(_C._vp(h))
     assert s["S"] == 9 and s["fac"] == 1 and s["fac_matched_pairs"] == 4
+
+
+@pytest.mark.parametrize("UL", [8, 16, 32, 64])
+def test_arc_streams_of_the_utterance_minor_kernels(tmp_path, golden_dir, UL):
+    """The arc streams the utterance-minor kernels walk (fst_graph.cpp: build_stream_host) are built on the HOST for several
+    graphs and checked record by record against the graph's row tables (crf_debug_stream_check): every row with one entering
+    pair once, its records = its arcs in order, end-of-bundle flags, at most 8 bundles per task; the other rows in the rest
+    list.  Graphs: T o LM synthetic, an estimated n-gram graph with rows of hundreds of arcs, random general graphs (states
+    entered with several labels), the reference's 9-state fixture."""
+    import json
+    from cat_amd.ctc_crf import _C
+
+    def check(path, want):
+        h = _C.compile_graph_host_only(path)
+        st = _C.graph_stats(h)
+        r = _C.debug_stream_check(h, UL, want)
+        _C._lib.crf_graph_destroy(_C._vp(h))
+        return st, r
+
+    p = str(tmp_path / "tolm.fst")
+    den_lm.synth_den_lm(72, 300, 10, seed=1, path=p)
+    st, r = check(p, 64)
+    # both directions: every arc is a record exactly once, except the arcs of the rows that are not in the streams (the start
+    # state: nobody enters it, so it is a per-row case in both directions -- its out-arcs are missing from the backward stream)
+    assert r["rest_rows"] <= 2 and 2 * st["A"] - st["max_out_deg"] <= r["arc_records"] <= 2 * st["A"] and r["tasks"] >= 2
+    assert r["steps"] * (256 // UL) * 1 >= r["arc_records"] // 2             # (padding only adds)
+    st, r2 = check(p, 100000)                                    # more tasks wanted than bundles exist: still whole bundles
+    assert r2["arc_records"] == r["arc_records"] and r2["tasks"] >= r["tasks"]   # (a task has at least 64 steps)
+    V = 40                                                       # (the corpus of test_factored_layout_takes_an_estimated_ngram_graph)
+    rng = np.random.default_rng(3)
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(1200):
+        sq, a, b = [], 0, 0
+        for _ in range(int(rng.integers(8, 30))):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b]))
+            sq.append(c)
+            a, b = b, c
+        seqs.append(sq)
+    q = str(tmp_path / "est.fst")
+    den_lm.prep_den_lm(seqs, V, q, 4, 3, 150)
+    st, r = check(q, 16)
+    assert 2 * st["A"] - st["max_out_deg"] <= r["arc_records"] <= 2 * st["A"] and st["max_in_deg"] > 64
+    for c in json.load(open(os.path.join(golden_dir, "kat_random.json"))):
+        st, r = check(os.path.join(golden_dir, c["fst"]), 4)
+        assert r["arc_records"] <= 2 * st["A"]
+    st, r = check(os.path.join(golden_dir, "den_lm_fixture.fst"), 4)
+    assert r["arc_records"] > 0
