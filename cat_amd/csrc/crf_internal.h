@@ -153,6 +153,24 @@ struct BatchDev {
 //   [batch][AL lane groups][4 records {entry * UL | flag, weight bits}]     (bit 31 of a batch's first record: the bundle ends)
 // which the wave copies to LDS 4 KB at a time, one chunk ahead: its memory queue holds the gathers of the state vector --
 // D batches deep -- and, at bundle ends, a row's stores and the emissions of the bundle after the next.
+// Which (utterance group, direction) combo a workgroup of crf_batch_frame_kernel works for, and which of the combo's
+// workgroups ("chunks") it is -- from its block id alone.  Block b sits on XCD b % 8 (observed; a matter of speed only):
+//   #combos <  8: XCD x serves combo x % #combos together with the other XCDs of that residue, the combo's chunks dealt
+//                 round-robin among them;
+//   #combos >= 8: XCD x serves the combos x, x + 8, ..., its slots dealt round-robin among them.
+// grid = 8 * nslot blocks.  Every (combo, chunk < nchunk(combo)) is taken by exactly one block (tests/test_abi.py).
+__host__ __device__ inline void bat_decode(int block, int grid, int ncombo, int *combo, int *chunk, int *nchunk) {
+    const int x = block & 7, slot = block >> 3, nslot = grid >> 3;
+    if (ncombo >= 8) {
+        const int ncx = (ncombo - x + 7) >> 3, k = slot % ncx;
+        *combo = x + 8 * k; *chunk = slot / ncx; *nchunk = (nslot - k + ncx - 1) / ncx;
+    } else {
+        *combo = x % ncombo;
+        const int k = x / ncombo, nk = (8 - *combo + ncombo - 1) / ncombo;
+        *chunk = slot * nk + k; *nchunk = nslot * nk;
+    }
+}
+
 struct StreamDirDev {
     const int4 *tasks;       // [ntasks] {first batch, batches, first bundle, bundles}
     const int2 *recs;        // [batches][AL][4] (+ 8 KB of padding)
@@ -232,6 +250,8 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out);
 // Host-side construction + self-check of the arc streams (tests; works on host-only graphs).
 int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4);
+// Host-side check of bat_decode for one (grid, #combos): 0 = every (combo, chunk) exactly once.
+int debug_check_decode(int nslot, int ncombo);
 int read_fst_file(const char *path, int64_t *S, std::vector<int32_t> *src, std::vector<int32_t> *dst,
                   std::vector<int32_t> *lab, std::vector<float> *w, std::vector<float> *start_w,
                   std::vector<float> *end_w);

@@ -2491,17 +2491,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
     const int uq = lane % LG, sj = lane / LG;                      // stream: utterances 4 uq .. 4 uq + 3, row sj of the bundle
     const int T = p.T, S = p.S, P = p.P;
     int combo, chunk, nchunk;
-    {
-        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3, ncombo = 2 * p.ngrp;
-        if (ncombo >= 8) {
-            const int ncx = (ncombo - x + 7) >> 3, k = slot % ncx;
-            combo = x + 8 * k; chunk = slot / ncx; nchunk = (nslot - k + ncx - 1) / ncx;
-        } else {
-            combo = x % ncombo;
-            const int k = x / ncombo, nk = (8 - combo + ncombo - 1) / ncombo;
-            chunk = slot * nk + k; nchunk = nslot * nk;
-        }
-    }
+    bat_decode((int)blockIdx.x, (int)gridDim.x, 2 * p.ngrp, &combo, &chunk, &nchunk);   // (crf_internal.h)
     const int dir = combo & 1, grp = combo >> 1;
     const int u = grp * UL + ul;
     const int lx = u < p.B ? p.lx[u] : 0;

@@ -402,6 +402,26 @@ static int stream_task_steps(const HostGraph *h, int AL, int want) {
     return task_steps;
 }
 
+int debug_check_decode(int nslot, int ncombo) {
+    if (nslot < 1 || ncombo < 1) { set_error("debug_check_decode: bad arguments"); return CRF_ERR_ARG; }
+    std::map<std::pair<int, int>, int> seen;
+    std::vector<int> nch((size_t)ncombo, -1);
+    for (int b = 0; b < 8 * nslot; ++b) {
+        int combo, chunk, nchunk;
+        bat_decode(b, 8 * nslot, ncombo, &combo, &chunk, &nchunk);
+        if (combo < 0 || combo >= ncombo) continue;      // (more XCDs than combos' residues can fill: a block without work)
+        if (chunk < 0 || chunk >= nchunk) { set_error("bat_decode: chunk out of range"); return CRF_ERR_ARG; }
+        if (nch[(size_t)combo] >= 0 && nch[(size_t)combo] != nchunk) { set_error("bat_decode: blocks of a combo disagree on its chunk count"); return CRF_ERR_ARG; }
+        nch[(size_t)combo] = nchunk;
+        if (seen[{combo, chunk}]++) { set_error("bat_decode: a (combo, chunk) is taken twice"); return CRF_ERR_ARG; }
+    }
+    for (int c = 0; c < ncombo; ++c) {
+        if (nch[(size_t)c] < 1) { set_error("bat_decode: a combo has no workgroup"); return CRF_ERR_ARG; }
+        for (int k = 0; k < nch[(size_t)c]; ++k) if (!seen.count({c, k})) { set_error("bat_decode: a chunk of a combo is missing"); return CRF_ERR_ARG; }
+    }
+    return CRF_OK;
+}
+
 // Builds the arc streams of both directions on the host and checks them (check_stream_host); no device needed.
 int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4) {
     if (!h || !(UL == 8 || UL == 16 || UL == 32 || UL == 64) || want < 1 || !out4) { set_error("debug_check_streams: bad arguments"); return CRF_ERR_ARG; }
@@ -773,6 +793,8 @@ int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
     for (int i = 0; i < n && i < 24; ++i) out[i] = v[i];
     return CRF_OK;
 }
+
+int crf_debug_decode_check(int nslot, int ncombo) { return crf::debug_check_decode(nslot, ncombo); }
 
 int crf_debug_stream_check(const crf_graph *g, int UL, int want, int64_t *out4) {
     if (!g || !g->h) { crf::set_error("null graph"); return CRF_ERR_ARG; }

@@ -89,6 +89,10 @@ int crf_den_kernels(const crf_graph *g, int64_t B, int64_t T, int64_t V);
  * directions summed. */
 int crf_debug_stream_check(const crf_graph *g, int UL, int want, int64_t *out4);
 
+/* Test aid: the block -> (utterance group, direction, chunk) mapping of the utterance-minor frame kernel for a grid of
+ * 8 * nslot workgroups and `ncombo` combos: 0 when every (combo, chunk) is taken by exactly one workgroup. */
+int crf_debug_decode_check(int nslot, int ncombo);
+
 /* The hot path.  Replaces, in one call and with no host synchronisation:
  *   gpu_ctc  (binding.cpp:86-117  -> compute_ctc_loss, ctc_entrypoint.cu:29-60)
  *   gpu_den  (binding.cpp:65-84   -> compute_alpha + compute_beta_and_grad, den_calculate.cu:427-481)

@@ -147,3 +147,17 @@ def test_factored_layout_takes_an_estimated_ngram_graph(tmp_path):
     assert st["max_in_deg"] > 80                          # longer than a lane
     assert st["fac"] == 1 and st["fac_fwd_slots"] > 0 and st["fac_bwd_slots"] > 0
     assert st["fac_matched_pairs"] >= (st["S"] - 1) // 2 - 2
+
+
+def test_utterance_minor_block_decode():
+    """crf_batch_frame_kernel finds its (utterance group, direction) combo and its chunk from the block id (crf_internal.h:
+    bat_decode, shared by the kernel and this check): for every combo count and grid the host launches -- nslot is at least
+    ceil(#combos / 8) -- every (combo, chunk) must be taken by exactly one workgroup."""
+    import ctc_crf
+    core = ctc_crf._C
+    core._lib.crf_debug_decode_check.argtypes = [ctypes.c_int, ctypes.c_int]
+    for ncombo in range(2, 66, 2):                              # 2 directions x 1..32 groups
+        for nslot in {(ncombo + 7) // 8, (ncombo + 7) // 8 + 1, 7, 16, 33, 128}:
+            if nslot >= (ncombo + 7) // 8:
+                rc = core._lib.crf_debug_decode_check(nslot, ncombo)
+                assert rc == 0, (ncombo, nslot, core._lib.crf_last_error().decode())
