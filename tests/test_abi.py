@@ -161,3 +161,39 @@ def test_utterance_minor_block_decode():
             if nslot >= (ncombo + 7) // 8:
                 rc = core._lib.crf_debug_decode_check(nslot, ncombo)
                 assert rc == 0, (ncombo, nslot, core._lib.crf_last_error().decode())
+
+
+def test_which_kernels_take_which_graph(tmp_path):
+    """crf_den_kernels on host-only graphs: the benchmark graph -> factored (one CU per recursion); 1.5 x its size -> generic
+    register-resident over K CUs; beyond four CUs' registers -> utterance-minor, or round 1's streaming kernels with
+    CRF_NO_BATCH=1; with CRF_NO_FACTORED=1 the benchmark graph takes the generic layout (K = 2)."""
+    import ctc_crf
+    core = ctc_crf._C
+
+    def which(H, d, **env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            p = os.path.join(str(tmp_path), f"g{H}_{d}.fst")
+            if not os.path.exists(p):
+                synth_den_lm(72, H, d, 0, path=p)
+            h = core.compile_graph_host_only(p)
+            st = core.graph_stats(h)
+            k = core.den_kernels(h, 64, 1500, 72)
+            core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+            return k, st
+        finally:
+            for k_, v in old.items():
+                if v is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v
+
+    k, st = which(2048, 24)
+    assert k == "factored" and st["fac"] == 1
+    k, st = which(2048, 24, CRF_NO_FACTORED=1)
+    assert k == "resident" and st["res_K"] == 2
+    k, st = which(3072, 24)
+    assert k == "resident" and st["fac"] == 0 and st["res_K"] == 4
+    k, st = which(4096, 24)                                       # 8193 states: needs the 64 KiB state-vector buffers
+    assert k == "resident" and st["res_K"] == 4 and st["S"] == 8193
