@@ -1574,9 +1574,24 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                         if constexpr (ML) {
                             const unsigned lg = (lgbits >> (3u * ks)) & 7u;
                             if (lg) {
+                                // DPP for groups of up to 16 lanes (pair swap, quad half swap, mirror of 8, mirror of 16: after
+                                // each step every lane of the growing group holds the group's sum, so ANY lane of the other half
+                                // will do); a __shfl_xor is a ds_bpermute round trip (~100+ cycles each, dependent) and cost the
+                                // graphs with long rows -- every den_lm estimated from text -- a quarter of the frame
+#ifndef CRF_AB_ML_SHFL
+#define CRF_DPP_ADD(ctrl) tot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), ctrl, 0xf, 0xf, false))
+                                CRF_DPP_ADD(0xB1);                            // quad_perm [1,0,3,2]
+                                if (lg >= 2) CRF_DPP_ADD(0x4E);               // quad_perm [2,3,0,1]
+                                if (lg >= 3) CRF_DPP_ADD(0x141);              // row_half_mirror
+                                if (lg >= 4) CRF_DPP_ADD(0x140);              // row_mirror
+#undef CRF_DPP_ADD
+                                if (lg >= 5) tot += __shfl_xor(tot, 16, 64);
+                                if (lg >= 6) tot += __shfl_xor(tot, 32, 64);
+#else
 #pragma unroll
                                 for (int q = 0; q < 6; ++q)
                                     if ((unsigned)q < lg) tot += __shfl_xor(tot, 1 << q, 64);
+#endif
                             }
                         }
                         if constexpr (RC) {
