@@ -113,6 +113,23 @@ __device__ __forceinline__ float wave_max(float v) {
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+// LDS float maximum without a returned value (ds_max_f32; the intrinsic, not atomicrmw: the compiler's atomic optimiser turns a
+// same-address atomicrmw of several lanes into a scalar loop over the active lanes)
+__device__ __forceinline__ void lds_fmax(float *lds_ptr, float v) {
+    (void)__builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float *)lds_ptr, v, 0, 0, false);
+}
+// maximum over each row of 16 lanes of NON-NEGATIVE values, left in every lane of the row: on the float bits as integers (they
+// order alike, and an integer maximum takes the DPP operand directly -- fmaxf costs two canonicalising v_max per step on top)
+__device__ __forceinline__ float row_max16(float v) {
+    int b = __builtin_bit_cast(int, v);
+#define CRF_DPP_IMAXB(ctrl) b = max(b, __builtin_amdgcn_update_dpp(0, b, ctrl, 0xf, 0xf, false))
+    CRF_DPP_IMAXB(0x128);
+    CRF_DPP_IMAXB(0x124);
+    CRF_DPP_IMAXB(0x122);
+    CRF_DPP_IMAXB(0x121);
+#undef CRF_DPP_IMAXB
+    return __builtin_bit_cast(float, b);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1001,6 +1018,7 @@ __device__ __forceinline__ float res_fetch(gu64 *slot, float *v, int lo, int hi,
 constexpr int kResBatch = 6;   // measured: 5 -> 6 = -2% (fewer, longer straight-line blocks); 10 spills
 static_assert(kResNCH % kResBatch == 0, "kResNCH must be a multiple of kResBatch");
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Packed math: the four products of a chunk are two v_pk_fma_f32 lanes (PMC showed the frame loop is
 // as much VALU-issue-bound as LDS-bound: ~530 VALU instructions per wave and frame before packing).
 // The 4*kResBatch gathers of a batch; the products are chained FMAs into the row accumulator (measured:
@@ -1462,6 +1480,15 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     float zpart = 0.f;
     for (int s = tid; s < 2 * Gp; s += NTH) X[s] = 0.f;
     if (tid < 2) EP[tid * Vp + V] = 0.f;
+#ifndef CRF_AB_OLDWM
+    // The frame maximum is FOUR LDS words per frame (three sets in rotation: read / accumulated by ds_max_f32 / cleared), one per
+    // row of 16 lanes: a wave's frame top reads them with one ds_read_b128 and works the scale out on the scalar unit; with twelve wave maxima per frame every wave spent ~17 VALU instructions there and ~8 more in the tail --
+    // the frame is bound by instruction issue (timing build: a wave with NO rows still took 520 cycles per frame).
+    if (tid < 12) wm[tid] = 0.f;                             // [3 frames][4 rows of 16 lanes]: distinct addresses per lane (a same-address
+                                                             // LDS atomic of several lanes is turned into a scalar loop by the compiler)
+    const bool rowlead = (lane & 15) == 0;
+    int sr = i0 % 3;                                         // word read by the next frame
+#endif
     if (lx > 0)
         for (int v = tid; v < V; v += NTH) {
             if (DIR == 0) EP[par0 * Vp + v] = p.ep[(bt0 + i0) * V + v];                 // e'_t of the first frame
@@ -1492,8 +1519,13 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         } else {
             for (int r = tid; r < 2 * R; r += NTH) zpart += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
         }
+#ifndef CRF_AB_OLDWM
+        m0 = row_max16(m0);
+        if (rowlead) lds_fmax(wm + sr * 4 + (lane >> 4), m0);
+#else
         m0 = wave_max(m0);
         if (lane == 0) wm[par0 * NW + wave] = m0;
+#endif
     }
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // arcs and tables have landed (see crf_res_chain_kernel)
@@ -1536,7 +1568,15 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #pragma unroll
             for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; if (v < V) epn[q] = er[v]; }
         }
+#ifndef CRF_AB_OLDWM
+        const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
+        const f32x4 m4 = *(const f32x4 *)(wm + sr * 4);
+        const float mfr = fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w));
+        const int ksc = rescale_exp(__uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mfr))));   // (uniform: scalar unit)
+        if (wave == 0 && lane < 4) wm[sz * 4 + lane] = 0.f;
+#else
         const int ksc = rescale_exp(res_frame_max<NW>(wm + par * NW));
+#endif
         const float sc = pow2f(ksc);
         if (DIR == 1) last_sc = sc;
         float *Orow;
@@ -1699,8 +1739,14 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             if (lane == 0 && i == 150) { g_tm[o + 8] = (unsigned long long)nch; g_tm[o + 9] = (unsigned long long)__builtin_popcount(ends); }
         }
 #endif
+#ifndef CRF_AB_OLDWM
+        mymax = row_max16(mymax);
+        if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), mymax);
+        sr = sw;
+#else
         mymax = wave_max(mymax);
         if (lane == 0) wm[(1 - par) * NW + wave] = mymax;
+#endif
         if (pre) {
             float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;
 #pragma unroll
@@ -2007,7 +2053,6 @@ __global__ __launch_bounds__(NT, (NCPT == 1 && EPR == 1 && NT == kGDThreads) ? C
     }
     if (tid < 4) nrm[tid] = 0.f;
     // rows are multiples of 64 floats and 256-byte aligned: 16-byte loads, prefetched one frame ahead
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 qr[kGDRowRegs], br[kGDRowRegs];
     float ern[EPR], rwn[EPR];   // next frame's emissions and (accumulate mode) grad row
 #define CRF_GD_FETCH(t)                                                                                  \
@@ -2376,7 +2421,6 @@ __device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int 
 // the gathers -- D batches of kStreamBatch in flight, consumed in order behind partial vmcnt waits -- and a row's stores;
 // a wait for something just requested happens nowhere.  epi(acc, m, e) is called at every bundle end with the row's
 // descriptor {state, pair, label} and the four utterances' emissions et[label].
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kStreamBatch = 4, kStreamChunk = 128;   // steps per batch; batches * AL per 4 KB chunk (batches in flight: template parameter D)
 constexpr int kStreamBundles = 8;                     // bundles per task at most (fst_graph.cpp: build_stream_dir)
 constexpr int kStreamRecB = kStreamChunk * 32;        // bytes of a chunk of records

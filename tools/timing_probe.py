@@ -26,7 +26,9 @@ def main():
     dev = torch.device("cuda:0")
     B, T, V = 64, 1500, 72
     fst = os.path.join(tempfile.mkdtemp(prefix="crfprobe_"), "den_lm.fst")
-    g = synth_den_lm(V, 2048, 24, seed=0, path=fst)
+    H, D = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2048, 24)   # histories, fan-out of the synthetic den_lm
+    g = synth_den_lm(V, H, D, seed=0, path=fst)
+    print(f"den_lm H={H} d={D}: S={g['S']} A={g['A']}")
     ctx = ctc_crf.CRFContext(fst, 0)  # noqa: F841
     logits, labels, lx, ly = make_batch(g, B, T, V, seed=0, ragged=False)
     x = torch.tensor(logits, device=dev, requires_grad=True)
