@@ -204,6 +204,13 @@ __device__ __forceinline__ int rescale_exp(float m) {
     return k < -100 ? -100 : (k > 100 ? 100 : k);
 }
 __device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
+// the same from the float BITS of a non-negative maximum (integer operations only: on a wave-uniform value they run on the
+// scalar unit; a float compare would not)
+__device__ __forceinline__ int rescale_exp_bits(unsigned bits) {
+    if (bits == 0u) return 0;
+    const int k = kScaleExp + 127 - (int)((bits >> 23) & 0xffu);
+    return k < -100 ? -100 : (k > 100 ? 100 : k);
+}
 
 // ---------------------------------------------------------------------------------------------
 // prep: e[b][t][v] = exp(logp[b][t][v] - max_v) * 2^kEpExp, mx[b][t] = max_v   (one wave per frame)
@@ -1462,9 +1469,9 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     } else if (DIR == 1) {
         f32x2 *RW = (f32x2 *)RMc;                            // the weights of the two extra arcs of a row
         for (int r = tid; r < R; r += NTH) { const int4 m = p.brow_meta[r]; RW[r] = f32x2{__int_as_float(m.y), __int_as_float(m.z)}; }
-        auto fix = [&](unsigned w) {                         // labels: 0xffff = none -> emission 0 at EP[V]
+        auto fix = [&](unsigned w) {                         // emission byte offsets: 0xffff = no label -> emission 0 at EP[V]
             const unsigned l0 = w & 0xffffu, l1 = w >> 16;
-            return (l0 == 0xffffu ? (unsigned)V : l0) | ((l1 == 0xffffu ? (unsigned)V : l1) << 16);
+            return (l0 == 0xffffu ? (unsigned)V * 4u : l0) | ((l1 == 0xffffu ? (unsigned)V * 4u : l1) << 16);
         };
         rc01 = fix(rc01); rc11 = fix(rc11); rc21 = fix(rc21);
     }
@@ -1504,7 +1511,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         if (i0 > 0) {                                        // resume
             float *Xc = X + par0 * Gp;
             for (int s = tid; s < G; s += NTH) { const float v = state[s]; Xc[s] = v; m0 = fmaxf(m0, v); }
-            E = __float_as_int(state[Gp]);
+            E = __builtin_amdgcn_readfirstlane(__float_as_int(state[Gp]));   // (uniform: E lives on the scalar unit)
         } else if (DIR == 0) {
             for (int s = tid; s < G; s += NTH) { const float v = p.x_start[s] * pow2f(kScaleExp); X[s] = v; m0 = fmaxf(m0, v); }
         } else if (lx > 0) {
@@ -1545,6 +1552,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         ++next_stage;
         next_bound = next_stage < p.nb ? p.bound[next_stage] : 0x7fffffff;
     };
+    const bool pre_w = wave * kWave < V;                     // this wave holds emissions
     float last_sc = 1.f;                                     // scale of the last frame (rowless states, after the loop)
     float epn[kEpRegsR] = {};                               // next emission row, in flight across the frame (waves that hold emissions only)
     auto frame = [&](const int par, int i) __attribute__((always_inline)) {
@@ -1562,7 +1570,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         const int tpre = DIR == 0 ? t + 1 : t - 2;
         // (only the waves that hold emissions take part in the prefetch: the compiler waits for vmcnt(0) around these
         // loads -- i.e. for the acknowledgement of the previous frame's row stores -- and the other waves need not)
-        const bool pre = (DIR == 0 ? (t + 1 < lx) : (t >= 2)) && wave * kWave < V;
+        const bool pre = pre_w && (DIR == 0 ? (t + 1 < lx) : (t >= 2));
         if (pre) {
             const float *er = p.ep + (bt0 + tpre) * V;
 #pragma unroll
@@ -1570,9 +1578,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         }
 #ifndef CRF_AB_OLDWM
         const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
-        const f32x4 m4 = *(const f32x4 *)(wm + sr * 4);
-        const float mfr = fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w));
-        const int ksc = rescale_exp(__uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(mfr))));   // (uniform: scalar unit)
+        const int4 m4 = *(const int4 *)(wm + sr * 4);          // (non-negative floats: their bits order like integers)
+        const int ksc = rescale_exp_bits((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
         if (wave == 0 && lane < 4) wm[sz * 4 + lane] = 0.f;
 #else
         const int ksc = rescale_exp(res_frame_max<NW>(wm + par * NW));
@@ -1643,7 +1650,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 
                             if (DIR == 0) {   // k0 = main label | tail label << 16, k1 = tail weight; U, L, A at rid, R + rid, 2R + rid
                                 const float uold = *(const float *)(xb + r4);                   // U_t of the row's pair
-                                const float em = EPu[k0 & 0xffffu], et = EPu[k0 >> 16];
+                                const float em = *(const float *)((const char *)EPu + (k0 & 0xffffu)), et = *(const float *)((const char *)EPu + (k0 >> 16));   // (byte offsets)
                                 const float rv = tot * sc;                                      // q_t[pair of the main state]
                                 const float qt = __uint_as_float(k1) * uold * sc;               // q_t[pair of the tail state]
                                 if (flagged) {
@@ -1658,10 +1665,10 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                                 *(float *)(xnb + r4 + dup) = Up;
                                 *(float *)(xnb + r4 + 4u * (unsigned)R) = Lp;
                                 *(float *)(xnb + r4 + 8u * (unsigned)R) = Ap;
-                                mymax = fmaxf(mymax, Up);
+                                mymax = __int_as_float(max(__float_as_int(mymax), __float_as_int(Up)));   // (non-negative: bits order like integers; fmaxf canonicalises first)
                             } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16
                                 const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
-                                const float e0 = EPu[k1 & 0xffffu], e1 = EPu[k1 >> 16];
+                                const float e0 = *(const float *)((const char *)EPu + (k1 & 0xffffu)), e1 = *(const float *)((const char *)EPu + (k1 >> 16));
                                 const f32x2 w01 = *(const f32x2 *)(RMc + 2u * r4);
                                 const float craw = tot;                                         // common out-arcs of the row's states
                                 f32x2 bv;                                                        // b_t of the two states
@@ -1679,7 +1686,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                                 *(f32x2 *)(xnb + 2u * r4) = zv;
                                 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
                                 *(f32x2u *)(xnb + 2u * r4 + dup) = zv;
-                                mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
+                                mymax = __int_as_float(max(__float_as_int(mymax), max(__float_as_int(zv.x), __float_as_int(zv.y))));
                             }
                         } else {
                         const int4 m = *(const int4 *)(RMc + 4u * r4);

@@ -1006,7 +1006,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
                 if (r < 0) continue;
                 const int4 m = frow_meta[rid];
                 const size_t t = (size_t)sl.w * kWave + lane, w0 = (size_t)kFac3ArcCh * 6 + 2 * (size_t)sl.ord;
-                fo.arcs[w0 * gm->threads + t] = ((unsigned)m.x >> 16) | ((unsigned)m.w << 16);   // main label | tail label << 16
+                fo.arcs[w0 * gm->threads + t] = (((unsigned)m.x >> 16) * 4u) | (((unsigned)m.w * 4u) << 16);   // BYTE offsets of the two emissions: main label * 4 | tail label * 4 << 16
                 fo.arcs[(w0 + 1) * gm->threads + t] = (unsigned)m.z;                             // tail weight (0: no tail)
             }
     const int Rq = 2 * Rf;
@@ -1155,7 +1155,10 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
                 const int4 m = brow_meta[rid];
                 const size_t t = (size_t)sl.w * kWave + lane, w0 = (size_t)kFac3ArcCh * 6 + 2 * (size_t)sl.ord;
                 bo.arcs[w0 * gm->threads + t] = (unsigned)m.x;
-                bo.arcs[(w0 + 1) * gm->threads + t] = (unsigned)m.w;
+                {   // byte offsets of the two emissions (0xffff = no label)
+                    const unsigned l0 = (unsigned)m.w & 0xffffu, l1 = (unsigned)m.w >> 16;
+                    bo.arcs[(w0 + 1) * gm->threads + t] = (l0 == 0xffffu ? 0xffffu : l0 * 4u) | ((l1 == 0xffffu ? 0xffffu : l1 * 4u) << 16);
+                }
             }
 
     // ---- 5. grad pass list: one (Q position, BP position) per pair, label-sorted (pairs already are), chunked
