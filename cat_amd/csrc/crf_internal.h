@@ -108,6 +108,7 @@ struct FacDev {
                                //      plain rows: U = A = sink, tail weight 0
     int NT;                    // unused (0)
     int threads;               // workgroup size the tables were built for: 768 (21 chunks per thread) or 512 (30)
+    int rcl;                   // 768 threads with the row constants in an LDS table read one slice ahead (any number of slices per wave)
     int multilane;             // some rows lie on several adjacent lanes (wave_info.w != 0 somewhere): kernel variant with the butterfly
     const float *x_start, *x_end;   // [Gf]
     // backward: rows = one or two states with common out-arcs; z entry of output o of row r = 2r + o.

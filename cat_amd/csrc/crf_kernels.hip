@@ -1411,7 +1411,7 @@ struct FacParams {
 // 768 x 21 (3 waves per SIMD at <= 168 VGPRs -- the frame is latency-bound, a third wave fills the gaps).
 // ML: some rows are cut into pieces on adjacent lanes (graphs with long rows; a separate instantiation, the check costs the
 // row epilogue of the others 2 %)
-template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML>
+template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML, bool RL>
 __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, const int b) {
     constexpr int NW = NTH / kWave;
     // 768-thread geometry: the last chunk slot of a thread holds ROW CONSTANTS instead of arcs -- two words for each of
@@ -1419,8 +1419,14 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     // (res_layout.cpp, "implicit"): a row epilogue asks for everything it needs from LDS in ONE round trip.  With a
     // table of row constants in LDS it was a chain of three (constants -> the values they point to -> emissions),
     // ~320 cycles of a wave's time per slice, 70 % of the frame loop (timing build).
-    constexpr bool RC = NTH == kFac3Threads;
-    constexpr int NCHA = RC ? kFac3ArcCh : NCH;              // chunk slots that hold arcs
+    // RL (768 threads): the row constants are a TABLE in LDS after all -- 8 (forward) / 16 (backward) bytes per row, read one
+    // slice AHEAD (the next slice's constants are requested in the epilogue of this one and arrive behind its gathers), so an
+    // epilogue is still one round trip, a wave may finish any number of slices per frame, and no select between registers
+    // is needed (with three slices that select is ~10 VALU instructions per epilogue).  For graphs with many short rows.
+    static_assert(!RL || NTH == kFac3Threads, "the row-constant table goes with the 768-thread geometry");
+    constexpr bool IMP = NTH == kFac3Threads;                // entries of a row lie where its row id says
+    constexpr bool RC = IMP && !RL;
+    constexpr int NCHA = IMP ? kFac3ArcCh : NCH;             // chunk slots that hold arcs
     constexpr int RCW = NCHA * 6;                            // first row-constant word
     static_assert(NCHA % NB == 0, "chunks per thread must be a multiple of the batch");
 
@@ -1434,7 +1440,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     const int64_t bt0 = (int64_t)b * p.T;
     float *X = lds;                                          // [2][Gp]
     char *RMc = (char *)(X + 2 * Gp);                        // int4[R]
-    float *EP = (float *)(RMc + (size_t)R * 16);             // [2][Vp]
+    float *EP = (float *)(RMc + (RL ? (size_t)(R + 64) * (DIR == 0 ? 8 : 16) : (size_t)R * 16));   // [2][Vp]  (RL: 64 rows of slack for the read-ahead)
     float *wm = EP + 2 * Vp;                                 // [2][NW]
     double *red = (double *)(wm + 2 * NW);            // [NW]
     if (tid == 0 && p.started && p.i0 == 0) atomicAdd(p.started, 1);   // this workgroup holds its CU: see crf_gate_kernel
@@ -1456,7 +1462,22 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     const int nch = __builtin_amdgcn_readfirstlane(wi.y);
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
     const unsigned lgbits = __builtin_amdgcn_readfirstlane(wi.w);   // 3 bits per slice: its rows are cut into 2^lg pieces on adjacent lanes
-    if (!RC) {
+    if (RL) {
+        if (DIR == 0) {
+            uint2 *RT = (uint2 *)RMc;                        // {emission byte offsets main | tail << 16, tail weight}
+            for (int r = tid; r < R; r += NTH) {
+                const int4 m = p.frow_meta[r];
+                RT[r] = uint2{(((unsigned)m.x >> 16) * 4u) | (((unsigned)m.w * 4u) << 16), (unsigned)m.z};
+            }
+        } else {
+            uint4 *RT = (uint4 *)RMc;                        // {z byte offsets of the two extra arcs, emission byte offsets, their weights}
+            for (int r = tid; r < R; r += NTH) {
+                const int4 m = p.brow_meta[r];
+                const unsigned l0 = (unsigned)m.w & 0xffffu, l1 = (unsigned)m.w >> 16;   // 0xffff = no label: emission 0 at EP[V]
+                RT[r] = uint4{(unsigned)m.x, ((l0 == 0xffffu ? (unsigned)V : l0) * 4u) | (((l1 == 0xffffu ? (unsigned)V : l1) * 4u) << 16), (unsigned)m.y, (unsigned)m.z};
+            }
+        }
+    } else if (!RC) {
         int4 *RM = (int4 *)RMc;
         for (int r = tid; r < R; r += NTH) {
             int4 m = DIR == 0 ? p.frow_meta[r] : p.brow_meta[r];
@@ -1604,6 +1625,9 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         float mymax = 0.f;
         CRF_TM(tm_on, tm_i + 1);
         unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
+        typedef std::conditional_t<DIR == 0, uint2, uint4> rct_t;
+        [[maybe_unused]] rct_t kc{};                  // RL: constants of the slice that ends next
+        if constexpr (RL) kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * r4);
 #pragma unroll
         for (int c0 = 0; c0 < NCHA; c0 += NB) {
             constexpr int nb = NB;
@@ -1641,12 +1665,20 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #endif
                             }
                         }
-                        if constexpr (RC) {
-                            // (masks, not ?: -- the compiler turns a three-way select of registers by a uniform index
-                            // into an indexed array, which it then cannot keep in registers)
-                            const unsigned s0 = 0u - (unsigned)(ks == 0), s1 = 0u - (unsigned)(ks == 1), s2 = 0u - (unsigned)(ks >= 2);
-                            const unsigned k0 = (rc00 & s0) | (rc10 & s1) | (rc20 & s2);
-                            const unsigned k1 = (rc01 & s0) | (rc11 & s1) | (rc21 & s2);
+                        if constexpr (IMP) {
+                            unsigned k0, k1;
+                            [[maybe_unused]] f32x2 wrl{};
+                            if constexpr (RC) {
+                                // (masks, not ?: -- the compiler turns a three-way select of registers by a uniform index
+                                // into an indexed array, which it then cannot keep in registers)
+                                const unsigned s0 = 0u - (unsigned)(ks == 0), s1 = 0u - (unsigned)(ks == 1), s2 = 0u - (unsigned)(ks >= 2);
+                                k0 = (rc00 & s0) | (rc10 & s1) | (rc20 & s2);
+                                k1 = (rc01 & s0) | (rc11 & s1) | (rc21 & s2);
+                            } else {
+                                k0 = kc.x; k1 = kc.y;
+                                if constexpr (DIR == 1) wrl = f32x2{__uint_as_float(kc.z), __uint_as_float(kc.w)};
+                                kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * (r4 + kWave * 4u));   // the next slice's (64 rows of slack behind the table)
+                            }
 
                             if (DIR == 0) {   // k0 = main label | tail label << 16, k1 = tail weight; U, L, A at rid, R + rid, 2R + rid
                                 const float uold = *(const float *)(xb + r4);                   // U_t of the row's pair
@@ -1669,7 +1701,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                             } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16
                                 const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
                                 const float e0 = *(const float *)((const char *)EPu + (k1 & 0xffffu)), e1 = *(const float *)((const char *)EPu + (k1 >> 16));
-                                const f32x2 w01 = *(const f32x2 *)(RMc + 2u * r4);
+                                const f32x2 w01 = RL ? wrl : *(const f32x2 *)(RMc + 2u * r4);
                                 const float craw = tot;                                         // common out-arcs of the row's states
                                 f32x2 bv;                                                        // b_t of the two states
                                 bv.x = fmaf(w01.x, z0, craw) * sc;
@@ -1816,12 +1848,12 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 // guaranteed inside a training process (HIP maps all streams of a process onto GPU_MAX_HW_QUEUES = 4 queues; with
 // RCCL's and torch's streams around, the recursions were observed to run one after the other: 5.3 instead of 3.25 ms).
 // NBF / NBB: chunks gathered per batch, forward / backward.
-template <bool FLAG, int NTH, int NCH, int NBF, int NBB, bool ML>
+template <bool FLAG, int NTH, int NCH, int NBF, int NBB, bool ML, bool RL = false>
 __global__ __launch_bounds__(NTH) void crf_fac_pair_kernel(FacParams pf, FacParams pb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = pf.B;
-    if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML>(pf, lds, (int)blockIdx.x);
-    else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML>(pb, lds, (int)blockIdx.x - B);
+    if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML, RL>(pf, lds, (int)blockIdx.x);
+    else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - B);
 }
 
 // Holds a (side) stream until `target` workgroups of the den kernels have started, i.e. own their compute
@@ -3154,8 +3186,12 @@ static bool use_resident(const HostGraph *h, int64_t V) {
 
 // the factored layout (one CU per recursion) is preferred whenever the graph has it; CRF_NO_FACTORED=1 at
 // graph creation keeps the generic resident kernels
+static size_t fac_lds_bytes(const HostGraph *h, int V, int dir);
 static bool use_factored(const HostGraph *h, int64_t V) {
-    return h && h->dev.fac.ok && V <= (int64_t)kEpRegsR * kResThreads;
+    // (the layout was budgeted for the graph's own label range, res_layout.cpp: a call with far more classes than the den_lm
+    // has labels may not fit the LDS any more and takes the next kernel family)
+    return h && h->dev.fac.ok && V <= (int64_t)kEpRegsR * kResThreads &&
+           std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1)) <= (size_t)160 * 1024;
 }
 
 // LDS of the robust fallback kernels (the larger of the two directions)
@@ -3420,7 +3456,8 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     const FacDev &F = h->dev.fac;
     const FacDirDev &L = dir == 0 ? F.f : F.b;
     const int nw = F.threads / kWave;
-    return (size_t)2 * rup64(L.G) * 4 + (size_t)L.R * 16 +
+    const size_t table = F.rcl ? (size_t)(L.R + 64) * (dir == 0 ? 8 : 16) : (size_t)L.R * 16;   // row constants (fac_chain_body)
+    return (size_t)2 * rup64(L.G) * 4 + table +
            ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }
 #ifndef CRF_FAC3_NB_F
@@ -3451,14 +3488,18 @@ static FacParams fac_params(const LossParams &lp, int dir, int *started, int i0,
 template <bool FLAG>
 static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *fstate, float *bstate,
                            int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
-    static LdsMark m3, m3m, m5;
+    static LdsMark m3, m3m, m3l, m5;
     const FacDev &F = lp.g.fac;
     const bool g3 = F.threads == kFac3Threads, ml = F.multilane != 0;
     const FacParams pf = fac_params(lp, 0, started, i0, i1, fstate, nb, bound, stage_cnt);
     const FacParams pb = fac_params(lp, 1, started, i0, i1, bstate, nb, bound, stage_cnt);
     const dim3 grid((unsigned)(2 * lp.B));
     int rc;
-    if (g3 && ml) {
+    if (g3 && F.rcl) {
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true>;
+        if ((rc = ensure_lds((const void *)k, lds, m3l, "fac pair"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else if (g3 && ml) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true>;
         if ((rc = ensure_lds((const void *)k, lds, m3m, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);

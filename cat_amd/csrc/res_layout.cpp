@@ -26,6 +26,10 @@ struct Geom { int threads, waves, nch, words, maxsl, multilane; };   // maxsl: s
 constexpr Geom kGeomRes{kResThreads, kResWaves, kResNCH, kResWords, 0, 0};
 constexpr Geom kGeomFac512{kResThreads, kResWaves, kResNCH, kResWords, 0, 1};   // factored layout, 512 threads (row constants in LDS)
 constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3NCH * 6, kFac3MaxSl, 1};
+// ... and 768 threads with the row constants in an LDS table that the kernel reads one slice AHEAD (crf_kernels.hip, RL): any
+// number of slices per wave up to the ten that the 3-bit fields of wave_info.w hold -- graphs with many short rows (a den_lm
+// estimated from text: 4 000 rows = 63 slices at 100 k arcs) keep three waves per SIMD instead of falling to 512 threads
+constexpr Geom kGeomFac3L{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3ArcCh * 6, 10, 1};
 
 struct DirOut {
     std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
@@ -35,6 +39,7 @@ struct DirOut {
     std::vector<int> cu_row_off;  // [K+1]
     int64_t slots = 0, conflicts = 0;
     int est_cost = 0;             // max over CUs and waves of (chunks + kEpiCost * slices): the frame-time estimate
+    int simd_cost = 0;            // ... and the busiest SIMD's sum of it (waves w, w + 4, ... share a SIMD)
 };
 
 inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / kResW)); }
@@ -42,13 +47,14 @@ inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / 
 // Step 1: decide where every row lives (CU, wave, slice, lane) from the row LENGTHS only.
 struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; int ord; int lg = 0; };   // ord: number of the slice within its wave;
                                                       // lg > 0: every row of the slice is cut into 2^lg pieces on 2^lg adjacent lanes
-bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm = kGeomRes) {
+bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm, int piece) {
     o->arcs.assign((size_t)K * gm.words * gm.threads, 0u);
     o->wave_info.assign((size_t)K * gm.waves, uint4{0u, 0u, 0u, 0u});
     o->rid_of_row.assign(rows.size(), -1);
     o->row_of.clear();
     o->cu_row_off.assign((size_t)K + 1, 0);
     o->est_cost = 0;
+    o->simd_cost = 0;
     slices->clear();
     for (int k = 0; k < K; ++k) {
         std::vector<int> mine;
@@ -67,8 +73,8 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                 int lg = 0;
                 const int n = chunks_of(rows[r].size());
                 if (!gm.multilane || n <= gm.nch) return 0;
-                // pieces of at most half a lane's budget: long pieces (a 30-chunk slice fills a wave) pack badly
-                while (lg < 6 && (n + (1 << lg) - 1) / (1 << lg) > (gm.nch + 1) / 2) ++lg;
+                // pieces of at most `piece` chunks (place_rows tries several sizes)
+                while (lg < 6 && (n + (1 << lg) - 1) / (1 << lg) > piece) ++lg;
                 return lg;
             };
             size_t i = 0;
@@ -174,7 +180,9 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                 for (int j = 0; j < nsl; ++j) fprintf(stderr, " %d", len[j]);
                 fprintf(stderr, "\n[res_layout] K=%d cu=%d:", K, k);
                 for (int w = 0; w < gm.waves; ++w) fprintf(stderr, " w%d(%dch,%zusl)", w, load[w], lists[w].size());
-                fprintf(stderr, "\n");
+                int simd[4] = {0, 0, 0, 0}, tot = 0;
+                for (int w = 0; w < gm.waves; ++w) { simd[w & 3] += cost[w]; tot += cost[w]; }
+                fprintf(stderr, " | cost (chunks + %d per slice): total %d, busiest SIMD %d\n", kEpiCost, tot, std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3])));
             }
         }
         if (!packed) {
@@ -188,7 +196,13 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
             return false;  // does not fit with this K
         }
         o->est_cost = std::max(o->est_cost, *std::max_element(cost.begin(), cost.end()));
+        for (int g4 = 0; g4 < 4; ++g4) {
+            int c = 0;
+            for (int w = g4; w < gm.waves; w += 4) c += cost[w];
+            o->simd_cost = std::max(o->simd_cost, c);
+        }
         int rid = o->cu_row_off[k];
+        int nlong = 0, own_off = 0;                             // multi-lane rows so far; owner lane (within its group) of the current one
         for (int w = 0; w < gm.waves; ++w) {
             unsigned ends = 0;
             int c0 = 0;
@@ -201,7 +215,16 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
                 SliceAt sl{k, w, c0, len[j], rid, {}, ord++, lgs[j]};
                 for (int lane = 0; lane < kWave; ++lane) {
                     const int r = lanes[j][lane];
-                    const bool first = r >= 0 && (lane & ((1 << lgs[j]) - 1)) == 0;   // the lane that owns the row's outputs
+                    // the lane that owns the row's outputs: after the butterfly every lane of the group holds the row's sum, so any
+                    // of them will do -- and with implicit entries (factored 768-thread layouts) the row id IS the LDS position of
+                    // the row's entry: "the first lane" would put the long rows of an n-gram LM, its most gathered entries, on
+                    // banks 0 and 16 only (measured by pack_arcs' model: extra LDS cycles per frame 1 919 -> see DESIGN).  Rotate.
+                    const int gmask = (1 << lgs[j]) - 1;
+                    bool first = r >= 0 && (lane & gmask) == 0;
+                    if (gm.maxsl && lgs[j] > 0 && r >= 0 && !(getenv("CRF_RES_OWNER_FIRST") && atoi(getenv("CRF_RES_OWNER_FIRST")))) {
+                        if ((lane & gmask) == 0) { own_off = (nlong + (nlong >> lgs[j])) & gmask; ++nlong; }
+                        first = (lane & gmask) == own_off;
+                    }
                     sl.rows.push_back(r);
                     o->row_of.push_back(first ? r : -1);
                     if (first) o->rid_of_row[r] = rid + lane;
@@ -214,6 +237,33 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         }
         o->cu_row_off[(size_t)k + 1] = rid;
     }
+    return true;
+}
+
+// Rows longer than a lane's registers are cut into pieces on adjacent lanes (multilane geometries), and the piece size is a
+// trade: short pieces pack well but every 64 lanes of pieces are a slice of their own with a row epilogue of its own (16 lanes
+// per row: four rows per epilogue), long pieces mean fewer slices and fewer padding rows but may not pack at all.  The cost
+// model (chunks + kEpiCost per slice, busiest SIMD) follows the measured frame time closely (den_lm of 40 000 sentences:
+// model 1.40 x the benchmark graph's frame, measured 1.38 x), so try a few sizes and keep the cheapest packing.
+bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm = kGeomRes) {
+    const int half = (gm.nch + 1) / 2;
+    bool any_long = false;
+    if (gm.multilane)
+        for (auto &r : rows) if (chunks_of(r.size()) > gm.nch) { any_long = true; break; }
+    const int piece_env = getenv("CRF_RES_PIECE") ? atoi(getenv("CRF_RES_PIECE")) : 0;
+    if (!any_long || piece_env > 0) return place_rows_piece(rows, row_cu, K, o, slices, gm, piece_env > 0 ? std::min(piece_env, gm.nch) : half);
+    bool have = false;
+    DirOut best;
+    std::vector<SliceAt> best_slices;
+    for (int piece : {gm.nch * 4 / 5, gm.nch * 7 / 10, gm.nch * 3 / 5, half}) {
+        DirOut cand;
+        std::vector<SliceAt> cs;
+        if (!place_rows_piece(rows, row_cu, K, &cand, &cs, gm, piece)) continue;
+        if (!have || cand.simd_cost < best.simd_cost) { best = std::move(cand); best_slices = std::move(cs); have = true; }
+    }
+    if (!have) return false;
+    *o = std::move(best);
+    *slices = std::move(best_slices);
     return true;
 }
 
@@ -821,7 +871,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // =================================================================================================
 static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
                                const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
-                               const std::vector<float> &end_lin, bool allow3, bool *retry512, bool use_dup, bool *retry_nodup) {
+                               const std::vector<float> &end_lin, int level, bool *retry_next, int dup_mask, int *new_mask) {
     FacDev &F = h->dev.fac;
     F = FacDev{};
     if ((getenv("CRF_NO_FACTORED") && atoi(getenv("CRF_NO_FACTORED"))) || (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT")))) return CRF_OK;
@@ -882,6 +932,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // and the row of s2 updates all three in its epilogue: L' = e'[l2] * rowsum, A' = e'[l1] * w * U, U' = A' + L'
     // (no subtraction anywhere) -- the row of s1 disappears.  A matched pair without that structure is
     // un-matched again (generic graphs: everything below still works, there is just nothing to save).
+    const int max_lab = *std::max_element(pair_lab.begin(), pair_lab.end());
     std::vector<int> tail_of(S, -1);   // main state -> its tail state
     std::vector<float> tail_w(S, 0.f);
     for (int s = 0; s < S; ++s) {
@@ -909,14 +960,20 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // Geometry: 768 threads (3 waves per SIMD at <= 168 VGPRs; 20 chunks of arcs and the constants of up to 3 rows per
     // thread) when both directions fit it, else 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces
     // the latter.
-    const Geom *gm = allow3 ? &kGeomFac3 : &kGeomFac512;
+    const Geom *gm = level == 0 ? &kGeomFac3 : level == 1 ? &kGeomFac3L : &kGeomFac512;
+    const bool allow3 = level < 2;                // a larger geometry is left to try
+    const bool rcregs = level == 0;               // row constants in registers
     const bool implicit = gm->maxsl > 0;   // entries numbered by row id, row constants in registers (below)
     // entries (512-thread layout): [U of every pair][sink][L of every pair][A of every pair][plain states]
     std::vector<int> entU(S, -1), ent(S, -1);   // entU: by main state; ent: a[s] itself (L, A or plain)
     // ... and a SECOND copy of the U entries (and the sink, which padding rows write) behind everything, on
     // other banks: [U][sink][L][A][plain] [pad] [U'][sink'] -- see pack_arcs
     static const int bank_shift = getenv("CRF_FAC_BANK_SHIFT") ? atoi(getenv("CRF_FAC_BANK_SHIFT")) & 31 : 5;
-    const bool no_dup = !use_dup || (getenv("CRF_FAC_NO_DUP") && atoi(getenv("CRF_FAC_NO_DUP")));
+    // second copy of the gathered entries: per direction (dup_mask bit 0 forward, bit 1 backward); a direction that turns out
+    // not to fit with it clears its bit in *new_mask and the caller builds again
+    const bool env_nodup = getenv("CRF_FAC_NO_DUP") && atoi(getenv("CRF_FAC_NO_DUP"));
+    const bool no_dupf = !(dup_mask & 1) || env_nodup, no_dupb = !(dup_mask & 2) || env_nodup;
+    *new_mask = dup_mask;
     int nent = 0;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) entU[s] = nent++;
     int nU = nent;
@@ -950,7 +1007,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     DirOut fo;
     std::vector<SliceAt> fslices;
     if (!place_rows(fsub, std::vector<int>(fsub.size(), 0), 1, &fo, &fslices, *gm)) {
-        if (allow3) { *retry512 = true; return CRF_OK; }
+        if (allow3) { *retry_next = true; return CRF_OK; }
         return give_up("forward rows do not fit one CU");
     }
     const int Rf = fo.cu_row_off[1];
@@ -976,10 +1033,11 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         ent = nentS; entU = nentU; sink = nsink; nent = nx; nU = Rf;
     }
     int fdup = 0;                                        // entries between the two copies
-    if (!no_dup) { fdup = nent; while ((fdup & 31) != bank_shift) ++fdup; }
+    if (!no_dupf) { fdup = nent; while ((fdup & 31) != bank_shift) ++fdup; }
     const int Gf = fdup ? fdup + nU + 1 : nent;
     if ((size_t)Gf * 4 > 65536) {
-        if (allow3) { *retry512 = true; return CRF_OK; }
+        if (!no_dupf) { *new_mask = dup_mask & ~1; return CRF_OK; }   // first without the second copy of the U entries
+        if (allow3) { *retry_next = true; return CRF_OK; }
         return give_up("forward gather vector > 64 KiB");
     }
     pack_arcs(fsub, fslices, &fo, 4, *gm, fdup ? nU : 0, fdup);
@@ -999,7 +1057,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             frow_meta[rid] = int4{(sink * 4) | (pair_lab[p] << 16), (ent[s] * 4) | ((sink * 4) << 16), 0, 0};
         }
     }
-    if (implicit)   // row constants of the slice number `ord` of a wave: words (kFac3ArcCh * 6 + 2 * ord) and the next of its threads
+    if (rcregs)   // row constants of the slice number `ord` of a wave: words (kFac3ArcCh * 6 + 2 * ord) and the next of its threads
         for (const SliceAt &sl : fslices)
             for (int lane = 0; lane < kWave; ++lane) {
                 const int rid = sl.rid0 + lane, r = fo.row_of[rid];
@@ -1104,14 +1162,17 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     DirOut bo;
     std::vector<SliceAt> bslices;
     if (!place_rows(bsub, std::vector<int>(bsub.size(), 0), 1, &bo, &bslices, *gm)) {
-        if (allow3) { *retry512 = true; return CRF_OK; }   // both directions then use the larger per-thread budget
+        if (allow3) { *retry_next = true; return CRF_OK; }   // both directions then use the larger per-thread budget
         return give_up("backward rows do not fit one CU");
     }
     const int Rb = bo.cu_row_off[1], Gb0 = 2 * Rb + 2, zsink = 2 * Rb;
     int bdup = 0;                                        // second copy of every z entry: [z (2 Rb)][sink pair] [pad] [z'][sink']
-    if (!no_dup) { bdup = Gb0; while ((bdup & 31) != bank_shift) ++bdup; }
+    if (!no_dupb) { bdup = Gb0; while ((bdup & 31) != bank_shift) ++bdup; }
     const int Gb = bdup ? bdup + Gb0 : Gb0;
-    if ((size_t)Gb * 4 > 65536) return give_up("backward gather vector > 64 KiB");
+    if ((size_t)Gb * 4 > 65536) {
+        if (!no_dupb) { *new_mask = dup_mask & ~2; return CRF_OK; }
+        return give_up("backward gather vector > 64 KiB");
+    }
     std::vector<int> zpos(S, -1);   // BP / z position of state s: 2*rid + output
     for (int rid = 0; rid < Rb; ++rid) {
         const int r = bo.row_of[rid];
@@ -1148,7 +1209,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     }
 
     if (bdup) for (int z = 0; z < 2 * Rb; ++z) { z_lab[bdup + z] = z_lab[z]; z_end[bdup + z] = z_end[z]; }
-    if (implicit)   // row constants in registers: {extra-arc z offsets, labels (0xffff = none)}; the two extra weights stay in LDS
+    if (rcregs)   // row constants in registers: {extra-arc z offsets, labels (0xffff = none)}; the two extra weights stay in LDS
         for (const SliceAt &sl : bslices)
             for (int lane = 0; lane < kWave; ++lane) {
                 const int rid = sl.rid0 + lane;
@@ -1162,7 +1223,6 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             }
 
     // ---- 5. grad pass list: one (Q position, BP position) per pair, label-sorted (pairs already are), chunked
-    const int max_lab = *std::max_element(pair_lab.begin(), pair_lab.end());
     std::vector<int> gq, gb, gchunk{0}, glab((size_t)max_lab + 2, 0);
     for (int p = 0; p < P; ++p) { gq.push_back(fpos[p]); gb.push_back(zpos[pair_dst[p]]); }
     {
@@ -1182,11 +1242,19 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (verbose)
         fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
                 (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
-    {   // LDS of the recursion kernels (crf_kernels.hip fac_lds_bytes; emission rows etc. budgeted for V <= 1000): two state
-        // vectors + 16 bytes per row.  Too much with the second copy of the gathered entries: build again without it.
-        auto need = [](int G, int R) { return (size_t)2 * ((G + 63) / 64 * 64) * 4 + (size_t)R * 16 + 10240; };
-        if (std::max(need(Gf, Rf), need(Gb, Rb)) > (size_t)160 * 1024) {
-            if (!no_dup) { *retry_nodup = true; return CRF_OK; }
+    {   // LDS of the recursion kernels (crf_kernels.hip fac_lds_bytes): two state vectors + the row constants + two emission rows
+        // (budgeted for the graph's own label range, at least 256: a call with more classes than fit falls back to the other
+        // kernel families, crf_kernels.hip use_factored).  Too much with the second copy of the gathered entries: build that
+        // direction again without it.  (level 1: the forward table has 8 bytes per row, and both have 64 rows of slack.)
+        const int V0 = std::max(max_lab + 1, 256);
+        const size_t tail = ((size_t)2 * ((V0 + 1 + 63) / 64 * 64) + 4 * (size_t)gm->waves + 16) * 4 + 256;
+        auto need = [&](int G, int R, int rb) { return (size_t)2 * ((G + 63) / 64 * 64) * 4 + (size_t)(R + (level == 1 ? 64 : 0)) * rb + tail; };
+        const bool f_ok = need(Gf, Rf, level == 1 ? 8 : 16) <= (size_t)160 * 1024, b_ok = need(Gb, Rb, 16) <= (size_t)160 * 1024;
+        if (!f_ok || !b_ok) {
+            int m = dup_mask;
+            if (!f_ok && !no_dupf) m &= ~1;
+            if (!b_ok && !no_dupb) m &= ~2;
+            if (m != dup_mask) { *new_mask = m; return CRF_OK; }
             return give_up("state vectors and row constants exceed the LDS");
         }
     }
@@ -1195,7 +1263,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     for (auto &wi : fo.wave_info) if (wi.w) F.multilane = 1;
     for (auto &wi : bo.wave_info) if (wi.w) F.multilane = 1;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
-    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads;
+    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads; F.rcl = level == 1;
     int rc;
     if ((rc = up(h, fo.arcs, &F.f.arcs)) || (rc = up(h, fo.wave_info, &F.f.wave_info)) || (rc = up(h, bo.arcs, &F.b.arcs)) ||
         (rc = up(h, bo.wave_info, &F.b.wave_info)) || (rc = up(h, frow_meta, &F.frow_meta)) ||
@@ -1214,14 +1282,22 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                    const std::vector<float> &end_lin) {
     // Geometry: 768 threads x 21 chunks (3 waves per SIMD at <= 168 VGPRs) when both directions fit it, else
     // 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces the latter.
+    // ... then 768 threads with the row constants in LDS (any number of slices per wave; CRF_FAC_RCL=1 starts there,
+    // CRF_FAC_NO_RCL=1 skips it).  Each geometry first with the second copy of the gathered entries, then without it in the direction(s) that do not fit.
     const bool want3 = !(getenv("CRF_FAC_THREADS") && atoi(getenv("CRF_FAC_THREADS")) == 512);
-    bool retry = false, nodup = false;
-    int rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, want3, &retry, true, &nodup);
-    if (rc == CRF_OK && nodup) { nodup = false; rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, want3, &retry, false, &nodup); }
-    if (rc == CRF_OK && retry) {
-        nodup = false;
-        rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, false, &retry, true, &nodup);
-        if (rc == CRF_OK && nodup) rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, false, &retry, false, &nodup);
+    const bool no_rcl = getenv("CRF_FAC_NO_RCL") && atoi(getenv("CRF_FAC_NO_RCL"));
+    const bool from_rcl = getenv("CRF_FAC_RCL") && atoi(getenv("CRF_FAC_RCL"));
+    int rc = CRF_OK;
+    for (int level = want3 ? (from_rcl ? 1 : 0) : 2; level <= 2; ++level) {
+        if (level == 1 && no_rcl) continue;
+        bool retry = false;
+        int mask = 3, nm = 3;
+        for (;;) {
+            rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, level, &retry, mask, &nm);
+            if (rc != CRF_OK || retry || nm == mask) break;
+            mask = nm;
+        }
+        if (rc != CRF_OK || !retry) break;
     }
     return rc;
 }

@@ -68,7 +68,9 @@ int crf_graph_dims(const crf_graph *g, int64_t *num_states, int64_t *num_arcs, i
  * (0 = graph too large, streaming kernels are used), forward / backward arc slots incl. padding,
  * forward / backward extra LDS cycles (busiest bank per half-wave gather), forward_rows*100000 + backward_rows;
  * out[16..23] = factored layout (one CU per recursion, T o LM structure): available (0/1), matched state pairs,
- * weights re-gauged (0/1), single-gather (tail) rows, forward / backward arc slots, fused backward rows, Gf*100000 + Gb.
+ * weights re-gauged (0/1), single-gather (tail) rows, forward / backward arc slots, fused backward rows, Gf*100000 + Gb;
+ * out[24] = geometry of the factored kernels: 0 = 768 threads, row constants in registers (at most 3 slices of rows per wave),
+ * 1 = 768 threads, row constants in an LDS table, 2 = 512 threads; -1 = no factored layout.
  * A graph created with device < 0 is compiled on the host
  * only (no GPU needed) and can be used with crf_graph_dims / crf_graph_stats / crf_graph_destroy. */
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n);

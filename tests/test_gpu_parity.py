@@ -27,7 +27,7 @@ def crf():
     return ctc_crf
 
 
-MODES = ["factored", "resident", "streaming", "batch"]
+MODES = ["factored", "factored_rcl", "resident", "streaming", "batch"]
 
 
 class _env:
@@ -55,9 +55,12 @@ class _mode:
         self.mode = mode
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("CRF_NO_RESIDENT", "CRF_NO_FACTORED", "CRF_NO_BATCH")}
+        self.old = {k: os.environ.get(k) for k in ("CRF_NO_RESIDENT", "CRF_NO_FACTORED", "CRF_NO_BATCH", "CRF_FAC_RCL")}
         os.environ["CRF_NO_RESIDENT"] = "1" if self.mode in ("streaming", "batch") else "0"
-        os.environ["CRF_NO_FACTORED"] = "0" if self.mode == "factored" else "1"
+        os.environ["CRF_NO_FACTORED"] = "0" if self.mode.startswith("factored") else "1"
+        # "factored_rcl": the factored kernels' 768-thread variant with the row constants in an LDS table (what graphs with more
+        # than three slices of rows per wave take by themselves), forced for every graph with the T o LM structure
+        os.environ["CRF_FAC_RCL"] = "1" if self.mode == "factored_rcl" else "0"
         # "batch": the utterance-minor kernels (one launch per frame), what graphs that fit no register-resident layout
         # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (CRF_NO_BATCH is read per call,
         # so it stays set for the life of the test process's calls in this mode: see run_hip)
@@ -80,6 +83,8 @@ def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mo
             assert st["res_K"] == 0 and st["fac"] == 0
         if mode == "resident":
             assert st["fac"] == 0
+        if mode == "factored_rcl" and st["fac"]:
+            assert st["fac_geom"] in (1, 2)                      # (2: neither 768-thread geometry took the graph)
         x = torch.tensor(logits, device="cuda:0", requires_grad=True)
         crit = crf.CTC_CRF_LOSS(lamb=lamb, size_average=size_average)
         loss = crit(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32),
@@ -211,7 +216,7 @@ def test_fused_log_softmax(crf, tmp_path, mode, dtype):
     del ctx
 
 
-@pytest.mark.parametrize("mode,V", [("factored", 40), ("resident", 40), ("streaming", 40), ("factored", 150)])
+@pytest.mark.parametrize("mode,V", [("factored", 40), ("factored_rcl", 40), ("resident", 40), ("streaming", 40), ("factored", 150), ("factored_rcl", 150)])
 def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
     """A den_lm ESTIMATED from text (cat_amd.den_lm.prep_den_lm) has the in-degree profile of a real
     n-gram LM: the low-order history states are entered from hundreds of states.  The factored layout cuts such rows
@@ -240,11 +245,49 @@ def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
         labels += lab; ly.append(len(lab))
     ref = oracle.ctc_crf(g, logits, np.array(labels, dtype=np.int32), lx, np.array(ly, dtype=np.int32), lamb=0.1)
     loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode=mode)
-    if mode == "factored":
+    if mode.startswith("factored"):
         with _mode(mode):
             ctx = crf.CRFContext(p, 0)
-        assert crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))["fac"] == 1
+        st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+        assert st["fac"] == 1 and st["fac_geom"] == (1 if mode == "factored_rcl" else 0)
         del ctx
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+
+
+def test_estimated_den_lm_with_many_rows(crf, tmp_path):
+    """The den_lm of tools/bench_fst.py's largest point (40 000 sentences, 72 tokens: S = 6 836, 100 k arcs, in-degree up to
+    970): 71 slices of forward rows -- more than the three per wave whose constants fit registers -- so the compiler
+    picks, by itself, the 768-thread kernels with the row constants in an LDS table (fac_geom 1; round 1 and most of round 2
+    ran this graph on the 512-thread geometry).  Ragged batch against the fp64 oracle."""
+    from cat_amd import den_lm
+    V = 72
+    rng = np.random.default_rng(0)
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(40000):
+        L, sq, a, b = int(rng.integers(10, 40)), [], 0, 0
+        for _ in range(L):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
+        seqs.append(sq)
+    p = str(tmp_path / "den_est_big.fst")
+    den_lm.prep_den_lm(seqs, V, p, 4, 3, 2000)
+    g = fst_io.read_fst(p)
+    assert g["S"] > 6000
+    B, T = 4, 48
+    logits = rng.normal(size=(B, T, V)).astype(np.float32) * 2.0
+    logits = logits - np.log(np.exp(logits).sum(-1, keepdims=True))
+    lx = np.array([48, 48, 31, 2], dtype=np.int32)
+    labels, ly = [], []
+    for b in range(B):
+        lab = seqs[b][:max(1, int(lx[b]) // 6)]
+        labels += lab; ly.append(len(lab))
+    ref = oracle.ctc_crf(g, logits, np.array(labels, dtype=np.int32), lx, np.array(ly, dtype=np.int32), lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1)
+    ctx = crf.CRFContext(p, 0)
+    st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+    del ctx
+    assert st["fac"] == 1 and st["fac_geom"] == 1
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
 

@@ -26,7 +26,7 @@ fst = os.path.join(tempfile.mkdtemp(), "den_lm.fst")
 g = den_lm.prep_den_lm(seqs, V, fst, 4, 3, extra)
 ctx = ctc_crf.CRFContext(fst, 0)
 st = ctc_crf._C.graph_stats(ctc_crf._C.graph_for(torch.device("cuda", 0)))
-kind = "factored" if st["fac"] else f"resident K={st['res_K']}" if st["res_K"] else "streaming"
+kind = f"factored (geometry {st['fac_geom']})" if st["fac"] else f"resident K={st['res_K']}" if st["res_K"] else "streaming"
 print(f"den_lm from {nsent} sentences: S={g['S']} A={g['A']} max in/out degree {st['max_in_deg']}/{st['max_out_deg']} -> {kind} kernels")
 gr = fst_io.read_fst(fst)
 labels, ly = [], []
