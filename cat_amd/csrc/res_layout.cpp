@@ -267,6 +267,57 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
     return true;
 }
 
+// Grad pass (crf_grad_den_kernel): thread c of a workgroup walks the <= kChunk (Q position, BP position) pairs of chunk c, so
+// at step j the 64 lanes of a wave gather Qs[q_j of their chunk] and then Bs[b_j of their chunk] from the rows staged in LDS --
+// positions scattered by the layouts, ~3.5 lanes of a half-wave on the busiest bank (bank = index mod 32, halves of 32 lanes).
+// The order of a chunk's pairs is free (one sum per chunk): arrange it, wave by wave and step by step, so that each lane takes
+// the remaining pair whose two banks are least used at that step (equal address = broadcast, free).
+// Returns the LDS cycles per frame (busiest bank per half-wave gather, summed) before and after.
+void arrange_grad_pairs(std::vector<int> *gq, std::vector<int> *gb, const std::vector<int> &gchunk, int64_t *before, int64_t *after) {
+    const int NC = (int)gchunk.size() - 1;
+    auto load_of = [](const std::vector<int> (&bk)[32]) { size_t m = 0; for (auto &v : bk) m = std::max(m, v.size()); return (int64_t)m; };
+    auto add = [](std::vector<int> (&bk)[32], int a) { auto &v = bk[a & 31]; if (std::find(v.begin(), v.end(), a) == v.end()) v.push_back(a); };
+    auto cost_with = [](const std::vector<int> (&bk)[32], int a) { const auto &v = bk[a & 31]; return (int)v.size() + (std::find(v.begin(), v.end(), a) == v.end() ? 1 : 0); };
+    *before = *after = 0;
+    const bool on = !(getenv("CRF_NO_GRAD_ARRANGE") && atoi(getenv("CRF_NO_GRAD_ARRANGE")));
+    for (int c0 = 0; c0 < NC; c0 += 32) {                       // one half-wave: chunks [c0, c0 + 32)
+        const int nl = std::min(32, NC - c0);
+        std::vector<std::vector<std::pair<int, int>>> rem(nl);
+        int maxlen = 0;
+        for (int l = 0; l < nl; ++l) {
+            for (int i = gchunk[c0 + l]; i < gchunk[c0 + l + 1]; ++i) rem[l].push_back({(*gq)[i], (*gb)[i]});
+            maxlen = std::max(maxlen, (int)rem[l].size());
+        }
+        for (int j = 0; j < maxlen; ++j) {                       // as listed
+            std::vector<int> bq[32], bb[32];
+            for (int l = 0; l < nl; ++l) if (j < (int)rem[l].size()) { add(bq, rem[l][j].first); add(bb, rem[l][j].second); }
+            *before += load_of(bq) + load_of(bb);
+        }
+        std::vector<std::vector<std::pair<int, int>>> out(nl);
+        for (int j = 0; j < maxlen; ++j) {
+            std::vector<int> bq[32], bb[32];
+            std::vector<int> order;
+            for (int l = 0; l < nl; ++l) if (!rem[l].empty()) order.push_back(l);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rem[a].size() < rem[b].size(); });   // fewest choices first
+            for (int l : order) {
+                size_t best = 0;
+                int bc = 1 << 30;
+                for (size_t i = 0; i < rem[l].size(); ++i) {
+                    const int cq = cost_with(bq, rem[l][i].first), cb = cost_with(bb, rem[l][i].second);
+                    const int c = on ? std::max(cq, cb) * 64 + cq + cb : (int)i;
+                    if (c < bc) { bc = c; best = i; }
+                }
+                add(bq, rem[l][best].first); add(bb, rem[l][best].second);
+                out[l].push_back(rem[l][best]);
+                rem[l].erase(rem[l].begin() + (long)best);
+            }
+            *after += load_of(bq) + load_of(bb);
+        }
+        for (int l = 0; l < nl; ++l)
+            for (size_t i = 0; i < out[l].size(); ++i) { (*gq)[gchunk[c0 + l] + (int)i] = out[l][i].first; (*gb)[gchunk[c0 + l] + (int)i] = out[l][i].second; }
+    }
+}
+
 // Step 2: put the arcs (gather indices already renumbered) into the (chunk, slot) positions of their
 // slice.  One position = ONE ds_read_b32 gather per wave, serviced in two 32-lane halves over 32 banks
 // (bank = index mod 32, MI355X_MICROARCH.md LDS table): the order of a row's arcs is free.
@@ -840,6 +891,10 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             }
             glab[(size_t)max_lab + 1] = (int)gchunk.size() - 1;
         }
+        {
+            int64_t gcb = 0, gca = 0;
+            arrange_grad_pairs(&gq, &gb, gchunk, &gcb, &gca);
+        }
         R.K = K;
         R.f.R = Rf; R.f.G = Gf; R.b.R = Rb; R.b.G = Gb;
         R.NC = (int)gchunk.size() - 1;
@@ -871,7 +926,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // =================================================================================================
 static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
                                const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
-                               const std::vector<float> &end_lin, int level, bool *retry_next, int dup_mask, int *new_mask) {
+                               const std::vector<float> &end_lin, int level, bool *retry_next, int dup_mask, int *new_mask, bool short_only = false, bool *long_bail = nullptr) {
     FacDev &F = h->dev.fac;
     F = FacDev{};
     if ((getenv("CRF_NO_FACTORED") && atoi(getenv("CRF_NO_FACTORED"))) || (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT")))) return CRF_OK;
@@ -1004,6 +1059,9 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             else fsub[i].push_back({ent[s], a[u].second});
         }
     }
+    if (short_only)   // graphs with rows longer than a lane's registers (every den_lm estimated from text) run 2-3 % faster with the
+        for (auto &r : fsub)   // row constants in the LDS table (level 1; measured): leave them to it
+            if (chunks_of(r.size()) > gm->nch) { if (long_bail) *long_bail = true; *retry_next = true; return CRF_OK; }
     DirOut fo;
     std::vector<SliceAt> fslices;
     if (!place_rows(fsub, std::vector<int>(fsub.size(), 0), 1, &fo, &fslices, *gm)) {
@@ -1159,6 +1217,9 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     }
     Rows bsub(brow.size());
     for (size_t i = 0; i < brow.size(); ++i) bsub[i] = brow[i].arcs;   // pair ids for now; lengths are all placement needs
+    if (short_only)
+        for (auto &r : bsub)
+            if (chunks_of(r.size()) > gm->nch) { if (long_bail) *long_bail = true; *retry_next = true; return CRF_OK; }
     DirOut bo;
     std::vector<SliceAt> bslices;
     if (!place_rows(bsub, std::vector<int>(bsub.size(), 0), 1, &bo, &bslices, *gm)) {
@@ -1237,6 +1298,9 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         glab[(size_t)max_lab + 1] = (int)gchunk.size() - 1;
     }
     for (int p = 1; p < P; ++p) if (pair_lab[p] < pair_lab[p - 1]) return give_up("pairs are not label-sorted");
+    int64_t gcb = 0, gca = 0;
+    arrange_grad_pairs(&gq, &gb, gchunk, &gcb, &gca);
+    if (verbose) fprintf(stderr, "[fac_layout] grad pass: LDS cycles per frame for the pair gathers %lld as listed, %lld arranged (%d chunks)\n", (long long)gcb, (long long)gca, (int)gchunk.size() - 1);
 
     h->fac_stats = FacBuildStats{1, nmatched, nsolo, (int64_t)tail_rows.size(), fo.slots, bo.slots, nfused, Gf, Gb};
     if (verbose)
@@ -1288,12 +1352,19 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     const bool no_rcl = getenv("CRF_FAC_NO_RCL") && atoi(getenv("CRF_FAC_NO_RCL"));
     const bool from_rcl = getenv("CRF_FAC_RCL") && atoi(getenv("CRF_FAC_RCL"));
     int rc = CRF_OK;
-    for (int level = want3 ? (from_rcl ? 1 : 0) : 2; level <= 2; ++level) {
-        if (level == 1 && no_rcl) continue;
+    struct Try { int level; bool short_only; };
+    std::vector<Try> plan;
+    if (!want3) plan = {{2, false}};
+    else if (from_rcl) plan = {{1, false}, {2, false}};
+    else if (no_rcl) plan = {{0, false}, {2, false}};
+    else plan = {{0, true}, {1, false}, {0, false}, {2, false}};   // level 0 only for graphs without long rows -- unless level 1 does not take them
+    bool long_bail = false;
+    for (const Try &t : plan) {
+        if (t.level == 0 && !t.short_only && plan.size() == 4 && !long_bail) continue;   // level 0 has been tried in full already
         bool retry = false;
         int mask = 3, nm = 3;
         for (;;) {
-            rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, level, &retry, mask, &nm);
+            rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, t.level, &retry, mask, &nm, t.short_only, &long_bail);
             if (rc != CRF_OK || retry || nm == mask) break;
             mask = nm;
         }
