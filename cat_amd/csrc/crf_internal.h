@@ -175,11 +175,22 @@ __host__ __device__ inline void bat_decode(int block, int grid, int ncombo, int 
 struct StreamDirDev {
     const int4 *tasks;       // [ntasks] {first batch, batches, first bundle, bundles}
     const int2 *recs;        // [batches][AL][4] (+ 8 KB of padding)
-    const int4 *meta;        // [bundles][AL] {state (-1: padding row), pair id, label, 0}
+    const int4 *meta;        // [bundles][AL] {state (-1: padding row), pair id, label, 0}; factored streams: [bundles][AL][3], below
     const int *rest;         // [nrest] rows (indices into BatchDev::frow / brow) that are not in the stream
     int ntasks, nrest;
 };
-struct StreamDev { int ok, AL, want; StreamDirDev f, b; };   // want: tasks per direction the tables were cut for
+// FACTORED streams (T o LM graphs, StreamDev::fac): the two states (g, blank) = "tail" and (g, token) = "main" of an LM history
+// feed the same rows with the same weights, so -- as in the register-resident factored layout (FacDev) -- the forward vector
+// gets an entry U[g] = a[tail] + a[main] behind the S states (NU of them) that serves both arcs with ONE record, and the tail
+// row (two arcs, from the pair itself) is folded into the epilogue of the main row; backward, the two states have the same
+// out-arcs but at most one each, so ONE row sums the common arcs and its epilogue adds each state's extra arc.  Half the
+// records, i.e. half the gathers of the state vectors -- what a launch of crf_batch_frame_kernel is bound by.
+// A row's descriptor is three int4:
+//   {state 0 (-1: padding row), its pair, its label, 0}  {state 1 (-1: none), its pair, its label, 0}
+//   forward:  {entry of U (S + k), tail weight bits, 0, 0}            state 0 = main, state 1 = tail
+//   backward: {entry (pair id) of state 0's extra arc, its weight bits, the same for state 1}     (weight 0: no extra arc)
+struct StreamDev { int ok, AL, want; StreamDirDev f, b; int fac, NU; const float *x_start; };   // want: tasks per direction the tables were cut for;
+                                                                                             // x_start [S + NU]: a_0 incl. the U entries (fac)
 
 // The denominator graph as the kernels see it (all pointers device memory).
 // A "pair" is a distinct (destination state, label); pairs are numbered in forward-ELL row order.
@@ -210,6 +221,20 @@ struct GraphDev {
 struct ResBuildStats { int K = 0; int64_t slots_f = 0, slots_b = 0, conflicts_f = 0, conflicts_b = 0; };
 struct FacBuildStats { int ok = 0; int64_t matched = 0, solo = 0, tail = 0, slots_f = 0, slots_b = 0, fused = 0, Gf = 0, Gb = 0; };
 
+// host tables of the factored streams (fst_graph.cpp build_batch_factored)
+struct FacRowH {
+    int st0 = -1, pr0 = 0, lab0 = 0, st1 = -1, pr1 = 0, lab1 = 0;   // outputs: state, pair, label (st1 = -1: one output)
+    int x0 = 0, x1 = 0;                                            // forward: x0 = U entry; backward: entries of the extra arcs
+    int w0 = 0, w1 = 0;                                            // forward: w0 = tail weight bits; backward: the extra arcs' weight bits
+    std::vector<int2> recs;                                        // {entry, weight bits}
+};
+struct FacBatchH {
+    int ok = 0, NU = 0;
+    std::vector<FacRowH> frows, brows;  // stream rows, most records first
+    std::vector<int> frest, brest;      // rows (indices into BatchDev::frow / brow) left to the row-at-a-time path
+    std::vector<float> x_start;         // [S + NU]
+    int64_t recs_f = 0, recs_b = 0;     // records (statistics)
+};
 struct HostGraph {
     int device = 0;
     int64_t S = 0, A = 0, P = 0;
@@ -226,6 +251,7 @@ struct HostGraph {
     std::vector<int4> hb_frow, hb_brow;
     std::vector<int> hb_frow_d, hb_brow_s;
     std::vector<StreamDev *> streams;   // one per (AL, tasks wanted) used so far
+    FacBatchH fb;                       // factored rows of the utterance-minor kernels (T o LM graphs), see StreamDev
     int res_rows_cu_f = 0, res_rows_cu_b = 0;  // max rows of one CU (LDS carve of the resident kernels)
 };
 
@@ -249,6 +275,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // Arc streams for UL (8, 16, 32 or 64) utterances per group cut into about `want` tasks per direction, built and uploaded
 // on first use (thread-safe; a graph keeps every variant it has been asked for).
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out);
+bool stream_fac(const HostGraph *h, int UL);   // factored streams for groups of UL utterances?
 // Host-side construction + self-check of the arc streams (tests; works on host-only graphs).
 int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4);
 // Host-side check of bat_decode for one (grid, #combos): 0 = every (combo, chunk) exactly once.

@@ -2349,11 +2349,13 @@ struct BatchParams {
     BatchDev g;
     StreamDev st;                  // arc streams for AL = 64 / UL lane groups
     const float *start_lin, *end_lin;
+    const float *x_start;          // [SX] a_0 of the forward vector's entries: the S states, then the U entries of factored streams
     int S, P, B, Bp, T, V, max_label, ngrp;
+    int SX;                        // entries of the forward vector (S + StreamDev::NU)
     const int *lx;
     const float *ep, *moff;        // [B][T][V] e' (prep kernel), [B][T] log-likelihood offset per frame
     float *ept;                    // [T][grp][V][UL] e' transposed
-    float *Af, *Zb;                // [2][grp][S][UL], [2][grp][P][UL]
+    float *Af, *Zb;                // [2][grp][SX][UL], [2][grp][P][UL]
     float *Q, *BP;                 // [T][grp][P][UL]
     unsigned *mxf, *mxb;           // [3][Bp] maxima of the vectors (float bits; the values are non-negative)
     int *Ef, *Fb;                  // [Bp] running exponents
@@ -2387,10 +2389,10 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_transpose_kernel(BatchP
 __global__ __launch_bounds__(kBatThreads) void crf_batch_init_kernel(BatchParams p) {
     const int64_t i = (int64_t)blockIdx.x * kBatThreads + threadIdx.x;
     const int UL = p.Bp / p.ngrp;
-    if (i < (int64_t)p.S * p.Bp) p.Af[i] = p.start_lin[(i / UL) % p.S] * pow2f(kScaleExp);
+    if (i < (int64_t)p.SX * p.Bp) p.Af[i] = p.x_start[(i / UL) % p.SX] * pow2f(kScaleExp);
     if (blockIdx.x == 0) {
         float m = 0.f;
-        for (int s = threadIdx.x; s < p.S; s += kBatThreads) m = fmaxf(m, p.start_lin[s]);
+        for (int s = threadIdx.x; s < p.SX; s += kBatThreads) m = fmaxf(m, p.x_start[s]);
         __shared__ float red[kBatWaves];
         m = wave_max(m);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -2463,14 +2465,20 @@ __device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int 
 constexpr int kStreamBatch = 4, kStreamChunk = 128;   // steps per batch; batches * AL per 4 KB chunk (batches in flight: template parameter D)
 constexpr int kStreamBundles = 8;                     // bundles per task at most (fst_graph.cpp: build_stream_dir)
 constexpr int kStreamRecB = kStreamChunk * 32;        // bytes of a chunk of records
+// Factored streams (NM = 3 descriptor words per row, crf_internal.h StreamDev): the ring holds NR values per row instead of the
+// one emission row -- forward {e[label 0], e[label 1], U of the row's couple}, backward {e[label 0], e[label 1], z of the two
+// extra arcs} -- all known from the descriptor, so all requested a bundle ahead like the emissions; epi gets them as e[NR].
 constexpr int kStreamLds = 2 * kStreamRecB + 2 * 64 * 16 + kStreamBundles * 32 * 16;   // per wave: records (2 halves) | emission ring | descriptors
-template <int UL, int D, typename Epi>
+template <int UL, bool FAC>
+constexpr int stream_lds() { return FAC ? 2 * kStreamRecB + 2 * 64 * 16 * 4 + kStreamBundles * (256 / UL) * 48 : kStreamLds; }
+template <int UL, int D, int NM, int NR, typename Epi>
 __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, const float *__restrict__ X, const float *__restrict__ et,
                                            int uq, int aj, int lane, char *ldsw, int tmi, Epi &&epi) {
     constexpr int LG = UL / 4, AL = 64 / LG, CB = kStreamChunk / AL;
     static_assert(kStreamBatch == 4 && CB % D == 0 && CB >= D, "a chunk holds a whole number of pipeline rounds");
-    f32x4 *elds = (f32x4 *)(ldsw + 2 * kStreamRecB);               // [2][lane]
-    int4 *mlds = (int4 *)(ldsw + 2 * kStreamRecB + 2 * 64 * 16);   // [bundle][AL]
+    static_assert((NM == 1 && NR == 1) || (NM == 3 && (NR == 3 || NR == 4)), "plain or factored rows");
+    f32x4 *elds = (f32x4 *)(ldsw + 2 * kStreamRecB);               // [2][NR][lane]
+    int4 *mlds = (int4 *)(ldsw + 2 * kStreamRecB + 2 * 64 * 16 * (NM == 1 ? 1 : 4));   // [bundle][AL][NM]
     const int4 tk = sd.tasks[task];
     const int b0 = __builtin_amdgcn_readfirstlane(tk.x), nb = __builtin_amdgcn_readfirstlane(tk.y);
     const int bund0 = __builtin_amdgcn_readfirstlane(tk.z), nbund = __builtin_amdgcn_readfirstlane(tk.w);
@@ -2478,24 +2486,33 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, con
     const int4 *gsrc = (const int4 *)sd.recs + (size_t)b0 * AL * 2 + lane;   // a chunk = 256 int4: four per lane (the stream is padded)
     {   // chunk 0 -> LDS half 0 (the only wait for something just requested: once per task)
         const int4 s0 = gsrc[0], s1 = gsrc[64], s2 = gsrc[128], s3 = gsrc[192];
-        const int4 *mp = sd.meta + (size_t)bund0 * AL;
-        constexpr int NM = (kStreamBundles * AL + 63) / 64;
-        int4 mm[NM];
+        const int4 *mp = sd.meta + (size_t)bund0 * AL * NM;
+        constexpr int NMW = (kStreamBundles * AL * NM + 63) / 64;
+        int4 mm[NMW];
 #pragma unroll
-        for (int q = 0; q < NM; ++q) mm[q] = (q * 64 + lane < nbund * AL) ? mp[q * 64 + lane] : int4{-1, 0, 0, 0};
+        for (int q = 0; q < NMW; ++q) mm[q] = (q * 64 + lane < nbund * AL * NM) ? mp[q * 64 + lane] : int4{-1, 0, 0, 0};
         *(int4 *)(ldsw + lane * 16) = s0; *(int4 *)(ldsw + (64 + lane) * 16) = s1;
         *(int4 *)(ldsw + (128 + lane) * 16) = s2; *(int4 *)(ldsw + (192 + lane) * 16) = s3;
 #pragma unroll
-        for (int q = 0; q < NM; ++q) mlds[q * 64 + lane] = mm[q];
+        for (int q = 0; q < NMW; ++q)
+            if ((NMW * 64 == kStreamBundles * AL * NM) || q * 64 + lane < kStreamBundles * AL * NM) mlds[q * 64 + lane] = mm[q];   // (the slice ends there)
     }
     CRF_TM(tmi >= 0, tmi + 3);
     int4 st0 = gsrc[256], st1 = gsrc[320], st2 = gsrc[384], st3 = gsrc[448];   // chunk 1 (padding if there is none)
     gsrc += 512;
     const f32x4 *et4 = (const f32x4 *)et + uq;                     // et[label * UL + 4 uq ..]
-    // emissions of bundles 0 and 1 -> ring (written once the first gathers are out), bundle 2 -> eA
-    const f32x4 ei0 = et4[(size_t)mlds[aj].z * LG];
-    const f32x4 ei1 = et4[(size_t)mlds[(nbund > 1 ? AL : 0) + aj].z * LG];
-    f32x4 eA = et4[(size_t)mlds[(nbund > 2 ? 2 * AL : 0) + aj].z * LG];
+    const f32x4 *X4 = (const f32x4 *)X + uq;                       // X[entry * UL + 4 uq ..]
+    // value k of the row (bundle bd, lane group aj): emissions of its label(s), entries its epilogue reads
+    auto ringsrc = [&](const int bd, const int k) __attribute__((always_inline)) -> f32x4 {
+        const int4 *m = mlds + ((size_t)bd * AL + aj) * NM;
+        if (k == 0) return et4[(size_t)m[0].z * LG];
+        if (k == 1) return et4[(size_t)m[NM > 1 ? 1 : 0].z * LG];
+        return X4[(size_t)(k == 2 ? m[NM > 1 ? 2 : 0].x : m[NM > 1 ? 2 : 0].z) * LG];
+    };
+    // values of bundles 0 and 1 -> ring (written once the first gathers are out), bundle 2 -> eA
+    f32x4 ei0[NR], ei1[NR], eA[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { ei0[k] = ringsrc(0, k); ei1[k] = ringsrc(nbund > 1 ? 1 : 0, k); eA[k] = ringsrc(nbund > 2 ? 2 : 0, k); }
     const unsigned uq16 = (unsigned)uq * 16u;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     f32x4 x[D][4];
@@ -2524,11 +2541,17 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, con
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc = __builtin_elementwise_fma(x[j][k], (f32x4){w[j][k], w[j][k], w[j][k], w[j][k]}, acc);
         if (fl[j] & 1u) {                                          // (uniform) the rows of the bundle end with this batch
-            const f32x4 e = elds[(bund & 1) * 64 + lane];
-            epi(acc, mlds[bund * AL + aj], e);
+            f32x4 e[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) e[k] = elds[((bund & 1) * NR + k) * 64 + lane];
+            epi(acc, mlds + ((size_t)bund * AL + aj) * NM, e);
             acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            elds[(bund & 1) * 64 + lane] = eA;                     // emissions of bundle + 2 (asked for one bundle ago)
-            if (bund + 3 < nbund) eA = et4[(size_t)mlds[(bund + 3) * AL + aj].z * LG];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) elds[((bund & 1) * NR + k) * 64 + lane] = eA[k];   // values of bundle + 2 (asked for one bundle ago)
+            if (bund + 3 < nbund) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) eA[k] = ringsrc(bund + 3, k);
+            }
             ++bund;
         }
     };
@@ -2544,7 +2567,8 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, con
 #pragma unroll
     for (int j = 0; j < D - 1; ++j)
         if (j < nb) issue(j, j);
-    elds[lane] = ei0; elds[64 + lane] = ei1;                       // (older than the gathers just issued)
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { elds[k * 64 + lane] = ei0[k]; elds[(NR + k) * 64 + lane] = ei1[k]; }   // (older than the gathers just issued)
     CRF_TM(tmi >= 0, tmi + 4);
 #ifdef CRF_TIMING
     if (tmi >= 0 && lane == 0) { g_tm[tmi + 8] = (unsigned long long)nb; g_tm[tmi + 9] = (unsigned long long)nbund; }
@@ -2573,12 +2597,13 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, con
 //   #combos >= 8: XCD x serves the combos x, x + 8, ..., its slots dealt round-robin among them.
 // The waves of a combo take the tasks of its arc stream (rows with one entering pair: all of a T o LM graph) and then the
 // remaining rows one at a time (bat_row_sum: one utterance per lane, 64 / UL arcs of the row side by side).
-template <int UL, int D>
+template <int UL, int D, bool FAC = false>
 __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParams p) {
     constexpr int ALR = 64 / UL;                                   // rest rows: arc lanes per utterance
     constexpr int LG = UL / 4;                                     // stream: lanes per row (64 / LG rows side by side)
+    constexpr int NM = FAC ? 3 : 1;                                // descriptor words per stream row
     __shared__ unsigned umax[UL];                                  // maximum of the vector this workgroup wrote, per utterance (float bits)
-    __shared__ __attribute__((aligned(16))) char stage[kBatWaves][kStreamLds];   // bat_stream: records, emission ring, descriptors of a wave's task
+    __shared__ __attribute__((aligned(16))) char stage[kBatWaves][stream_lds<UL, FAC>()];   // bat_stream: records, value ring, descriptors of a wave's task
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (timing build: launch 700, four workgroups of the first XCD x their four waves, 16 stamps each from g_tm[14000])
@@ -2600,8 +2625,8 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
     const int w0 = chunk * kBatWaves + wave, NW = nchunk * kBatWaves;   // this wave among the waves of its combo
     const bool lead = chunk == 0 && wave == 0 && aj == 0;          // one writer per utterance for the scalars
     const BatchDev &g = p.g;
-    const size_t gS = (size_t)grp * S * UL, gP = (size_t)grp * P * UL, gV = (size_t)grp * p.V * UL;
-    const size_t Sall = (size_t)S * p.Bp, Pall = (size_t)P * p.Bp, Vall = (size_t)p.V * p.Bp;
+    const size_t gS = (size_t)grp * p.SX * UL, gP = (size_t)grp * P * UL, gV = (size_t)grp * p.V * UL;
+    const size_t Sall = (size_t)p.SX * p.Bp, Pall = (size_t)P * p.Bp, Vall = (size_t)p.V * p.Bp;
     if (tid < UL) umax[tid] = 0u;
     __syncthreads();
     CRF_TM(tmi >= 0 && lx4[0] + lx4[1] + lx4[2] + lx4[3] + lx >= 0, tmi + 1);   // (the scalar loads have landed)
@@ -2626,19 +2651,33 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
         const float *et = p.ept + (size_t)t * Vall + gV;
         float *Qt = p.Q + (size_t)t * Pall + gP;
         for (int task = w0; task < p.st.f.ntasks; task += NW)
-            bat_stream<UL, D>(p.st.f, task, Ac, et, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 &m, const f32x4 &e) __attribute__((always_inline)) {
-                if (m.x < 0) return;                               // padding row of the last bundle
+            bat_stream<UL, D, NM, FAC ? 3 : 1>(p.st.f, task, Ac, et, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
+                if (m[0].x < 0) return;                            // padding row of the last bundle
                 // an utterance that has ended keeps a_lx where it is: nobody writes that buffer for it again
                 // (crf_batch_zsum_kernel reads it there)
-                const f32x4 q = acc * sc4, an = e * q;
-                float *qp = Qt + (size_t)m.y * UL + 4 * uq, *ap = An + (size_t)m.x * UL + 4 * uq;
+                const f32x4 q = acc * sc4, an = e[0] * q;
+                float *qp = Qt + (size_t)m[0].y * UL + 4 * uq, *ap = An + (size_t)m[0].x * UL + 4 * uq;
                 if (all4) { *(f32x4 *)qp = q; *(f32x4 *)ap = an; }
                 else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) if (act4[c]) { qp[c] = q[c]; ap[c] = an[c]; }
                 }
+                f32x4 top = an;                                    // the largest entry this row writes
+                if constexpr (FAC) {
+                    if (m[1].x >= 0) {                             // the couple's tail row, folded in: q = w * U_t, and U_{t+1} = both states' a
+                        const float tw = __int_as_float(m[2].y);
+                        const f32x4 qt = e[2] * (f32x4){tw, tw, tw, tw} * sc4, at = e[1] * qt, un = an + at;
+                        float *qp1 = Qt + (size_t)m[1].y * UL + 4 * uq, *ap1 = An + (size_t)m[1].x * UL + 4 * uq, *up = An + (size_t)m[2].x * UL + 4 * uq;
+                        if (all4) { *(f32x4 *)qp1 = qt; *(f32x4 *)ap1 = at; *(f32x4 *)up = un; }
+                        else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (act4[c]) mymax4[c] = fmaxf(mymax4[c], an[c]);
+                            for (int c = 0; c < 4; ++c) if (act4[c]) { qp1[c] = qt[c]; ap1[c] = at[c]; up[c] = un[c]; }
+                        }
+                        top = un;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (act4[c]) mymax4[c] = fmaxf(mymax4[c], top[c]);
             });
         for (int i = w0; i < p.st.f.nrest; i += NW) {
             const int r = __builtin_amdgcn_readfirstlane(p.st.f.rest[i]);
@@ -2689,31 +2728,40 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
         const bool any_active = __ballot(active) != 0ull;
         if (any_active || __ballot(starts) != 0ull)
             for (int task = w0; task < p.st.b.ntasks; task += NW)
-                bat_stream<UL, D>(p.st.b, task, Zc, ep1, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 &m, const f32x4 &e) __attribute__((always_inline)) {
-                    if (m.x < 0) return;
-                    const f32x4 bv = acc * sc4;
-                    if (t == 0) {
-                        const float st = p.start_lin[m.x];
-                        if (st != 0.f) {
+                bat_stream<UL, D, NM, FAC ? 4 : 1>(p.st.b, task, Zc, ep1, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
+                    if (m[0].x < 0) return;
+                    // one output (plain rows), or the two states of a couple: the common out-arcs' sum + each state's extra arc
+                    auto output = [&](const f32x4 &bv, const int st_, const int pr_, const f32x4 &em) __attribute__((always_inline)) {
+                        if (t == 0) {
+                            const float st = p.start_lin[st_];
+                            if (st != 0.f) {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) if (act4[c]) atomicAdd(&p.zb[u4 + c], st * bv[c]);
-                        }
-                        return;
-                    }
-                    float *bp = BPt + (size_t)m.y * UL + 4 * uq, *zp = Zn + (size_t)m.y * UL + 4 * uq;
-                    if (all4) {
-                        const f32x4 z = e * bv;
-                        *(f32x4 *)bp = bv; *(f32x4 *)zp = z;
-                        mymax4 = __builtin_elementwise_max(mymax4, z);
-                    } else {
-                        const float eend = p.end_lin[m.x] * pow2f(kScaleExp);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (act4[c] || st4[c]) {
-                                const float out = act4[c] ? bv[c] : eend, z = e[c] * out;
-                                bp[c] = out; zp[c] = z;
-                                mymax4[c] = fmaxf(mymax4[c], z);
+                                for (int c = 0; c < 4; ++c) if (act4[c]) atomicAdd(&p.zb[u4 + c], st * bv[c]);
                             }
+                            return;
+                        }
+                        float *bp = BPt + (size_t)pr_ * UL + 4 * uq, *zp = Zn + (size_t)pr_ * UL + 4 * uq;
+                        if (all4) {
+                            const f32x4 z = em * bv;
+                            *(f32x4 *)bp = bv; *(f32x4 *)zp = z;
+                            mymax4 = __builtin_elementwise_max(mymax4, z);
+                        } else {
+                            const float eend = p.end_lin[st_] * pow2f(kScaleExp);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                if (act4[c] || st4[c]) {
+                                    const float out = act4[c] ? bv[c] : eend, z = em[c] * out;
+                                    bp[c] = out; zp[c] = z;
+                                    mymax4[c] = fmaxf(mymax4[c], z);
+                                }
+                        }
+                    };
+                    if constexpr (FAC) {
+                        const float w0 = __int_as_float(m[2].y), w1 = __int_as_float(m[2].w);
+                        output(__builtin_elementwise_fma(e[2], (f32x4){w0, w0, w0, w0}, acc) * sc4, m[0].x, m[0].y, e[0]);
+                        if (m[1].x >= 0) output(__builtin_elementwise_fma(e[3], (f32x4){w1, w1, w1, w1}, acc) * sc4, m[1].x, m[1].y, e[1]);
+                    } else {
+                        output(acc * sc4, m[0].x, m[0].y, e[0]);
                     }
                 });
         for (int i = w0; i < p.st.b.nrest; i += NW) {
@@ -2773,7 +2821,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_zsum_kernel(BatchParams
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ul = lane % UL, aj = lane / UL, u = blockIdx.z * UL + ul;
     const int lxu = u < p.B ? p.lx[u] : 0;                         // a_lx sits in the buffer frame lx - 1 wrote: parity lx & 1
-    const float *Af = p.Af + (size_t)(lxu & 1) * p.S * p.Bp + (size_t)blockIdx.z * p.S * UL;
+    const float *Af = p.Af + (size_t)(lxu & 1) * p.SX * p.Bp + (size_t)blockIdx.z * p.SX * UL;
     const int s0 = (blockIdx.x * kBatWaves + wave) * 64;
     float acc = 0.f;
     for (int s = s0 + aj; s < min(s0 + 64, p.S); s += AL) acc = fmaf(Af[(size_t)s * UL + ul], p.end_lin[s], acc);
@@ -3239,7 +3287,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_xch = o; o = al(o + w.xch_bytes + 256 + 8 * B);   // granules | error word, start counter | per-utterance progress of the two den recursions
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.off_ept = o; o = al(o + (w.bat ? T * V * w.Bp * 4 : 0));
-    w.off_Af = o; o = al(o + (w.bat ? 2 * (int64_t)h->dev.S * w.Bp * 4 : 0));
+    w.off_Af = o; o = al(o + (w.bat ? 2 * ((int64_t)h->dev.S + (h->fb.ok ? h->fb.NU : 0)) * w.Bp * 4 : 0));   // (+ the U entries of factored streams)
     w.off_Zb = o; o = al(o + (w.bat ? 2 * (int64_t)h->dev.P * w.Bp * 4 : 0));
     w.off_bsm = o; o = al(o + (w.bat ? 12 * w.Bp * 4 : 0));        // mxf[3], mxb[3], Ef, Fb, zs, zb
     w.gv = h && !w.res && !w.bat && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
@@ -3842,15 +3890,21 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // one task per wave, ONE round of workgroups (a second round with a fraction of the device doubled the launch):
         // the tasks wanted per direction follow from the occupancy the runtime reports, shared by the combos
         const int64_t ncombo = 2 * (int64_t)ngrp;
+        const bool bfac = stream_fac(g->h, w.UL);                  // factored streams (T o LM graphs, groups of >= 32 utterances)
         int wg_cu = 0;
         {
-            const void *fn = w.UL == 64 ? (const void *)crf_batch_frame_kernel<64, 4> : w.UL == 32 ? (const void *)crf_batch_frame_kernel<32, 4>
+            const void *fn = w.UL == 64 ? (bfac ? (const void *)crf_batch_frame_kernel<64, 4, true> : (const void *)crf_batch_frame_kernel<64, 4>)
+                           : w.UL == 32 ? (bfac ? (const void *)crf_batch_frame_kernel<32, 4, true> : (const void *)crf_batch_frame_kernel<32, 4>)
                            : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16, 4> : (const void *)crf_batch_frame_kernel<8, 4>;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, fn, kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = 2; }
         }
-        const int want = (int)std::max<int64_t>(16, (int64_t)ncu_dev * wg_cu * kBatWaves * 15 / 16 / ncombo);
+        static const int fill_env = getenv("CRF_BAT_FILL") ? atoi(getenv("CRF_BAT_FILL")) : 0;   // percent of the device's slots one launch takes (probe: two callers side by side)
+        const int64_t fill = fill_env > 0 && fill_env <= 100 ? fill_env : 100;
+        const int want = (int)std::max<int64_t>(16, (int64_t)ncu_dev * wg_cu * kBatWaves * 15 / 16 * fill / 100 / ncombo);
         const StreamDev *sdv = nullptr;
         if ((rc = ensure_stream_tables(g->h, w.UL, want, &sdv))) return rc;
+        if ((sdv->fac != 0) != bfac) { set_error("arc streams: factored / plain mismatch"); return CRF_ERR_ARG; }
+        bp.SX = h->dev.S + sdv->NU; bp.x_start = sdv->x_start;
         bp.st = *sdv;
         // 8 * nslot workgroups (block b -> XCD b % 8, slot b / 8): every combo gets at least one wave per task of its arc
         // stream (crf_batch_frame_kernel: a combo has nslot * nk or about nslot / ncx workgroups)
@@ -3867,13 +3921,17 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             default: hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(kBatThreads), 0, stream, __VA_ARGS__); break;   \
         }
         CRF_BAT_UL(crf_batch_transpose_kernel, dim3((unsigned)((V + 63) / 64), (unsigned)T, ngrp), bp);
-        hipLaunchKernelGGL(crf_batch_init_kernel, dim3((unsigned)(((int64_t)h->dev.S * w.Bp + kBatThreads - 1) / kBatThreads)), dim3(kBatThreads), 0, stream, bp);
+        hipLaunchKernelGGL(crf_batch_init_kernel, dim3((unsigned)(((int64_t)bp.SX * w.Bp + kBatThreads - 1) / kBatThreads)), dim3(kBatThreads), 0, stream, bp);
         LAUNCH_CHECK("crf_batch_init_kernel");
         for (int j = 0; j <= (int)T; ++j) {
             bp.j = j;
             switch (w.UL) {   // (4: batches of gathers in flight per wave; 2 measured 6 % slower, 8 needs more registers than a wave has)
-                case 64: hipLaunchKernelGGL((crf_batch_frame_kernel<64, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                case 32: hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                case 64: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<64, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
+                         else hipLaunchKernelGGL((crf_batch_frame_kernel<64, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
+                         break;
+                case 32: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
+                         else hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
+                         break;
                 case 16: hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
                 default: hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
             }

@@ -239,17 +239,14 @@ int upload(HostGraph *h, const std::vector<T> &v, const T **out) {
 
 // One direction's arc stream (crf_internal.h: StreamDirDev).  rows / row_st / arcs: the BatchDev tables of that direction.
 struct StreamHost { std::vector<int4> tasks, meta; std::vector<int2> recs; std::vector<int> rest; };
-static int build_stream_host(int AL, int UL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
-                             const std::vector<int2> &arcs, StreamHost *sh) {
+// a stream row: NM descriptor words and its records
+struct SRow { int4 m[3]; const int2 *recs; int n; };
+// rows (most records first) -> bundles of AL rows -> tasks of at most `maxb` bundles and about task_steps steps
+static int build_stream_rows(int AL, int UL, int task_steps, int maxb, int NM, const std::vector<SRow> &srows, StreamHost *sh) {
     constexpr int kB = 4;                                 // steps per batch (crf_kernels.hip: kStreamBatch)
-    std::vector<int> simple, rest;
-    for (int r = 0; r < (int)rows.size(); ++r) {
-        const int4 &d = rows[(size_t)r];
-        if ((d.w & 0x40000000) && d.y > d.x) simple.push_back(r); else rest.push_back(r);   // (rows are most-arcs-first already)
-    }
     std::vector<int4> tasks, meta;
     std::vector<int2> recs;
-    const int nbund = ((int)simple.size() + AL - 1) / AL;
+    const int nbund = ((int)srows.size() + AL - 1) / AL;
     int task_b0 = 0, task_batch0 = 0, task_steps_now = 0;
     auto close_task = [&](int b1) {
         if (b1 == task_b0) return;
@@ -261,29 +258,21 @@ static int build_stream_host(int AL, int UL, int task_steps, const std::vector<i
         int len = 0;
         for (int aj = 0; aj < AL; ++aj) {
             const int i = b * AL + aj;
-            if (i < (int)simple.size()) len = std::max(len, rows[(size_t)simple[(size_t)i]].y - rows[(size_t)simple[(size_t)i]].x);
+            if (i < (int)srows.size()) len = std::max(len, srows[(size_t)i].n);
         }
         const int nbat = (len + kB - 1) / kB;             // every row of the bundle padded to whole batches
-        if (task_steps_now > 0 && (task_steps_now + nbat * kB > task_steps || b - task_b0 >= 8)) close_task(b);   // (8: kStreamBundles)
-        int n[32] = {0}, a0[32] = {0};
+        if (task_steps_now > 0 && (task_steps_now + nbat * kB > task_steps || b - task_b0 >= maxb)) close_task(b);
         for (int aj = 0; aj < AL; ++aj) {
             const int i = b * AL + aj;
-            int4 m{-1, 0, 0, 0};
-            if (i < (int)simple.size()) {
-                const int r = simple[(size_t)i];
-                const int4 &d = rows[(size_t)r];
-                m = int4{row_st[(size_t)r], d.z, d.w & 0xffff, 0};
-                n[aj] = d.y - d.x; a0[aj] = d.x;
-            }
-            meta.push_back(m);
+            for (int q = 0; q < NM; ++q) meta.push_back(i < (int)srows.size() ? srows[(size_t)i].m[q] : (q == 0 ? int4{-1, 0, 0, 0} : int4{-1, 0, 0, 0}));
         }
         for (int bt = 0; bt < nbat; ++bt)
             for (int aj = 0; aj < AL; ++aj)
                 for (int k = 0; k < kB; ++k) {
-                    const int st = bt * kB + k;
+                    const int st = bt * kB + k, i = b * AL + aj;
                     int2 rcd{0, 0};
-                    if (st < n[aj]) {
-                        rcd = arcs[(size_t)a0[aj] + st];
+                    if (i < (int)srows.size() && st < srows[(size_t)i].n) {
+                        rcd = srows[(size_t)i].recs[st];
                         // the kernels want entry * UL (UL utterances per entry), below 2^29 so that the byte offset fits 31 bits
                         if (rcd.x < 0 || (int64_t)rcd.x * UL >= (1ll << 29)) { set_error("arc stream: index does not fit"); return CRF_ERR_ARG; }
                         rcd.x *= UL;
@@ -295,8 +284,31 @@ static int build_stream_host(int AL, int UL, int task_steps, const std::vector<i
     }
     close_task(nbund);
     for (int k = 0; k < 1024; ++k) recs.push_back(int2{0, 0});            // the kernels stage whole 4 KB chunks, one chunk ahead
-    sh->tasks = std::move(tasks); sh->meta = std::move(meta); sh->recs = std::move(recs); sh->rest = std::move(rest);
+    sh->tasks = std::move(tasks); sh->meta = std::move(meta); sh->recs = std::move(recs);
     return CRF_OK;
+}
+static int build_stream_host(int AL, int UL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
+                             const std::vector<int2> &arcs, StreamHost *sh) {
+    std::vector<SRow> srows;
+    std::vector<int> rest;
+    for (int r = 0; r < (int)rows.size(); ++r) {
+        const int4 &d = rows[(size_t)r];
+        if ((d.w & 0x40000000) && d.y > d.x)               // (rows are most-arcs-first already)
+            srows.push_back(SRow{{int4{row_st[(size_t)r], d.z, d.w & 0xffff, 0}, int4{-1, 0, 0, 0}, int4{0, 0, 0, 0}}, arcs.data() + d.x, d.y - d.x});
+        else rest.push_back(r);
+    }
+    const int rc = build_stream_rows(AL, UL, task_steps, 8, 1, srows, sh);   // (8: kStreamBundles)
+    sh->rest = std::move(rest);
+    return rc;
+}
+// ... and of the factored rows (three descriptor words per row)
+static int build_stream_host_fac(int AL, int UL, int task_steps, const std::vector<FacRowH> &rows, const std::vector<int> &rest, StreamHost *sh) {
+    std::vector<SRow> srows;
+    for (const FacRowH &r : rows)
+        srows.push_back(SRow{{int4{r.st0, r.pr0, r.lab0, 0}, int4{r.st1, r.pr1, r.lab1, 0}, int4{r.x0, r.w0, r.x1, r.w1}}, r.recs.data(), (int)r.recs.size()});
+    const int rc = build_stream_rows(AL, UL, task_steps, 8, 3, srows, sh);
+    sh->rest = rest;
+    return rc;
 }
 
 static int build_stream_dir(HostGraph *h, int AL, int UL, int task_steps, const std::vector<int4> &rows, const std::vector<int> &row_st,
@@ -389,14 +401,203 @@ int upload_ell(HostGraph *h, const EllHost &e, EllDev *d) {
 
 }  // namespace
 
+// Factored rows of the utterance-minor kernels (crf_internal.h: StreamDev) from the BatchDev tables.  Structure detection as
+// in the register-resident factored layout (res_layout.cpp build_factored), restated on these tables:
+//   tail t, main o:  t has one entering pair whose two arcs come from t itself and from o with the same weight bits; both
+//                    states have exactly one entering pair; a state is in at most one such couple;
+//   forward rows:    every other one-pair row, the arcs from a couple's two states with equal weights merged into one record
+//                    reading U = S + k; the main row carries its tail as second output;
+//   backward rows:   a couple whose out-arcs are common except at most one each shares a row.
+// Anything that does not fit stays what it was (one-pair rows: plain stream rows; the others: the row-at-a-time path).
+// Used when at least half of the states are in couples.
+static void build_batch_factored(HostGraph *h, int S, const std::vector<int4> &frow, const std::vector<int> &frow_d, const std::vector<int2> &farcs,
+                                 const std::vector<int4> &brow, const std::vector<int> &brow_s, const std::vector<int2> &barcs,
+                                 const std::vector<float> &start_lin) {
+    FacBatchH &F = h->fb;
+    F = FacBatchH();
+    if (getenv("CRF_BAT_NO_FAC") && atoi(getenv("CRF_BAT_NO_FAC"))) return;
+    std::vector<int> fr_of(S, -1), br_of(S, -1);
+    for (int r = 0; r < S; ++r) { fr_of[(size_t)frow_d[(size_t)r]] = r; br_of[(size_t)brow_s[(size_t)r]] = r; }
+    auto fsimple = [&](int s) { const int4 &d = frow[(size_t)fr_of[(size_t)s]]; return (d.w & 0x40000000) && d.y > d.x; };
+    auto bsimple = [&](int s) { const int4 &d = brow[(size_t)br_of[(size_t)s]]; return (d.w & 0x40000000) && d.y > d.x; };
+    std::vector<int> main_of(S, -1), tail_of(S, -1), uidx(S, -1), tailw(S, 0);
+    int NU = 0;
+    for (int t = 0; t < S; ++t) {
+        if (!fsimple(t)) continue;
+        const int4 &d = frow[(size_t)fr_of[(size_t)t]];
+        if (d.y - d.x != 2) continue;
+        const int2 a = farcs[(size_t)d.x], b = farcs[(size_t)d.x + 1];
+        if (a.y != b.y) continue;
+        const int o = a.x == t ? b.x : b.x == t ? a.x : -1;
+        if (o < 0 || o == t || !fsimple(o)) continue;
+        if (main_of[(size_t)t] >= 0 || tail_of[(size_t)t] >= 0 || main_of[(size_t)o] >= 0 || tail_of[(size_t)o] >= 0) continue;
+        main_of[(size_t)t] = o; tail_of[(size_t)o] = t; tailw[(size_t)o] = a.y;
+    }
+    // (a main state must not itself look like a tail that was skipped: nothing to check -- couples are disjoint by construction)
+    for (int o = 0; o < S; ++o) if (tail_of[(size_t)o] >= 0) uidx[(size_t)o] = NU++;
+    if ((int64_t)NU * 4 < S) return;
+    auto couple_main = [&](int s) { return tail_of[(size_t)s] >= 0 ? s : main_of[(size_t)s]; };   // main state of s's couple, -1: none
+    // forward
+    for (int r = 0; r < S; ++r) {
+        const int s = frow_d[(size_t)r];
+        const int4 &d = frow[(size_t)r];
+        if (!((d.w & 0x40000000) && d.y > d.x)) { F.frest.push_back(r); continue; }
+        if (main_of[(size_t)s] >= 0) continue;                        // a tail: computed by its main row
+        FacRowH row;
+        row.st0 = s; row.pr0 = d.z; row.lab0 = d.w & 0xffff;
+        if (tail_of[(size_t)s] >= 0) {
+            const int t = tail_of[(size_t)s];
+            const int4 &dt = frow[(size_t)fr_of[(size_t)t]];
+            row.st1 = t; row.pr1 = dt.z; row.lab1 = dt.w & 0xffff; row.x0 = S + uidx[(size_t)s]; row.w0 = tailw[(size_t)s];
+        }
+        std::map<std::pair<int, int>, std::vector<int>> by;          // (couple's main, weight bits) -> arcs
+        for (int k = d.x; k < d.y; ++k) by[{couple_main(farcs[(size_t)k].x), farcs[(size_t)k].y}].push_back(k);
+        std::vector<char> used((size_t)(d.y - d.x), 0);
+        for (int k = d.x; k < d.y; ++k) {
+            if (used[(size_t)(k - d.x)]) continue;
+            used[(size_t)(k - d.x)] = 1;
+            const int src = farcs[(size_t)k].x, mn = couple_main(src);
+            int partner = -1;
+            if (mn >= 0) {
+                const int other = src == mn ? tail_of[(size_t)mn] : mn;
+                for (int q : by[{mn, farcs[(size_t)k].y}]) if (!used[(size_t)(q - d.x)] && farcs[(size_t)q].x == other) { partner = q; break; }
+            }
+            if (partner >= 0) { used[(size_t)(partner - d.x)] = 1; row.recs.push_back(int2{S + uidx[(size_t)mn], farcs[(size_t)k].y}); }
+            else row.recs.push_back(farcs[(size_t)k]);
+        }
+        F.recs_f += (int64_t)row.recs.size();
+        F.frows.push_back(std::move(row));
+    }
+    // backward
+    std::vector<char> done(S, 0);
+    for (int r = 0; r < S; ++r) {
+        const int s = brow_s[(size_t)r];
+        const int4 &d = brow[(size_t)r];
+        if (!((d.w & 0x40000000) && d.y > d.x)) { F.brest.push_back(r); continue; }
+        if (done[(size_t)s]) continue;
+        done[(size_t)s] = 1;
+        FacRowH row;
+        row.st0 = s; row.pr0 = d.z; row.lab0 = d.w & 0xffff;
+        const int mn = couple_main(s), m = mn < 0 ? -1 : (s == mn ? tail_of[(size_t)mn] : mn);
+        bool fused = false;
+        if (m >= 0 && !done[(size_t)m] && bsimple(m)) {
+            const int4 &dm = brow[(size_t)br_of[(size_t)m]];
+            std::vector<std::pair<int, int>> a, b, common, ea, eb;
+            for (int k = d.x; k < d.y; ++k) a.push_back({barcs[(size_t)k].x, barcs[(size_t)k].y});
+            for (int k = dm.x; k < dm.y; ++k) b.push_back({barcs[(size_t)k].x, barcs[(size_t)k].y});
+            std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+            std::set_intersection(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(common));
+            std::set_difference(a.begin(), a.end(), common.begin(), common.end(), std::back_inserter(ea));
+            std::set_difference(b.begin(), b.end(), common.begin(), common.end(), std::back_inserter(eb));
+            if (!common.empty() && ea.size() <= 1 && eb.size() <= 1) {
+                fused = true;
+                done[(size_t)m] = 1;
+                row.st1 = m; row.pr1 = dm.z; row.lab1 = dm.w & 0xffff;
+                if (!ea.empty()) { row.x0 = ea[0].first; row.w0 = ea[0].second; }
+                if (!eb.empty()) { row.x1 = eb[0].first; row.w1 = eb[0].second; }
+                for (auto &c : common) row.recs.push_back(int2{c.first, c.second});
+            }
+        }
+        if (!fused) for (int k = d.x; k < d.y; ++k) row.recs.push_back(barcs[(size_t)k]);
+        F.recs_b += (int64_t)row.recs.size();
+        F.brows.push_back(std::move(row));
+    }
+    auto by_len = [](const FacRowH &x, const FacRowH &y) { return x.recs.size() > y.recs.size(); };
+    std::stable_sort(F.frows.begin(), F.frows.end(), by_len);
+    std::stable_sort(F.brows.begin(), F.brows.end(), by_len);
+    F.x_start.assign((size_t)S + NU, 0.f);
+    for (int s2 = 0; s2 < S; ++s2) {
+        F.x_start[(size_t)s2] = start_lin[(size_t)s2];
+        if (tail_of[(size_t)s2] >= 0) F.x_start[(size_t)S + uidx[(size_t)s2]] = start_lin[(size_t)s2] + start_lin[(size_t)tail_of[(size_t)s2]];
+    }
+    F.NU = NU;
+    F.ok = 1;
+}
+
+// Host check of the factored rows (tests; no GPU): on random vectors, one step of both recursions through the factored rows
+// (U entries, folded tail rows, fused backward rows) equals the step through the plain tables, pair by pair and state by
+// state (fp64, 1e-12).  out: {NU, forward records, backward records, plain arcs}.
+int debug_check_facbatch(const HostGraph *h, int64_t *out4) {
+    const FacBatchH &F = h->fb;
+    for (int i = 0; i < 4; ++i) out4[i] = 0;
+    if (!F.ok) return CRF_OK;
+    auto fl = [](int b) { float f; memcpy(&f, &b, 4); return (double)f; };
+    const int S = (int)h->S, P = (int)h->P;
+    uint64_t rng = 88172645463325252ull;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (double)(rng % 1000003) / 1000003.0 + 0.01; };
+    std::vector<double> a((size_t)S), z((size_t)P), x((size_t)S + F.NU, 0.0);
+    for (auto &v : a) v = rnd();
+    for (auto &v : z) v = rnd();
+    // U entries from the couples: found through the forward rows' second outputs
+    for (int s = 0; s < S; ++s) x[(size_t)s] = a[(size_t)s];
+    for (const FacRowH &r : F.frows) if (r.st1 >= 0) x[(size_t)r.x0] = a[(size_t)r.st0] + a[(size_t)r.st1];
+    auto fail = [&](const char *why) { set_error(std::string("factored batch rows: ") + why); return CRF_ERR_ARG; };
+    std::vector<double> q_plain((size_t)P, -1.0), q_fac((size_t)P, -1.0), b_plain((size_t)S, -1.0), b_fac((size_t)S, -1.0);
+    std::vector<char> in_rest_f((size_t)S, 0), in_rest_b((size_t)S, 0);
+    for (int r : F.frest) in_rest_f[(size_t)r] = 1;
+    for (int r : F.brest) in_rest_b[(size_t)r] = 1;
+    for (int r = 0; r < S; ++r) {
+        const int4 &d = h->hb_frow[(size_t)r];
+        if (in_rest_f[(size_t)r]) continue;
+        double acc = 0.0;
+        for (int k = d.x; k < d.y; ++k) acc += fl(h->hb_farcs[(size_t)k].y) * a[(size_t)h->hb_farcs[(size_t)k].x];
+        q_plain[(size_t)d.z] = acc;
+    }
+    for (const FacRowH &r : F.frows) {
+        double acc = 0.0;
+        for (const int2 &c : r.recs) acc += fl(c.y) * x[(size_t)c.x];
+        if (q_fac[(size_t)r.pr0] >= 0.0) return fail("a pair is produced twice (forward)");
+        q_fac[(size_t)r.pr0] = acc;
+        if (r.st1 >= 0) { if (q_fac[(size_t)r.pr1] >= 0.0) return fail("a pair is produced twice (forward, tail)"); q_fac[(size_t)r.pr1] = fl(r.w0) * x[(size_t)r.x0]; }
+    }
+    for (int p2 = 0; p2 < P; ++p2) {
+        if ((q_plain[(size_t)p2] < 0.0) != (q_fac[(size_t)p2] < 0.0)) return fail("forward rows do not cover the one-pair rows");
+        if (q_plain[(size_t)p2] >= 0.0 && std::fabs(q_plain[(size_t)p2] - q_fac[(size_t)p2]) > 1e-9 * std::fabs(q_plain[(size_t)p2])) return fail("a forward row's sum differs");
+    }
+    for (int r = 0; r < S; ++r) {
+        const int4 &d = h->hb_brow[(size_t)r];
+        if (in_rest_b[(size_t)r]) continue;
+        double acc = 0.0;
+        for (int k = d.x; k < d.y; ++k) acc += fl(h->hb_barcs[(size_t)k].y) * z[(size_t)h->hb_barcs[(size_t)k].x];
+        b_plain[(size_t)h->hb_brow_s[(size_t)r]] = acc;
+    }
+    for (const FacRowH &r : F.brows) {
+        double acc = 0.0;
+        for (const int2 &c : r.recs) acc += fl(c.y) * z[(size_t)c.x];
+        if (b_fac[(size_t)r.st0] >= 0.0) return fail("a state is produced twice (backward)");
+        b_fac[(size_t)r.st0] = acc + fl(r.w0) * z[(size_t)r.x0];
+        if (r.st1 >= 0) { if (b_fac[(size_t)r.st1] >= 0.0) return fail("a state is produced twice (backward, mate)"); b_fac[(size_t)r.st1] = acc + fl(r.w1) * z[(size_t)r.x1]; }
+    }
+    for (int s = 0; s < S; ++s) {
+        if ((b_plain[(size_t)s] < 0.0) != (b_fac[(size_t)s] < 0.0)) return fail("backward rows do not cover the one-pair rows");
+        if (b_plain[(size_t)s] >= 0.0 && std::fabs(b_plain[(size_t)s] - b_fac[(size_t)s]) > 1e-9 * std::fabs(b_plain[(size_t)s])) return fail("a backward row's sum differs");
+    }
+    // descriptors: pairs and labels as in the plain tables
+    std::vector<int> fr_of((size_t)S, -1), br_of((size_t)S, -1);
+    for (int r = 0; r < S; ++r) { fr_of[(size_t)h->hb_frow_d[(size_t)r]] = r; br_of[(size_t)h->hb_brow_s[(size_t)r]] = r; }
+    auto desc_ok = [&](const std::vector<int4> &rows, const std::vector<int> &of, int st, int pr, int lab) {
+        const int4 &d = rows[(size_t)of[(size_t)st]];
+        return (d.w & 0x40000000) && d.z == pr && (d.w & 0xffff) == lab;
+    };
+    for (const FacRowH &r : F.frows) if (!desc_ok(h->hb_frow, fr_of, r.st0, r.pr0, r.lab0) || (r.st1 >= 0 && !desc_ok(h->hb_frow, fr_of, r.st1, r.pr1, r.lab1))) return fail("forward descriptor");
+    for (const FacRowH &r : F.brows) if (!desc_ok(h->hb_brow, br_of, r.st0, r.pr0, r.lab0) || (r.st1 >= 0 && !desc_ok(h->hb_brow, br_of, r.st1, r.pr1, r.lab1))) return fail("backward descriptor");
+    out4[0] = F.NU; out4[1] = F.recs_f; out4[2] = F.recs_b; out4[3] = h->A;
+    return CRF_OK;
+}
+
 // steps per task: the longer direction's steps (rows padded to whole batches of 4) over the tasks wanted; CRF_BAT_TASK overrides
-static int stream_task_steps(const HostGraph *h, int AL, int want) {
+static int stream_task_steps(const HostGraph *h, int AL, int want, bool fac = false) {
     auto steps_of = [&](const std::vector<int4> &rows) {
         int64_t n = 0;
         for (const int4 &d : rows) if ((d.w & 0x40000000) && d.y > d.x) n += (d.y - d.x + 3) / 4 * 4;
         return (n + AL - 1) / AL;                         // (rows of a bundle have about the same length)
     };
-    const int64_t steps = std::max(steps_of(h->hb_frow), steps_of(h->hb_brow));
+    auto steps_fac = [&](const std::vector<FacRowH> &rows) {
+        int64_t n = 0;
+        for (const FacRowH &r : rows) n += ((int64_t)r.recs.size() + 3) / 4 * 4;
+        return (n + AL - 1) / AL;
+    };
+    const int64_t steps = fac ? std::max(steps_fac(h->fb.frows), steps_fac(h->fb.brows)) : std::max(steps_of(h->hb_frow), steps_of(h->hb_brow));
     int task_steps = (int)std::min<int64_t>(4096, std::max<int64_t>(64, ((steps + want - 1) / want + 3) / 4 * 4));
     if (getenv("CRF_BAT_TASK")) task_steps = std::max(8, atoi(getenv("CRF_BAT_TASK")));
     return task_steps;
@@ -439,19 +640,39 @@ int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4) {
     return CRF_OK;
 }
 
+bool stream_fac(const HostGraph *h, int UL) { return h && h->fb.ok && UL >= 32 && !(getenv("CRF_BAT_NO_FAC") && atoi(getenv("CRF_BAT_NO_FAC"))); }
+
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) {
     const int AL = 256 / std::max(UL, 1);                 // lane groups: a lane takes 4 utterances, UL / 4 lanes a row
     static std::mutex mu;
     if (!h || !(UL == 8 || UL == 16 || UL == 32 || UL == 64) || want < 1 || !h->dev.bat.ok) { set_error("ensure_stream_tables: bad arguments"); return CRF_ERR_ARG; }
     std::lock_guard<std::mutex> lock(mu);
+    const bool fac = stream_fac(h, UL);
     for (StreamDev *sd : h->streams)
-        if (sd->AL == AL && sd->want == want) { *out = sd; return CRF_OK; }
-    const int task_steps = stream_task_steps(h, AL, want);
+        if (sd->AL == AL && sd->want == want && (sd->fac != 0) == fac) { *out = sd; return CRF_OK; }
+    // factored streams for T o LM graphs (groups of at least 32 utterances: the row descriptors of 64 / (UL / 4) rows times
+    // eight bundles must fit the wave's slice of LDS beside the records)
+    const int task_steps = stream_task_steps(h, AL, want, fac);
     int prev = 0;
     if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(h->device) != hipSuccess) { set_error("ensure_stream_tables: cannot select the graph's device"); return CRF_ERR_HIP; }
     auto *sd = new StreamDev();
-    int rc = build_stream_dir(h, AL, UL, task_steps, h->hb_frow, h->hb_frow_d, h->hb_farcs, &sd->f);
-    if (!rc) rc = build_stream_dir(h, AL, UL, task_steps, h->hb_brow, h->hb_brow_s, h->hb_barcs, &sd->b);
+    int rc = CRF_OK;
+    if (fac) {
+        for (int dir = 0; dir < 2 && !rc; ++dir) {
+            StreamHost sh;
+            StreamDirDev *o = dir == 0 ? &sd->f : &sd->b;
+            rc = build_stream_host_fac(AL, UL, task_steps, dir == 0 ? h->fb.frows : h->fb.brows, dir == 0 ? h->fb.frest : h->fb.brest, &sh);
+            if (rc) break;
+            o->ntasks = (int)sh.tasks.size(); o->nrest = (int)sh.rest.size();
+            if ((rc = upload(h, sh.tasks, &o->tasks)) || (rc = upload(h, sh.recs, &o->recs)) || (rc = upload(h, sh.meta, &o->meta)) || (rc = upload(h, sh.rest, &o->rest))) break;
+        }
+        if (!rc) rc = upload(h, h->fb.x_start, &sd->x_start);
+        sd->fac = 1; sd->NU = h->fb.NU;
+    } else {
+        rc = build_stream_dir(h, AL, UL, task_steps, h->hb_frow, h->hb_frow_d, h->hb_farcs, &sd->f);
+        if (!rc) rc = build_stream_dir(h, AL, UL, task_steps, h->hb_brow, h->hb_brow_s, h->hb_barcs, &sd->b);
+        sd->fac = 0; sd->NU = 0; sd->x_start = h->dev.start_lin;
+    }
     (void)hipSetDevice(prev);
     if (rc) { delete sd; return rc; }
     sd->AL = AL; sd->want = want; sd->ok = 1;
@@ -684,6 +905,7 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     d0.NC = (int)chunk_off.size() - 1;
     h->hb_farcs = b_farcs; h->hb_barcs = b_barcs; h->hb_frow = b_frow; h->hb_brow = b_brow;   // (kept: arc streams are cut from them on first use)
     h->hb_frow_d = b_frow_d; h->hb_brow_s = b_brow_s;
+    build_batch_factored(h, (int)S, b_frow, b_frow_d, b_farcs, b_brow, b_brow_s, b_barcs, start_lin);
     if (device < 0) {  // host-only compile (diagnostics / CPU tests): tables are built, nothing is uploaded
         h->device = -1;
         int rcr = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon);
@@ -796,6 +1018,11 @@ int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
 }
 
 int crf_debug_decode_check(int nslot, int ncombo) { return crf::debug_check_decode(nslot, ncombo); }
+
+int crf_debug_facbatch_check(const crf_graph *g, int64_t *out4) {
+    if (!g || !g->h || !out4) { crf::set_error("null argument"); return CRF_ERR_ARG; }
+    return crf::debug_check_facbatch(g->h, out4);
+}
 
 int crf_debug_stream_check(const crf_graph *g, int UL, int want, int64_t *out4) {
     if (!g || !g->h) { crf::set_error("null graph"); return CRF_ERR_ARG; }

@@ -56,7 +56,7 @@ _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
-    "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
+    "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
     "crf_last_error", "crf_version",
 )
 
@@ -123,6 +123,15 @@ def debug_stream_check(handle: int, UL: int, want: int):
     _lib.crf_debug_stream_check.restype = ctypes.c_int
     _check(_lib.crf_debug_stream_check(_vp(handle), UL, want, out))
     return {"tasks": int(out[0]), "rest_rows": int(out[1]), "steps": int(out[2]), "arc_records": int(out[3])}
+
+
+def debug_facbatch_check(handle: int):
+    """Host-side check of the factored rows of the utterance-minor kernels (include/ctc_crf_hip.h)."""
+    out = (_i64 * 4)()
+    _lib.crf_debug_facbatch_check.argtypes = [_vp, ctypes.POINTER(_i64)]
+    _lib.crf_debug_facbatch_check.restype = ctypes.c_int
+    _check(_lib.crf_debug_facbatch_check(_vp(handle), out))
+    return {"NU": int(out[0]), "fwd_records": int(out[1]), "bwd_records": int(out[2]), "arcs": int(out[3])}
 
 
 def timing_read(n: int = 16384):

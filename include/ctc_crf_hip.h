@@ -94,6 +94,10 @@ int crf_debug_stream_check(const crf_graph *g, int UL, int want, int64_t *out4);
 /* Test aid: the block -> (utterance group, direction, chunk) mapping of the utterance-minor frame kernel for a grid of
  * 8 * nslot workgroups and `ncombo` combos: 0 when every (combo, chunk) is taken by exactly one workgroup. */
 int crf_debug_decode_check(int nslot, int ncombo);
+/* Host check of the factored rows of the utterance-minor kernels (T o LM graphs; no GPU): one step of both recursions through
+ * them equals the step through the plain tables on random vectors.  out4: {U entries, forward records, backward records, arcs};
+ * all zero when the graph has no such rows. */
+int crf_debug_facbatch_check(const crf_graph *g, int64_t *out4);
 
 /* The hot path.  Replaces, in one call and with no host synchronisation:
  *   gpu_ctc  (binding.cpp:86-117  -> compute_ctc_loss, ctc_entrypoint.cu:29-60)

@@ -163,6 +163,40 @@ def test_reference_fixture_layout(golden_dir):
     assert s["S"] == 9 and s["fac"] == 1 and s["fac_matched_pairs"] == 4
 
 
+def test_factored_rows_of_the_utterance_minor_kernels(tmp_path, golden_dir):
+    """T o LM graphs get FACTORED rows for the utterance-minor kernels (fst_graph.cpp build_batch_factored: an entry U = a[tail] +
+    a[main] per couple of states, the tail row folded into the main row, one backward row per couple).  Host check
+    (crf_debug_facbatch_check): one step of both recursions through the factored rows equals the step through the plain tables
+    on random vectors, every one-pair row is produced exactly once, descriptors carry the plain tables' pairs and labels.
+    Records halve; graphs without the structure get none."""
+    from cat_amd.ctc_crf import _C
+
+    def check(path):
+        h = _C.compile_graph_host_only(path)
+        r = _C.debug_facbatch_check(h)
+        st = _C.graph_stats(h)
+        _C._lib.crf_graph_destroy(_C._vp(h))
+        return st, r
+
+    p = str(tmp_path / "tolm.fst")
+    den_lm.synth_den_lm(72, 300, 10, seed=1, path=p)
+    st, r = check(p)
+    assert r["NU"] == 299 and r["arcs"] == st["A"]               # every history but the start's is a couple
+    assert r["fwd_records"] < 0.55 * st["A"] and r["bwd_records"] < 0.55 * st["A"]
+    st, r = check(os.path.join(golden_dir, "den_lm_fixture.fst"))   # the reference's own 9-state graph: 4 couples
+    assert r["NU"] == 4 and r["fwd_records"] < st["A"] and r["bwd_records"] < st["A"]
+    for i in range(6):                                           # random general graphs: no couples, no factored rows
+        st, r = check(os.path.join(golden_dir, f"rand{i}.fst"))
+        assert r["NU"] == 0 and r["fwd_records"] == 0
+    from tests.util import transform_graph                       # a renumbered, reordered, weight-pushed copy (re-gauged by the compiler)
+    from oracle import fst_io
+    g = fst_io.read_fst(p)
+    q = str(tmp_path / "pushed.fst")
+    transform_graph(g, q, seed=3, renumber=True, reorder=True, push=True)
+    st, r = check(q)
+    assert st["regauged"] == 1 and r["NU"] == 299
+
+
 @pytest.mark.parametrize("UL", [8, 16, 32, 64])
 def test_arc_streams_of_the_utterance_minor_kernels(tmp_path, golden_dir, UL):
     """The arc streams the utterance-minor kernels walk (fst_graph.cpp: build_stream_host) are built on the HOST for several

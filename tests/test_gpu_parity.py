@@ -163,7 +163,7 @@ def test_synth_vs_oracle_ragged(crf, tmp_path, seed, B, T, vocab, hist, fan, mod
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
-@pytest.mark.parametrize("B,ul", [(20, 8), (41, 8), (33, 8), (64, 16), (40, 16), (70, 32), (70, 64)])
+@pytest.mark.parametrize("B,ul", [(20, 8), (41, 8), (33, 8), (64, 16), (40, 16), (70, 32), (70, 64), (70, -32), (70, -64)])
 def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
     """Utterance-minor kernels with several utterance groups: 3 groups (6 combos on 8 XCDs, uneven), 6 groups (12 combos:
     two per XCD on four of them), 3 / 3 / 2 groups of 16 / 32 / 64 with padding utterances in the last one -- the
@@ -172,13 +172,50 @@ def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
     g, p = small_synth(tmp_path, 12, 40, 6, 5)
     logits, labels, lx, ly = make_batch(g, B, 31, 12, seed=B, ragged=True)
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
-    with _env(CRF_BAT_UL=ul):
+    # groups of 32 / 64 utterances take the FACTORED streams (U entries, folded tail rows, fused backward rows: the graph is
+    # T o LM); ul < 0: the same groups on the plain streams (CRF_BAT_NO_FAC=1)
+    with _env(CRF_BAT_UL=abs(ul), CRF_BAT_NO_FAC=1 if ul < 0 else 0):
         loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode="batch")
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
     for b in range(B):
         assert rel_err(grad[b], ref["grad"][b]) <= TOL, b
         assert np.all(grad[b, lx[b]:] == 0.0)
+
+
+@pytest.mark.parametrize("ul", [32, 64])
+def test_batch_kernels_factored_streams_estimated_graph(crf, tmp_path, ul):
+    """Factored streams of the utterance-minor kernels on an ESTIMATED den_lm (long rows, couples beside plain states, states
+    the couple detection leaves alone) against the fp64 oracle; the host check of the factored rows on the same graph."""
+    from cat_amd import den_lm
+    V = 40
+    rng = np.random.default_rng(7)
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(1500):
+        L, sq, a, b = int(rng.integers(8, 30)), [], 0, 0
+        for _ in range(L):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
+        seqs.append(sq)
+    p = str(tmp_path / "den_est.fst")
+    den_lm.prep_den_lm(seqs, V, p, 4, 3, 150)
+    g = fst_io.read_fst(p)
+    hh = crf._C.compile_graph_host_only(p)
+    chk = crf._C.debug_facbatch_check(hh)
+    assert chk["NU"] >= g["S"] // 2 - 2 and chk["fwd_records"] < 0.6 * g["A"] and chk["bwd_records"] < 0.6 * g["A"]
+    B, T = 5, 60
+    logits = rng.normal(size=(B, T, V)).astype(np.float32) * 2.0
+    logits = logits - np.log(np.exp(logits).sum(-1, keepdims=True))
+    lx = np.array([60, 47, 33, 60, 1], dtype=np.int32)
+    labels, ly = [], []
+    for b in range(B):
+        lab = seqs[b][:max(1, int(lx[b]) // 6)]
+        labels += lab; ly.append(len(lab))
+    ref = oracle.ctc_crf(g, logits, np.array(labels, dtype=np.int32), lx, np.array(ly, dtype=np.int32), lamb=0.1)
+    with _env(CRF_BAT_UL=ul):
+        loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode="batch")
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
 
 
 @pytest.mark.parametrize("mode", MODES)
