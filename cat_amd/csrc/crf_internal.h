@@ -172,6 +172,9 @@ __host__ __device__ inline void bat_decode(int block, int grid, int ncombo, int 
     }
 }
 
+// bundles per task at most: 8; factored streams of groups of 16 / 8 utterances 4 / 2 (three descriptor words for each of the
+// 16 / 32 rows of a bundle: the wave's slice of LDS)
+__host__ __device__ constexpr int stream_max_bundles(int UL, bool fac) { return !fac || UL >= 32 ? 8 : UL == 16 ? 4 : 2; }
 struct StreamDirDev {
     const int4 *tasks;       // [ntasks] {first batch, batches, first bundle, bundles}
     const int2 *recs;        // [batches][AL][4] (+ 8 KB of padding)

@@ -2469,8 +2469,10 @@ constexpr int kStreamRecB = kStreamChunk * 32;        // bytes of a chunk of rec
 // one emission row -- forward {e[label 0], e[label 1], U of the row's couple}, backward {e[label 0], e[label 1], z of the two
 // extra arcs} -- all known from the descriptor, so all requested a bundle ahead like the emissions; epi gets them as e[NR].
 constexpr int kStreamLds = 2 * kStreamRecB + 2 * 64 * 16 + kStreamBundles * 32 * 16;   // per wave: records (2 halves) | emission ring | descriptors
+// (factored streams of small utterance groups -- many rows side by side -- have tasks of fewer bundles, so that a workgroup's
+// four slices stay below half of the LDS: crf_internal.h stream_max_bundles, shared with the host's task cutter)
 template <int UL, bool FAC>
-constexpr int stream_lds() { return FAC ? 2 * kStreamRecB + 2 * 64 * 16 * 4 + kStreamBundles * (256 / UL) * 48 : kStreamLds; }
+constexpr int stream_lds() { return FAC ? 2 * kStreamRecB + 2 * 64 * 16 * 4 + stream_max_bundles(UL, true) * (256 / UL) * 48 : kStreamLds; }
 template <int UL, int D, int NM, int NR, typename Epi>
 __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, const float *__restrict__ X, const float *__restrict__ et,
                                            int uq, int aj, int lane, char *ldsw, int tmi, Epi &&epi) {
@@ -2487,7 +2489,8 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, con
     {   // chunk 0 -> LDS half 0 (the only wait for something just requested: once per task)
         const int4 s0 = gsrc[0], s1 = gsrc[64], s2 = gsrc[128], s3 = gsrc[192];
         const int4 *mp = sd.meta + (size_t)bund0 * AL * NM;
-        constexpr int NMW = (kStreamBundles * AL * NM + 63) / 64;
+        constexpr int MAXB = stream_max_bundles(UL, NM == 3);
+        constexpr int NMW = (MAXB * AL * NM + 63) / 64;
         int4 mm[NMW];
 #pragma unroll
         for (int q = 0; q < NMW; ++q) mm[q] = (q * 64 + lane < nbund * AL * NM) ? mp[q * 64 + lane] : int4{-1, 0, 0, 0};
@@ -2495,7 +2498,7 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, con
         *(int4 *)(ldsw + (128 + lane) * 16) = s2; *(int4 *)(ldsw + (192 + lane) * 16) = s3;
 #pragma unroll
         for (int q = 0; q < NMW; ++q)
-            if ((NMW * 64 == kStreamBundles * AL * NM) || q * 64 + lane < kStreamBundles * AL * NM) mlds[q * 64 + lane] = mm[q];   // (the slice ends there)
+            if ((NMW * 64 == MAXB * AL * NM) || q * 64 + lane < MAXB * AL * NM) mlds[q * 64 + lane] = mm[q];   // (the slice ends there)
     }
     CRF_TM(tmi >= 0, tmi + 3);
     int4 st0 = gsrc[256], st1 = gsrc[320], st2 = gsrc[384], st3 = gsrc[448];   // chunk 1 (padding if there is none)
@@ -3895,7 +3898,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         {
             const void *fn = w.UL == 64 ? (bfac ? (const void *)crf_batch_frame_kernel<64, 4, true> : (const void *)crf_batch_frame_kernel<64, 4>)
                            : w.UL == 32 ? (bfac ? (const void *)crf_batch_frame_kernel<32, 4, true> : (const void *)crf_batch_frame_kernel<32, 4>)
-                           : w.UL == 16 ? (const void *)crf_batch_frame_kernel<16, 4> : (const void *)crf_batch_frame_kernel<8, 4>;
+                           : w.UL == 16 ? (bfac ? (const void *)crf_batch_frame_kernel<16, 4, true> : (const void *)crf_batch_frame_kernel<16, 4>)
+                           : (bfac ? (const void *)crf_batch_frame_kernel<8, 4, true> : (const void *)crf_batch_frame_kernel<8, 4>);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, fn, kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = 2; }
         }
         static const int fill_env = getenv("CRF_BAT_FILL") ? atoi(getenv("CRF_BAT_FILL")) : 0;   // percent of the device's slots one launch takes (probe: two callers side by side)
@@ -3932,8 +3936,12 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
                 case 32: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
                          else hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
                          break;
-                case 16: hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
-                default: hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp); break;
+                case 16: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
+                         else hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
+                         break;
+                default: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
+                         else hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
+                         break;
             }
         }
         LAUNCH_CHECK("crf_batch_frame_kernel");

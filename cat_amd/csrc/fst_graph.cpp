@@ -306,7 +306,7 @@ static int build_stream_host_fac(int AL, int UL, int task_steps, const std::vect
     std::vector<SRow> srows;
     for (const FacRowH &r : rows)
         srows.push_back(SRow{{int4{r.st0, r.pr0, r.lab0, 0}, int4{r.st1, r.pr1, r.lab1, 0}, int4{r.x0, r.w0, r.x1, r.w1}}, r.recs.data(), (int)r.recs.size()});
-    const int rc = build_stream_rows(AL, UL, task_steps, 8, 3, srows, sh);
+    const int rc = build_stream_rows(AL, UL, task_steps, stream_max_bundles(UL, true), 3, srows, sh);
     sh->rest = rest;
     return rc;
 }
@@ -640,7 +640,7 @@ int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4) {
     return CRF_OK;
 }
 
-bool stream_fac(const HostGraph *h, int UL) { return h && h->fb.ok && UL >= 32 && !(getenv("CRF_BAT_NO_FAC") && atoi(getenv("CRF_BAT_NO_FAC"))); }
+bool stream_fac(const HostGraph *h, int UL) { (void)UL; return h && h->fb.ok && !(getenv("CRF_BAT_NO_FAC") && atoi(getenv("CRF_BAT_NO_FAC"))); }
 
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) {
     const int AL = 256 / std::max(UL, 1);                 // lane groups: a lane takes 4 utterances, UL / 4 lanes a row
@@ -650,8 +650,7 @@ int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) 
     const bool fac = stream_fac(h, UL);
     for (StreamDev *sd : h->streams)
         if (sd->AL == AL && sd->want == want && (sd->fac != 0) == fac) { *out = sd; return CRF_OK; }
-    // factored streams for T o LM graphs (groups of at least 32 utterances: the row descriptors of 64 / (UL / 4) rows times
-    // eight bundles must fit the wave's slice of LDS beside the records)
+    // factored streams for T o LM graphs
     const int task_steps = stream_task_steps(h, AL, want, fac);
     int prev = 0;
     if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(h->device) != hipSuccess) { set_error("ensure_stream_tables: cannot select the graph's device"); return CRF_ERR_HIP; }

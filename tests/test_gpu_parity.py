@@ -163,7 +163,7 @@ def test_synth_vs_oracle_ragged(crf, tmp_path, seed, B, T, vocab, hist, fan, mod
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
-@pytest.mark.parametrize("B,ul", [(20, 8), (41, 8), (33, 8), (64, 16), (40, 16), (70, 32), (70, 64), (70, -32), (70, -64)])
+@pytest.mark.parametrize("B,ul", [(20, 8), (41, 8), (33, 8), (64, 16), (40, 16), (70, 32), (70, 64), (41, -8), (64, -16), (70, -32), (70, -64)])
 def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
     """Utterance-minor kernels with several utterance groups: 3 groups (6 combos on 8 XCDs, uneven), 6 groups (12 combos:
     two per XCD on four of them), 3 / 3 / 2 groups of 16 / 32 / 64 with padding utterances in the last one -- the
@@ -172,8 +172,8 @@ def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
     g, p = small_synth(tmp_path, 12, 40, 6, 5)
     logits, labels, lx, ly = make_batch(g, B, 31, 12, seed=B, ragged=True)
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
-    # groups of 32 / 64 utterances take the FACTORED streams (U entries, folded tail rows, fused backward rows: the graph is
-    # T o LM); ul < 0: the same groups on the plain streams (CRF_BAT_NO_FAC=1)
+    # the graph is T o LM: FACTORED streams (U entries, folded tail rows, fused backward rows; tasks of at most 8 / 8 / 4 / 2
+    # bundles for groups of 64 / 32 / 16 / 8); ul < 0: the same groups on the plain streams (CRF_BAT_NO_FAC=1)
     with _env(CRF_BAT_UL=abs(ul), CRF_BAT_NO_FAC=1 if ul < 0 else 0):
         loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode="batch")
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
@@ -183,7 +183,7 @@ def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
-@pytest.mark.parametrize("ul", [32, 64])
+@pytest.mark.parametrize("ul", [8, 16, 32, 64])
 def test_batch_kernels_factored_streams_estimated_graph(crf, tmp_path, ul):
     """Factored streams of the utterance-minor kernels on an ESTIMATED den_lm (long rows, couples beside plain states, states
     the couple detection leaves alone) against the fp64 oracle; the host check of the factored rows on the same graph."""

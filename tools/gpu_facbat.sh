@@ -10,3 +10,9 @@ import json,sys
 d=json.loads(sys.stdin.read()); k=d['roofline']['kernels_ms']
 print('[$e] large: %.1f utt/s, %.3f ms/step, den %.2f ms, grad %.2f ms' % (d['value'], d['ms_per_step'], k.get('den_fwd_chain',-1), k.get('grad',-1)))"
 done | tee $OUT/facbat_${TAG}_large.txt
+for e in "X=0" "CRF_BAT_NO_FAC=1"; do
+  env $e timeout 600 python bench.py --no-cpu-baseline --B 8 --T 3000 --V 5000 --histories 32768 --fanout 64 --steps 2 --warmup 1 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); k=d['roofline']['kernels_ms']
+print('[$e] c5: %.1f utt/s, %.3f ms/step, den %.2f ms, grad %.2f ms' % (d['value'], d['ms_per_step'], k.get('den_fwd_chain',-1), k.get('grad',-1)))"
+done | tee $OUT/facbat_${TAG}_c5.txt
