@@ -2474,14 +2474,13 @@ constexpr int kStreamLds = 2 * kStreamRecB + 2 * 64 * 16 + kStreamBundles * 32 *
 template <int UL, bool FAC>
 constexpr int stream_lds() { return FAC ? 2 * kStreamRecB + 2 * 64 * 16 * 4 + stream_max_bundles(UL, true) * (256 / UL) * 48 : kStreamLds; }
 template <int UL, int D, int NM, int NR, typename Epi>
-__device__ __forceinline__ void bat_stream(const StreamDirDev &sd, int task, const float *__restrict__ X, const float *__restrict__ et,
+__device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk, const float *__restrict__ X, const float *__restrict__ et,
                                            int uq, int aj, int lane, char *ldsw, int tmi, Epi &&epi) {
     constexpr int LG = UL / 4, AL = 64 / LG, CB = kStreamChunk / AL;
     static_assert(kStreamBatch == 4 && CB % D == 0 && CB >= D, "a chunk holds a whole number of pipeline rounds");
     static_assert((NM == 1 && NR == 1) || (NM == 3 && (NR == 3 || NR == 4)), "plain or factored rows");
     f32x4 *elds = (f32x4 *)(ldsw + 2 * kStreamRecB);               // [2][NR][lane]
     int4 *mlds = (int4 *)(ldsw + 2 * kStreamRecB + 2 * 64 * 16 * (NM == 1 ? 1 : 4));   // [bundle][AL][NM]
-    const int4 tk = sd.tasks[task];
     const int b0 = __builtin_amdgcn_readfirstlane(tk.x), nb = __builtin_amdgcn_readfirstlane(tk.y);
     const int bund0 = __builtin_amdgcn_readfirstlane(tk.z), nbund = __builtin_amdgcn_readfirstlane(tk.w);
     CRF_TM(tmi >= 0, tmi + 2);
@@ -2626,6 +2625,11 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
 #pragma unroll
     for (int c = 0; c < 4; ++c) lx4[c] = u4 + c < p.B ? p.lx[u4 + c] : 0;
     const int w0 = chunk * kBatWaves + wave, NW = nchunk * kBatWaves;   // this wave among the waves of its combo
+    // the wave's first task descriptor: asked for before anything else (it heads the chain descriptor -> records and row
+    // descriptors -> emissions -> first gathers, three dependent trips to a cold L2 at the start of every launch)
+    const StreamDirDev &sdd = dir == 0 ? p.st.f : p.st.b;
+    int4 tk0 = int4{0, 0, 0, 0};
+    if (w0 < sdd.ntasks) tk0 = sdd.tasks[w0];
     const bool lead = chunk == 0 && wave == 0 && aj == 0;          // one writer per utterance for the scalars
     const BatchDev &g = p.g;
     const size_t gS = (size_t)grp * p.SX * UL, gP = (size_t)grp * P * UL, gV = (size_t)grp * p.V * UL;
@@ -2654,7 +2658,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
         const float *et = p.ept + (size_t)t * Vall + gV;
         float *Qt = p.Q + (size_t)t * Pall + gP;
         for (int task = w0; task < p.st.f.ntasks; task += NW)
-            bat_stream<UL, D, NM, FAC ? 3 : 1>(p.st.f, task, Ac, et, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
+            bat_stream<UL, D, NM, FAC ? 3 : 1>(p.st.f, task == w0 ? tk0 : p.st.f.tasks[task], Ac, et, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
                 if (m[0].x < 0) return;                            // padding row of the last bundle
                 // an utterance that has ended keeps a_lx where it is: nobody writes that buffer for it again
                 // (crf_batch_zsum_kernel reads it there)
@@ -2731,7 +2735,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
         const bool any_active = __ballot(active) != 0ull;
         if (any_active || __ballot(starts) != 0ull)
             for (int task = w0; task < p.st.b.ntasks; task += NW)
-                bat_stream<UL, D, NM, FAC ? 4 : 1>(p.st.b, task, Zc, ep1, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
+                bat_stream<UL, D, NM, FAC ? 4 : 1>(p.st.b, task == w0 ? tk0 : p.st.b.tasks[task], Zc, ep1, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
                     if (m[0].x < 0) return;
                     // one output (plain rows), or the two states of a couple: the common out-arcs' sum + each state's extra arc
                     auto output = [&](const f32x4 &bv, const int st_, const int pr_, const f32x4 &em) __attribute__((always_inline)) {
@@ -3902,8 +3906,12 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
                            : (bfac ? (const void *)crf_batch_frame_kernel<8, 4, true> : (const void *)crf_batch_frame_kernel<8, 4>);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, fn, kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = 2; }
         }
-        static const int fill_env = getenv("CRF_BAT_FILL") ? atoi(getenv("CRF_BAT_FILL")) : 0;   // percent of the device's slots one launch takes (probe: two callers side by side)
-        const int64_t fill = fill_env > 0 && fill_env <= 100 ? fill_env : 100;
+        // ... times 70 %: a launch is bound by the L2s and the fabric, not by the CUs, and fewer, longer tasks pay the task set-up
+        // (three dependent trips to a cold L2) less often.  Measured, S = 16 385 / B = 64 (repeatable to 0.3 %): 100 / 85 / 70 /
+        // 60 / 55 / 45 / 35 % -> 30.7 / 29.5 / 28.8 / 30.6 / 31.8 / 28.5 / 31.3 ms per step (the dips: workgroups per XCD just
+        // above a multiple of its 32 CUs); config #5 at B = 8: 100 / 70 / 50 % -> 145.3 / 143.6 / 152.6 ms.  CRF_BAT_FILL overrides.
+        static const int fill_env = getenv("CRF_BAT_FILL") ? atoi(getenv("CRF_BAT_FILL")) : 0;
+        const int64_t fill = fill_env > 0 && fill_env <= 100 ? fill_env : 70;
         const int want = (int)std::max<int64_t>(16, (int64_t)ncu_dev * wg_cu * kBatWaves * 15 / 16 * fill / 100 / ncombo);
         const StreamDev *sdv = nullptr;
         if ((rc = ensure_stream_tables(g->h, w.UL, want, &sdv))) return rc;
