@@ -264,7 +264,7 @@ static int build_stream_rows(int AL, int UL, int task_steps, int maxb, int NM, c
         if (task_steps_now > 0 && (task_steps_now + nbat * kB > task_steps || b - task_b0 >= maxb)) close_task(b);
         for (int aj = 0; aj < AL; ++aj) {
             const int i = b * AL + aj;
-            for (int q = 0; q < NM; ++q) meta.push_back(i < (int)srows.size() ? srows[(size_t)i].m[q] : (q == 0 ? int4{-1, 0, 0, 0} : int4{-1, 0, 0, 0}));
+            for (int q = 0; q < NM; ++q) meta.push_back(i < (int)srows.size() ? srows[(size_t)i].m[q] : int4{-1, 0, 0, 0});   // (padding row: state -1)
         }
         for (int bt = 0; bt < nbat; ++bt)
             for (int aj = 0; aj < AL; ++aj)
@@ -623,11 +623,78 @@ int debug_check_decode(int nslot, int ncombo) {
     return CRF_OK;
 }
 
+// Structure check of a stream against the rows it was cut from (any descriptor width): bundle i holds rows [i * AL, (i + 1) * AL)
+// in order, records = the row's records (entry * UL) followed by null records up to the bundle's whole batches, the end flag in
+// the first record of the bundle's last batch for every lane group and nowhere else, descriptors word for word, a task has
+// at most maxb bundles and the tasks cover the bundles in order.  out: {tasks, 0, steps, records that are not padding}.
+static int check_stream_rows(int AL, int UL, int NM, int maxb, const StreamHost &sh, const std::vector<SRow> &srows, int64_t *out) {
+    constexpr int kB = 4;
+    auto fail = [&](const char *why) { set_error(std::string("arc stream check (rows): ") + why); return CRF_ERR_ARG; };
+    int next_bundle = 0;
+    int64_t steps = 0, real = 0;
+    for (const int4 &t : sh.tasks) {
+        if (t.w < 1 || t.w > maxb) return fail("a task has no or too many bundles");
+        if (t.z != next_bundle) return fail("the tasks do not cover the bundles in order");
+        next_bundle += t.w;
+        int batch = t.x;
+        for (int b = 0; b < t.w; ++b) {
+            int nbat = 0;
+            for (;;) {
+                if (batch + nbat >= t.x + t.y) return fail("a bundle runs past its task");
+                const int2 first = sh.recs[((size_t)(batch + nbat) * AL + 0) * kB];
+                ++nbat;
+                if (first.x < 0) break;
+            }
+            for (int aj = 0; aj < AL; ++aj) {
+                const int i = (t.z + b) * AL + aj;
+                const bool have = i < (int)srows.size();
+                for (int q = 0; q < NM; ++q) {
+                    const int4 m = sh.meta[((size_t)(t.z + b) * AL + aj) * NM + q], w = have ? srows[(size_t)i].m[q] : int4{-1, 0, 0, 0};
+                    if (m.x != w.x || m.y != w.y || m.z != w.z || m.w != w.w) return fail("a descriptor word");
+                }
+                const int n = have ? srows[(size_t)i].n : 0;
+                if (n > nbat * kB) return fail("a row is longer than its bundle");
+                for (int st = 0; st < nbat * kB; ++st) {
+                    const int2 rc = sh.recs[((size_t)(batch + st / kB) * AL + aj) * kB + st % kB];
+                    if ((rc.x < 0) != (st == (nbat - 1) * kB)) return fail("end-of-bundle flag");
+                    const int idx = rc.x & 0x7fffffff;
+                    if (st < n) {
+                        if (idx != srows[(size_t)i].recs[st].x * UL || rc.y != srows[(size_t)i].recs[st].y) return fail("a record is not its row's");
+                        ++real;
+                    } else if (idx != 0 || rc.y != 0) return fail("padding record is not null");
+                }
+            }
+            batch += nbat; steps += (int64_t)nbat * kB;
+        }
+        if (batch != t.x + t.y) return fail("batches of a task");
+    }
+    if (next_bundle != ((int)srows.size() + AL - 1) / AL) return fail("bundles missing");
+    out[0] += (int64_t)sh.tasks.size(); out[2] += steps; out[3] += real;
+    return CRF_OK;
+}
+
 // Builds the arc streams of both directions on the host and checks them (check_stream_host); no device needed.
 int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4) {
+    const bool fac = UL < 0;                             // -UL: the factored streams (graphs with factored rows)
+    if (fac) UL = -UL;
     if (!h || !(UL == 8 || UL == 16 || UL == 32 || UL == 64) || want < 1 || !out4) { set_error("debug_check_streams: bad arguments"); return CRF_ERR_ARG; }
-    const int AL = 256 / UL, task_steps = stream_task_steps(h, AL, want);
+    const int AL = 256 / UL, task_steps = stream_task_steps(h, AL, want, fac);
     for (int i = 0; i < 4; ++i) out4[i] = 0;
+    if (fac) {
+        if (!h->fb.ok) return CRF_OK;
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::vector<FacRowH> &rows = dir == 0 ? h->fb.frows : h->fb.brows;
+            std::vector<SRow> srows;
+            for (const FacRowH &r : rows)
+                srows.push_back(SRow{{int4{r.st0, r.pr0, r.lab0, 0}, int4{r.st1, r.pr1, r.lab1, 0}, int4{r.x0, r.w0, r.x1, r.w1}}, r.recs.data(), (int)r.recs.size()});
+            StreamHost sh;
+            int rc = build_stream_host_fac(AL, UL, task_steps, rows, dir == 0 ? h->fb.frest : h->fb.brest, &sh);
+            if (!rc) rc = check_stream_rows(AL, UL, 3, stream_max_bundles(UL, true), sh, srows, out4);
+            if (rc) return rc;
+            out4[1] += (int64_t)sh.rest.size();
+        }
+        return CRF_OK;
+    }
     for (int dir = 0; dir < 2; ++dir) {
         const std::vector<int4> &rows = dir == 0 ? h->hb_frow : h->hb_brow;
         const std::vector<int> &st = dir == 0 ? h->hb_frow_d : h->hb_brow_s;

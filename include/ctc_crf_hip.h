@@ -88,7 +88,8 @@ int crf_den_kernels(const crf_graph *g, int64_t B, int64_t T, int64_t V);
 /* Test aid (no reference counterpart): builds the arc streams of the utterance-minor kernels for UL utterances per group and
  * about `want` tasks per direction ON THE HOST and checks them against the graph's row tables (every row once, records = arcs,
  * flags, task limits); works on host-only graphs.  out4 = {tasks, rows outside the streams, steps, arc records}, both
- * directions summed. */
+ * directions summed.  UL < 0: the FACTORED streams for -UL utterances per group (T o LM graphs; all zero for other graphs):
+ * records, flags, the three descriptor words of every row and the bundles-per-task limit against the factored rows. */
 int crf_debug_stream_check(const crf_graph *g, int UL, int want, int64_t *out4);
 
 /* Test aid: the block -> (utterance group, direction, chunk) mapping of the utterance-minor frame kernel for a grid of

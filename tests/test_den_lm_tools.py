@@ -181,6 +181,7 @@ def test_factored_rows_of_the_utterance_minor_kernels(tmp_path, golden_dir):
     p = str(tmp_path / "tolm.fst")
     den_lm.synth_den_lm(72, 300, 10, seed=1, path=p)
     st, r = check(p)
+    r0 = r
     assert r["NU"] == 299 and r["arcs"] == st["A"]               # every history but the start's is a couple
     assert r["fwd_records"] < 0.55 * st["A"] and r["bwd_records"] < 0.55 * st["A"]
     st, r = check(os.path.join(golden_dir, "den_lm_fixture.fst"))   # the reference's own 9-state graph: 4 couples
@@ -188,6 +189,14 @@ def test_factored_rows_of_the_utterance_minor_kernels(tmp_path, golden_dir):
     for i in range(6):                                           # random general graphs: no couples, no factored rows
         st, r = check(os.path.join(golden_dir, f"rand{i}.fst"))
         assert r["NU"] == 0 and r["fwd_records"] == 0
+    # the streams cut from the factored rows, for every group size: records = the rows' records, flags, three descriptor words
+    # per row, at most 8 / 8 / 4 / 2 bundles per task
+    h = _C.compile_graph_host_only(p)
+    for UL in (8, 16, 32, 64):
+        s4 = _C.debug_stream_check(h, -UL, 64)
+        assert s4["arc_records"] == r0["fwd_records"] + r0["bwd_records"]   # every record of every factored row exactly once
+        assert s4["rest_rows"] <= 2 and s4["tasks"] >= 2
+    _C._lib.crf_graph_destroy(_C._vp(h))
     from tests.util import transform_graph                       # a renumbered, reordered, weight-pushed copy (re-gauged by the compiler)
     from oracle import fst_io
     g = fst_io.read_fst(p)
