@@ -221,8 +221,8 @@ def main():
     gstats = ctc_crf._C.graph_stats(ctc_crf._C.graph_for(dev))
     den_path = ctc_crf._C.den_kernels(ctc_crf._C.graph_for(dev), B, T, V)   # what a call of this shape takes (asked of the library)
     batch_path = den_path == "batch"
-    kname = {"factored": "crf_fac_pair_kernel", "resident": "crf_res_pair_kernel", "batch": "crf_batch_frame_kernel",
-             "streaming": "crf_den_pair_kernel"}[den_path]
+    kname = {"factored": "crf_fac2_pair_kernel" if gstats.get("fac_geom") == 3 else "crf_fac_pair_kernel", "resident": "crf_res_pair_kernel",
+             "batch": "crf_batch_frame_kernel", "streaming": "crf_den_pair_kernel"}[den_path]
     launches = (T + 1) if batch_path else 1     # utterance-minor kernels: one launch per frame (forward frame j + backward frame T-j)
     # HBM traffic from the PMC counters: measured by tools/gpu_prof.sh (separate rocprofv3 --pmc passes) and committed
     # keyed by workload; any other workload prints null instead of a number that does not belong to it
@@ -344,7 +344,9 @@ def main():
                                    f"H={args.histories}, d={args.fanout}, seed 0): S={dims['S']} states, "
                                    f"A={dims['A']} arcs, P={dims['P']} (dst,label) pairs; "
                                    f"{'ragged lx' if args.ragged else 'lx = T'}, ly = lx//6, lamb={args.lamb}",
-                       "den_kernels": ("factored register-resident, 1 CU per recursion and utterance, forward + backward one launch; the grad "
+                       "den_kernels": ("factored register-resident, 2 CUs per recursion and utterance (products exchanged through L2 every "
+                                       "frame), forward + backward one launch" if den_path == "factored" and gstats.get("fac_geom") == 3 else
+                                       "factored register-resident, 1 CU per recursion and utterance, forward + backward one launch; the grad "
                                        "pass follows them in stages released by stream-level waits" if den_path == "factored" else
                                        f"register-resident, K={gstats['res_K']} CUs per recursion" if den_path == "resident" else
                                        "utterance-minor (state vectors [state][utterance] in global memory, arcs read once per frame for the "

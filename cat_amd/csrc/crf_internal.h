@@ -99,6 +99,7 @@ struct FacDirDev {
     int R;                   // rows incl. padding (multiple of 64)
     int G;                   // gather-vector entries (floats) incl. the sink pair at [G-2, G-1]
     int dup;                 // byte distance of the SECOND copy of the gathered entries (other LDS banks), see pack_arcs
+    int cu_row[3];           // FacDev::K = 2: rows [cu_row[k], cu_row[k + 1]) belong to CU k (arcs and wave_info are [K][...])
 };
 struct FacDev {
     int ok;                    // 0 = not available for this graph
@@ -108,6 +109,8 @@ struct FacDev {
                                //      plain rows: U = A = sink, tail weight 0
     int NT;                    // unused (0)
     int threads;               // workgroup size the tables were built for: 768 (21 chunks per thread) or 512 (30)
+    int K;                     // CUs per recursion: 1, or 2 (graphs of 120 k - 240 k arcs: each CU holds half of the rows and the whole
+                               // state vector, the products cross through L2 every frame like the generic layout's; rcl geometry only)
     int rcl;                   // 768 threads with the row constants in an LDS table read one slice ahead (any number of slices per wave)
     int multilane;             // some rows lie on several adjacent lanes (wave_info.w != 0 somewhere): kernel variant with the butterfly
     const float *x_start, *x_end;   // [Gf]

@@ -986,23 +986,24 @@ __device__ __forceinline__ void res_publish(gu64 *slot, int i, unsigned tag, flo
     }
 }
 // Fetch entries [lo,hi) published by a peer into LDS `v`; returns the largest value seen.
+template <int NT = kResThreads>
 __device__ __forceinline__ float res_fetch(gu64 *slot, float *v, int lo, int hi, unsigned tag, int *err, int tid) {
     float mx = 0.f;
-    for (int base = lo; base < hi; base += kPoll * kResThreads) {
+    for (int base = lo; base < hi; base += kPoll * NT) {
         unsigned pending = 0;
 #pragma unroll
         for (int q = 0; q < kPoll; ++q)
-            if (base + q * kResThreads + tid < hi) pending |= 1u << q;
+            if (base + q * NT + tid < hi) pending |= 1u << q;
         for (unsigned spins = 0; pending; ++spins) {
             unsigned long long gv[kPoll];
 #pragma unroll
             for (int q = 0; q < kPoll; ++q)
-                if (pending >> q & 1) gv[q] = __hip_atomic_load(slot + base + q * kResThreads + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pending >> q & 1) gv[q] = __hip_atomic_load(slot + base + q * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int q = 0; q < kPoll; ++q)
                 if ((pending >> q & 1) && (unsigned)(gv[q] >> 32) == tag) {
                     const float x = __uint_as_float((unsigned)gv[q]);
-                    v[base + q * kResThreads + tid] = x;
+                    v[base + q * NT + tid] = x;
                     mx = fmaxf(mx, x);
                     pending &= ~(1u << q);
                 }
@@ -1403,6 +1404,10 @@ struct FacParams {
     double *cb_mxs;
     int *cb_F;
     int *redo;                  // [2][B], see LossParams
+    // two CUs per recursion (FacDev::K = 2): the utterances [b0, b0 + nbu) of this launch, the exchange granules, the error word
+    int K, b0, nbu, Gf, Gb;
+    unsigned long long *xch;
+    int *err;
 };
 
 // FLAG: publish stage flags and store rows write-through (one instantiation per use: the frame loop has no
@@ -1411,8 +1416,14 @@ struct FacParams {
 // 768 x 21 (3 waves per SIMD at <= 168 VGPRs -- the frame is latency-bound, a third wave fills the gaps).
 // ML: some rows are cut into pieces on adjacent lanes (graphs with long rows; a separate instantiation, the check costs the
 // row epilogue of the others 2 %)
-template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML, bool RL>
-__device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, const int b) {
+// K2: TWO CUs per recursion (graphs of 120 k - 240 k arcs).  Each CU holds half of the rows (its share of the arc registers)
+// and the WHOLE state vector: what its row epilogues produce -- U', L', A' of a forward row, the two z of a backward row -- is
+// also published as {frame tag, value} granules (res_chain_body's protocol: the data is the flag), and after its last chunk the
+// CU fetches the peer's entries into its own vector before the frame barrier.  Table geometry (RL) only, one copy of the
+// gathered entries, no stages (2 B x 2 workgroups are every CU of the device: nothing runs beside the recursions).
+template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML, bool RL, bool K2 = false>
+__device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, const int b, const int k = 0) {
+    static_assert(!K2 || (RL && !FLAG), "two CUs per recursion: table geometry, no stage flags");
     constexpr int NW = NTH / kWave;
     // 768-thread geometry: the last chunk slot of a thread holds ROW CONSTANTS instead of arcs -- two words for each of
     // the (at most three) rows the lane finishes per frame -- and the entries of a row sit where its row id says
@@ -1444,11 +1455,19 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     float *wm = EP + 2 * Vp;                                 // [2][NW]
     double *red = (double *)(wm + 2 * NW);            // [NW]
     if (tid == 0 && p.started && p.i0 == 0) atomicAdd(p.started, 1);   // this workgroup holds its CU: see crf_gate_kernel
+    [[maybe_unused]] const bool lead = !K2 || k == 0;        // the CU that writes what exists once per recursion (exponents, logZ)
+    [[maybe_unused]] gu64 *xchd = nullptr;                   // K2: this recursion's granules, [2 slots][G]
+    [[maybe_unused]] gu64 *hs = nullptr;                     // K2: two handshake words of this recursion
+    [[maybe_unused]] bool same_l2 = false;
+    if constexpr (K2) {
+        xchd = (gu64 *)p.xch + (DIR == 0 ? 0 : (size_t)p.B * 2 * (size_t)p.Gf) + (size_t)b * 2 * (size_t)G;
+        hs = (gu64 *)p.xch + (size_t)p.B * 2 * ((size_t)p.Gf + (size_t)p.Gb) + ((size_t)DIR * p.B + b) * kResMaxK;
+    }
 
     unsigned A[(NCH * 6)];
     unsigned rc00 = 0, rc01 = 0, rc10 = 0, rc11 = 0, rc20 = 0, rc21 = 0;   // row constants of the lane's (up to) three rows: scalars,
     {                                                                      // not array elements (a select between array elements
-        const unsigned *src = L.arcs + tid;                               // becomes a variable index and the array leaves the registers)
+        const unsigned *src = L.arcs + (K2 ? (size_t)k * (NCH * 6) * NTH : (size_t)0) + tid;   // becomes a variable index and the array leaves the registers)
 #pragma unroll
         for (int i = 0; i < (RC ? RCW : NCH * 6); ++i) A[i] = src[(size_t)i * NTH];
         if (RC) {
@@ -1457,7 +1476,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             rc20 = src[(size_t)(RCW + 4) * NTH]; rc21 = src[(size_t)(RCW + 5) * NTH];
         }
     }
-    const uint4 wi = L.wave_info[wave];
+    const uint4 wi = L.wave_info[(K2 ? k * NW : 0) + wave];
     const unsigned ends = __builtin_amdgcn_readfirstlane(wi.x);
     const int nch = __builtin_amdgcn_readfirstlane(wi.y);
     const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
@@ -1542,10 +1561,10 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                 X[z] = v; m0 = fmaxf(m0, v);
             }
             float *BProw = p.Out + (bt0 + lx - 1) * p.Rout;
-            for (int r = tid; r < 2 * R; r += NTH) BProw[r] = p.brow_end[r] * pow2f(kScaleExp);
-            if (tid == 0) p.Eout[bt0 + lx - 1] = E;
+            if (lead) for (int r = tid; r < 2 * R; r += NTH) BProw[r] = p.brow_end[r] * pow2f(kScaleExp);
+            if (tid == 0 && lead) p.Eout[bt0 + lx - 1] = E;
         } else {
-            for (int r = tid; r < 2 * R; r += NTH) zpart += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
+            if (lead) for (int r = tid; r < 2 * R; r += NTH) zpart += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
         }
 #ifndef CRF_AB_OLDWM
         m0 = row_max16(m0);
@@ -1556,6 +1575,25 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #endif
     }
     __syncthreads();
+    if constexpr (K2) {
+        // where is my peer?  (res_chain_body: both publish the id of their XCD, write-through; both on one XCD => plain stores
+        // into the shared L2 are enough for the hand-off, otherwise write-through stores.  Both take the decision from the same
+        // two ids.)
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;  // HW_REG_XCC_ID[3:0]
+        if (tid == 0) __hip_atomic_store(hs + k, (1ull << 32) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int same = 1;
+        if (tid == 0) {
+            unsigned long long g = 0;
+            for (unsigned spins = 0; (g >> 32) != 1ull; ++spins) {
+                g = __hip_atomic_load(hs + (1 - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (spins > (1u << 22)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            same = ((unsigned)g & 0xf) == my_xcc && (g >> 32) == 1ull;
+        }
+        same_l2 = __syncthreads_and(same) != 0;
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // arcs and tables have landed (see crf_res_chain_kernel)
 
     // Stage flags (p.nb > 1): when the recursion reaches iteration bound[k], the rows of all earlier iterations
@@ -1610,12 +1648,12 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         float *Orow;
         if (DIR == 0) {
             E += ksc;
-            if (tid == 0) p.Eout[bt0 + t] = E;
+            if (tid == 0 && lead) p.Eout[bt0 + t] = E;
             E += kEpExp;
             Orow = p.Out + (bt0 + t) * p.Rout;
         } else {
             E += ksc + kEpExp;
-            if (t > 0 && tid == 0) p.Eout[bt0 + t - 1] = E;
+            if (t > 0 && tid == 0 && lead) p.Eout[bt0 + t - 1] = E;
             Orow = t > 0 ? p.Out + (bt0 + t - 1) * p.Rout : p.Row0 + (int64_t)b * p.Rout;
         }
         unsigned ends_f = ends;
@@ -1625,6 +1663,9 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         float mymax = 0.f;
         CRF_TM(tm_on, tm_i + 1);
         unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
+        [[maybe_unused]] gu64 *slot = nullptr;        // K2: the granules of the vector this frame produces
+        [[maybe_unused]] const unsigned tag = (unsigned)(i + 1);
+        if constexpr (K2) slot = xchd + (size_t)(1 - par) * G;
         typedef std::conditional_t<DIR == 0, uint2, uint4> rct_t;
         [[maybe_unused]] rct_t kc{};                  // RL: constants of the slice that ends next
         if constexpr (RL) kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * r4);
@@ -1697,6 +1738,10 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                                 *(float *)(xnb + r4 + dup) = Up;
                                 *(float *)(xnb + r4 + 4u * (unsigned)R) = Lp;
                                 *(float *)(xnb + r4 + 8u * (unsigned)R) = Ap;
+                                if constexpr (K2) {           // entries rid, R + rid, 2 R + rid of the peer's vector
+                                    gu64 *gs = (gu64 *)((char *)slot + 2u * r4);
+                                    res_publish(gs, 0, tag, Up, same_l2); res_publish(gs, R, tag, Lp, same_l2); res_publish(gs, 2 * R, tag, Ap, same_l2);
+                                }
                                 mymax = __int_as_float(max(__float_as_int(mymax), __float_as_int(Up)));   // (non-negative: bits order like integers; fmaxf canonicalises first)
                             } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16
                                 const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
@@ -1718,6 +1763,10 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                                 *(f32x2 *)(xnb + 2u * r4) = zv;
                                 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
                                 *(f32x2u *)(xnb + 2u * r4 + dup) = zv;
+                                if constexpr (K2) {           // entries 2 rid, 2 rid + 1
+                                    gu64 *gs = (gu64 *)((char *)slot + 4u * r4);
+                                    res_publish(gs, 0, tag, zv.x, same_l2); res_publish(gs, 1, tag, zv.y, same_l2);
+                                }
                                 mymax = __int_as_float(max(__float_as_int(mymax), max(__float_as_int(zv.x), __float_as_int(zv.y))));
                             }
                         } else {
@@ -1778,6 +1827,19 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             if (lane == 0 && i == 150) { g_tm[o + 8] = (unsigned long long)nch; g_tm[o + 9] = (unsigned long long)__builtin_popcount(ends); }
         }
 #endif
+        if constexpr (K2) {   // the peer's entries (published from its row epilogues) into this CU's vector
+            const int p0 = L.cu_row[1 - k], p1 = L.cu_row[2 - k];
+            float *Xn = (float *)xnb;
+            float fm;
+            if (DIR == 0) {
+                fm = res_fetch<NTH>(slot, Xn, p0, p1, tag, p.err, tid);
+                fm = fmaxf(fm, res_fetch<NTH>(slot, Xn, R + p0, R + p1, tag, p.err, tid));
+                fm = fmaxf(fm, res_fetch<NTH>(slot, Xn, 2 * R + p0, 2 * R + p1, tag, p.err, tid));
+            } else {
+                fm = res_fetch<NTH>(slot, Xn, 2 * p0, 2 * p1, tag, p.err, tid);
+            }
+            mymax = fmaxf(mymax, fm);
+        }
 #ifndef CRF_AB_OLDWM
         mymax = row_max16(mymax);
         if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), mymax);
@@ -1820,6 +1882,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     if (flagged)
         while (next_stage < p.nb) publish_stage();           // the rest (at least the last stage: bound = T)
     if (DIR == 0) {
+        if (!lead) return;                                   // (the vector is complete on both CUs)
         const float *Xf = X + (lx & 1) * Gp;
         float part = 0.f;
         for (int s = tid; s < G; s += NTH) part += Xf[s] * p.x_end[s];
@@ -1830,13 +1893,30 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         if (lx > 0) {
             __syncthreads();  // drains vmcnt: this workgroup's own stores to the spare row are visible to it
             const float *r0 = p.Row0 + (int64_t)b * p.Rout;
-            for (int r = tid; r < 2 * R; r += NTH) zpart += p.brow_start[r] * r0[r];
+            const int ra = K2 ? 2 * L.cu_row[k] : 0, rb = K2 ? 2 * L.cu_row[k + 1] : 2 * R;   // the rows this CU wrote
+            for (int r = ra + tid; r < rb; r += NTH) zpart += p.brow_start[r] * r0[r];
             // states without a row: b_0 = (sum over their arcs of w * z_0) * (scale of the last frame); z_0 is the vector the
             // last frame read
             const float *Xl = X + ((lx - 1) & 1) * Gp;
-            for (int a = tid; a < p.nbx; a += NTH) zpart += p.bx_w[a] * Xl[p.bx_idx[a]] * last_sc;
-        } else if (tid == 0) zpart += p.bx_se * pow2f(kScaleExp);
-        const float zb = res_block_sum<NW>(zpart, (float *)red, tid);
+            if (lead) for (int a = tid; a < p.nbx; a += NTH) zpart += p.bx_w[a] * Xl[p.bx_idx[a]] * last_sc;
+        } else if (tid == 0 && lead) zpart += p.bx_se * pow2f(kScaleExp);
+        float zb = res_block_sum<NW>(zpart, (float *)red, tid);
+        if constexpr (K2) {   // the peer's part of the sum: one more granule through the handshake words (tag 2)
+            if (!lead) {
+                if (tid == 0) __hip_atomic_store(hs + k, (2ull << 32) | __float_as_uint(zb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if (tid == 0) {
+                unsigned long long g = 0;
+                for (unsigned spins = 0; (g >> 32) != 2ull; ++spins) {
+                    g = __hip_atomic_load(hs + (1 - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (spins > (1u << 22)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if ((spins & 255u) == 255u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                zb += (g >> 32) == 2ull ? __uint_as_float((unsigned)g) : 0.f;
+            }
+        }
         const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
         if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E; p.cb_mxs[b] = mxs; if (!(zb > 0.f && zb < INFINITY)) p.redo[p.B + b] = 1; }
     }
@@ -1854,6 +1934,22 @@ __global__ __launch_bounds__(NTH) void crf_fac_pair_kernel(FacParams pf, FacPara
     const int B = pf.B;
     if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML, RL>(pf, lds, (int)blockIdx.x);
     else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - B);
+}
+// ... with TWO CUs per recursion: 2 * nbu * 2 workgroups for the utterances [b0, b0 + nbu), forward recursions first; the
+// two CUs of a recursion 8 block ids apart (block x is observed on XCD x % 8: one L2 for the hand-off; a matter of speed only)
+template <int NTH, int NCH, int NBF, int NBB>
+__global__ __launch_bounds__(NTH) void crf_fac2_pair_kernel(FacParams pf, FacParams pb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int K = 2;
+    const int total = pf.nbu * K;
+    const bool fwd = (int)blockIdx.x < total;
+    const int x = fwd ? (int)blockIdx.x : (int)blockIdx.x - total;
+    const int full = total / (8 * K) * (8 * K);
+    int b, k;
+    if (x < full) { const int grp = x / (8 * K), within = x % (8 * K); k = within / 8; b = pf.b0 + grp * 8 + within % 8; }
+    else { const int y = x - full; k = y % K; b = pf.b0 + full / K + y / K; }
+    if (fwd) fac_chain_body<0, false, NTH, NCH, NBF, true, true, true>(pf, lds, b, k);
+    else fac_chain_body<1, false, NTH, NCH, NBB, true, true, true>(pb, lds, b, k);
 }
 
 // Holds a (side) stream until `target` workgroups of the den kernels have started, i.e. own their compute
@@ -2614,7 +2710,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
     char *ldsw = stage[wave];
     const int ul = lane % UL, aj = lane / UL;                      // rest rows and the per-utterance scalars: utterance ul of the group
     const int uq = lane % LG, sj = lane / LG;                      // stream: utterances 4 uq .. 4 uq + 3, row sj of the bundle
-    const int T = p.T, S = p.S, P = p.P;
+    const int T = p.T, P = p.P;
     int combo, chunk, nchunk;
     bat_decode((int)blockIdx.x, (int)gridDim.x, 2 * p.ngrp, &combo, &chunk, &nchunk);   // (crf_internal.h)
     const int dir = combo & 1, grp = combo >> 1;
@@ -3290,7 +3386,8 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_ECB = o; o = al(o + B * T * 4);
     w.off_pb = o; o = al(o + 32 * B * 8);
     // tagged granules [2 slots] of both directions, then one XCD-id word per CU of every recursion
-    w.xch_bytes = (w.res && !w.fac && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8) : 0;
+    w.xch_bytes = (w.res && !w.fac && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8)
+                : (w.fac && h->dev.fac.K > 1) ? al((B * 2 * ((int64_t)h->dev.fac.f.G + h->dev.fac.b.G) + 2 * B * kResMaxK) * 8) : 0;
     w.off_xch = o; o = al(o + w.xch_bytes + 256 + 8 * B);   // granules | error word, start counter | per-utterance progress of the two den recursions
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.off_ept = o; o = al(o + (w.bat ? T * V * w.Bp * 4 : 0));
@@ -3536,7 +3633,23 @@ static FacParams fac_params(const LossParams &lp, int dir, int *started, int i0,
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F; p.redo = lp.redo;
+    p.K = F.K; p.b0 = 0; p.nbu = lp.B; p.Gf = F.f.G; p.Gb = F.b.G; p.xch = lp.xch; p.err = lp.err;
     return p;
+}
+// factored recursions over TWO CUs each, utterances [b0, b0 + nbu): every workgroup of a launch must be resident at once
+// (its peer spins on it), so the caller launches groups of at most CUs / 4 utterances
+static int launch_fac2_pair(const LossParams &lp, size_t lds, hipStream_t st, int b0, int nbu) {
+    static LdsMark mk;
+    FacParams pf = fac_params(lp, 0, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
+    FacParams pb = fac_params(lp, 1, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
+    pf.b0 = pb.b0 = b0; pf.nbu = pb.nbu = nbu;
+    auto *k = crf_fac2_pair_kernel<kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B>;
+    int rc;
+    if ((rc = ensure_lds((const void *)k, lds, mk, "fac2 pair"))) return rc;
+    hipLaunchKernelGGL(k, dim3((unsigned)(2 * nbu * 2)), dim3(kFac3Threads), lds, st, pf, pb);
+    hipError_t e;
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac2_pair_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return CRF_OK;
 }
 // factored recursions, iterations [i0, i1) of both directions as one grid of 2B workgroups; FLAG: publish stage counters
 // (both directions bump the same counters: a stage is complete at 2B) and store the rows write-through
@@ -3719,7 +3832,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     else hipLaunchKernelGGL(crf_prep_kernel<64>, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
     prof_mark(0, true, stream);
     LAUNCH_CHECK("crf_prep_kernel");
-    if (res && !fac && (w.xch_bytes > 0 || !have_flags)) {  // exchange granules (tags) and the error word start at zero in every call
+    if (res && (!fac || w.xch_bytes > 0) && (w.xch_bytes > 0 || !have_flags)) {  // exchange granules (tags) and the error word start at zero in every call
         if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256 + 8 * (size_t)B, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
     }
 
@@ -3770,7 +3883,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const bool segmode = use_segments.load();
     static const int stages_env = getenv("CRF_STAGES") ? atoi(getenv("CRF_STAGES")) : 0;
     const int pieces = stages_env > 0 ? stages_env : (segmode ? 4 : 12);   // measured: 4 / 8 / 12 pieces -> call 4.06 / 3.98 / 3.93 ms (flags)
-    const bool staged = fac && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && 2 * B <= ncu_dev / 2;
+    const bool staged = fac && h->dev.fac.K == 1 && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && 2 * B <= ncu_dev / 2;
     // Stage bounds.  Nothing can be released before the two recursions have met, so the first stage ends at half of
     // the frames or later; after that a piece of `piece` iterations releases 2 * piece / 16 frame blocks per
     // utterance.  The grad pass has half of the chip and is bandwidth-bound there (~2 TB/s against the 2.2 TB/s the
@@ -3856,7 +3969,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     auto launch_den = [&](hipStream_t st) -> int {
         prof_mark(1, false, st); prof_mark(2, false, st);
         int r2 = CRF_OK;
-        if (fac) {
+        if (fac && h->dev.fac.K > 1) {
+            const int grp = std::max(1, ncu_dev / 4);
+            for (int b0 = 0; b0 < (int)B && !r2; b0 += grp) r2 = launch_fac2_pair(p, lds_fac, st, b0, std::min(grp, (int)B - b0));
+        } else if (fac) {
             r2 = launch_fac_pair<false>(p, lds_fac, st, started, 0, (int)T, fstate, bstate);
         } else if (res) {
             // K CUs per utterance and direction exchange the state vector through L2 every frame.  With K > 1 every

@@ -924,9 +924,26 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // =================================================================================================
 // Factored layout (crf_internal.h: FacDev).
 // =================================================================================================
+// rows -> K CUs: longest first onto the CU with the fewest chunks so far (ties: fewest rows)
+static std::vector<int> deal_rows(const Rows &rows, int K) {
+    std::vector<int> cu(rows.size(), 0);
+    if (K <= 1) return cu;
+    std::vector<int> ord(rows.size());
+    for (size_t i = 0; i < rows.size(); ++i) ord[i] = (int)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return rows[(size_t)a].size() > rows[(size_t)b].size(); });
+    std::vector<int64_t> load((size_t)K, 0), cnt((size_t)K, 0);
+    for (int r : ord) {
+        int best = 0;
+        for (int k = 1; k < K; ++k)
+            if (load[(size_t)k] < load[(size_t)best] || (load[(size_t)k] == load[(size_t)best] && cnt[(size_t)k] < cnt[(size_t)best])) best = k;
+        cu[(size_t)r] = best; load[(size_t)best] += chunks_of(rows[(size_t)r].size()); cnt[(size_t)best]++;
+    }
+    return cu;
+}
+
 static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
                                const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
-                               const std::vector<float> &end_lin, int level, bool *retry_next, int dup_mask, int *new_mask, bool short_only = false, bool *long_bail = nullptr) {
+                               const std::vector<float> &end_lin, int level, bool *retry_next, int dup_mask, int *new_mask, bool short_only = false, bool *long_bail = nullptr, int K = 1) {
     FacDev &F = h->dev.fac;
     F = FacDev{};
     if ((getenv("CRF_NO_FACTORED") && atoi(getenv("CRF_NO_FACTORED"))) || (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT")))) return CRF_OK;
@@ -1027,7 +1044,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // second copy of the gathered entries: per direction (dup_mask bit 0 forward, bit 1 backward); a direction that turns out
     // not to fit with it clears its bit in *new_mask and the caller builds again
     const bool env_nodup = getenv("CRF_FAC_NO_DUP") && atoi(getenv("CRF_FAC_NO_DUP"));
-    const bool no_dupf = !(dup_mask & 1) || env_nodup, no_dupb = !(dup_mask & 2) || env_nodup;
+    const bool no_dupf = !(dup_mask & 1) || env_nodup || K > 1, no_dupb = !(dup_mask & 2) || env_nodup || K > 1;   // (two CUs: one copy, the peers' entries are fetched into it)
     *new_mask = dup_mask;
     int nent = 0;
     for (int s = 0; s < S; ++s) if (tail_of[s] >= 0) entU[s] = nent++;
@@ -1064,11 +1081,11 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             if (chunks_of(r.size()) > gm->nch) { if (long_bail) *long_bail = true; *retry_next = true; return CRF_OK; }
     DirOut fo;
     std::vector<SliceAt> fslices;
-    if (!place_rows(fsub, std::vector<int>(fsub.size(), 0), 1, &fo, &fslices, *gm)) {
+    if (!place_rows(fsub, deal_rows(fsub, K), K, &fo, &fslices, *gm)) {
         if (allow3) { *retry_next = true; return CRF_OK; }
         return give_up("forward rows do not fit one CU");
     }
-    const int Rf = fo.cu_row_off[1];
+    const int Rf = fo.cu_row_off[(size_t)K];
     if (implicit) {
         // 768-thread layout: the entries of a row are where its row id says -- U at rid, L at Rf + rid, A at 2 Rf + rid
         // (then the states nobody enters, a zero entry for padding gathers, and the second copy of the U entries) -- so
@@ -1222,11 +1239,11 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             if (chunks_of(r.size()) > gm->nch) { if (long_bail) *long_bail = true; *retry_next = true; return CRF_OK; }
     DirOut bo;
     std::vector<SliceAt> bslices;
-    if (!place_rows(bsub, std::vector<int>(bsub.size(), 0), 1, &bo, &bslices, *gm)) {
+    if (!place_rows(bsub, deal_rows(bsub, K), K, &bo, &bslices, *gm)) {
         if (allow3) { *retry_next = true; return CRF_OK; }   // both directions then use the larger per-thread budget
         return give_up("backward rows do not fit one CU");
     }
-    const int Rb = bo.cu_row_off[1], Gb0 = 2 * Rb + 2, zsink = 2 * Rb;
+    const int Rb = bo.cu_row_off[(size_t)K], Gb0 = 2 * Rb + 2, zsink = 2 * Rb;
     int bdup = 0;                                        // second copy of every z entry: [z (2 Rb)][sink pair] [pad] [z'][sink']
     if (!no_dupb) { bdup = Gb0; while ((bdup & 31) != bank_shift) ++bdup; }
     const int Gb = bdup ? bdup + Gb0 : Gb0;
@@ -1327,7 +1344,8 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     for (auto &wi : fo.wave_info) if (wi.w) F.multilane = 1;
     for (auto &wi : bo.wave_info) if (wi.w) F.multilane = 1;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
-    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads; F.rcl = level == 1;
+    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads; F.rcl = level == 1; F.K = K;
+    for (int k = 0; k <= 2; ++k) { F.f.cu_row[k] = fo.cu_row_off[(size_t)std::min(k, K)]; F.b.cu_row[k] = bo.cu_row_off[(size_t)std::min(k, K)]; }
     int rc;
     if ((rc = up(h, fo.arcs, &F.f.arcs)) || (rc = up(h, fo.wave_info, &F.f.wave_info)) || (rc = up(h, bo.arcs, &F.b.arcs)) ||
         (rc = up(h, bo.wave_info, &F.b.wave_info)) || (rc = up(h, frow_meta, &F.frow_meta)) ||
@@ -1352,19 +1370,23 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     const bool no_rcl = getenv("CRF_FAC_NO_RCL") && atoi(getenv("CRF_FAC_NO_RCL"));
     const bool from_rcl = getenv("CRF_FAC_RCL") && atoi(getenv("CRF_FAC_RCL"));
     int rc = CRF_OK;
-    struct Try { int level; bool short_only; };
+    struct Try { int level; bool short_only; int K = 1; };
     std::vector<Try> plan;
     if (!want3) plan = {{2, false}};
+    else if (getenv("CRF_FAC_K2") && atoi(getenv("CRF_FAC_K2"))) plan = {{1, false, 2}, {2, false}};   // (tests: two CUs per recursion for any T o LM graph)
     else if (from_rcl) plan = {{1, false}, {2, false}};
     else if (no_rcl) plan = {{0, false}, {2, false}};
-    else plan = {{0, true}, {1, false}, {0, false}, {2, false}};   // level 0 only for graphs without long rows -- unless level 1 does not take them
+    else plan = {{0, true}, {1, false}, {0, false}, {1, false, 2}, {2, false}};   // level 0 only for graphs without long rows -- unless level 1 does
+                                                                   // not take them; then two CUs per recursion (table geometry), then 512 threads
+    const bool no_k2 = getenv("CRF_FAC_NO_K2") && atoi(getenv("CRF_FAC_NO_K2"));
     bool long_bail = false;
     for (const Try &t : plan) {
-        if (t.level == 0 && !t.short_only && plan.size() == 4 && !long_bail) continue;   // level 0 has been tried in full already
+        if (t.level == 0 && !t.short_only && plan.size() == 5 && !long_bail) continue;   // level 0 has been tried in full already
+        if (t.K > 1 && no_k2) continue;
         bool retry = false;
         int mask = 3, nm = 3;
         for (;;) {
-            rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, t.level, &retry, mask, &nm, t.short_only, &long_bail);
+            rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, t.level, &retry, mask, &nm, t.short_only, &long_bail, t.K);
             if (rc != CRF_OK || retry || nm == mask) break;
             mask = nm;
         }

@@ -70,7 +70,8 @@ int crf_graph_dims(const crf_graph *g, int64_t *num_states, int64_t *num_arcs, i
  * out[16..23] = factored layout (one CU per recursion, T o LM structure): available (0/1), matched state pairs,
  * weights re-gauged (0/1), single-gather (tail) rows, forward / backward arc slots, fused backward rows, Gf*100000 + Gb;
  * out[24] = geometry of the factored kernels: 0 = 768 threads, row constants in registers (at most 3 slices of rows per wave),
- * 1 = 768 threads, row constants in an LDS table, 2 = 512 threads; -1 = no factored layout.
+ * 1 = 768 threads, row constants in an LDS table, 2 = 512 threads, 3 = as 1 over TWO compute units per recursion; -1 = no
+ * factored layout.
  * A graph created with device < 0 is compiled on the host
  * only (no GPU needed) and can be used with crf_graph_dims / crf_graph_stats / crf_graph_destroy. */
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n);

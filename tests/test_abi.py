@@ -164,8 +164,8 @@ def test_utterance_minor_block_decode():
 
 
 def test_which_kernels_take_which_graph(tmp_path):
-    """crf_den_kernels on host-only graphs: the benchmark graph -> factored (one CU per recursion); 1.5 x its size -> generic
-    register-resident over K CUs; beyond four CUs' registers -> utterance-minor, or round 1's streaming kernels with
+    """crf_den_kernels on host-only graphs: the benchmark graph -> factored (one CU per recursion); 1.5 x - 2 x its size -> factored
+    over two CUs per recursion (without that: generic register-resident over K = 4 CUs); beyond four CUs' registers -> utterance-minor, or round 1's streaming kernels with
     CRF_NO_BATCH=1; with CRF_NO_FACTORED=1 the benchmark graph takes the generic layout (K = 2)."""
     import ctc_crf
     core = ctc_crf._C
@@ -193,7 +193,11 @@ def test_which_kernels_take_which_graph(tmp_path):
     assert k == "factored" and st["fac"] == 1
     k, st = which(2048, 24, CRF_NO_FACTORED=1)
     assert k == "resident" and st["res_K"] == 2
-    k, st = which(3072, 24)
+    k, st = which(3072, 24)                                       # 1.5 x: the factored layout over TWO CUs per recursion
+    assert k == "factored" and st["fac"] == 1 and st["fac_geom"] == 3
+    k, st = which(3072, 24, CRF_FAC_NO_K2=1)                      # ... without it: the generic layout, K = 4
     assert k == "resident" and st["fac"] == 0 and st["res_K"] == 4
-    k, st = which(4096, 24)                                       # 8193 states: needs the 64 KiB state-vector buffers
-    assert k == "resident" and st["res_K"] == 4 and st["S"] == 8193
+    k, st = which(4096, 24)                                       # 8193 states, 208 k arcs
+    assert k == "factored" and st["fac_geom"] == 3 and st["S"] == 8193
+    k, st = which(4096, 24, CRF_FAC_NO_K2=1)                      # (needs the 64 KiB state-vector buffers)
+    assert k == "resident" and st["res_K"] == 4

@@ -27,7 +27,7 @@ def crf():
     return ctc_crf
 
 
-MODES = ["factored", "factored_rcl", "resident", "streaming", "batch"]
+MODES = ["factored", "factored_rcl", "factored_k2", "resident", "streaming", "batch"]
 
 
 class _env:
@@ -55,13 +55,16 @@ class _mode:
         self.mode = mode
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("CRF_NO_RESIDENT", "CRF_NO_FACTORED", "CRF_NO_BATCH", "CRF_FAC_RCL", "CRF_FAC_NO_RCL")}
+        self.old = {k: os.environ.get(k) for k in ("CRF_NO_RESIDENT", "CRF_NO_FACTORED", "CRF_NO_BATCH", "CRF_FAC_RCL", "CRF_FAC_NO_RCL", "CRF_FAC_K2")}
         os.environ["CRF_NO_RESIDENT"] = "1" if self.mode in ("streaming", "batch") else "0"
         os.environ["CRF_NO_FACTORED"] = "0" if self.mode.startswith("factored") else "1"
         # "factored_rcl": the factored kernels' 768-thread variant with the row constants in an LDS table (what graphs with more
         # than three slices of rows per wave take by themselves), forced for every graph with the T o LM structure
         os.environ["CRF_FAC_RCL"] = "1" if self.mode == "factored_rcl" else "0"
         os.environ["CRF_FAC_NO_RCL"] = "1" if self.mode == "factored_rc" else "0"   # row constants in registers even for long rows
+        # "factored_k2": the factored kernels over TWO compute units per recursion (what T o LM graphs of 120 k - 240 k arcs
+        # take by themselves), forced for every graph with the structure
+        os.environ["CRF_FAC_K2"] = "1" if self.mode == "factored_k2" else "0"
         # "batch": the utterance-minor kernels (one launch per frame), what graphs that fit no register-resident layout
         # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (CRF_NO_BATCH is read per call,
         # so it stays set for the life of the test process's calls in this mode: see run_hip)
@@ -86,6 +89,8 @@ def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mo
             assert st["fac"] == 0
         if mode == "factored_rcl" and st["fac"]:
             assert st["fac_geom"] in (1, 2)                      # (2: neither 768-thread geometry took the graph)
+        if mode == "factored_k2" and st["fac"]:
+            assert st["fac_geom"] in (3, 2)
         x = torch.tensor(logits, device="cuda:0", requires_grad=True)
         crit = crf.CTC_CRF_LOSS(lamb=lamb, size_average=size_average)
         loss = crit(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32),
@@ -181,6 +186,29 @@ def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
     for b in range(B):
         assert rel_err(grad[b], ref["grad"][b]) <= TOL, b
         assert np.all(grad[b, lx[b]:] == 0.0)
+
+
+@pytest.mark.parametrize("B", [16, 21])
+def test_factored_layout_over_two_cus(crf, tmp_path, B):
+    """The factored kernels with TWO compute units per recursion (fac_geom 3; forced here, graphs of 120 k - 240 k arcs take it by
+    themselves): with 16 utterances the two CUs of a recursion are 8 block ids apart -- one XCD, plain stores through the shared
+    L2 -- with 21 the last five recursions' CUs are neighbours (write-through hand-off); ragged lengths incl. an empty and a
+    one-frame utterance, against the fp64 oracle.  The per-utterance costs of both directions must agree (logZ from the forward
+    vector on CU 0, from the backward rows of both CUs)."""
+    g, p = small_synth(tmp_path, 24, 96, 8, 13)
+    logits, labels, lx, ly = make_batch(g, B, 47, 24, seed=B, ragged=True)
+    lx = np.array(lx); ly = np.array(ly); labels = list(labels)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode="factored_k2")
+    with _mode("factored_k2"):
+        ctx = crf.CRFContext(p, 0)
+        st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+        del ctx
+    assert st["fac"] == 1 and st["fac_geom"] == 3
+    assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
+    assert rel_err(grad, ref["grad"]) <= TOL
+    for b in range(B):
+        assert rel_err(grad[b], ref["grad"][b]) <= TOL, b
 
 
 @pytest.mark.parametrize("ul", [8, 16, 32, 64])
