@@ -111,6 +111,8 @@ struct FacDev {
     int threads;               // workgroup size the tables were built for: 768 (21 chunks per thread) or 512 (30)
     int K;                     // CUs per recursion: 1, or 2 (graphs of 120 k - 240 k arcs: each CU holds half of the rows and the whole
                                // state vector, the products cross through L2 every frame like the generic layout's; rcl geometry only)
+    const int *xlist;          // K = 2, forward: the L / A entries (and plain states) CU k fetches from its peer every frame,
+    int xlist_off[3];          //   [xlist_off[k], xlist_off[k + 1]); the U entries cross as a range, everything once more at the end
     int rcl;                   // 768 threads with the row constants in an LDS table read one slice ahead (any number of slices per wave)
     int multilane;             // some rows lie on several adjacent lanes (wave_info.w != 0 somewhere): kernel variant with the butterfly
     const float *x_start, *x_end;   // [Gf]

@@ -1019,6 +1019,24 @@ __device__ __forceinline__ float res_fetch(gu64 *slot, float *v, int lo, int hi,
     return mx;
 }
 
+// ... the same for a LIST of entries (one per thread and round)
+template <int NT>
+__device__ __forceinline__ float res_fetch_list(gu64 *slot, float *v, const int *__restrict__ list, int l0, int l1, unsigned tag, int *err, int tid) {
+    float mx = 0.f;
+    for (int j = l0 + tid; j < l1; j += NT) {
+        const int e = list[j];
+        for (unsigned spins = 0;; ++spins) {
+            const unsigned long long g = __hip_atomic_load(slot + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(g >> 32) == tag) { const float x = __uint_as_float((unsigned)g); v[e] = x; mx = fmaxf(mx, x); break; }
+            if (spins > (1u << 24)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (spins > 64) __builtin_amdgcn_s_sleep(8);
+            else if (spins > 2) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return mx;
+}
+
 // Chunk sums in batches of kResBatch chunks: the 4*kResBatch gathers of a batch are one straight-line
 // block (no branch between them), so every wave keeps 24 independent ds_read_b32 in flight -- with
 // only 2 waves per SIMD that, not occupancy, is what hides the LDS latency.  The (uniform) slice-end
@@ -1406,6 +1424,8 @@ struct FacParams {
     int *redo;                  // [2][B], see LossParams
     // two CUs per recursion (FacDev::K = 2): the utterances [b0, b0 + nbu) of this launch, the exchange granules, the error word
     int K, b0, nbu, Gf, Gb;
+    const int *xlist;           // forward: the L / A entries this CU fetches every frame (FacDev::xlist), [xl0, xl1)
+    int xlist_off[3];
     unsigned long long *xch;
     int *err;
 };
@@ -1832,9 +1852,17 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             float *Xn = (float *)xnb;
             float fm;
             if (DIR == 0) {
+                // the U entries, and of the L / A entries those this CU's rows gather (a list) -- all of them after the last frame
+                // (logZ; only the CU that computes it)
                 fm = res_fetch<NTH>(slot, Xn, p0, p1, tag, p.err, tid);
-                fm = fmaxf(fm, res_fetch<NTH>(slot, Xn, R + p0, R + p1, tag, p.err, tid));
-                fm = fmaxf(fm, res_fetch<NTH>(slot, Xn, 2 * R + p0, 2 * R + p1, tag, p.err, tid));
+                if (i == lx - 1) {
+                    if (lead) {
+                        fm = fmaxf(fm, res_fetch<NTH>(slot, Xn, R + p0, R + p1, tag, p.err, tid));
+                        fm = fmaxf(fm, res_fetch<NTH>(slot, Xn, 2 * R + p0, 2 * R + p1, tag, p.err, tid));
+                    }
+                } else {
+                    fm = fmaxf(fm, res_fetch_list<NTH>(slot, Xn, p.xlist, p.xlist_off[k], p.xlist_off[k + 1], tag, p.err, tid));
+                }
             } else {
                 fm = res_fetch<NTH>(slot, Xn, 2 * p0, 2 * p1, tag, p.err, tid);
             }
@@ -3633,7 +3661,7 @@ static FacParams fac_params(const LossParams &lp, int dir, int *started, int i0,
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F; p.redo = lp.redo;
-    p.K = F.K; p.b0 = 0; p.nbu = lp.B; p.Gf = F.f.G; p.Gb = F.b.G; p.xch = lp.xch; p.err = lp.err;
+    p.K = F.K; p.b0 = 0; p.nbu = lp.B; p.Gf = F.f.G; p.Gb = F.b.G; p.xch = lp.xch; p.err = lp.err; p.xlist = F.xlist; for (int k = 0; k < 3; ++k) p.xlist_off[k] = F.xlist_off[k];
     return p;
 }
 // factored recursions over TWO CUs each, utterances [b0, b0 + nbu): every workgroup of a launch must be resident at once

@@ -1116,6 +1116,32 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         return give_up("forward gather vector > 64 KiB");
     }
     pack_arcs(fsub, fslices, &fo, 4, *gm, fdup ? nU : 0, fdup);
+    // two CUs: the U entries cross every frame as one contiguous range per CU; of the L and A entries (and the plain states, which
+    // sit in the L range) only those that a row of the OTHER CU gathers -- in T o LM the L entry of a couple is read by its own
+    // row alone (the token's self-loop) -- as a list per CU; everything once more after the last frame, for logZ.
+    std::vector<int> xlist;                      // entries CU 0 fetches, then those CU 1 fetches
+    int xlist_off[3] = {0, 0, 0};
+    if (K > 1 && implicit) {
+        auto cu_of_rid = [&](int rid) { int k = 0; while (k + 1 < K && rid >= fo.cu_row_off[(size_t)k + 1]) ++k; return k; };
+        std::vector<std::vector<int>> need((size_t)K);
+        for (size_t r = 0; r < fsub.size(); ++r) {
+            const int rid = fo.rid_of_row[r];
+            if (rid < 0) continue;
+            const int mycu = cu_of_rid(rid);
+            for (auto &a : fsub[r])
+                if (a.first >= Rf && a.first < 3 * Rf && cu_of_rid(a.first % Rf) != mycu) need[(size_t)mycu].push_back(a.first);
+        }
+        for (int k = 0; k < K && k < 2; ++k) {
+            auto &v = need[(size_t)k];
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            xlist_off[k] = (int)xlist.size();
+            xlist.insert(xlist.end(), v.begin(), v.end());
+        }
+        xlist_off[2] = (int)xlist.size();
+        if (verbose) fprintf(stderr, "[fac_layout] two CUs: of %d L / A entries per CU, CU 0 fetches %d and CU 1 %d every frame\n", 2 * (Rf / K), xlist_off[1] - xlist_off[0], xlist_off[2] - xlist_off[1]);
+    }
+    if (xlist.empty()) xlist.push_back(0);
     const int NT = 0;
     std::vector<int> fpos(P, -1);   // position of pair p in the Q row: main rows [0, Rf), their tails [Rf, 2 Rf)
     std::vector<int4> frow_meta(Rf, int4{sink * 4, (sink * 4) | ((sink * 4) << 16), 0, 0});   // padding rows: all to the sink
@@ -1345,6 +1371,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     for (auto &wi : bo.wave_info) if (wi.w) F.multilane = 1;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
     F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads; F.rcl = level == 1; F.K = K;
+    for (int k = 0; k < 3; ++k) F.xlist_off[k] = xlist_off[k];
     for (int k = 0; k <= 2; ++k) { F.f.cu_row[k] = fo.cu_row_off[(size_t)std::min(k, K)]; F.b.cu_row[k] = bo.cu_row_off[(size_t)std::min(k, K)]; }
     int rc;
     if ((rc = up(h, fo.arcs, &F.f.arcs)) || (rc = up(h, fo.wave_info, &F.f.wave_info)) || (rc = up(h, bo.arcs, &F.b.arcs)) ||
@@ -1352,7 +1379,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         (rc = up(h, x_start, &F.x_start)) || (rc = up(h, x_end, &F.x_end)) || (rc = up(h, brow_meta, &F.brow_meta)) ||
         (rc = up(h, z_lab, &F.z_lab)) || (rc = up(h, z_end, &F.z_end)) || (rc = up(h, brow_start, &F.brow_start)) ||
         (rc = up(h, brow_end, &F.brow_end)) || (rc = up(h, bx_idx, &F.bx_idx)) || (rc = up(h, bx_w, &F.bx_w)) || (rc = up(h, gq, &F.gq)) || (rc = up(h, gb, &F.gb)) ||
-        (rc = up(h, gchunk, &F.chunk_off)) || (rc = up(h, glab, &F.lab_chunk_off)))
+        (rc = up(h, gchunk, &F.chunk_off)) || (rc = up(h, glab, &F.lab_chunk_off)) || (rc = up(h, xlist, &F.xlist)))
         return rc;
     F.ok = 1;
     return CRF_OK;

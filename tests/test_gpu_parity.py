@@ -282,7 +282,7 @@ def test_fused_log_softmax(crf, tmp_path, mode, dtype):
     del ctx
 
 
-@pytest.mark.parametrize("mode,V", [("factored", 40), ("factored_rc", 40), ("resident", 40), ("streaming", 40), ("factored", 150), ("factored_rc", 150)])
+@pytest.mark.parametrize("mode,V", [("factored", 40), ("factored_rc", 40), ("factored_k2", 40), ("resident", 40), ("streaming", 40), ("factored", 150), ("factored_rc", 150), ("factored_k2", 150)])
 def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
     """A den_lm ESTIMATED from text (cat_amd.den_lm.prep_den_lm) has the in-degree profile of a real
     n-gram LM: the low-order history states are entered from hundreds of states.  The factored layout cuts such rows
@@ -316,7 +316,7 @@ def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
             ctx = crf.CRFContext(p, 0)
         st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
         # rows that are still longer than a lane's 80 arcs after the factorisation: the LDS-table variant by default
-        assert st["fac"] == 1 and (st["fac_geom"] == 0 if mode == "factored_rc" else st["fac_geom"] in (0, 1))
+        assert st["fac"] == 1 and (st["fac_geom"] == 0 if mode == "factored_rc" else st["fac_geom"] == 3 if mode == "factored_k2" else st["fac_geom"] in (0, 1))
         del ctx
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
