@@ -1704,7 +1704,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                         // leaves the row's sum in every lane of the group, the first one owns the outputs
                         float tot = acc.x + acc.y;
                         if constexpr (ML) {
-                            const unsigned lg = (lgbits >> (3u * ks)) & 7u;
+                            const unsigned lg = ks < 10u ? (lgbits >> (3u * ks)) & 7u : 0u;   // (ten 3-bit fields; later slices have whole rows)
                             if (lg) {
                                 // DPP for groups of up to 16 lanes (pair swap, quad half swap, mirror of 8, mirror of 16: after
                                 // each step every lane of the growing group holds the group's sum, so ANY lane of the other half

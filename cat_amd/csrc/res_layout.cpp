@@ -209,9 +209,17 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
             const int wave_row0 = rid;
             int ord = 0;
             unsigned lgbits = 0;
+            // wave_info.w has ten 3-bit fields: slices of multi-lane rows come first in their wave (the kernels read lg = 0 for
+            // slice numbers >= 10); a wave with more than ten of them does not fit this geometry
+            std::stable_partition(lists[w].begin(), lists[w].end(), [&](int j) { return lgs[(size_t)j] > 0; });
+            {
+                int nml = 0;
+                for (int j : lists[w]) nml += lgs[(size_t)j] > 0;
+                if (nml > 10) return false;
+            }
             for (int j : lists[w]) {
                 ends |= 1u << (c0 + len[j] - 1);
-                lgbits |= (unsigned)lgs[j] << (3 * ord);
+                if (ord < 10) lgbits |= (unsigned)lgs[j] << (3 * ord);
                 SliceAt sl{k, w, c0, len[j], rid, {}, ord++, lgs[j]};
                 for (int lane = 0; lane < kWave; ++lane) {
                     const int r = lanes[j][lane];
