@@ -211,7 +211,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
             unsigned lgbits = 0;
             // wave_info.w has ten 3-bit fields: slices of multi-lane rows come first in their wave (the kernels read lg = 0 for
             // slice numbers >= 10); a wave with more than ten of them does not fit this geometry
-            std::stable_partition(lists[w].begin(), lists[w].end(), [&](int j) { return lgs[(size_t)j] > 0; });
+            if (lists[w].size() > 10) std::stable_partition(lists[w].begin(), lists[w].end(), [&](int j) { return lgs[(size_t)j] > 0; });
             {
                 int nml = 0;
                 for (int j : lists[w]) nml += lgs[(size_t)j] > 0;
