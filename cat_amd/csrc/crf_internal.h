@@ -243,6 +243,15 @@ struct FacBatchH {
     std::vector<float> x_start;         // [S + NU]
     int64_t recs_f = 0, recs_b = 0;     // records (statistics)
 };
+// host copy of the factored register-resident layout's tables (res_layout.cpp: kept for debug_emulate_factored, the CPU check)
+struct FacHostCopy {
+    std::vector<unsigned> farcs, barcs;
+    std::vector<uint4> fwi, bwi;
+    std::vector<int4> frow_meta, brow_meta;
+    std::vector<float> x_start, x_end, z_end, brow_start, brow_end, bx_w, start_lin, end_lin;
+    std::vector<int> z_lab, bx_idx, xlist;
+    int words = 0;                      // words per thread of the arc tables
+};
 struct HostGraph {
     int device = 0;
     int64_t S = 0, A = 0, P = 0;
@@ -260,6 +269,7 @@ struct HostGraph {
     std::vector<int> hb_frow_d, hb_brow_s;
     std::vector<StreamDev *> streams;   // one per (AL, tasks wanted) used so far
     FacBatchH fb;                       // factored rows of the utterance-minor kernels (T o LM graphs), see StreamDev
+    FacHostCopy fh;                     // host copy of dev.fac's tables
     int res_rows_cu_f = 0, res_rows_cu_b = 0;  // max rows of one CU (LDS carve of the resident kernels)
 };
 
@@ -282,6 +292,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                    const std::vector<float> &start_lin, const std::vector<float> &end_lin);
 // Arc streams for UL (8, 16, 32 or 64) utterances per group cut into about `want` tasks per direction, built and uploaded
 // on first use (thread-safe; a graph keeps every variant it has been asked for).
+int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out3);
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out);
 bool stream_fac(const HostGraph *h, int UL);   // factored streams for groups of UL utterances?
 // Host-side construction + self-check of the arc streams (tests; works on host-only graphs).

@@ -1085,6 +1085,11 @@ int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
 
 int crf_debug_decode_check(int nslot, int ncombo) { return crf::debug_check_decode(nslot, ncombo); }
 
+int crf_debug_fac_emulate(const crf_graph *g, int T, unsigned seed, double *out3) {
+    if (!g || !g->h || !out3 || T < 1) { crf::set_error("bad argument"); return CRF_ERR_ARG; }
+    return crf::debug_emulate_factored(g->h, T, seed, out3);
+}
+
 int crf_debug_facbatch_check(const crf_graph *g, int64_t *out4) {
     if (!g || !g->h || !out4) { crf::set_error("null argument"); return CRF_ERR_ARG; }
     return crf::debug_check_facbatch(g->h, out4);

@@ -1390,6 +1390,10 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         (rc = up(h, gchunk, &F.chunk_off)) || (rc = up(h, glab, &F.lab_chunk_off)) || (rc = up(h, xlist, &F.xlist)))
         return rc;
     F.ok = 1;
+    FacHostCopy &C = h->fh;
+    C.farcs = fo.arcs; C.barcs = bo.arcs; C.fwi = fo.wave_info; C.bwi = bo.wave_info; C.frow_meta = frow_meta; C.brow_meta = brow_meta;
+    C.x_start = x_start; C.x_end = x_end; C.z_end = z_end; C.brow_start = brow_start; C.brow_end = brow_end; C.bx_w = bx_w;
+    C.start_lin = start_lin; C.end_lin = end_lin; C.z_lab = z_lab; C.bx_idx = bx_idx; C.xlist = xlist; C.words = gm->words;
     return CRF_OK;
 }
 
@@ -1427,6 +1431,176 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         }
         if (rc != CRF_OK || !retry) break;
     }
+    return rc;
+}
+
+
+// CPU emulation of the factored recursion kernels' DATA FLOW on the layout tables (tests; no GPU): the packed arc words of
+// every CU / wave / lane, slice ends, the butterfly over multi-lane rows, row constants (registers or table), implicit or
+// tabulated entries, the second copy, the rowless states, and for two CUs per recursion a private vector per CU that only
+// receives what the kernel fetches (the peer's U range, its list of L / A entries; everything the kernel does not fetch is
+// NaN, so a gather of an entry that never crosses poisons the result).  fp64, no rescaling, random emissions, T frames.
+// out3 = {plain forward sum over the graph's own tables, factored forward, factored backward}; they must agree.
+int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out3) {
+    const FacDev &F = h->dev.fac;
+    const FacHostCopy &C = h->fh;
+    out3[0] = out3[1] = out3[2] = 0.0;
+    if (!F.ok || C.words == 0) { set_error("no factored layout"); return CRF_ERR_UNSUPPORTED; }
+    auto fail = [&](const std::string &why) { set_error("factored layout emulation: " + why); return CRF_ERR_ARG; };
+    const int S = (int)h->S, V = h->dev.max_label + 1, NTH = F.threads, NW = NTH / kWave, K = F.K, words = C.words;
+    const bool implicit = NTH == kFac3Threads, rcregs = implicit && !F.rcl;
+    uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return 0.5 + (double)(rng % 1000003) / 1000003.0; };
+    std::vector<std::vector<double>> e((size_t)T, std::vector<double>((size_t)V + 1, 0.0));   // e[t][V] = 0: "no label"
+    for (auto &row : e) for (int v = 0; v < V; ++v) row[(size_t)v] = rnd();
+    auto fl = [](unsigned b) { float f; memcpy(&f, &b, 4); return (double)f; };
+    const double nan = std::nan("");
+    // ---- plain forward recursion on the utterance-minor row tables (graphs whose rows all have one entering pair)
+    {
+        std::vector<double> a(C.start_lin.begin(), C.start_lin.end()), an((size_t)S);
+        for (int t = 0; t < T; ++t) {
+            for (int r = 0; r < S; ++r) {
+                const int4 &d = h->hb_frow[(size_t)r];
+                double acc = 0.0;
+                if (d.y > d.x) {
+                    if (!(d.w & 0x40000000)) return fail("the plain reference needs rows with one entering pair");
+                    for (int k2 = d.x; k2 < d.y; ++k2) acc += fl((unsigned)h->hb_farcs[(size_t)k2].y) * a[(size_t)h->hb_farcs[(size_t)k2].x];
+                    acc *= e[(size_t)t][(size_t)(d.w & 0xffff)];
+                }
+                an[(size_t)h->hb_frow_d[(size_t)r]] = acc;
+            }
+            a.swap(an);
+        }
+        for (int s2 = 0; s2 < S; ++s2) out3[0] += a[(size_t)s2] * C.end_lin[(size_t)s2];
+    }
+    // ---- the factored layout, one direction
+    auto run = [&](int dir, double *result) -> int {
+        const FacDirDev &L = dir == 0 ? F.f : F.b;
+        const std::vector<unsigned> &A = dir == 0 ? C.farcs : C.barcs;
+        const std::vector<uint4> &WI = dir == 0 ? C.fwi : C.bwi;
+        const int G = L.G, R = L.R, dup = L.dup / 4;
+        if ((int)A.size() != K * words * NTH || (int)WI.size() != K * NW) return fail("table sizes");
+        std::vector<std::vector<double>> X[2];
+        for (int q = 0; q < 2; ++q) X[q].assign((size_t)K, std::vector<double>((size_t)G, 0.0));
+        std::vector<double> b0rows((size_t)2 * R, 0.0);
+        for (int k = 0; k < K; ++k)
+            for (int z = 0; z < G; ++z)
+                X[0][(size_t)k][(size_t)z] = dir == 0 ? (double)C.x_start[(size_t)z]
+                                                      : e[(size_t)T - 1][(size_t)(C.z_lab[(size_t)z] < 0 ? V : C.z_lab[(size_t)z])] * (double)C.z_end[(size_t)z];
+        const int produced = dir == 0 ? 3 * R : 2 * R;          // entries [0, produced) are written by rows
+        for (int i = 0; i < T; ++i) {
+            const int par = i & 1, t = dir == 0 ? i : T - 1 - i;
+            const std::vector<double> &em = dir == 0 ? e[(size_t)t] : e[(size_t)(t >= 1 ? t - 1 : 0)];
+            for (int k = 0; k < K; ++k) {
+                const std::vector<double> &src = X[par][(size_t)k];
+                std::vector<double> &dst = X[1 - par][(size_t)k];
+                if (K > 1) for (int z = 0; z < produced && z < G; ++z) dst[(size_t)z] = nan;
+                for (int w = 0; w < NW; ++w) {
+                    const uint4 wi = WI[(size_t)k * NW + w];
+                    const unsigned ends = wi.x, lgbits = wi.w;
+                    const int nch = (int)wi.y;
+                    int row = (int)wi.z, slice = 0;
+                    if (nch > (implicit ? kFac3ArcCh : words / 6)) return fail("a wave uses more chunks than the geometry has");
+                    double acc[kWave];
+                    for (double &x : acc) x = 0.0;
+                    for (int c = 0; c < nch; ++c) {
+                        for (int lane = 0; lane < kWave; ++lane) {
+                            const size_t base = (size_t)k * words * NTH + (size_t)(w * kWave + lane);
+                            auto W = [&](int j) { return A[base + (size_t)(6 * c + j) * NTH]; };
+                            const unsigned i01 = W(0), i23 = W(1);
+                            const unsigned offs[4] = {i01 & 0xffffu, i01 >> 16, i23 & 0xffffu, i23 >> 16};
+                            for (int q = 0; q < 4; ++q) {
+                                if (offs[q] % 4 || (int)(offs[q] / 4) >= G) return fail("a gather offset outside the vector");
+                                const double wq = fl(W(2 + q));
+                                if (wq != 0.0) acc[lane] += wq * src[offs[q] / 4];     // (padding gathers: weight 0)
+                            }
+                        }
+                        if (!(ends >> c & 1u)) continue;
+                        const unsigned lg = slice < 10 ? (lgbits >> (3 * slice)) & 7u : 0u;
+                        double tot[kWave];
+                        for (int lane = 0; lane < kWave; ++lane) {
+                            const int g0 = lane & ~((1 << lg) - 1);
+                            double sacc = 0.0;
+                            for (int q = 0; q < (1 << lg); ++q) sacc += acc[g0 + q];
+                            tot[lane] = sacc;
+                        }
+                        for (int lane = 0; lane < kWave; ++lane) {
+                            const int rid = row + lane;
+                            if (rid < L.cu_row[k] || rid >= L.cu_row[k + 1]) return fail("a wave's row outside its CU's range");
+                            if (dir == 0) {
+                                const int4 m = C.frow_meta[(size_t)rid];
+                                unsigned lab_m = (unsigned)m.x >> 16, lab_t = (unsigned)m.w;
+                                double tw = fl((unsigned)m.z);
+                                if (rcregs) {   // the register copies of the constants must say the same
+                                    const size_t base = (size_t)k * words * NTH + (size_t)(w * kWave + lane);
+                                    const unsigned k0 = A[base + (size_t)(kFac3ArcCh * 6 + 2 * slice) * NTH], k1 = A[base + (size_t)(kFac3ArcCh * 6 + 2 * slice + 1) * NTH];
+                                    if (slice >= kFac3MaxSl) return fail("more slices in a wave than row-constant registers");
+                                    if (k0 != ((lab_m * 4u) | ((lab_t * 4u) << 16)) || k1 != (unsigned)m.z) return fail("forward row constants in registers differ from the table");
+                                }
+                                const int uo = implicit ? rid : (m.x & 0xffff) / 4, lo = implicit ? R + rid : (m.y & 0xffff) / 4, ao = implicit ? 2 * R + rid : (int)((unsigned)m.y >> 16) / 4;
+                                if (implicit && tw != 0.0 && ((m.x & 0xffff) / 4 != rid || (m.y & 0xffff) / 4 != R + rid || (int)((unsigned)m.y >> 16) / 4 != 2 * R + rid))
+                                    return fail("implicit entries differ from the row table");
+                                const double uold = src[(size_t)uo], rv = tot[lane], qt = tw * uold;
+                                const double Lp = em[(size_t)lab_m] * rv, Ap = em[(size_t)lab_t] * qt, Up = Lp + Ap;
+                                dst[(size_t)uo] = Up; dst[(size_t)lo] = Lp; dst[(size_t)ao] = Ap;
+                                if (dup) dst[(size_t)uo + dup] = Up;
+                            } else {
+                                const int4 m = C.brow_meta[(size_t)rid];
+                                const unsigned o0 = (unsigned)m.x & 0xffffu, o1 = (unsigned)m.x >> 16, l0 = (unsigned)m.w & 0xffffu, l1 = (unsigned)m.w >> 16;
+                                if (rcregs) {
+                                    const size_t base = (size_t)k * words * NTH + (size_t)(w * kWave + lane);
+                                    const unsigned k0 = A[base + (size_t)(kFac3ArcCh * 6 + 2 * slice) * NTH], k1 = A[base + (size_t)(kFac3ArcCh * 6 + 2 * slice + 1) * NTH];
+                                    if (slice >= kFac3MaxSl) return fail("more slices in a wave than row-constant registers");
+                                    const unsigned want1 = (l0 == 0xffffu ? 0xffffu : l0 * 4u) | ((l1 == 0xffffu ? 0xffffu : l1 * 4u) << 16);
+                                    if (k0 != (unsigned)m.x || k1 != want1) return fail("backward row constants in registers differ from the table");
+                                }
+                                const double z0 = src[o0 / 4], z1 = src[o1 / 4];
+                                const double bv0 = fl((unsigned)m.y) * z0 + tot[lane], bv1 = fl((unsigned)m.z) * z1 + tot[lane];
+                                if (t == 0) { b0rows[(size_t)2 * rid] = bv0; b0rows[(size_t)2 * rid + 1] = bv1; }
+                                const double zv0 = em[(size_t)(l0 == 0xffffu ? V : l0)] * bv0, zv1 = em[(size_t)(l1 == 0xffffu ? V : l1)] * bv1;
+                                dst[(size_t)2 * rid] = zv0; dst[(size_t)2 * rid + 1] = zv1;
+                                if (dup) { dst[(size_t)2 * rid + dup] = zv0; dst[(size_t)2 * rid + 1 + dup] = zv1; }
+                            }
+                        }
+                        for (double &x : acc) x = 0.0;
+                        row += kWave; ++slice;
+                    }
+                }
+            }
+            if (K > 1) {   // what the kernel fetches from the peer
+                for (int k = 0; k < K; ++k) {
+                    const std::vector<double> &peer = X[1 - par][(size_t)(1 - k)];
+                    std::vector<double> &mine = X[1 - par][(size_t)k];
+                    const int p0 = L.cu_row[1 - k], p1 = L.cu_row[2 - k];
+                    if (dir == 0) {
+                        for (int z = p0; z < p1; ++z) mine[(size_t)z] = peer[(size_t)z];
+                        if (i == T - 1) { if (k == 0) for (int z = p0; z < p1; ++z) { mine[(size_t)R + z] = peer[(size_t)R + z]; mine[(size_t)2 * R + z] = peer[(size_t)2 * R + z]; } }
+                        else if (!(getenv("CRF_EMU_DROP_LIST") && atoi(getenv("CRF_EMU_DROP_LIST")))) for (int j = F.xlist_off[k]; j < F.xlist_off[k + 1]; ++j) {   // (negative control of the test)
+                            const int en = C.xlist[(size_t)j], rid = en % R;
+                            if (en < R || en >= 3 * R || rid < p0 || rid >= p1) return fail("a listed entry is not an L / A entry of the peer");
+                            mine[(size_t)en] = peer[(size_t)en];
+                        }
+                    } else {
+                        for (int z = 2 * p0; z < 2 * p1; ++z) mine[(size_t)z] = peer[(size_t)z];
+                    }
+                }
+            }
+            if (dir == 0 && i == 0)   // entries no row produces still hold a_0 in the buffer frame 0 read from: cleared
+                for (int k = 0; k < K; ++k) for (int z = 0; z < G; ++z) if (C.x_start[(size_t)z] != 0.f) X[0][(size_t)k][(size_t)z] = 0.0;
+        }
+        double sum = 0.0;
+        if (dir == 0) {
+            for (int z = 0; z < G; ++z) if (C.x_end[(size_t)z] != 0.f) sum += X[T & 1][0][(size_t)z] * (double)C.x_end[(size_t)z];
+        } else {
+            for (int r = 0; r < 2 * R; ++r) if (C.brow_start[(size_t)r] != 0.f) sum += (double)C.brow_start[(size_t)r] * b0rows[(size_t)r];
+            const std::vector<double> &Xl = X[(T - 1) & 1][0];
+            for (int a2 = 0; a2 < F.nbx; ++a2) sum += (double)C.bx_w[(size_t)a2] * Xl[(size_t)C.bx_idx[(size_t)a2]];
+        }
+        *result = sum;
+        return CRF_OK;
+    };
+    int rc = run(0, &out3[1]);
+    if (!rc) rc = run(1, &out3[2]);
     return rc;
 }
 

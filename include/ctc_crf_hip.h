@@ -100,6 +100,11 @@ int crf_debug_decode_check(int nslot, int ncombo);
  * them equals the step through the plain tables on random vectors.  out4: {U entries, forward records, backward records, arcs};
  * all zero when the graph has no such rows. */
 int crf_debug_facbatch_check(const crf_graph *g, int64_t *out4);
+/* Test aid (no GPU): emulates the data flow of the factored register-resident kernels on the layout tables of a (host-only)
+ * graph for T frames of random emissions -- packed arc words, slice ends, multi-lane rows, row constants, entries, second copy,
+ * rowless states, and with two compute units per recursion exactly what crosses between them (a gather of anything else yields
+ * NaN).  out3 = {sum over end states by the graph's own row tables, factored forward, factored backward}: all three agree. */
+int crf_debug_fac_emulate(const crf_graph *g, int T, unsigned seed, double *out3);
 
 /* The hot path.  Replaces, in one call and with no host synchronisation:
  *   gpu_ctc  (binding.cpp:86-117  -> compute_ctc_loss, ctc_entrypoint.cu:29-60)

@@ -201,3 +201,66 @@ def test_which_kernels_take_which_graph(tmp_path):
     assert k == "factored" and st["fac_geom"] == 3 and st["S"] == 8193
     k, st = which(4096, 24, CRF_FAC_NO_K2=1)                      # (needs the 64 KiB state-vector buffers)
     assert k == "resident" and st["res_K"] == 4
+
+
+def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
+    """crf_debug_fac_emulate walks the factored register-resident layout's tables the way the kernels do -- packed arc words of
+    every CU / wave / lane, slice ends, butterfly over multi-lane rows, row constants (registers and LDS table), implicit and
+    tabulated entries, second copy, rowless states -- for a few frames of random emissions in fp64: forward and backward sums
+    through the layout = the sum through the graph's own row tables.  Every geometry (768 threads with the constants in registers
+    / in the table, 512 threads, two CUs per recursion), with and without the second copy; graphs: small T o LM, the reference's
+    9-state fixture, an estimated n-gram graph with multi-lane rows, the benchmark graph, and a graph of 1.5 x its size (which
+    takes two CUs by itself).  With two CUs each has a private vector that receives only what the kernel fetches; the negative
+    control (the list of L / A entries dropped) must poison the sums."""
+    import math
+    import ctc_crf
+    from cat_amd import den_lm
+    core = ctc_crf._C
+
+    def emu(path, T=5, **env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            h = core.compile_graph_host_only(path)
+            st = core.graph_stats(h)
+            r = core.debug_fac_emulate(h, T, 7)
+            core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+            return st["fac_geom"], r
+        finally:
+            for k_, v in old.items():
+                if v is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v
+
+    def agree(r):
+        return all(math.isfinite(x) and x > 0 for x in r) and abs(r[1] - r[0]) <= 1e-9 * r[0] and abs(r[2] - r[0]) <= 1e-9 * r[0]
+
+    small = os.path.join(str(tmp_path), "small.fst")
+    synth_den_lm(24, 96, 8, seed=13, path=small)
+    V = 40
+    rng = np.random.default_rng(3)
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(1200):
+        L, sq, a, b = int(rng.integers(8, 30)), [], 0, 0
+        for _ in range(L):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
+        seqs.append(sq)
+    est = os.path.join(str(tmp_path), "est.fst")
+    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150)
+    for path in (small, os.path.join(golden_dir, "den_lm_fixture.fst"), est):
+        for env, geom in (({}, (0, 1)), ({"CRF_FAC_NO_RCL": 1}, (0,)), ({"CRF_FAC_RCL": 1}, (1,)), ({"CRF_FAC_K2": 1}, (3,)), ({"CRF_FAC_THREADS": 512}, (2,)),
+                          ({"CRF_FAC_NO_DUP": 1}, (0, 1))):
+            g, r = emu(path, **env)
+            assert g in geom and agree(r), (path, env, g, r)
+    g, r = emu(small, CRF_FAC_K2=1, CRF_EMU_DROP_LIST=1)          # negative control
+    assert g == 3 and not agree(r)
+    bench = os.path.join(str(tmp_path), "bench.fst")
+    synth_den_lm(72, 2048, 24, seed=0, path=bench)
+    g, r = emu(bench, T=3)
+    assert g == 0 and agree(r)
+    mid = os.path.join(str(tmp_path), "mid.fst")
+    synth_den_lm(72, 3072, 24, seed=0, path=mid)
+    g, r = emu(mid, T=3)
+    assert g == 3 and agree(r)
