@@ -188,11 +188,12 @@ def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
-@pytest.mark.parametrize("B", [16, 21])
+@pytest.mark.parametrize("B", [16, 21, 70])
 def test_factored_layout_over_two_cus(crf, tmp_path, B):
     """The factored kernels with TWO compute units per recursion (fac_geom 3; forced here, graphs of 120 k - 240 k arcs take it by
     themselves): with 16 utterances the two CUs of a recursion are 8 block ids apart -- one XCD, plain stores through the shared
-    L2 -- with 21 the last five recursions' CUs are neighbours (write-through hand-off); ragged lengths incl. an empty and a
+    L2 -- with 21 the last five recursions' CUs are neighbours (write-through hand-off), 70 utterances are two launches (every
+    workgroup of a launch must be resident: at most CUs / 4 utterances each); ragged lengths incl. an empty and a
     one-frame utterance, against the fp64 oracle.  The per-utterance costs of both directions must agree (logZ from the forward
     vector on CU 0, from the backward rows of both CUs)."""
     g, p = small_synth(tmp_path, 24, 96, 8, 13)
