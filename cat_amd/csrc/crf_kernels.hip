@@ -3390,10 +3390,13 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     const bool force_bat = getenv("CRF_FORCE_BATCH") && atoi(getenv("CRF_FORCE_BATCH"));
     w.bat = h && h->dev.bat.ok && (force_bat || (!w.res && !(getenv("CRF_NO_BATCH") && atoi(getenv("CRF_NO_BATCH")))));
     if (w.bat) w.res = w.fac = false;
-    // utterances per group: as wide as the batch allows (an arc is fetched once per group), but one group's state vector
-    // [S][UL] has to stay in an XCD's 4 MiB L2 next to the arc stream: at most ~2.25 MB (CRF_BAT_UL overrides, for sweeps)
+    // utterances per group: as wide as the batch allows (an arc is fetched once per group); 32 instead of 64 when a group's state
+    // vector [S][64] would not stay in an XCD's 4 MiB L2 next to the arc stream (> ~2.25 MB) -- but never narrower than 32 for
+    // that reason: every group reads the whole arc stream again and narrower gathers are partial lines (measured: S = 16 385,
+    // B = 64: UL 64 / 32 / 16 -> 31.6 / 29.7 / 34.5 ms; config #5 with B = 64, where not even [S][8] fits: UL 64 / 32 / 8 -> 379 /
+    // 271 / 569 ms).  CRF_BAT_UL overrides, for sweeps.
     w.UL = B > 32 ? 64 : B > 16 ? 32 : B > 8 ? 16 : 8;
-    if (h) while (w.UL > 8 && std::max<int64_t>(h->dev.S, h->dev.P) * w.UL * 4 > (int64_t)(2.25 * 1024 * 1024)) w.UL >>= 1;
+    if (h && w.UL == 64 && std::max<int64_t>(h->dev.S, h->dev.P) * w.UL * 4 > (int64_t)(2.25 * 1024 * 1024)) w.UL = 32;
     if (const char *e = getenv("CRF_BAT_UL")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) w.UL = v; }
     w.Bp = (B + w.UL - 1) / w.UL * w.UL;
     // (rows are at least Pr wide: the robust fallback stores them in pair order, whatever layout the fast kernels use)
