@@ -250,6 +250,7 @@ struct FacHostCopy {
     std::vector<int4> frow_meta, brow_meta;
     std::vector<float> x_start, x_end, z_end, brow_start, brow_end, bx_w, start_lin, end_lin;
     std::vector<int> z_lab, bx_idx, xlist;
+    std::vector<int> gq, gb, gchunk, glab;   // grad pass lists
     int words = 0;                      // words per thread of the arc tables
 };
 struct HostGraph {

@@ -1394,6 +1394,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     C.farcs = fo.arcs; C.barcs = bo.arcs; C.fwi = fo.wave_info; C.bwi = bo.wave_info; C.frow_meta = frow_meta; C.brow_meta = brow_meta;
     C.x_start = x_start; C.x_end = x_end; C.z_end = z_end; C.brow_start = brow_start; C.brow_end = brow_end; C.bx_w = bx_w;
     C.start_lin = start_lin; C.end_lin = end_lin; C.z_lab = z_lab; C.bx_idx = bx_idx; C.xlist = xlist; C.words = gm->words;
+    C.gq = gq; C.gb = gb; C.gchunk = gchunk; C.glab = glab;
     return CRF_OK;
 }
 
@@ -1473,6 +1474,10 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
         }
         for (int s2 = 0; s2 < S; ++s2) out3[0] += a[(size_t)s2] * C.end_lin[(size_t)s2];
     }
+    // rows as the recursions store them for the grad pass: Q[t] = {row sums of the main rows, w * U of their tail rows},
+    // BP[t] = b_{t+1} of the (up to) two states of every backward row; BP[T - 1] = the end weights
+    std::vector<std::vector<double>> Qrows((size_t)T, std::vector<double>((size_t)2 * F.f.R, 0.0)), BProws((size_t)T, std::vector<double>((size_t)2 * F.b.R, 0.0));
+    for (int r = 0; r < 2 * F.b.R; ++r) BProws[(size_t)T - 1][(size_t)r] = (double)C.brow_end[(size_t)r];
     // ---- the factored layout, one direction
     auto run = [&](int dir, double *result) -> int {
         const FacDirDev &L = dir == 0 ? F.f : F.b;
@@ -1541,6 +1546,7 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
                                 if (implicit && tw != 0.0 && ((m.x & 0xffff) / 4 != rid || (m.y & 0xffff) / 4 != R + rid || (int)((unsigned)m.y >> 16) / 4 != 2 * R + rid))
                                     return fail("implicit entries differ from the row table");
                                 const double uold = src[(size_t)uo], rv = tot[lane], qt = tw * uold;
+                                Qrows[(size_t)t][(size_t)rid] = rv; Qrows[(size_t)t][(size_t)R + rid] = qt;
                                 const double Lp = em[(size_t)lab_m] * rv, Ap = em[(size_t)lab_t] * qt, Up = Lp + Ap;
                                 dst[(size_t)uo] = Up; dst[(size_t)lo] = Lp; dst[(size_t)ao] = Ap;
                                 if (dup) dst[(size_t)uo + dup] = Up;
@@ -1557,6 +1563,7 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
                                 const double z0 = src[o0 / 4], z1 = src[o1 / 4];
                                 const double bv0 = fl((unsigned)m.y) * z0 + tot[lane], bv1 = fl((unsigned)m.z) * z1 + tot[lane];
                                 if (t == 0) { b0rows[(size_t)2 * rid] = bv0; b0rows[(size_t)2 * rid + 1] = bv1; }
+                                else { BProws[(size_t)t - 1][(size_t)2 * rid] = bv0; BProws[(size_t)t - 1][(size_t)2 * rid + 1] = bv1; }
                                 const double zv0 = em[(size_t)(l0 == 0xffffu ? V : l0)] * bv0, zv1 = em[(size_t)(l1 == 0xffffu ? V : l1)] * bv1;
                                 dst[(size_t)2 * rid] = zv0; dst[(size_t)2 * rid + 1] = zv1;
                                 if (dup) { dst[(size_t)2 * rid + dup] = zv0; dst[(size_t)2 * rid + 1 + dup] = zv1; }
@@ -1601,7 +1608,28 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
     };
     int rc = run(0, &out3[1]);
     if (!rc) rc = run(1, &out3[2]);
-    return rc;
+    if (rc) return rc;
+    // ---- the grad pass's lists: for every frame, sum over the label-sorted (Q position, BP position) pairs of
+    // e_t[label] * Q[t][q] * BP[t][b] is the total path mass again
+    const int NC = (int)C.gchunk.size() - 1;
+    for (int t = 0; t < T; ++t) {
+        double tot = 0.0;
+        for (int v = 0; v < V && v + 1 < (int)C.glab.size(); ++v)
+            for (int c = C.glab[(size_t)v]; c < C.glab[(size_t)v + 1]; ++c) {
+                if (c < 0 || c >= NC) return fail("label -> chunk table");
+                if (C.gchunk[(size_t)c + 1] - C.gchunk[(size_t)c] > kChunk) return fail("a grad chunk is longer than kChunk");
+                double sc = 0.0;
+                for (int j = C.gchunk[(size_t)c]; j < C.gchunk[(size_t)c + 1]; ++j) {
+                    const int q = C.gq[(size_t)j], b = C.gb[(size_t)j];
+                    if (q < 0 || q >= 2 * F.f.R || b < 0 || b >= 2 * F.b.R) return fail("a grad pair outside the rows");
+                    sc += Qrows[(size_t)t][(size_t)q] * BProws[(size_t)t][(size_t)b];
+                }
+                tot += e[(size_t)t][(size_t)v] * sc;
+            }
+        if (getenv("CRF_EMU_VERBOSE")) fprintf(stderr, "[emu] frame %d: pair-list mass %.12g, path mass %.12g\n", t, tot, out3[0]);
+        if (!(std::fabs(tot - out3[0]) <= 1e-9 * std::fabs(out3[0]))) return fail("the grad pass's pair lists do not give the path mass at frame " + std::to_string(t));
+    }
+    return CRF_OK;
 }
 
 }  // namespace crf
