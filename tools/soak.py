@@ -1,7 +1,8 @@
-"""tools/soak.py [calls] -- the loss at the benchmarked shape (B=64, T=1500, V=72, factored staged schedule), the same two batches
+"""tools/soak.py [calls [histories]] -- the loss at the benchmarked shape (B=64, T=1500, V=72, factored staged schedule), the same two batches
 alternating for `calls` calls back to back into a NaN-poisoned workspace, with two extra busy streams in the process; every
 result is compared with the first one of its batch (loss and a gradient checksum): an intermittent stage-ordering race would
-show as a differing or NaN result."""
+show as a differing or NaN result.  histories = 3072: the same soak on a graph that takes the factored layout over TWO CUs
+per recursion (hand-off through tagged granules every frame; the noise streams then compete for the CUs its workgroups spin on)."""
 import os
 import sys
 import tempfile
@@ -19,9 +20,11 @@ calls = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 dev = torch.device("cuda:0")
 B, T, V = 64, 1500, 72
 fst = os.path.join(tempfile.mkdtemp(prefix="crfsoak_"), "den_lm.fst")
-g = synth_den_lm(V, 2048, 24, seed=0, path=fst)
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+g = synth_den_lm(V, H, 24, seed=0, path=fst)
 ctx = ctc_crf.CRFContext(fst, 0)
 gh = _C.graph_for(dev)
+print("den_lm H=%d: S=%d A=%d, factored geometry %d, kernels: %s" % (H, g["S"], g["A"], _C.graph_stats(gh)["fac_geom"], _C.den_kernels(gh, B, T, V)))
 data = []
 for seed, ragged in ((0, False), (5, True)):
     lg, lab, lx, ly = make_batch(g, B, T, V, seed=seed, ragged=ragged)
