@@ -31,15 +31,19 @@ def _slice(logits, labels, lx, ly, idx):
     return logits[idx], lab.astype(np.int32), lx[idx], ly[idx]
 
 
-def test_metric_shape_vs_oracle_poisoned(crf, tmp_path_factory):
+@pytest.mark.parametrize("H,geom", [(2048, 0), (3072, 3)])
+def test_metric_shape_vs_oracle_poisoned(crf, tmp_path_factory, H, geom):
+    """H = 2048: the benchmark graph (one CU per recursion, staged grad pass).  H = 3072 (S = 6 145, 156 k arcs): the same
+    shape on the factored layout over TWO CUs per recursion -- 256 workgroups = every CU of the device, the products
+    handed over through L2 every frame, which only a full-size batch exercises."""
     from cat_amd.den_lm import synth_den_lm
     p = os.path.join(str(tmp_path_factory.mktemp("denlm")), "den_lm_v72.fst")
-    g = synth_den_lm(72, 2048, 24, 0, path=p)
+    g = synth_den_lm(72, H, 24, 0, path=p)
     B, T, V, lamb = 64, 1500, 72, 0.1
     core = crf._C
     ctx = crf.CRFContext(p, 0)
     st = core.graph_stats(core.graph_for(torch.device("cuda", 0)))
-    assert st["fac"] == 1                                   # the default (factored, staged) schedule is what is tested
+    assert st["fac"] == 1 and st["fac_geom"] == geom       # the default schedule for that graph is what is tested
     batches = [make_batch(g, B, T, V, seed=0, ragged=True), make_batch(g, B, T, V, seed=7, ragged=False)]
     core.set_debug_poison(True)
     try:
