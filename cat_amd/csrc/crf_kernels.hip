@@ -2587,7 +2587,7 @@ __device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int 
 // a wait for something just requested happens nowhere.  epi(acc, m, e) is called at every bundle end with the row's
 // descriptor {state, pair, label} and the four utterances' emissions et[label].
 constexpr int kStreamBatch = 4, kStreamChunk = 128;   // steps per batch; batches * AL per 4 KB chunk (batches in flight: template parameter D)
-constexpr int kStreamBundles = 8;                     // bundles per task at most (fst_graph.cpp: build_stream_dir)
+constexpr int kStreamBundles = 8;                     // bundles per task at most (plain streams; factored: crf_internal.h stream_max_bundles)
 constexpr int kStreamRecB = kStreamChunk * 32;        // bytes of a chunk of records
 // Factored streams (NM = 3 descriptor words per row, crf_internal.h StreamDev): the ring holds NR values per row instead of the
 // one emission row -- forward {e[label 0], e[label 1], U of the row's couple}, backward {e[label 0], e[label 1], z of the two

@@ -189,8 +189,9 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
             if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"))) {
                 int tot = 0;
                 for (int j = 0; j < nsl; ++j) tot += len[j];
-                fprintf(stderr, "[res_layout] K=%d cu=%d does not fit: %d slices, %d chunks in all, capacity %d waves x %d chunks%s\n", K, k, nsl, tot,
-                        gm.waves, gm.nch, gm.maxsl ? " (3 slices per wave)" : "");
+                fprintf(stderr, "[res_layout] K=%d cu=%d does not fit: %d slices, %d chunks in all, capacity %d waves x %d chunks", K, k, nsl, tot, gm.waves, gm.nch);
+                if (gm.maxsl) fprintf(stderr, " (%d slices per wave)", gm.maxsl);
+                fprintf(stderr, "\n");
                 fprintf(stderr, "[res_layout]   slice lengths (lg):"); for (int j = 0; j < nsl; ++j) fprintf(stderr, " %d(%d)", len[j], lgs[j]); fprintf(stderr, "\n");
             }
             return false;  // does not fit with this K
