@@ -253,6 +253,13 @@ struct FacHostCopy {
     std::vector<int> gq, gb, gchunk, glab;   // grad pass lists
     int words = 0;                      // words per thread of the arc tables
 };
+// host copy of the generic register-resident layout's tables (debug_emulate_resident)
+struct ResHostCopy {
+    std::vector<unsigned> farcs, barcs;
+    std::vector<uint4> fwi, bwi;
+    std::vector<int> flab, blab, fcu, bcu, fown, bown, z_lab, gq, gb, gchunk, glab;
+    std::vector<float> x_start, x_end, z_end, brow_start, brow_end;
+};
 struct HostGraph {
     int device = 0;
     int64_t S = 0, A = 0, P = 0;
@@ -271,6 +278,9 @@ struct HostGraph {
     std::vector<StreamDev *> streams;   // one per (AL, tasks wanted) used so far
     FacBatchH fb;                       // factored rows of the utterance-minor kernels (T o LM graphs), see StreamDev
     FacHostCopy fh;                     // host copy of dev.fac's tables
+    ResHostCopy rh;                     // host copy of dev.res's tables
+    std::vector<int> h_src, h_dst, h_lab;   // the graph's arcs as compiled (graphs of up to 2^20 arcs: the emulations' plain reference)
+    std::vector<float> h_w, h_start, h_end; // exp(weight), exp(start), exp(end)
     int res_rows_cu_f = 0, res_rows_cu_b = 0;  // max rows of one CU (LDS carve of the resident kernels)
 };
 
@@ -294,6 +304,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // Arc streams for UL (8, 16, 32 or 64) utterances per group cut into about `want` tasks per direction, built and uploaded
 // on first use (thread-safe; a graph keeps every variant it has been asked for).
 int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out3);
+int debug_emulate_resident(const HostGraph *h, int T, unsigned seed, double *out3);
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out);
 bool stream_fac(const HostGraph *h, int UL);   // factored streams for groups of UL utterances?
 // Host-side construction + self-check of the arc streams (tests; works on host-only graphs).

@@ -972,6 +972,12 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     h->hb_farcs = b_farcs; h->hb_barcs = b_barcs; h->hb_frow = b_frow; h->hb_brow = b_brow;   // (kept: arc streams are cut from them on first use)
     h->hb_frow_d = b_frow_d; h->hb_brow_s = b_brow_s;
     build_batch_factored(h, (int)S, b_frow, b_frow_d, b_farcs, b_brow, b_brow_s, b_barcs, start_lin);
+    if (A <= (1 << 20)) {   // (kept for the CPU emulations of the layouts: their reference is the recursion over these arcs)
+        h->h_src.assign(src, src + A); h->h_dst.assign(dst, dst + A); h->h_lab.assign(lab, lab + A);
+        h->h_w.resize((size_t)A);
+        for (int64_t k = 0; k < A; ++k) h->h_w[(size_t)k] = expf(w[k]);
+        h->h_start = start_lin; h->h_end = end_lin;
+    }
     if (device < 0) {  // host-only compile (diagnostics / CPU tests): tables are built, nothing is uploaded
         h->device = -1;
         int rcr = build_resident(h, (int)S, P, tmp_dst, tmp_lab, frows, out_arcs_tmp, start_lin, end_lin, canon);
@@ -1088,6 +1094,11 @@ int crf_debug_decode_check(int nslot, int ncombo) { return crf::debug_check_deco
 int crf_debug_fac_emulate(const crf_graph *g, int T, unsigned seed, double *out3) {
     if (!g || !g->h || !out3 || T < 1) { crf::set_error("bad argument"); return CRF_ERR_ARG; }
     return crf::debug_emulate_factored(g->h, T, seed, out3);
+}
+
+int crf_debug_res_emulate(const crf_graph *g, int T, unsigned seed, double *out3) {
+    if (!g || !g->h || !out3 || T < 1) { crf::set_error("bad argument"); return CRF_ERR_ARG; }
+    return crf::debug_emulate_resident(g->h, T, seed, out3);
 }
 
 int crf_debug_facbatch_check(const crf_graph *g, int64_t *out4) {

@@ -925,6 +925,10 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             (rc = up(h, brow_end, &R.brow_end)) || (rc = up(h, bcsr, &R.bcsr)) || (rc = up(h, gq, &R.gq)) ||
             (rc = up(h, gb, &R.gb)) || (rc = up(h, gchunk, &R.chunk_off)) || (rc = up(h, glab, &R.lab_chunk_off)))
             return rc;
+        ResHostCopy &C = h->rh;
+        C.farcs = fo.arcs; C.barcs = bo.arcs; C.fwi = fo.wave_info; C.bwi = bo.wave_info; C.flab = flab; C.blab = blab;
+        C.fcu = fo.cu_row_off; C.bcu = bo.cu_row_off; C.fown = xoff; C.bown = zoff; C.z_lab = z_lab; C.gq = gq; C.gb = gb; C.gchunk = gchunk; C.glab = glab;
+        C.x_start = x_start; C.x_end = x_end; C.z_end = z_end; C.brow_start = brow_start; C.brow_end = brow_end;
         return CRF_OK;
     }
     return CRF_OK;  // K stays 0: not resident
@@ -1443,6 +1447,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // receives what the kernel fetches (the peer's U range, its list of L / A entries; everything the kernel does not fetch is
 // NaN, so a gather of an entry that never crosses poisons the result).  fp64, no rescaling, random emissions, T frames.
 // out3 = {plain forward sum over the graph's own tables, factored forward, factored backward}; they must agree.
+static double plain_forward(const HostGraph *h, const std::vector<std::vector<double>> &e);
 int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out3) {
     const FacDev &F = h->dev.fac;
     const FacHostCopy &C = h->fh;
@@ -1457,24 +1462,8 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
     for (auto &row : e) for (int v = 0; v < V; ++v) row[(size_t)v] = rnd();
     auto fl = [](unsigned b) { float f; memcpy(&f, &b, 4); return (double)f; };
     const double nan = std::nan("");
-    // ---- plain forward recursion on the utterance-minor row tables (graphs whose rows all have one entering pair)
-    {
-        std::vector<double> a(C.start_lin.begin(), C.start_lin.end()), an((size_t)S);
-        for (int t = 0; t < T; ++t) {
-            for (int r = 0; r < S; ++r) {
-                const int4 &d = h->hb_frow[(size_t)r];
-                double acc = 0.0;
-                if (d.y > d.x) {
-                    if (!(d.w & 0x40000000)) return fail("the plain reference needs rows with one entering pair");
-                    for (int k2 = d.x; k2 < d.y; ++k2) acc += fl((unsigned)h->hb_farcs[(size_t)k2].y) * a[(size_t)h->hb_farcs[(size_t)k2].x];
-                    acc *= e[(size_t)t][(size_t)(d.w & 0xffff)];
-                }
-                an[(size_t)h->hb_frow_d[(size_t)r]] = acc;
-            }
-            a.swap(an);
-        }
-        for (int s2 = 0; s2 < S; ++s2) out3[0] += a[(size_t)s2] * C.end_lin[(size_t)s2];
-    }
+    if (h->h_src.empty() && h->A > 0) { set_error("the graph's arcs were not kept (more than 2^20)"); return CRF_ERR_UNSUPPORTED; }
+    out3[0] = plain_forward(h, e);
     // rows as the recursions store them for the grad pass: Q[t] = {row sums of the main rows, w * U of their tail rows},
     // BP[t] = b_{t+1} of the (up to) two states of every backward row; BP[T - 1] = the end weights
     std::vector<std::vector<double>> Qrows((size_t)T, std::vector<double>((size_t)2 * F.f.R, 0.0)), BProws((size_t)T, std::vector<double>((size_t)2 * F.b.R, 0.0));
@@ -1628,6 +1617,124 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
                 tot += e[(size_t)t][(size_t)v] * sc;
             }
         if (getenv("CRF_EMU_VERBOSE")) fprintf(stderr, "[emu] frame %d: pair-list mass %.12g, path mass %.12g\n", t, tot, out3[0]);
+        if (!(std::fabs(tot - out3[0]) <= 1e-9 * std::fabs(out3[0]))) return fail("the grad pass's pair lists do not give the path mass at frame " + std::to_string(t));
+    }
+    return CRF_OK;
+}
+
+
+// plain recursion over the graph's arcs (the emulations' reference): sum over end states after T frames of emissions e
+static double plain_forward(const HostGraph *h, const std::vector<std::vector<double>> &e) {
+    const int S = (int)h->S;
+    std::vector<double> a(h->h_start.begin(), h->h_start.end()), an((size_t)S);
+    for (size_t t = 0; t < e.size(); ++t) {
+        std::fill(an.begin(), an.end(), 0.0);
+        for (size_t k = 0; k < h->h_src.size(); ++k) an[(size_t)h->h_dst[k]] += e[t][(size_t)h->h_lab[k]] * (double)h->h_w[k] * a[(size_t)h->h_src[k]];
+        a.swap(an);
+    }
+    double z = 0.0;
+    for (int s2 = 0; s2 < S; ++s2) z += a[(size_t)s2] * (double)h->h_end[(size_t)s2];
+    return z;
+}
+
+// CPU emulation of the GENERIC register-resident kernels' data flow on the layout tables (tests; no GPU): every row -- pair
+// rows forward, state copies backward -- sums its packed arcs and produces ONE entry, own_off[k] + (row - cu_row_off[k]);
+// every produced entry crosses to the peers, so one vector per direction serves all CUs here.
+int debug_emulate_resident(const HostGraph *h, int T, unsigned seed, double *out3) {
+    const ResDev &R = h->dev.res;
+    const ResHostCopy &C = h->rh;
+    out3[0] = out3[1] = out3[2] = 0.0;
+    if (R.K < 1 || C.farcs.empty()) { set_error("no generic register-resident layout"); return CRF_ERR_UNSUPPORTED; }
+    if (h->h_src.empty() && h->A > 0) { set_error("the graph's arcs were not kept (more than 2^20)"); return CRF_ERR_UNSUPPORTED; }
+    auto fail = [&](const std::string &why) { set_error("generic layout emulation: " + why); return CRF_ERR_ARG; };
+    const int V = h->dev.max_label + 1, K = R.K;
+    uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return 0.5 + (double)(rng % 1000003) / 1000003.0; };
+    std::vector<std::vector<double>> e((size_t)T, std::vector<double>((size_t)V + 1, 0.0));
+    for (auto &row : e) for (int v = 0; v < V; ++v) row[(size_t)v] = rnd();
+    auto fl = [](unsigned b) { float f; memcpy(&f, &b, 4); return (double)f; };
+    out3[0] = plain_forward(h, e);
+    std::vector<std::vector<double>> Qrows((size_t)T, std::vector<double>((size_t)R.f.R, 0.0)), BProws((size_t)T, std::vector<double>((size_t)R.b.R, 0.0));
+    for (int r = 0; r < R.b.R; ++r) BProws[(size_t)T - 1][(size_t)r] = (double)C.brow_end[(size_t)r];
+    auto run = [&](int dir, double *result) -> int {
+        const ResDirDev &L = dir == 0 ? R.f : R.b;
+        const std::vector<unsigned> &A = dir == 0 ? C.farcs : C.barcs;
+        const std::vector<uint4> &WI = dir == 0 ? C.fwi : C.bwi;
+        const std::vector<int> &lab = dir == 0 ? C.flab : C.blab, &cu = dir == 0 ? C.fcu : C.bcu, &own = dir == 0 ? C.fown : C.bown;
+        const int G = L.G, NTH = kResThreads, NW = kResWaves, words = kResWords;
+        if ((int)A.size() != K * words * NTH || (int)WI.size() != K * NW || (int)cu.size() < K + 1 || (int)own.size() < K + 1) return fail("table sizes");
+        std::vector<double> X[2] = {std::vector<double>((size_t)G, 0.0), std::vector<double>((size_t)G, 0.0)}, b0rows((size_t)L.R, 0.0);
+        std::vector<char> produced((size_t)G, 0);
+        for (int z = 0; z < G; ++z) X[0][(size_t)z] = dir == 0 ? (double)C.x_start[(size_t)z] : e[(size_t)T - 1][(size_t)(C.z_lab[(size_t)z] < 0 ? V : C.z_lab[(size_t)z])] * (double)C.z_end[(size_t)z];
+        for (int i = 0; i < T; ++i) {
+            const int par = i & 1, t = dir == 0 ? i : T - 1 - i;
+            const std::vector<double> &em = dir == 0 ? e[(size_t)t] : e[(size_t)(t >= 1 ? t - 1 : 0)];
+            const std::vector<double> &src = X[par];
+            std::vector<double> &dst = X[1 - par];
+            for (int k = 0; k < K; ++k)
+                for (int w = 0; w < NW; ++w) {
+                    const uint4 wi = WI[(size_t)k * NW + w];
+                    const unsigned ends = wi.x;
+                    const int nch = (int)wi.y;
+                    int row = (int)wi.z;
+                    if (nch > kResNCH) return fail("a wave uses more chunks than a thread has");
+                    double acc[kWave];
+                    for (double &x : acc) x = 0.0;
+                    for (int c = 0; c < nch; ++c) {
+                        for (int lane = 0; lane < kWave; ++lane) {
+                            const size_t base = (size_t)k * words * NTH + (size_t)(w * kWave + lane);
+                            auto W = [&](int j) { return A[base + (size_t)(6 * c + j) * NTH]; };
+                            const unsigned i01 = W(0), i23 = W(1);
+                            const unsigned offs[4] = {i01 & 0xffffu, i01 >> 16, i23 & 0xffffu, i23 >> 16};
+                            for (int q = 0; q < 4; ++q) {
+                                if (offs[q] % 4 || (int)(offs[q] / 4) >= G) return fail("a gather offset outside the vector");
+                                const double wq = fl(W(2 + q));
+                                if (wq != 0.0) acc[lane] += wq * src[offs[q] / 4];
+                            }
+                        }
+                        if (!(ends >> c & 1u)) continue;
+                        for (int lane = 0; lane < kWave; ++lane) {
+                            const int rid = row + lane;
+                            if (rid < cu[(size_t)k] || rid >= cu[(size_t)k + 1]) return fail("a wave's row outside its CU's range");
+                            const int en = own[(size_t)k] + (rid - cu[(size_t)k]);
+                            if (en < 0 || en >= G) return fail("a produced entry outside the vector");
+                            if (i == 0) { if (produced[(size_t)en]) return fail("two rows produce one entry"); produced[(size_t)en] = 1; }
+                            const double rv = acc[lane];
+                            const int l = lab[(size_t)rid];
+                            if (dir == 0) Qrows[(size_t)t][(size_t)rid] = rv;
+                            else if (t == 0) b0rows[(size_t)rid] = rv;
+                            else BProws[(size_t)t - 1][(size_t)rid] = rv;
+                            dst[(size_t)en] = em[(size_t)(l < 0 || l > V ? V : l)] * rv;
+                        }
+                        for (double &x : acc) x = 0.0;
+                        row += kWave;
+                    }
+                }
+            if (dir == 0 && i == 0) for (int z = 0; z < G; ++z) if (C.x_start[(size_t)z] != 0.f) X[0][(size_t)z] = 0.0;
+        }
+        double sum = 0.0;
+        if (dir == 0) for (int z = 0; z < G; ++z) sum += X[T & 1][(size_t)z] * (double)C.x_end[(size_t)z];
+        else for (int r = 0; r < L.R; ++r) sum += (double)C.brow_start[(size_t)r] * b0rows[(size_t)r];
+        *result = sum;
+        return CRF_OK;
+    };
+    int rc = run(0, &out3[1]);
+    if (!rc) rc = run(1, &out3[2]);
+    if (rc) return rc;
+    const int NC = (int)C.gchunk.size() - 1;
+    for (int t = 0; t < T; ++t) {
+        double tot = 0.0;
+        for (int v = 0; v < V && v + 1 < (int)C.glab.size(); ++v)
+            for (int c = C.glab[(size_t)v]; c < C.glab[(size_t)v + 1]; ++c) {
+                if (c < 0 || c >= NC) return fail("label -> chunk table");
+                double sc = 0.0;
+                for (int j = C.gchunk[(size_t)c]; j < C.gchunk[(size_t)c + 1]; ++j) {
+                    const int q = C.gq[(size_t)j], b = C.gb[(size_t)j];
+                    if (q < 0 || q >= R.f.R || b < 0 || b >= R.b.R) return fail("a grad pair outside the rows");
+                    sc += Qrows[(size_t)t][(size_t)q] * BProws[(size_t)t][(size_t)b];
+                }
+                tot += e[(size_t)t][(size_t)v] * sc;
+            }
         if (!(std::fabs(tot - out3[0]) <= 1e-9 * std::fabs(out3[0]))) return fail("the grad pass's pair lists do not give the path mass at frame " + std::to_string(t));
     }
     return CRF_OK;

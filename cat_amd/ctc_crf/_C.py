@@ -56,7 +56,7 @@ _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
-    "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
+    "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_debug_res_emulate", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
     "crf_last_error", "crf_version",
 )
 
@@ -140,6 +140,15 @@ def debug_fac_emulate(handle: int, T: int = 6, seed: int = 1):
     _lib.crf_debug_fac_emulate.argtypes = [_vp, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
     _lib.crf_debug_fac_emulate.restype = ctypes.c_int
     _check(_lib.crf_debug_fac_emulate(_vp(handle), T, seed, out))
+    return float(out[0]), float(out[1]), float(out[2])
+
+
+def debug_res_emulate(handle: int, T: int = 6, seed: int = 1):
+    """CPU emulation of the generic register-resident kernels on the layout tables: (plain, forward, backward)."""
+    out = (ctypes.c_double * 3)()
+    _lib.crf_debug_res_emulate.argtypes = [_vp, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_double)]
+    _lib.crf_debug_res_emulate.restype = ctypes.c_int
+    _check(_lib.crf_debug_res_emulate(_vp(handle), T, seed, out))
     return float(out[0]), float(out[1]), float(out[2])
 
 

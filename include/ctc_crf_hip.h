@@ -105,6 +105,10 @@ int crf_debug_facbatch_check(const crf_graph *g, int64_t *out4);
  * rowless states, and with two compute units per recursion exactly what crosses between them (a gather of anything else yields
  * NaN).  out3 = {sum over end states by the graph's own row tables, factored forward, factored backward}: all three agree. */
 int crf_debug_fac_emulate(const crf_graph *g, int T, unsigned seed, double *out3);
+/* The same for the GENERIC register-resident layout over K compute units (any graph that fits: rows = pairs forward, state
+ * copies backward, one produced entry per row, every product exchanged): out3 = {sum by the recursion over the graph's arcs,
+ * layout forward, layout backward}; the grad pass's pair lists are checked frame by frame as well. */
+int crf_debug_res_emulate(const crf_graph *g, int T, unsigned seed, double *out3);
 
 /* The hot path.  Replaces, in one call and with no host synchronisation:
  *   gpu_ctc  (binding.cpp:86-117  -> compute_ctc_loss, ctc_entrypoint.cu:29-60)

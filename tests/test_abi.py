@@ -268,3 +268,65 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
     synth_den_lm(72, 3072, 24, seed=0, path=mid)
     g, r = emu(mid, T=3)
     assert g == 3 and agree(r)
+
+
+def test_generic_resident_layout_emulated_on_the_host(tmp_path, golden_dir):
+    """crf_debug_res_emulate: the generic register-resident layout (any graph that fits K <= 4 compute units: pair rows forward,
+    state copies backward, long rows split into sub-rows with virtual copies of their entry, one produced entry per row) walked
+    on the host like the kernels walk it, fp64: forward and backward sums = the recursion over the graph's arcs, every entry
+    has one producer, the grad pass's pair lists give the path mass in every frame.  Graphs: random general graphs (states
+    entered with several labels), the reference's fixture, T o LM small (K = 1, forced 2 and 4), an estimated n-gram graph
+    (rows of hundreds of arcs), the benchmark graph (K = 2) and one of 1.5 x its size (K = 4)."""
+    import math
+    import ctc_crf
+    from cat_amd import den_lm
+    core = ctc_crf._C
+
+    def emu(path, T=4, **env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            h = core.compile_graph_host_only(path)
+            st = core.graph_stats(h)
+            r = core.debug_res_emulate(h, T, 11)
+            core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+            return st["res_K"], r
+        finally:
+            for k_, v in old.items():
+                if v is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v
+
+    def agree(r):
+        return all(math.isfinite(x) and x > 0 for x in r) and abs(r[1] - r[0]) <= 1e-9 * r[0] and abs(r[2] - r[0]) <= 1e-9 * r[0]
+
+    for name in ["den_lm_fixture.fst"] + [f"rand{i}.fst" for i in range(6)]:
+        K, r = emu(os.path.join(golden_dir, name))
+        assert K == 1 and agree(r), (name, K, r)
+    small = os.path.join(str(tmp_path), "small.fst")
+    synth_den_lm(24, 96, 8, seed=13, path=small)
+    for mink in (1, 2, 4):
+        K, r = emu(small, CRF_RES_MINK=mink)
+        assert K == mink and agree(r), (mink, K, r)
+    V = 40
+    rng = np.random.default_rng(3)
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(1200):
+        L, sq, a, b = int(rng.integers(8, 30)), [], 0, 0
+        for _ in range(L):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
+        seqs.append(sq)
+    est = os.path.join(str(tmp_path), "est.fst")
+    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150)
+    K, r = emu(est)
+    assert K >= 1 and agree(r), (K, r)
+    bench = os.path.join(str(tmp_path), "bench.fst")
+    synth_den_lm(72, 2048, 24, seed=0, path=bench)
+    K, r = emu(bench, T=3)
+    assert K == 2 and agree(r)
+    mid = os.path.join(str(tmp_path), "mid.fst")
+    synth_den_lm(72, 3072, 24, seed=0, path=mid)
+    K, r = emu(mid, T=3)
+    assert K == 4 and agree(r)
