@@ -1470,8 +1470,14 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     const int XB = Gp * 4;                                   // bytes per state vector
     const int64_t bt0 = (int64_t)b * p.T;
     float *X = lds;                                          // [2][Gp]
-    char *RMc = (char *)(X + 2 * Gp);                        // int4[R]
-    float *EP = (float *)(RMc + (RL ? (size_t)(R + 64) * (DIR == 0 ? 8 : 16) : (size_t)R * 16));   // [2][Vp]  (RL: 64 rows of slack for the read-ahead)
+    // row table.  K2: only the rows of this CU, [tr0, tr1) -- RMc is then the table's VIRTUAL base, so that "RMc + row bytes * rid"
+    // addresses it by the global row id like everywhere else (the state vectors in front are longer than any such shift)
+    constexpr int kRowB = RL ? (DIR == 0 ? 8 : 16) : 16;
+    const int tr0 = K2 ? L.cu_row[k] : 0, tr1 = K2 ? L.cu_row[k + 1] : R;
+    const int trn = K2 ? max(L.cu_row[1] - L.cu_row[0], L.cu_row[2] - L.cu_row[1]) : R;   // rows the table has room for (both CUs the same: fac_lds_bytes)
+    char *RMc0 = (char *)(X + 2 * Gp);                       // int4[R]
+    char *RMc = RMc0 - (size_t)tr0 * kRowB;
+    float *EP = (float *)(RMc0 + (RL ? (size_t)(trn + 64) * kRowB : (size_t)R * 16));   // [2][Vp]  (RL: 64 rows of slack for the read-ahead)
     float *wm = EP + 2 * Vp;                                 // [2][NW]
     double *red = (double *)(wm + 2 * NW);            // [NW]
     if (tid == 0 && p.started && p.i0 == 0) atomicAdd(p.started, 1);   // this workgroup holds its CU: see crf_gate_kernel
@@ -1504,13 +1510,13 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     if (RL) {
         if (DIR == 0) {
             uint2 *RT = (uint2 *)RMc;                        // {emission byte offsets main | tail << 16, tail weight}
-            for (int r = tid; r < R; r += NTH) {
+            for (int r = tr0 + tid; r < tr1; r += NTH) {
                 const int4 m = p.frow_meta[r];
                 RT[r] = uint2{(((unsigned)m.x >> 16) * 4u) | (((unsigned)m.w * 4u) << 16), (unsigned)m.z};
             }
         } else {
             uint4 *RT = (uint4 *)RMc;                        // {z byte offsets of the two extra arcs, emission byte offsets, their weights}
-            for (int r = tid; r < R; r += NTH) {
+            for (int r = tr0 + tid; r < tr1; r += NTH) {
                 const int4 m = p.brow_meta[r];
                 const unsigned l0 = (unsigned)m.w & 0xffffu, l1 = (unsigned)m.w >> 16;   // 0xffff = no label: emission 0 at EP[V]
                 RT[r] = uint4{(unsigned)m.x, ((l0 == 0xffffu ? (unsigned)V : l0) * 4u) | (((l1 == 0xffffu ? (unsigned)V : l1) * 4u) << 16), (unsigned)m.y, (unsigned)m.z};
@@ -3639,7 +3645,8 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     const FacDev &F = h->dev.fac;
     const FacDirDev &L = dir == 0 ? F.f : F.b;
     const int nw = F.threads / kWave;
-    const size_t table = F.rcl ? (size_t)(L.R + 64) * (dir == 0 ? 8 : 16) : (size_t)L.R * 16;   // row constants (fac_chain_body)
+    const int trows = F.K > 1 ? std::max(L.cu_row[1] - L.cu_row[0], L.cu_row[2] - L.cu_row[1]) : L.R;   // two CUs: each holds its own rows' constants only
+    const size_t table = F.rcl ? (size_t)(trows + 64) * (dir == 0 ? 8 : 16) : (size_t)L.R * 16;   // row constants (fac_chain_body)
     return (size_t)2 * rup64(L.G) * 4 + table +
            ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }

@@ -1358,7 +1358,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     arrange_grad_pairs(&gq, &gb, gchunk, &gcb, &gca);
     if (verbose) fprintf(stderr, "[fac_layout] grad pass: LDS cycles per frame for the pair gathers %lld as listed, %lld arranged (%d chunks)\n", (long long)gcb, (long long)gca, (int)gchunk.size() - 1);
 
-    h->fac_stats = FacBuildStats{1, nmatched, nsolo, (int64_t)tail_rows.size(), fo.slots, bo.slots, nfused, Gf, Gb};
+    h->fac_stats = FacBuildStats{0, nmatched, nsolo, (int64_t)tail_rows.size(), fo.slots, bo.slots, nfused, Gf, Gb};   // (ok: set with F.ok below)
     if (verbose)
         fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
                 (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
@@ -1369,7 +1369,8 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         const int V0 = std::max(max_lab + 1, 256);
         const size_t tail = ((size_t)2 * ((V0 + 1 + 63) / 64 * 64) + 4 * (size_t)gm->waves + 16) * 4 + 256;
         auto need = [&](int G, int R, int rb) { return (size_t)2 * ((G + 63) / 64 * 64) * 4 + (size_t)(R + (level == 1 ? 64 : 0)) * rb + tail; };
-        const bool f_ok = need(Gf, Rf, level == 1 ? 8 : 16) <= (size_t)160 * 1024, b_ok = need(Gb, Rb, 16) <= (size_t)160 * 1024;
+        auto cu_rows = [&](const DirOut &o) { int m = 0; for (int k = 0; k < K; ++k) m = std::max(m, o.cu_row_off[(size_t)k + 1] - o.cu_row_off[(size_t)k]); return m; };   // (two CUs: a CU's table holds its own rows)
+        const bool f_ok = need(Gf, K > 1 ? cu_rows(fo) : Rf, level == 1 ? 8 : 16) <= (size_t)160 * 1024, b_ok = need(Gb, K > 1 ? cu_rows(bo) : Rb, 16) <= (size_t)160 * 1024;
         if (!f_ok || !b_ok) {
             int m = dup_mask;
             if (!f_ok && !no_dupf) m &= ~1;
@@ -1395,6 +1396,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         (rc = up(h, gchunk, &F.chunk_off)) || (rc = up(h, glab, &F.lab_chunk_off)) || (rc = up(h, xlist, &F.xlist)))
         return rc;
     F.ok = 1;
+    h->fac_stats.ok = 1;
     FacHostCopy &C = h->fh;
     C.farcs = fo.arcs; C.barcs = bo.arcs; C.fwi = fo.wave_info; C.bwi = bo.wave_info; C.frow_meta = frow_meta; C.brow_meta = brow_meta;
     C.x_start = x_start; C.x_end = x_end; C.z_end = z_end; C.brow_start = brow_start; C.brow_end = brow_end; C.bx_w = bx_w;
