@@ -235,7 +235,9 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
                     os.environ[k_] = v
 
     def agree(r):
-        return all(math.isfinite(x) and x > 0 for x in r) and abs(r[1] - r[0]) <= 1e-9 * r[0] and abs(r[2] - r[0]) <= 1e-9 * r[0]
+        # (backward: start weight x arc weight of the rowless states is ONE fp32 table constant -- a rounding of 6e-8 on those terms
+        # when the start weight is not 1, i.e. in re-gauged graphs)
+        return all(math.isfinite(x) and x > 0 for x in r) and abs(r[1] - r[0]) <= 1e-9 * r[0] and abs(r[2] - r[0]) <= 1e-6 * r[0]
 
     small = os.path.join(str(tmp_path), "small.fst")
     synth_den_lm(24, 96, 8, seed=13, path=small)
@@ -268,6 +270,15 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
     synth_den_lm(72, 3072, 24, seed=0, path=mid)
     g, r = emu(mid, T=3)
     assert g == 3 and agree(r)
+    from tests.util import transform_graph                       # renumbered, reordered, weight-pushed (re-gauged by the compiler), long rows
+    from oracle import fst_io
+    wide = os.path.join(str(tmp_path), "wide.fst")
+    synth_den_lm(150, 300, 120, seed=7, path=wide)
+    pushed = os.path.join(str(tmp_path), "pushed.fst")
+    transform_graph(fst_io.read_fst(wide), pushed, seed=7, renumber=True, reorder=True, push=True)
+    for env in ({}, {"CRF_FAC_K2": 1}, {"CRF_FAC_THREADS": 512}):
+        g, r = emu(pushed, **env)
+        assert g >= 0 and agree(r), (env, g, r)
 
 
 def test_generic_resident_layout_emulated_on_the_host(tmp_path, golden_dir):
@@ -299,7 +310,9 @@ def test_generic_resident_layout_emulated_on_the_host(tmp_path, golden_dir):
                     os.environ[k_] = v
 
     def agree(r):
-        return all(math.isfinite(x) and x > 0 for x in r) and abs(r[1] - r[0]) <= 1e-9 * r[0] and abs(r[2] - r[0]) <= 1e-9 * r[0]
+        # (backward: start weight x arc weight of the rowless states is ONE fp32 table constant -- a rounding of 6e-8 on those terms
+        # when the start weight is not 1, i.e. in re-gauged graphs)
+        return all(math.isfinite(x) and x > 0 for x in r) and abs(r[1] - r[0]) <= 1e-9 * r[0] and abs(r[2] - r[0]) <= 1e-6 * r[0]
 
     for name in ["den_lm_fixture.fst"] + [f"rand{i}.fst" for i in range(6)]:
         K, r = emu(os.path.join(golden_dir, name))
