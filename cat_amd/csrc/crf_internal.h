@@ -286,6 +286,62 @@ struct HostGraph {
 
 void set_error(const std::string &msg);
 
+// ---------------------------------------------------------------------------------------------
+// Debug / experiment switches of tests and tools: set with crf_debug_set(key, value) (include/ctc_crf_hip.h), NEVER read from
+// the environment -- the library's behaviour does not depend on the process environment.  One table: name, when it is read
+// (G = when a graph is created, C = per loss call, X = when a (device, stream) context is created), what it does.
+// ---------------------------------------------------------------------------------------------
+#define CRF_OPTS(X)                                                                                                           \
+    X(no_resident,      "G  no register-resident layout at all: the graph takes the utterance-minor or streaming kernels")   \
+    X(no_factored,      "G  no factored layout: T o LM graphs take the generic register-resident layout")                    \
+    X(fac_rcl,          "G  factored layout: row constants in the LDS table (fac_geom 1) for every graph")                   \
+    X(fac_no_rcl,       "G  factored layout: row constants in registers even for graphs with long rows")                     \
+    X(fac_k2,           "G  factored layout over TWO CUs per recursion (fac_geom 3) for every T o LM graph")                 \
+    X(fac_no_k2,        "G  never two CUs per recursion: graphs of 120 k - 240 k arcs take the generic layout")              \
+    X(fac_threads,      "G  512: the 512-thread geometry of the factored layout")                                            \
+    X(fac_no_dup,       "G  factored layout: no second copy of the gathered entries")                                        \
+    X(fac_bank_shift,   "G  factored layout: bank distance of the second copy (default 5)")                                  \
+    X(res_mink,         "G  generic layout: at least this many CUs per recursion")                                           \
+    X(res_epi,          "G  layout cost model: slice end in chunks (default 4)")                                             \
+    X(res_piece,        "G  multi-lane rows: piece size in percent of a lane's chunks (default: the cost model's choice)")   \
+    X(res_no_simd_order,"G  layout: no SIMD-aware placement of the waves' slice lists")                                      \
+    X(res_owner_first,  "G  multi-lane rows: the first lane of a group owns the outputs (no rotation)")                      \
+    X(no_bank_arrange,  "G  no bank-aware arc order (edge colouring) in the register-resident layouts")                      \
+    X(no_grad_arrange,  "G  grad pass: (Q, BP) pair lists in plain label order")                                             \
+    X(no_regauge,       "G  weight-pushed graphs are not re-gauged")                                                         \
+    X(regauge_minhash,  "G  re-gauging: find the two states of a history by min-hashing (what graphs of millions of arcs take)") \
+    X(verbose,          "G  print layout statistics to stderr")                                                             \
+    X(emu_drop_list,    "-  crf_debug_fac_emulate: drop the two-CU fetch list (negative control of the emulation)")          \
+    X(emu_verbose,      "-  crf_debug_fac_emulate: per-frame masses to stderr")                                              \
+    X(bat_no_fac,       "GC utterance-minor kernels: plain arc streams instead of the factored ones")                        \
+    X(bat_task,         "C  utterance-minor kernels: steps per task")                                                        \
+    X(bat_ul,           "C  utterance-minor kernels: utterances per group (8, 16, 32, 64)")                                  \
+    X(bat_fill,         "C  utterance-minor kernels: percent of the device's workgroup slots a launch takes (default 70)")   \
+    X(force_batch,      "C  utterance-minor kernels for every graph")                                                        \
+    X(no_batch,         "C  streaming kernels instead of the utterance-minor ones")                                          \
+    X(robust,           "C  0: never run the robust fallback, 1: every utterance takes it")                                  \
+    X(no_fast_grad,     "C  generic grad kernel instead of the streaming grad kernels")                                      \
+    X(no_overlap,       "C  no staged grad pass beside the recursions")                                                      \
+    X(segments,         "C  staged schedule by relaunching the recursions per stage (events) instead of stream-level waits") \
+    X(stages,           "C  number of grad stages")                                                                          \
+    X(piece,            "C  iterations per grad stage")                                                                      \
+    X(gd_full_grid,     "C  stage launches of the grad pass as full grids")                                                  \
+    X(ctc_after,        "C  0 / 1: numerator chains beside / after the denominator recursions")                              \
+    X(serial_chains,    "C  everything on the caller's stream")                                                              \
+    X(no_side_stream,   "X  no side stream for this context")                                                                \
+    X(fac_pipe,         "C  factored recursions: 0 = gather batches drained one by one, 2 = software-pipelined batches of 2 chunks")
+
+enum Opt : int {
+#define CRF_OPT_ENUM(name, doc) kOpt_##name,
+    CRF_OPTS(CRF_OPT_ENUM)
+#undef CRF_OPT_ENUM
+    kOptCount
+};
+int opt(Opt k, int dflt = 0);                       // the value set with crf_debug_set, `dflt` while unset
+inline bool opt_on(Opt k) { return opt(k, 0) != 0; }
+int opt_set(const char *key, int value, bool unset);   // CRF_OK or CRF_ERR_ARG (unknown key)
+const char *opt_list();                             // "name: doc\n" of every switch
+
 // Builds pairs, both ELL tables and the grad-pass chunk tables, and uploads them to `device`.
 int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, const int32_t *lab,
                   const float *w, const float *start_w, const float *end_w, int device, HostGraph **out);

@@ -1441,7 +1441,7 @@ struct FacParams {
 // also published as {frame tag, value} granules (res_chain_body's protocol: the data is the flag), and after its last chunk the
 // CU fetches the peer's entries into its own vector before the frame barrier.  Table geometry (RL) only, one copy of the
 // gathered entries, no stages (2 B x 2 workgroups are every CU of the device: nothing runs beside the recursions).
-template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML, bool RL, bool K2 = false>
+template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML, bool RL, bool K2 = false, int PIPE = 0>
 __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, const int b, const int k = 0) {
     static_assert(!K2 || (RL && !FLAG), "two CUs per recursion: table geometry, no stage flags");
     constexpr int NW = NTH / kWave;
@@ -1460,6 +1460,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     constexpr int NCHA = IMP ? kFac3ArcCh : NCH;             // chunk slots that hold arcs
     constexpr int RCW = NCHA * 6;                            // first row-constant word
     static_assert(NCHA % NB == 0, "chunks per thread must be a multiple of the batch");
+    static_assert(PIPE == 0 || NCHA % (PIPE > 0 ? PIPE : 1) == 0, "chunks per thread must be a multiple of the pipelined batch");
 
     const FacDirDev &L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1553,7 +1554,6 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     float zpart = 0.f;
     for (int s = tid; s < 2 * Gp; s += NTH) X[s] = 0.f;
     if (tid < 2) EP[tid * Vp + V] = 0.f;
-#ifndef CRF_AB_OLDWM
     // The frame maximum is FOUR LDS words per frame (three sets in rotation: read / accumulated by ds_max_f32 / cleared), one per
     // row of 16 lanes: a wave's frame top reads them with one ds_read_b128 and works the scale out on the scalar unit; with twelve wave maxima per frame every wave spent ~17 VALU instructions there and ~8 more in the tail --
     // the frame is bound by instruction issue (timing build: a wave with NO rows still took 520 cycles per frame).
@@ -1561,7 +1561,6 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                                                              // LDS atomic of several lanes is turned into a scalar loop by the compiler)
     const bool rowlead = (lane & 15) == 0;
     int sr = i0 % 3;                                         // word read by the next frame
-#endif
     if (lx > 0)
         for (int v = tid; v < V; v += NTH) {
             if (DIR == 0) EP[par0 * Vp + v] = p.ep[(bt0 + i0) * V + v];                 // e'_t of the first frame
@@ -1592,13 +1591,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         } else {
             if (lead) for (int r = tid; r < 2 * R; r += NTH) zpart += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
         }
-#ifndef CRF_AB_OLDWM
         m0 = row_max16(m0);
         if (rowlead) lds_fmax(wm + sr * 4 + (lane >> 4), m0);
-#else
-        m0 = wave_max(m0);
-        if (lane == 0) wm[par0 * NW + wave] = m0;
-#endif
     }
     __syncthreads();
     if constexpr (K2) {
@@ -1640,6 +1634,10 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     const bool pre_w = wave * kWave < V;                     // this wave holds emissions
     float last_sc = 1.f;                                     // scale of the last frame (rowless states, after the loop)
     float epn[kEpRegsR] = {};                               // next emission row, in flight across the frame (waves that hold emissions only)
+    // this utterance's emissions, rows and exponents (the frame loop adds 32-bit offsets: one s_mul instead of a 64-bit product per address)
+    const float *ep_b = p.ep + bt0 * V;
+    float *Out_b = p.Out + bt0 * p.Rout;
+    int *Eo_b = p.Eout + bt0;
     auto frame = [&](const int par, int i) __attribute__((always_inline)) {
         const int t = DIR == 0 ? i : lx - 1 - i;
         if (FLAG && i == next_bound) publish_stage();
@@ -1651,36 +1649,35 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #endif
         const char *xb = (const char *)lds + par * XB;
         char *xnb = (char *)lds + (1 - par) * XB;
+        constexpr int NP = PIPE > 0 ? PIPE : 1;
+        [[maybe_unused]] f32x2 ga01[NP], ga23[NP], gb01[NP], gb23[NP];   // PIPE: two sets of gathered entries in rotation
+        if constexpr (PIPE > 0) { CRF_RES_GATHER_N(ga01, ga23, A, xb, 0, NP); }   // the frame's first requests, ahead of its bookkeeping
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
         const int tpre = DIR == 0 ? t + 1 : t - 2;
         // (only the waves that hold emissions take part in the prefetch: the compiler waits for vmcnt(0) around these
         // loads -- i.e. for the acknowledgement of the previous frame's row stores -- and the other waves need not)
         const bool pre = pre_w && (DIR == 0 ? (t + 1 < lx) : (t >= 2));
         if (pre) {
-            const float *er = p.ep + (bt0 + tpre) * V;
+            const float *er = ep_b + (unsigned)tpre * (unsigned)V;   // (32-bit products: B * T * max(V, Rout) floats per utterance < 2^32, checked by the host)
 #pragma unroll
             for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; if (v < V) epn[q] = er[v]; }
         }
-#ifndef CRF_AB_OLDWM
         const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
         const int4 m4 = *(const int4 *)(wm + sr * 4);          // (non-negative floats: their bits order like integers)
         const int ksc = rescale_exp_bits((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
         if (wave == 0 && lane < 4) wm[sz * 4 + lane] = 0.f;
-#else
-        const int ksc = rescale_exp(res_frame_max<NW>(wm + par * NW));
-#endif
         const float sc = pow2f(ksc);
         if (DIR == 1) last_sc = sc;
         float *Orow;
         if (DIR == 0) {
             E += ksc;
-            if (tid == 0 && lead) p.Eout[bt0 + t] = E;
+            if (tid == 0 && lead) Eo_b[t] = E;
             E += kEpExp;
-            Orow = p.Out + (bt0 + t) * p.Rout;
+            Orow = Out_b + (unsigned)t * (unsigned)p.Rout;
         } else {
             E += ksc + kEpExp;
-            if (t > 0 && tid == 0 && lead) p.Eout[bt0 + t - 1] = E;
-            Orow = t > 0 ? p.Out + (bt0 + t - 1) * p.Rout : p.Row0 + (int64_t)b * p.Rout;
+            if (t > 0 && tid == 0 && lead) Eo_b[t - 1] = E;
+            Orow = t > 0 ? Out_b + (unsigned)(t - 1) * (unsigned)p.Rout : p.Row0 + (int64_t)b * p.Rout;
         }
         unsigned ends_f = ends;
         int nch_f = nch;
@@ -1695,6 +1692,139 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         typedef std::conditional_t<DIR == 0, uint2, uint4> rct_t;
         [[maybe_unused]] rct_t kc{};                  // RL: constants of the slice that ends next
         if constexpr (RL) kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * r4);
+        // the end of a slice (row): everything between the row's sum and its entries of the next vector
+        auto row_end = [&](const unsigned ks) __attribute__((always_inline)) {   // ks: slice number (uniform)
+            // rows longer than a lane's registers lie on 2^lg adjacent lanes (res_layout.cpp place_rows): a butterfly
+            // leaves the row's sum in every lane of the group, the first one owns the outputs
+            float tot = acc.x + acc.y;
+            if constexpr (ML) {
+                const unsigned lg = ks < 10u ? (lgbits >> (3u * ks)) & 7u : 0u;   // (ten 3-bit fields; later slices have whole rows)
+                if (lg) {
+                    // DPP for groups of up to 16 lanes (pair swap, quad half swap, mirror of 8, mirror of 16: after
+                    // each step every lane of the growing group holds the group's sum, so ANY lane of the other half
+                    // will do); a __shfl_xor is a ds_bpermute round trip (~100+ cycles each, dependent) and cost the
+                    // graphs with long rows -- every den_lm estimated from text -- a quarter of the frame
+#define CRF_DPP_ADD(ctrl) tot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), ctrl, 0xf, 0xf, false))
+                    CRF_DPP_ADD(0xB1);                            // quad_perm [1,0,3,2]
+                    if (lg >= 2) CRF_DPP_ADD(0x4E);               // quad_perm [2,3,0,1]
+                    if (lg >= 3) CRF_DPP_ADD(0x141);              // row_half_mirror
+                    if (lg >= 4) CRF_DPP_ADD(0x140);              // row_mirror
+#undef CRF_DPP_ADD
+                    if (lg >= 5) tot += __shfl_xor(tot, 16, 64);
+                    if (lg >= 6) tot += __shfl_xor(tot, 32, 64);
+                }
+            }
+            if constexpr (IMP) {
+                unsigned k0, k1;
+                [[maybe_unused]] f32x2 wrl{};
+                if constexpr (RC) {
+                    // (masks, not ?: -- the compiler turns a three-way select of registers by a uniform index
+                    // into an indexed array, which it then cannot keep in registers)
+                    const unsigned s0 = 0u - (unsigned)(ks == 0), s1 = 0u - (unsigned)(ks == 1), s2 = 0u - (unsigned)(ks >= 2);
+                    k0 = (rc00 & s0) | (rc10 & s1) | (rc20 & s2);
+                    k1 = (rc01 & s0) | (rc11 & s1) | (rc21 & s2);
+                } else {
+                    k0 = kc.x; k1 = kc.y;
+                    if constexpr (DIR == 1) wrl = f32x2{__uint_as_float(kc.z), __uint_as_float(kc.w)};
+                    kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * (r4 + kWave * 4u));   // the next slice's (64 rows of slack behind the table)
+                }
+
+                if (DIR == 0) {   // k0 = main label | tail label << 16, k1 = tail weight; U, L, A at rid, R + rid, 2R + rid
+                    const float uold = *(const float *)(xb + r4);                   // U_t of the row's pair
+                    const float em = *(const float *)((const char *)EPu + (k0 & 0xffffu)), et = *(const float *)((const char *)EPu + (k0 >> 16));   // (byte offsets)
+                    const float rv = tot * sc;                                      // q_t[pair of the main state]
+                    const float qt = __uint_as_float(k1) * uold * sc;               // q_t[pair of the tail state]
+                    if (flagged) {
+                        __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((unsigned *)((char *)Orow + r4 + 4u * (unsigned)R), __float_as_uint(qt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        *(float *)((char *)Orow + r4) = rv;
+                        *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
+                    }
+                    const float Lp = em * rv, Ap = et * qt, Up = Ap + Lp;           // a_{t+1}[main], [tail], their sum
+                    *(float *)(xnb + r4) = Up;
+                    *(float *)(xnb + r4 + dup) = Up;
+                    *(float *)(xnb + r4 + 4u * (unsigned)R) = Lp;
+                    *(float *)(xnb + r4 + 8u * (unsigned)R) = Ap;
+                    if constexpr (K2) {           // entries rid, R + rid, 2 R + rid of the peer's vector
+                        gu64 *gs = (gu64 *)((char *)slot + 2u * r4);
+                        res_publish(gs, 0, tag, Up, same_l2); res_publish(gs, R, tag, Lp, same_l2); res_publish(gs, 2 * R, tag, Ap, same_l2);
+                    }
+                    mymax = __int_as_float(max(__float_as_int(mymax), __float_as_int(Up)));   // (non-negative: bits order like integers; fmaxf canonicalises first)
+                } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16
+                    const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
+                    const float e0 = *(const float *)((const char *)EPu + (k1 & 0xffffu)), e1 = *(const float *)((const char *)EPu + (k1 >> 16));
+                    const f32x2 w01 = RL ? wrl : *(const f32x2 *)(RMc + 2u * r4);
+                    const float craw = tot;                                         // common out-arcs of the row's states
+                    f32x2 bv;                                                        // b_t of the two states
+                    bv.x = fmaf(w01.x, z0, craw) * sc;
+                    bv.y = fmaf(w01.y, z1, craw) * sc;
+                    if (flagged)
+                        __hip_atomic_store((unsigned long long *)((char *)Orow + 2u * r4),
+                                           (unsigned long long)__float_as_uint(bv.x) | ((unsigned long long)__float_as_uint(bv.y) << 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        *(f32x2 *)((char *)Orow + 2u * r4) = bv;
+                    f32x2 zv;                                                        // z_{t-1} of the pairs entering them
+                    zv.x = e0 * bv.x;
+                    zv.y = e1 * bv.y;
+                    *(f32x2 *)(xnb + 2u * r4) = zv;
+                    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                    *(f32x2u *)(xnb + 2u * r4 + dup) = zv;
+                    if constexpr (K2) {           // entries 2 rid, 2 rid + 1
+                        gu64 *gs = (gu64 *)((char *)slot + 4u * r4);
+                        res_publish(gs, 0, tag, zv.x, same_l2); res_publish(gs, 1, tag, zv.y, same_l2);
+                    }
+                    mymax = __int_as_float(max(__float_as_int(mymax), max(__float_as_int(zv.x), __float_as_int(zv.y))));
+                }
+            } else {
+            const int4 m = *(const int4 *)(RMc + 4u * r4);
+            if (DIR == 0) {
+                const float uold = *(const float *)(xb + (m.x & 0xffff));   // U_t of the row's pair
+                const float em = EPu[(unsigned)m.x >> 16], et = EPu[m.w];   // (requested together: one LDS round trip)
+                const float rv = tot * sc;                                  // q_t[pair of the main state]
+                const float qt = __int_as_float(m.z) * uold * sc;           // q_t[pair of the tail state]
+                if (flagged) {   // write-through: the grad pass reads the rows from other XCDs while this kernel runs
+                    __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((unsigned *)((char *)Orow + r4 + 4u * (unsigned)R), __float_as_uint(qt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *(float *)((char *)Orow + r4) = rv;
+                    *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
+                }
+                const float Lp = em * rv;                                   // a_{t+1}[main]
+                const float Ap = et * qt;                                   // a_{t+1}[tail]
+                const float Up = Ap + Lp;
+                *(float *)(xnb + (m.x & 0xffff)) = Up;
+                if (dup) *(float *)(xnb + (m.x & 0xffff) + dup) = Up;
+                *(float *)(xnb + (m.y & 0xffff)) = Lp;
+                *(float *)(xnb + ((unsigned)m.y >> 16)) = Ap;
+                mymax = fmaxf(mymax, Up);
+            } else {
+                const float craw = tot;                                     // common out-arcs of the row's states
+                const float z0 = *(const float *)(xb + (m.x & 0xffff)), z1 = *(const float *)(xb + ((unsigned)m.x >> 16));
+                const float e0 = EPu[m.w & 0xffff], e1 = EPu[(unsigned)m.w >> 16];
+                f32x2 bv;                                                    // b_t of the two states
+                bv.x = fmaf(__int_as_float(m.y), z0, craw) * sc;
+                bv.y = fmaf(__int_as_float(m.z), z1, craw) * sc;
+                if (flagged)
+                    __hip_atomic_store((unsigned long long *)((char *)Orow + 2u * r4),
+                                       (unsigned long long)__float_as_uint(bv.x) | ((unsigned long long)__float_as_uint(bv.y) << 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    *(f32x2 *)((char *)Orow + 2u * r4) = bv;
+                f32x2 zv;                                                    // z_{t-1} of the pairs entering them
+                zv.x = e0 * bv.x;
+                zv.y = e1 * bv.y;
+                *(f32x2 *)(xnb + 2u * r4) = zv;
+                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                if (dup) *(f32x2u *)(xnb + 2u * r4 + dup) = zv;   // the copy's distance is an odd number of floats: ds_write2_b32
+                mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
+            }
+            }
+            acc = f32x2{0.f, 0.f};
+            r4 += kWave * 4u;
+        };
+        if constexpr (PIPE == 0) {
 #pragma unroll
         for (int c0 = 0; c0 < NCHA; c0 += NB) {
             constexpr int nb = NB;
@@ -1704,146 +1834,35 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #pragma unroll
                 for (int ci = 0; ci < nb; ++ci) {
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
-                    if (ends_f >> (c0 + ci) & 1u) {
-                        const unsigned ks = (unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u));   // slice number (uniform)
-                        // rows longer than a lane's registers lie on 2^lg adjacent lanes (res_layout.cpp place_rows): a butterfly
-                        // leaves the row's sum in every lane of the group, the first one owns the outputs
-                        float tot = acc.x + acc.y;
-                        if constexpr (ML) {
-                            const unsigned lg = ks < 10u ? (lgbits >> (3u * ks)) & 7u : 0u;   // (ten 3-bit fields; later slices have whole rows)
-                            if (lg) {
-                                // DPP for groups of up to 16 lanes (pair swap, quad half swap, mirror of 8, mirror of 16: after
-                                // each step every lane of the growing group holds the group's sum, so ANY lane of the other half
-                                // will do); a __shfl_xor is a ds_bpermute round trip (~100+ cycles each, dependent) and cost the
-                                // graphs with long rows -- every den_lm estimated from text -- a quarter of the frame
-#ifndef CRF_AB_ML_SHFL
-#define CRF_DPP_ADD(ctrl) tot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), ctrl, 0xf, 0xf, false))
-                                CRF_DPP_ADD(0xB1);                            // quad_perm [1,0,3,2]
-                                if (lg >= 2) CRF_DPP_ADD(0x4E);               // quad_perm [2,3,0,1]
-                                if (lg >= 3) CRF_DPP_ADD(0x141);              // row_half_mirror
-                                if (lg >= 4) CRF_DPP_ADD(0x140);              // row_mirror
-#undef CRF_DPP_ADD
-                                if (lg >= 5) tot += __shfl_xor(tot, 16, 64);
-                                if (lg >= 6) tot += __shfl_xor(tot, 32, 64);
-#else
-#pragma unroll
-                                for (int q = 0; q < 6; ++q)
-                                    if ((unsigned)q < lg) tot += __shfl_xor(tot, 1 << q, 64);
-#endif
-                            }
-                        }
-                        if constexpr (IMP) {
-                            unsigned k0, k1;
-                            [[maybe_unused]] f32x2 wrl{};
-                            if constexpr (RC) {
-                                // (masks, not ?: -- the compiler turns a three-way select of registers by a uniform index
-                                // into an indexed array, which it then cannot keep in registers)
-                                const unsigned s0 = 0u - (unsigned)(ks == 0), s1 = 0u - (unsigned)(ks == 1), s2 = 0u - (unsigned)(ks >= 2);
-                                k0 = (rc00 & s0) | (rc10 & s1) | (rc20 & s2);
-                                k1 = (rc01 & s0) | (rc11 & s1) | (rc21 & s2);
-                            } else {
-                                k0 = kc.x; k1 = kc.y;
-                                if constexpr (DIR == 1) wrl = f32x2{__uint_as_float(kc.z), __uint_as_float(kc.w)};
-                                kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * (r4 + kWave * 4u));   // the next slice's (64 rows of slack behind the table)
-                            }
-
-                            if (DIR == 0) {   // k0 = main label | tail label << 16, k1 = tail weight; U, L, A at rid, R + rid, 2R + rid
-                                const float uold = *(const float *)(xb + r4);                   // U_t of the row's pair
-                                const float em = *(const float *)((const char *)EPu + (k0 & 0xffffu)), et = *(const float *)((const char *)EPu + (k0 >> 16));   // (byte offsets)
-                                const float rv = tot * sc;                                      // q_t[pair of the main state]
-                                const float qt = __uint_as_float(k1) * uold * sc;               // q_t[pair of the tail state]
-                                if (flagged) {
-                                    __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    __hip_atomic_store((unsigned *)((char *)Orow + r4 + 4u * (unsigned)R), __float_as_uint(qt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                } else {
-                                    *(float *)((char *)Orow + r4) = rv;
-                                    *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
-                                }
-                                const float Lp = em * rv, Ap = et * qt, Up = Ap + Lp;           // a_{t+1}[main], [tail], their sum
-                                *(float *)(xnb + r4) = Up;
-                                *(float *)(xnb + r4 + dup) = Up;
-                                *(float *)(xnb + r4 + 4u * (unsigned)R) = Lp;
-                                *(float *)(xnb + r4 + 8u * (unsigned)R) = Ap;
-                                if constexpr (K2) {           // entries rid, R + rid, 2 R + rid of the peer's vector
-                                    gu64 *gs = (gu64 *)((char *)slot + 2u * r4);
-                                    res_publish(gs, 0, tag, Up, same_l2); res_publish(gs, R, tag, Lp, same_l2); res_publish(gs, 2 * R, tag, Ap, same_l2);
-                                }
-                                mymax = __int_as_float(max(__float_as_int(mymax), __float_as_int(Up)));   // (non-negative: bits order like integers; fmaxf canonicalises first)
-                            } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16
-                                const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
-                                const float e0 = *(const float *)((const char *)EPu + (k1 & 0xffffu)), e1 = *(const float *)((const char *)EPu + (k1 >> 16));
-                                const f32x2 w01 = RL ? wrl : *(const f32x2 *)(RMc + 2u * r4);
-                                const float craw = tot;                                         // common out-arcs of the row's states
-                                f32x2 bv;                                                        // b_t of the two states
-                                bv.x = fmaf(w01.x, z0, craw) * sc;
-                                bv.y = fmaf(w01.y, z1, craw) * sc;
-                                if (flagged)
-                                    __hip_atomic_store((unsigned long long *)((char *)Orow + 2u * r4),
-                                                       (unsigned long long)__float_as_uint(bv.x) | ((unsigned long long)__float_as_uint(bv.y) << 32),
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                else
-                                    *(f32x2 *)((char *)Orow + 2u * r4) = bv;
-                                f32x2 zv;                                                        // z_{t-1} of the pairs entering them
-                                zv.x = e0 * bv.x;
-                                zv.y = e1 * bv.y;
-                                *(f32x2 *)(xnb + 2u * r4) = zv;
-                                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-                                *(f32x2u *)(xnb + 2u * r4 + dup) = zv;
-                                if constexpr (K2) {           // entries 2 rid, 2 rid + 1
-                                    gu64 *gs = (gu64 *)((char *)slot + 4u * r4);
-                                    res_publish(gs, 0, tag, zv.x, same_l2); res_publish(gs, 1, tag, zv.y, same_l2);
-                                }
-                                mymax = __int_as_float(max(__float_as_int(mymax), max(__float_as_int(zv.x), __float_as_int(zv.y))));
-                            }
-                        } else {
-                        const int4 m = *(const int4 *)(RMc + 4u * r4);
-                        if (DIR == 0) {
-                            const float uold = *(const float *)(xb + (m.x & 0xffff));   // U_t of the row's pair
-                            const float em = EPu[(unsigned)m.x >> 16], et = EPu[m.w];   // (requested together: one LDS round trip)
-                            const float rv = tot * sc;                                  // q_t[pair of the main state]
-                            const float qt = __int_as_float(m.z) * uold * sc;           // q_t[pair of the tail state]
-                            if (flagged) {   // write-through: the grad pass reads the rows from other XCDs while this kernel runs
-                                __hip_atomic_store((unsigned *)((char *)Orow + r4), __float_as_uint(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store((unsigned *)((char *)Orow + r4 + 4u * (unsigned)R), __float_as_uint(qt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            } else {
-                                *(float *)((char *)Orow + r4) = rv;
-                                *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
-                            }
-                            const float Lp = em * rv;                                   // a_{t+1}[main]
-                            const float Ap = et * qt;                                   // a_{t+1}[tail]
-                            const float Up = Ap + Lp;
-                            *(float *)(xnb + (m.x & 0xffff)) = Up;
-                            if (dup) *(float *)(xnb + (m.x & 0xffff) + dup) = Up;
-                            *(float *)(xnb + (m.y & 0xffff)) = Lp;
-                            *(float *)(xnb + ((unsigned)m.y >> 16)) = Ap;
-                            mymax = fmaxf(mymax, Up);
-                        } else {
-                            const float craw = tot;                                     // common out-arcs of the row's states
-                            const float z0 = *(const float *)(xb + (m.x & 0xffff)), z1 = *(const float *)(xb + ((unsigned)m.x >> 16));
-                            const float e0 = EPu[m.w & 0xffff], e1 = EPu[(unsigned)m.w >> 16];
-                            f32x2 bv;                                                    // b_t of the two states
-                            bv.x = fmaf(__int_as_float(m.y), z0, craw) * sc;
-                            bv.y = fmaf(__int_as_float(m.z), z1, craw) * sc;
-                            if (flagged)
-                                __hip_atomic_store((unsigned long long *)((char *)Orow + 2u * r4),
-                                                   (unsigned long long)__float_as_uint(bv.x) | ((unsigned long long)__float_as_uint(bv.y) << 32),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            else
-                                *(f32x2 *)((char *)Orow + 2u * r4) = bv;
-                            f32x2 zv;                                                    // z_{t-1} of the pairs entering them
-                            zv.x = e0 * bv.x;
-                            zv.y = e1 * bv.y;
-                            *(f32x2 *)(xnb + 2u * r4) = zv;
-                            typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-                            if (dup) *(f32x2u *)(xnb + 2u * r4 + dup) = zv;   // the copy's distance is an odd number of floats: ds_write2_b32
-                            mymax = fmaxf(mymax, fmaxf(zv.x, zv.y));
-                        }
-                        }
-                        acc = f32x2{0.f, 0.f};
-                        r4 += kWave * 4u;
-                    }
+                    if (ends_f >> (c0 + ci) & 1u) row_end((unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u)));
                 }
             }
+        }
+        } else {
+        // PIPE: the gathers of batch k + 1 are REQUESTED before the products of batch k are summed (two register sets in
+        // rotation, batches of PIPE chunks): without it a wave drains its LDS queue at every batch end -- address adds, requests
+        // and a full LDS round trip before the next FMA, five times per frame -- and the frame is a chain of such round trips
+        // (a wave's ~480 instructions take 3 200 - 4 300 cycles, in-kernel stamps).  lgkmcnt counts 15 at most, so batches of 2
+        // chunks (8 + 8 gathers in flight) are what the waits can express exactly.
+        // Control flow is a CHAIN (one exit per batch, no joins between a request and its use): the wait-count pass merges
+        // the states of the paths that meet at a join to the strictest one, and a conditional request ahead of a join made every
+        // later wait a full drain.  So the next batch is requested unconditionally while the current one is active (unused chunk
+        // slots hold offset 0 / weight 0: at most one batch of 4 * PIPE wasted gathers per wave), and the first batch at the frame top.
+        if (0 < nch_f) {
+#pragma unroll
+            for (int kb = 0; kb < NCHA / NP; ++kb) {
+                const int c0 = kb * NP;
+                if (kb + 1 < NCHA / NP) {
+                    if (kb & 1) { CRF_RES_GATHER_N(ga01, ga23, A, xb, c0 + NP, NP); } else { CRF_RES_GATHER_N(gb01, gb23, A, xb, c0 + NP, NP); }
+                }
+#pragma unroll
+                for (int ci = 0; ci < NP; ++ci) {
+                    if (kb & 1) { CRF_RES_CHUNK_ACC(acc, gb01, gb23, A, c0 + ci, ci); } else { CRF_RES_CHUNK_ACC(acc, ga01, ga23, A, c0 + ci, ci); }
+                    if (ends_f >> (c0 + ci) & 1u) row_end((unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u)));
+                }
+                if (!(c0 + NP < nch_f)) break;
+            }
+        }
         }
         CRF_TM(tm_on, tm_i + 2);
 #ifdef CRF_TIMING
@@ -1874,14 +1893,9 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             }
             mymax = fmaxf(mymax, fm);
         }
-#ifndef CRF_AB_OLDWM
         mymax = row_max16(mymax);
         if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), mymax);
         sr = sw;
-#else
-        mymax = wave_max(mymax);
-        if (lane == 0) wm[(1 - par) * NW + wave] = mymax;
-#endif
         if (pre) {
             float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;
 #pragma unroll
@@ -1962,12 +1976,13 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 // guaranteed inside a training process (HIP maps all streams of a process onto GPU_MAX_HW_QUEUES = 4 queues; with
 // RCCL's and torch's streams around, the recursions were observed to run one after the other: 5.3 instead of 3.25 ms).
 // NBF / NBB: chunks gathered per batch, forward / backward.
-template <bool FLAG, int NTH, int NCH, int NBF, int NBB, bool ML, bool RL = false>
+// PIPE > 0: software-pipelined gathers in batches of PIPE chunks (fac_chain_body)
+template <bool FLAG, int NTH, int NCH, int NBF, int NBB, bool ML, bool RL = false, int PIPE = 0>
 __global__ __launch_bounds__(NTH) void crf_fac_pair_kernel(FacParams pf, FacParams pb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = pf.B;
-    if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML, RL>(pf, lds, (int)blockIdx.x);
-    else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - B);
+    if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML, RL, false, PIPE>(pf, lds, (int)blockIdx.x);
+    else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML, RL, false, PIPE>(pb, lds, (int)blockIdx.x - B);
 }
 // ... with TWO CUs per recursion: 2 * nbu * 2 workgroups for the utterances [b0, b0 + nbu), forward recursions first; the
 // two CUs of a recursion 8 block ids apart (block x is observed on XCD x % 8: one L2 for the hand-off; a matter of speed only)
@@ -2117,12 +2132,9 @@ constexpr int kGDEpRegs = 4;                                      // V <= 4*256
 // the rows AND the emission row of frame t+1 are requested while frame t is reduced, the per-frame
 // exponents are read once per workgroup, and the barriers are LDS-only (sync_lds) -- __syncthreads()
 // would drain vmcnt, i.e. wait for the prefetch it has just issued (that alone was ~2/3 of this kernel).
-#ifndef CRF_GD_MINW
-#define CRF_GD_MINW 1   // 4: 128 VGPRs (spills 25) for a fourth workgroup per CU -- measured slower/faster: see DESIGN.md
-#endif
 // NT threads: 256, or 512 for graphs whose rows do not fit 256 threads' prefetch registers (5 float4 each per row)
 template <int NCPT, int EPR, int NT = kGDThreads>
-__global__ __launch_bounds__(NT, (NCPT == 1 && EPR == 1 && NT == kGDThreads) ? CRF_GD_MINW : 1) void crf_grad_den_kernel(LossParams p) {
+__global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
     const int tid = threadIdx.x;
@@ -2654,12 +2666,6 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk
     auto issue = [&](const int j, const int b) __attribute__((always_inline)) {   // gathers of batch b of the task into slot j
         const int4 *lp = (const int4 *)(ldsw + (((b % (2 * CB)) * AL + aj) * 32));
         int4 r0 = lp[0], r1 = lp[1];
-#if defined(CRF_BAT_DBG) && CRF_BAT_DBG == 2
-        r0.x &= 0x80000000; r0.z = 0; r1.x = 0; r1.z = 0;   // timing experiment: every gather reads entry 0
-#endif
-#if defined(CRF_BAT_DBG) && CRF_BAT_DBG == 3
-        r0.x &= 0x800fffff; r0.z &= 0xfffff; r1.x &= 0xfffff; r1.z &= 0xfffff;   // timing experiment: gathers confined to 4 MB / 64 = the first 1/8 .. 1/2 of the vector
-#endif
         // (a record's index is entry * UL with the flag in bit 31: the shift to bytes drops the flag -- one VALU per gather --
         // and the address is a 32-bit offset to a uniform base)
         fl[j] = (unsigned)__builtin_amdgcn_readfirstlane(r0.x) >> 31;
@@ -2769,9 +2775,6 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
     CRF_TM(tmi >= 0 && lx4[0] + lx4[1] + lx4[2] + lx4[3] + lx >= 0, tmi + 1);   // (the scalar loads have landed)
     float mymax = 0.f;                                             // rest rows: utterance ul
     f32x4 mymax4 = {0.f, 0.f, 0.f, 0.f};                           // stream: the lane's four utterances
-#if defined(CRF_BAT_DBG) && CRF_BAT_DBG == 1
-    if (p.j >= 0) return;   // timing experiment: the launch and nothing else
-#endif
     if (dir == 0) {
         const int t = p.j;
         if (t >= T) return;
@@ -3365,8 +3368,12 @@ static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 // the register-resident kernels are used whenever the graph fits them (res.K > 0) and V fits their
 // emission-row prefetch; CRF_NO_RESIDENT=1 at graph creation forces the streaming kernels
+static size_t res_lds_bytes(const HostGraph *h, int V, int dir, int rows_cu_max);
 static bool use_resident(const HostGraph *h, int64_t V) {
-    return h && h->dev.res.K > 0 && V <= (int64_t)kEpRegsR * kResThreads && h->dev.res.f.G <= kResGmax && h->dev.res.b.G <= kResGmax;
+    // (the two fixed 64 KiB state-vector buffers leave 32 KiB for the CU's row table and the emission rows: a K = 1 layout
+    // with ~6 k+ rows, or a call with far more classes than the den_lm has labels, takes the next kernel family instead)
+    return h && h->dev.res.K > 0 && V <= (int64_t)kEpRegsR * kResThreads && h->dev.res.f.G <= kResGmax && h->dev.res.b.G <= kResGmax &&
+           std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b)) <= (size_t)160 * 1024;
 }
 
 // the factored layout (one CU per recursion) is preferred whenever the graph has it; CRF_NO_FACTORED=1 at
@@ -3393,8 +3400,8 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.res = w.fac || use_resident(h, V);   // "res": register-resident kernels of either layout
     // graphs that fit neither register-resident layout take the utterance-minor kernels (CRF_NO_BATCH=1: the streaming
     // kernels instead; CRF_FORCE_BATCH=1: every graph, for tests)
-    const bool force_bat = getenv("CRF_FORCE_BATCH") && atoi(getenv("CRF_FORCE_BATCH"));
-    w.bat = h && h->dev.bat.ok && (force_bat || (!w.res && !(getenv("CRF_NO_BATCH") && atoi(getenv("CRF_NO_BATCH")))));
+    const bool force_bat = opt_on(kOpt_force_batch);
+    w.bat = h && h->dev.bat.ok && (force_bat || (!w.res && !opt_on(kOpt_no_batch)));
     if (w.bat) w.res = w.fac = false;
     // utterances per group: as wide as the batch allows (an arc is fetched once per group); 32 instead of 64 when a group's state
     // vector [S][64] would not stay in an XCD's 4 MiB L2 next to the arc stream (> ~2.25 MB) -- but never narrower than 32 for
@@ -3403,7 +3410,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     // 271 / 569 ms).  CRF_BAT_UL overrides, for sweeps.
     w.UL = B > 32 ? 64 : B > 16 ? 32 : B > 8 ? 16 : 8;
     if (h && w.UL == 64 && std::max<int64_t>(h->dev.S, h->dev.P) * w.UL * 4 > (int64_t)(2.25 * 1024 * 1024)) w.UL = 32;
-    if (const char *e = getenv("CRF_BAT_UL")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) w.UL = v; }
+    { const int v = opt(kOpt_bat_ul, 0); if (v == 8 || v == 16 || v == 32 || v == 64) w.UL = v; }
     w.Bp = (B + w.UL - 1) / w.UL * w.UL;
     // (rows are at least Pr wide: the robust fallback stores them in pair order, whatever layout the fast kernels use)
     w.Rq = h ? std::max<int64_t>(w.fac ? h->dev.fac.Rq : w.res ? h->dev.res.f.R : h->dev.Pr, h->dev.Pr) : 0;
@@ -3521,7 +3528,7 @@ static int get_ctx(hipStream_t owner, DevCtx **out) {
     // The side stream: the first of a few candidates that demonstrably runs beside the owner's stream (once per
     // context; the owner's stream is drained first so that both probe kernels start at once).  CRF_NO_SIDE_STREAM=1
     // skips it (everything then runs on the caller's stream, one kernel after the other).
-    const bool want_side = !(getenv("CRF_NO_SIDE_STREAM") && atoi(getenv("CRF_NO_SIDE_STREAM")));
+    const bool want_side = !opt_on(kOpt_no_side_stream);
     if (want_side && c->flags) {
         (void)hipStreamSynchronize(owner);
         for (int tries = 0; tries < 6 && !c->side; ++tries) {
@@ -3549,6 +3556,28 @@ static int get_ctx(hipStream_t owner, DevCtx **out) {
     *out = c;
     return CRF_OK;
 }
+
+// Grids whose workgroups WAIT FOR EACH OTHER (layouts over K > 1 CUs per recursion: every workgroup of a launch spins on its
+// peers) are sized to fill the device; two callers enqueueing such grids on different streams at once could each become
+// partially resident and wait for peers that are not (the bounded spins would then time out into the error word).  They are
+// chained per device: a caller's co-resident launch waits (stream-level, on an event) for the previous caller's.
+struct CoresChain { std::mutex mu; hipEvent_t ev{}; bool have = false; hipStream_t last{}; };
+static CoresChain g_cores[kMaxDev];
+struct CoresGuard {
+    CoresChain *c = nullptr; hipStream_t st{};
+    CoresGuard(bool needed, int dev, hipStream_t s) : st(s) {
+        if (!needed || dev < 0 || dev >= kMaxDev) return;
+        c = &g_cores[dev];
+        c->mu.lock();
+        if (c->have && c->last != st) (void)hipStreamWaitEvent(st, c->ev, 0);
+    }
+    ~CoresGuard() {
+        if (!c) return;
+        if (!c->have) c->have = hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) == hipSuccess;
+        if (c->have) { (void)hipEventRecord(c->ev, st); c->last = st; }
+        c->mu.unlock();
+    }
+};
 
 // Dynamic LDS above 64 KiB must be opted into per kernel AND per device (hipFuncSetAttribute acts on the current
 // device's copy of the function): high-water mark per device.
@@ -3650,6 +3679,13 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     return (size_t)2 * rup64(L.G) * 4 + table +
            ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }
+#ifndef CRF_FAC_PIPE_DEFAULT
+#define CRF_FAC_PIPE_DEFAULT 0
+#endif
+#ifndef CRF_FAC_PIPE_N
+#define CRF_FAC_PIPE_N 2
+#endif
+constexpr int kFacPipeDefault = CRF_FAC_PIPE_DEFAULT;   // crf_debug_set("fac_pipe", ...) overrides
 #ifndef CRF_FAC3_NB_F
 #define CRF_FAC3_NB_F 4
 #endif
@@ -3694,14 +3730,27 @@ static int launch_fac2_pair(const LossParams &lp, size_t lds, hipStream_t st, in
 template <bool FLAG>
 static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *fstate, float *bstate,
                            int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
-    static LdsMark m3, m3m, m3l, m5;
+    static LdsMark m3, m3m, m3l, m5, m3p, m3mp, m3lp;
     const FacDev &F = lp.g.fac;
     const bool g3 = F.threads == kFac3Threads, ml = F.multilane != 0;
     const FacParams pf = fac_params(lp, 0, started, i0, i1, fstate, nb, bound, stage_cnt);
     const FacParams pb = fac_params(lp, 1, started, i0, i1, bstate, nb, bound, stage_cnt);
     const dim3 grid((unsigned)(2 * lp.B));
     int rc;
-    if (g3 && F.rcl) {
+    const int pipe = opt(kOpt_fac_pipe, kFacPipeDefault);   // software-pipelined gather batches (fac_chain_body)
+    if (g3 && pipe > 0 && F.rcl) {
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true, CRF_FAC_PIPE_N>;
+        if ((rc = ensure_lds((const void *)k, lds, m3lp, "fac pair"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else if (g3 && pipe > 0 && ml) {
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, false, CRF_FAC_PIPE_N>;
+        if ((rc = ensure_lds((const void *)k, lds, m3mp, "fac pair"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else if (g3 && pipe > 0) {
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, false, false, CRF_FAC_PIPE_N>;
+        if ((rc = ensure_lds((const void *)k, lds, m3p, "fac pair"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else if (g3 && F.rcl) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true>;
         if ((rc = ensure_lds((const void *)k, lds, m3l, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
@@ -3789,6 +3838,9 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const WsLayout w = ws_layout(h, B, T, V, Sc);
     if (ws_bytes < w.total) { set_error("workspace too small: need " + std::to_string(w.total)); return CRF_ERR_WORKSPACE; }
     const bool res = den && w.res, gv = den && w.gv, fac = den && w.fac, bat = den && w.bat;
+    if (fac && T * std::max<int64_t>(V, std::max(w.Rq, w.Rb)) >= ((int64_t)1 << 32)) {   // (the factored frame loop adds 32-bit row offsets)
+        set_error("T * max(V, row length) >= 2^32 not supported by the factored kernels"); return CRF_ERR_UNSUPPORTED;
+    }
     size_t lds_chain = 0;
     if (den && !res && !bat) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0, gv), chain_lds_bytes(h, (int)V, Sc, 1, gv));
     if (res && !fac) lds_chain = std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b));
@@ -3833,7 +3885,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.redo = (int *)(pb + 16 * B);   // [2][B]
     // CRF_ROBUST: 0 = never run the robust fallback, 1 = every utterance takes it (tests, or "safe mode"); default: the
     // utterances the fast kernels flag
-    const int robust_env = getenv("CRF_ROBUST") ? atoi(getenv("CRF_ROBUST")) : -1;   // (read per call: tests switch it)
+    const int robust_env = opt(kOpt_robust, -1);   // (read per call: tests switch it)
     p.force_redo = (den && robust_env == 1) ? 1 : 0;
     p.xch = (unsigned long long *)(base + w.off_xch);
     p.err = (int *)(base + w.off_xch + w.xch_bytes);
@@ -3852,7 +3904,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const int64_t frames = B * T;
     // Two streams at most: the caller's and one side stream of this (device, caller stream)'s context.  Forward and
     // backward recursions are one grid each (denominator pair, numerator pair); the two grids are independent.
-    static const bool serial_env = getenv("CRF_SERIAL_CHAINS") && atoi(getenv("CRF_SERIAL_CHAINS")) != 0;
+    const bool serial_env = opt_on(kOpt_serial_chains);
     DevCtx *cx = nullptr;
     int rc;
     if ((rc = get_ctx(stream, &cx))) return rc;
@@ -3870,7 +3922,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     else hipLaunchKernelGGL(crf_prep_kernel<64>, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
     prof_mark(0, true, stream);
     LAUNCH_CHECK("crf_prep_kernel");
-    if (res && (!fac || w.xch_bytes > 0) && (w.xch_bytes > 0 || !have_flags)) {  // exchange granules (tags) and the error word start at zero in every call
+    if (res && (w.xch_bytes > 0 || !have_flags)) {  // exchange granules (tags) and the error word start at zero in every call
         if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256 + 8 * (size_t)B, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
     }
 
@@ -3901,10 +3953,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
     const bool gd_wide = den && (w.Rq > 4 * kGDRowRegs * kGDThreads || w.Rb > 4 * kGDRowRegs * kGDThreads);   // 512-thread grad workgroups
     const bool fast_den = den && w.Rq <= 8 * kGDRowRegs * kGDThreads && w.Rb <= 8 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
-                          gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
+                          gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !opt_on(kOpt_no_fast_grad);
     // numerator half of the grad pass: streaming kernel when the vocabulary fits its registers
     const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
-                          !(getenv("CRF_NO_FAST_GRAD") && atoi(getenv("CRF_NO_FAST_GRAD")));
+                          !opt_on(kOpt_no_fast_grad);
     // Factored den kernels: 2B workgroups, one CU each.  While that is at most half of the chip, everything else
     // runs BESIDE them on the other half, on the side stream: numerator chains, their grad half, and the den half of
     // the grad pass.  The den half of the grad pass needs rows of BOTH recursions, which work towards each other; it
@@ -3913,13 +3965,13 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     // (A grad pass that SPINS on progress counters of the running den kernels is faster still on a quiet device,
     // but with many launches queued ahead the den kernels were observed to stop for seconds while the waiting
     // workgroups kept their queue busy -- one kernel must never wait for another.)
-    static const bool no_overlap = getenv("CRF_NO_OVERLAP") && atoi(getenv("CRF_NO_OVERLAP")) != 0;   // diagnostics
+    const bool no_overlap = opt_on(kOpt_no_overlap);   // diagnostics
     // how stage k of the grad pass is released: a stream-level wait on a counter the running recursions bump
     // (default), or -- CRF_SEGMENTS=1, and automatically if hipStreamWaitValue32 is refused -- by cutting the
     // recursions into one launch per stage with an event after each (~40 us per relaunch, state parked in HBM)
-    static std::atomic<bool> use_segments{getenv("CRF_SEGMENTS") && atoi(getenv("CRF_SEGMENTS")) != 0};
-    const bool segmode = use_segments.load();
-    static const int stages_env = getenv("CRF_STAGES") ? atoi(getenv("CRF_STAGES")) : 0;
+    static std::atomic<bool> use_segments{false};      // set when hipStreamWaitValue32 is refused
+    const bool segmode = use_segments.load() || opt_on(kOpt_segments);
+    const int stages_env = opt(kOpt_stages, 0);
     const int pieces = stages_env > 0 ? stages_env : (segmode ? 4 : 12);   // measured: 4 / 8 / 12 pieces -> call 4.06 / 3.98 / 3.93 ms (flags)
     const bool staged = fac && h->dev.fac.K == 1 && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && 2 * B <= ncu_dev / 2;
     // Stage bounds.  Nothing can be released before the two recursions have met, so the first stage ends at half of
@@ -3943,7 +3995,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         } else {
             piece = 8 * kGDFrames;
             while ((kMaxStages - 2) * piece < (int)T - half && piece < (int)T) piece += 8 * kGDFrames;   // the stage counters cover T - half
-            static const int piece_env = getenv("CRF_PIECE") ? atoi(getenv("CRF_PIECE")) : 0;
+            const int piece_env = opt(kOpt_piece, 0);
             if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
             const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
             first = std::max(half, ((int)T - body + kGDFrames - 1) / kGDFrames * kGDFrames);
@@ -3965,7 +4017,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + 4 * rup64((int)V) + kGDFrames + rup64(gnc)) * sizeof(float);
         dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
         p.gd_nf = 0;
-        static const bool full_grid = getenv("CRF_GD_FULL_GRID") && atoi(getenv("CRF_GD_FULL_GRID"));
+        const bool full_grid = opt_on(kOpt_gd_full_grid);
         if (stage > 1 && !full_grid) {   // (stage 1 is the middle of every utterance: all blocks are candidates)
             p.gd_nf = (p.gd_bound[stage] - p.gd_bound[stage - 1] + kGDFrames - 1) / kGDFrames + 3;
             if (2 * p.gd_nf < (int)gg.x) gg.x = (unsigned)(2 * p.gd_nf); else p.gd_nf = 0;
@@ -4007,6 +4059,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     auto launch_den = [&](hipStream_t st) -> int {
         prof_mark(1, false, st); prof_mark(2, false, st);
         int r2 = CRF_OK;
+        const CoresGuard cores((fac && h->dev.fac.K > 1) || (res && !fac && h->dev.res.K > 1), cx->dev, st);
         if (fac && h->dev.fac.K > 1) {
             const int grp = std::max(1, ncu_dev / 4);
             for (int b0 = 0; b0 < (int)B && !r2; b0 += grp) r2 = launch_fac2_pair(p, lds_fac, st, b0, std::min(grp, (int)B - b0));
@@ -4064,7 +4117,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // (three dependent trips to a cold L2) less often.  Measured, S = 16 385 / B = 64 (repeatable to 0.3 %): 100 / 85 / 70 /
         // 60 / 55 / 45 / 35 % -> 30.7 / 29.5 / 28.8 / 30.6 / 31.8 / 28.5 / 31.3 ms per step (the dips: workgroups per XCD just
         // above a multiple of its 32 CUs); config #5 at B = 8: 100 / 70 / 50 % -> 145.3 / 143.6 / 152.6 ms.  CRF_BAT_FILL overrides.
-        static const int fill_env = getenv("CRF_BAT_FILL") ? atoi(getenv("CRF_BAT_FILL")) : 0;
+        const int fill_env = opt(kOpt_bat_fill, 0);
         const int64_t fill = fill_env > 0 && fill_env <= 100 ? fill_env : 70;
         const int want = (int)std::max<int64_t>(16, (int64_t)ncu_dev * wg_cu * kBatWaves * 15 / 16 * fill / 100 / ncombo);
         const StreamDev *sdv = nullptr;
@@ -4158,7 +4211,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // Denominator pair on the caller's stream, numerator pair beside it on the side stream -- unless the den
         // workgroups own every CU (register-resident layouts with 2B (x K) >= CUs): then the numerator recursions run
         // beside the DEN HALF of the grad pass instead (HBM-bound, small workgroups that share CUs happily).
-        static const int ctc_after_env = getenv("CRF_CTC_AFTER") ? atoi(getenv("CRF_CTC_AFTER")) : -1;
+        const int ctc_after_env = opt(kOpt_ctc_after, -1);
         const bool after = ctc_after_env >= 0 ? ctc_after_env != 0 : (res && (fac || h->dev.res.K > 1));
         if (!after) {
             if ((rc = fork_side())) return rc;

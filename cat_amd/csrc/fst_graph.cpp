@@ -7,6 +7,7 @@
 // end_weight = -Final, start_weight[start] = 0.  Epsilon input labels are rejected (the reference
 // would read logits[-1], fst_read.cc:55-56).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,41 @@ namespace crf {
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
+
+// debug / experiment switches (crf_internal.h: CRF_OPTS)
+static std::atomic<int> g_opt[kOptCount];
+static std::atomic<unsigned long long> g_opt_set{0};   // bit k: switch k has a value
+static_assert(kOptCount <= 64, "one bit per switch");
+static const char *const kOptName[kOptCount] = {
+#define CRF_OPT_NAME(name, doc) #name,
+    CRF_OPTS(CRF_OPT_NAME)
+#undef CRF_OPT_NAME
+};
+static const char *const kOptDoc[kOptCount] = {
+#define CRF_OPT_DOC(name, doc) doc,
+    CRF_OPTS(CRF_OPT_DOC)
+#undef CRF_OPT_DOC
+};
+int opt(Opt k, int dflt) { return (g_opt_set.load(std::memory_order_relaxed) >> (int)k & 1ull) ? g_opt[k].load(std::memory_order_relaxed) : dflt; }
+int opt_set(const char *key, int value, bool unset) {
+    if (!key) { set_error("crf_debug_set: null key"); return CRF_ERR_ARG; }
+    for (int k = 0; k < kOptCount; ++k)
+        if (!strcmp(key, kOptName[k])) {
+            if (unset) g_opt_set.fetch_and(~(1ull << k));
+            else { g_opt[k].store(value); g_opt_set.fetch_or(1ull << k); }
+            return CRF_OK;
+        }
+    set_error(std::string("crf_debug_set: unknown switch '") + key + "'");
+    return CRF_ERR_ARG;
+}
+const char *opt_list() {
+    static const std::string s = [] {
+        std::string r;
+        for (int k = 0; k < kOptCount; ++k) r += std::string(kOptName[k]) + ": " + kOptDoc[k] + "\n";
+        return r;
+    }();
+    return s.c_str();
+}
 const char *last_error_cstr() { return g_err.c_str(); }
 
 #define HIP_TRY(expr)                                                                             \
@@ -130,7 +166,7 @@ struct EllHost {
 // of 64; each slice is as wide as its first (longest) row, rounded up to an even arc count.
 EllHost build_ell(const std::vector<std::vector<std::pair<int, float>>> &rows) {
     EllHost e;
-    const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
+    const bool arrange = !opt_on(kOpt_no_bank_arrange);
     const int R = (int)rows.size();
     std::vector<int> order(R);
     std::iota(order.begin(), order.end(), 0);
@@ -415,7 +451,7 @@ static void build_batch_factored(HostGraph *h, int S, const std::vector<int4> &f
                                  const std::vector<float> &start_lin) {
     FacBatchH &F = h->fb;
     F = FacBatchH();
-    if (getenv("CRF_BAT_NO_FAC") && atoi(getenv("CRF_BAT_NO_FAC"))) return;
+    if (opt_on(kOpt_bat_no_fac)) return;
     std::vector<int> fr_of(S, -1), br_of(S, -1);
     for (int r = 0; r < S; ++r) { fr_of[(size_t)frow_d[(size_t)r]] = r; br_of[(size_t)brow_s[(size_t)r]] = r; }
     auto fsimple = [&](int s) { const int4 &d = frow[(size_t)fr_of[(size_t)s]]; return (d.w & 0x40000000) && d.y > d.x; };
@@ -599,7 +635,7 @@ static int stream_task_steps(const HostGraph *h, int AL, int want, bool fac = fa
     };
     const int64_t steps = fac ? std::max(steps_fac(h->fb.frows), steps_fac(h->fb.brows)) : std::max(steps_of(h->hb_frow), steps_of(h->hb_brow));
     int task_steps = (int)std::min<int64_t>(4096, std::max<int64_t>(64, ((steps + want - 1) / want + 3) / 4 * 4));
-    if (getenv("CRF_BAT_TASK")) task_steps = std::max(8, atoi(getenv("CRF_BAT_TASK")));
+    if (opt(kOpt_bat_task, 0) > 0) task_steps = std::max(8, opt(kOpt_bat_task, 0));
     return task_steps;
 }
 
@@ -707,7 +743,7 @@ int debug_check_streams(const HostGraph *h, int UL, int want, int64_t *out4) {
     return CRF_OK;
 }
 
-bool stream_fac(const HostGraph *h, int UL) { (void)UL; return h && h->fb.ok && !(getenv("CRF_BAT_NO_FAC") && atoi(getenv("CRF_BAT_NO_FAC"))); }
+bool stream_fac(const HostGraph *h, int UL) { (void)UL; return h && h->fb.ok && !opt_on(kOpt_bat_no_fac); }
 
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) {
     const int AL = 256 / std::max(UL, 1);                 // lane groups: a lane takes 4 utterances, UL / 4 lanes a row
@@ -758,22 +794,77 @@ int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out) 
 // Nothing happens to graphs that need nothing (all differences zero).  Returns true when the weights were changed.
 static bool regauge_pushed(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, const int32_t *lab,
                            std::vector<float> &w, std::vector<float> &start_w, std::vector<float> &end_w) {
-    if (getenv("CRF_NO_REGAUGE") && atoi(getenv("CRF_NO_REGAUGE"))) return false;
+    if (opt_on(kOpt_no_regauge)) return false;
     std::map<std::pair<int, int>, std::vector<int>> rows;           // (label, dst) -> arcs
     for (int64_t k = 0; k < A; ++k) rows[{(int)lab[k], (int)dst[k]}].push_back((int)k);
     struct Obs { uint64_t key; double d; };
     std::vector<Obs> obs;
-    for (auto &kv : rows) {
-        const std::vector<int> &a = kv.second;
-        if (a.size() < 2 || a.size() > 512) continue;   // (quadratic in the row length)
-        for (size_t u = 0; u < a.size(); ++u)
-            for (size_t v = u + 1; v < a.size(); ++v) {
-                int s1 = src[a[u]], s2 = src[a[v]];
-                double d = (double)w[(size_t)a[u]] - (double)w[(size_t)a[v]];
-                if (s1 == s2 || !std::isfinite(d)) continue;
-                if (s1 > s2) { std::swap(s1, s2); d = -d; }
-                obs.push_back({(uint64_t)s1 << 32 | (unsigned)s2, d});
+    int64_t nobs = 0;
+    for (auto &kv : rows) { const int64_t n = (int64_t)kv.second.size(); if (n >= 2 && n <= 512) nobs += n * (n - 1) / 2; }
+    if (nobs <= 30000000 && !opt_on(kOpt_regauge_minhash)) {
+        // every pair of states that meets in a row (quadratic in the row length: graphs up to a few hundred thousand arcs)
+        for (auto &kv : rows) {
+            const std::vector<int> &a = kv.second;
+            if (a.size() < 2 || a.size() > 512) continue;
+            for (size_t u = 0; u < a.size(); ++u)
+                for (size_t v = u + 1; v < a.size(); ++v) {
+                    int s1 = src[a[u]], s2 = src[a[v]];
+                    double d = (double)w[(size_t)a[u]] - (double)w[(size_t)a[v]];
+                    if (s1 == s2 || !std::isfinite(d)) continue;
+                    if (s1 > s2) { std::swap(s1, s2); d = -d; }
+                    obs.push_back({(uint64_t)s1 << 32 | (unsigned)s2, d});
+                }
+        }
+    } else {
+        // Large graphs (config #5: 4.3 M arcs in rows of 64 -- 134 M pairs, minutes of sorting): the two states of a history
+        // feed the SAME rows but one each, so they are found as near-duplicates -- twelve min-hashes over the set of rows a state
+        // feeds (two sets that differ in two of d + 2 elements share a min-hash with probability d / (d + 2)); only states that
+        // collide in one of them are compared, arc list against arc list.  O(A log A).
+        std::vector<int> rid((size_t)A);
+        { int r = 0; for (auto &kv : rows) { for (int k : kv.second) rid[(size_t)k] = r; ++r; } }
+        std::vector<int> order((size_t)A);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return src[x] != src[y] ? src[x] < src[y] : rid[(size_t)x] < rid[(size_t)y]; });
+        std::vector<int64_t> off((size_t)S + 1, 0);
+        for (int64_t k = 0; k < A; ++k) ++off[(size_t)src[k] + 1];
+        for (int64_t q = 0; q < S; ++q) off[(size_t)q + 1] += off[(size_t)q];
+        constexpr int NH = 12;
+        auto mix = [](uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; };
+        std::vector<uint64_t> pairs;
+        std::vector<std::pair<uint64_t, int>> mh((size_t)S);
+        for (int j = 0; j < NH; ++j) {
+            for (int64_t q = 0; q < S; ++q) {
+                uint64_t m = ~0ull;
+                for (int64_t i = off[(size_t)q]; i < off[(size_t)q + 1]; ++i) m = std::min(m, mix((uint64_t)rid[(size_t)order[(size_t)i]] * 0x9e3779b97f4a7c15ull + (uint64_t)j * 0x632be59bd9b4e019ull));
+                mh[(size_t)q] = {m, (int)q};
             }
+            std::sort(mh.begin(), mh.end());
+            for (size_t i = 0; i < mh.size();) {
+                size_t e = i;
+                while (e < mh.size() && mh[e].first == mh[i].first) ++e;
+                if (mh[i].first != ~0ull && e - i >= 2 && e - i <= 16)
+                    for (size_t u = i; u < e; ++u)
+                        for (size_t v = u + 1; v < e; ++v) pairs.push_back((uint64_t)std::min(mh[u].second, mh[v].second) << 32 | (unsigned)std::max(mh[u].second, mh[v].second));
+                i = e;
+            }
+        }
+        std::sort(pairs.begin(), pairs.end());
+        pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+        for (uint64_t key : pairs) {
+            const int s1 = (int)(key >> 32), s2 = (int)(key & 0xffffffffu);
+            int64_t i = off[(size_t)s1], j = off[(size_t)s2];
+            const int64_t ie = off[(size_t)s1 + 1], je = off[(size_t)s2 + 1];
+            while (i < ie && j < je) {
+                const int a1 = order[(size_t)i], a2 = order[(size_t)j];
+                if (rid[(size_t)a1] < rid[(size_t)a2]) ++i;
+                else if (rid[(size_t)a1] > rid[(size_t)a2]) ++j;
+                else {
+                    const double d = (double)w[(size_t)a1] - (double)w[(size_t)a2];
+                    if (std::isfinite(d)) obs.push_back({key, d});
+                    ++i; ++j;
+                }
+            }
+        }
     }
     std::sort(obs.begin(), obs.end(), [](const Obs &x, const Obs &y) { return x.key < y.key || (x.key == y.key && x.d < y.d); });
     struct Cand { uint64_t key; int n; double d; };
@@ -807,7 +898,7 @@ static bool regauge_pushed(int64_t S, int64_t A, const int32_t *src, const int32
         ++matched;
         if (std::fabs(c.d) > 1e-6) ++moved;
     }
-    if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE")))
+    if (opt_on(kOpt_verbose))
         fprintf(stderr, "[regauge] %lld candidate pairs, %lld matched, %lld with a non-zero difference (S = %lld)\n", (long long)cand.size(), (long long)matched, (long long)moved, (long long)S);
     if (moved * 8 < S) return false;                       // not a pushed T o LM graph (or nothing to undo)
     for (int64_t k = 0; k < A; ++k) w[(size_t)k] = (float)((double)w[(size_t)k] + g[dst[k]] - g[src[k]]);
@@ -815,14 +906,21 @@ static bool regauge_pushed(int64_t S, int64_t A, const int32_t *src, const int32
         if (std::isfinite(start_w[(size_t)s])) start_w[(size_t)s] = (float)((double)start_w[(size_t)s] + g[s]);
         if (std::isfinite(end_w[(size_t)s])) end_w[(size_t)s] = (float)((double)end_w[(size_t)s] - g[s]);
     }
-    for (auto &kv : rows) {                                // snap the weights of mates in a common row to the same bits
+    // Snap the weights of mates in a common row to the same bits -- within the ROUNDING of the pushed weights only (the file
+    // holds fp32 sums w + V(dst) - V(src): a few ulp of the weight's magnitude); a pair that differs by more is left alone
+    // (it then simply does not factor), so no path weight moves by more than float rounding.
+    double max_snap = 0.0;
+    for (auto &kv : rows) {
         const std::vector<int> &a = kv.second;
         if (a.size() < 2 || a.size() > 512) continue;   // (quadratic in the row length)
         for (size_t u = 0; u < a.size(); ++u)
-            for (size_t v = u + 1; v < a.size(); ++v)
-                if (mate[src[a[u]]] == src[a[v]] && std::fabs((double)w[(size_t)a[u]] - (double)w[(size_t)a[v]]) <= 2e-4)
-                    w[(size_t)a[v]] = w[(size_t)a[u]];
+            for (size_t v = u + 1; v < a.size(); ++v) {
+                if (mate[src[a[u]]] != src[a[v]]) continue;
+                const double wu = w[(size_t)a[u]], wv = w[(size_t)a[v]], df = std::fabs(wu - wv);
+                if (df <= 4e-6 * std::max(1.0, std::max(std::fabs(wu), std::fabs(wv)))) { w[(size_t)a[v]] = w[(size_t)a[u]]; max_snap = std::max(max_snap, df); }
+            }
     }
+    if (opt_on(kOpt_verbose)) fprintf(stderr, "[regauge] largest snapped log-weight difference %.3g\n", max_snap);
     return true;
 }
 
@@ -1112,6 +1210,9 @@ int crf_debug_stream_check(const crf_graph *g, int UL, int want, int64_t *out4) 
 }
 
 const char *crf_last_error(void) { return crf::last_error_cstr(); }
+int crf_debug_set(const char *key, int value) { return crf::opt_set(key, value, false); }
+int crf_debug_unset(const char *key) { return crf::opt_set(key, 0, true); }
+const char *crf_debug_list(void) { return crf::opt_list(); }
 const char *crf_version(void) { return "ctc_crf_hip 0.1.0 (gfx950)"; }
 
 }  // extern "C"

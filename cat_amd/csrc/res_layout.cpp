@@ -98,7 +98,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
         // frame waits for the slowest wave.  Step 1: best-fit-decreasing finds a feasible packing (the
         // registers are ~97% full for the benchmark graph, so balance-first heuristics do not even fit).
         // Step 2: a deterministic annealing over single moves and pair swaps lowers the maximum wave cost.
-        const int kEpiCost = getenv("CRF_RES_EPI") ? atoi(getenv("CRF_RES_EPI")) : 4;  // slice end, in chunks
+        const int kEpiCost = opt(kOpt_res_epi, 4);  // slice end, in chunks
         std::vector<int> wave_of(nsl, -1), load(gm.waves, 0), cnt(gm.waves, 0);
         bool packed = true;
         for (int j = 0; j < nsl && packed; ++j) {
@@ -117,7 +117,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
         if (packed) {
             auto wcost = [&](int w) { return load[w] + kEpiCost * cnt[w]; };
             // objective: (max cost, sum of squares) lexicographically, folded into one number
-            const bool by_simd = gm.maxsl && gm.waves % 4 == 0 && !(getenv("CRF_RES_NO_SIMD_ORDER") && atoi(getenv("CRF_RES_NO_SIMD_ORDER")));
+            const bool by_simd = gm.maxsl && gm.waves % 4 == 0 && !opt_on(kOpt_res_no_simd_order);
             auto objective = [&]() {
                 int64_t mx = 0, sq = 0;
                 if (by_simd) {   // waves w, w + 4, w + 8 share a SIMD and take turns on it: what the frame waits for is the busiest SIMD
@@ -175,7 +175,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
                     for (size_t i = 0; i < ws.size(); ++i) { lists[ws[i]] = nl[i]; load[ws[i]] = nload[i]; cnt[ws[i]] = ncnt[i]; cost[ws[i]] = ncost[i]; }
                 }
             }
-            if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"))) {
+            if (opt_on(kOpt_verbose)) {
                 fprintf(stderr, "[res_layout] lens:");
                 for (int j = 0; j < nsl; ++j) fprintf(stderr, " %d", len[j]);
                 fprintf(stderr, "\n[res_layout] K=%d cu=%d:", K, k);
@@ -186,7 +186,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
             }
         }
         if (!packed) {
-            if (getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"))) {
+            if (opt_on(kOpt_verbose)) {
                 int tot = 0;
                 for (int j = 0; j < nsl; ++j) tot += len[j];
                 fprintf(stderr, "[res_layout] K=%d cu=%d does not fit: %d slices, %d chunks in all, capacity %d waves x %d chunks", K, k, nsl, tot, gm.waves, gm.nch);
@@ -230,7 +230,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
                     // banks 0 and 16 only (measured by pack_arcs' model: extra LDS cycles per frame 1 919 -> see DESIGN).  Rotate.
                     const int gmask = (1 << lgs[j]) - 1;
                     bool first = r >= 0 && (lane & gmask) == 0;
-                    if (gm.maxsl && lgs[j] > 0 && r >= 0 && !(getenv("CRF_RES_OWNER_FIRST") && atoi(getenv("CRF_RES_OWNER_FIRST")))) {
+                    if (gm.maxsl && lgs[j] > 0 && r >= 0 && !opt_on(kOpt_res_owner_first)) {
                         if ((lane & gmask) == 0) { own_off = (nlong + (nlong >> lgs[j])) & gmask; ++nlong; }
                         first = (lane & gmask) == own_off;
                     }
@@ -259,7 +259,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
     bool any_long = false;
     if (gm.multilane)
         for (auto &r : rows) if (chunks_of(r.size()) > gm.nch) { any_long = true; break; }
-    const int piece_env = getenv("CRF_RES_PIECE") ? atoi(getenv("CRF_RES_PIECE")) : 0;
+    const int piece_env = opt(kOpt_res_piece, 0);
     if (!any_long || piece_env > 0) return place_rows_piece(rows, row_cu, K, o, slices, gm, piece_env > 0 ? std::min(piece_env, gm.nch) : half);
     bool have = false;
     DirOut best;
@@ -288,7 +288,7 @@ void arrange_grad_pairs(std::vector<int> *gq, std::vector<int> *gb, const std::v
     auto add = [](std::vector<int> (&bk)[32], int a) { auto &v = bk[a & 31]; if (std::find(v.begin(), v.end(), a) == v.end()) v.push_back(a); };
     auto cost_with = [](const std::vector<int> (&bk)[32], int a) { const auto &v = bk[a & 31]; return (int)v.size() + (std::find(v.begin(), v.end(), a) == v.end() ? 1 : 0); };
     *before = *after = 0;
-    const bool on = !(getenv("CRF_NO_GRAD_ARRANGE") && atoi(getenv("CRF_NO_GRAD_ARRANGE")));
+    const bool on = !opt_on(kOpt_no_grad_arrange);
     for (int c0 = 0; c0 < NC; c0 += 32) {                       // one half-wave: chunks [c0, c0 + 32)
         const int nl = std::min(32, NC - c0);
         std::vector<std::vector<std::pair<int, int>>> rem(nl);
@@ -343,7 +343,7 @@ void arrange_grad_pairs(std::vector<int> *gq, std::vector<int> *gb, const std::v
 // length) extra cycles -- 44 % on the benchmark graph; with a choice of two banks per arc nearly all of it goes.
 void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, int stride = 4, const Geom &gm = kGeomRes,
                int dup_n = 0, int dup_off = 0) {
-    const bool arrange = !(getenv("CRF_NO_BANK_ARRANGE") && atoi(getenv("CRF_NO_BANK_ARRANGE")));
+    const bool arrange = !opt_on(kOpt_no_bank_arrange);
     auto alt = [&](int idx) { return idx < 0 ? -1 : idx < dup_n ? idx + dup_off : (idx >= dup_off && idx < dup_off + dup_n) ? idx - dup_off : -1; };
     for (const SliceAt &sl : slices) {
         const int NI = sl.len * kResW;
@@ -449,7 +449,7 @@ void pack_arcs(const Rows &rows, const std::vector<SliceAt> &slices, DirOut *o, 
                     for (size_t i = ed.size(); i-- > 0 && surplus > 0;)
                         if (ed[i].bank == b) { ed[i].over = true; --surplus; }
                 }
-                if (getenv("CRF_PACK_DEBUG")) {
+                if (opt(kOpt_verbose, 0) >= 2) {
                     int mx = 0, nover = 0, tot = 0; for (int b = 0; b < 32; ++b) { mx = std::max(mx, load[b]); tot += load[b]; }
                     for (auto &e : ed) nover += e.over;
                     int nalt = 0; for (auto &e : ed) nalt += alt(e.idx) >= 0;
@@ -667,7 +667,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                    const std::vector<float> &end_lin, const std::vector<int> &label_sorted_pairs) {
     ResDev &R = h->dev.res;
     R = ResDev{};
-    if (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT"))) return CRF_OK;
+    if (opt_on(kOpt_no_resident)) return CRF_OK;
     // Rows may be SPLIT into sub-rows (pieces of <= thr arcs, thr a multiple of the chunk width).
     // Forward: a pair with many in-arcs becomes several sub-rows with the same (dst, label); everything
     // downstream is linear in q (a_{t+1}[dst] += e'*q, gamma = sum q*b), so sub-rows are simply separate
@@ -811,7 +811,7 @@ int build_resident(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     for (int p = 0; p < P; ++p) { fkey[p] = pair_dst[p]; gkey_b[p] = pair_dst[p]; }
     std::iota(state_id.begin(), state_id.end(), 0);
     gkey_f = state_id;
-    const int min_k = getenv("CRF_RES_MINK") ? std::max(1, atoi(getenv("CRF_RES_MINK"))) : 1;  // experiments
+    const int min_k = std::max(1, opt(kOpt_res_mink, 1));  // experiments
     for (int K = 1; K <= kResMaxK; K *= 2) {
         if (K < min_k) continue;
         std::vector<int> xoff, zoff;
@@ -959,8 +959,8 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
                                const std::vector<float> &end_lin, int level, bool *retry_next, int dup_mask, int *new_mask, bool short_only = false, bool *long_bail = nullptr, int K = 1) {
     FacDev &F = h->dev.fac;
     F = FacDev{};
-    if ((getenv("CRF_NO_FACTORED") && atoi(getenv("CRF_NO_FACTORED"))) || (getenv("CRF_NO_RESIDENT") && atoi(getenv("CRF_NO_RESIDENT")))) return CRF_OK;
-    const bool verbose = getenv("CRF_RES_VERBOSE") && atoi(getenv("CRF_RES_VERBOSE"));
+    if (opt_on(kOpt_no_factored) || opt_on(kOpt_no_resident)) return CRF_OK;
+    const bool verbose = opt_on(kOpt_verbose);
     auto give_up = [&](const char *why) { if (verbose) fprintf(stderr, "[fac_layout] not used: %s\n", why); return CRF_OK; };
     // ---- precondition: every state is entered with at most one label (true for T o LM: a state of the
     // composition remembers the last token), so "pair" and "destination state" are the same thing
@@ -1053,10 +1053,10 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     std::vector<int> entU(S, -1), ent(S, -1);   // entU: by main state; ent: a[s] itself (L, A or plain)
     // ... and a SECOND copy of the U entries (and the sink, which padding rows write) behind everything, on
     // other banks: [U][sink][L][A][plain] [pad] [U'][sink'] -- see pack_arcs
-    static const int bank_shift = getenv("CRF_FAC_BANK_SHIFT") ? atoi(getenv("CRF_FAC_BANK_SHIFT")) & 31 : 5;
+    const int bank_shift = opt(kOpt_fac_bank_shift, 5) & 31;
     // second copy of the gathered entries: per direction (dup_mask bit 0 forward, bit 1 backward); a direction that turns out
     // not to fit with it clears its bit in *new_mask and the caller builds again
-    const bool env_nodup = getenv("CRF_FAC_NO_DUP") && atoi(getenv("CRF_FAC_NO_DUP"));
+    const bool env_nodup = opt_on(kOpt_fac_no_dup);
     const bool no_dupf = !(dup_mask & 1) || env_nodup || K > 1, no_dupb = !(dup_mask & 2) || env_nodup || K > 1;   // (two CUs: one copy, the peers' entries are fetched into it)
     *new_mask = dup_mask;
     int nent = 0;
@@ -1413,19 +1413,19 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     // 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces the latter.
     // ... then 768 threads with the row constants in LDS (any number of slices per wave; CRF_FAC_RCL=1 starts there,
     // CRF_FAC_NO_RCL=1 skips it).  Each geometry first with the second copy of the gathered entries, then without it in the direction(s) that do not fit.
-    const bool want3 = !(getenv("CRF_FAC_THREADS") && atoi(getenv("CRF_FAC_THREADS")) == 512);
-    const bool no_rcl = getenv("CRF_FAC_NO_RCL") && atoi(getenv("CRF_FAC_NO_RCL"));
-    const bool from_rcl = getenv("CRF_FAC_RCL") && atoi(getenv("CRF_FAC_RCL"));
+    const bool want3 = !(opt(kOpt_fac_threads, 0) == 512);
+    const bool no_rcl = opt_on(kOpt_fac_no_rcl);
+    const bool from_rcl = opt_on(kOpt_fac_rcl);
     int rc = CRF_OK;
     struct Try { int level; bool short_only; int K = 1; };
     std::vector<Try> plan;
     if (!want3) plan = {{2, false}};
-    else if (getenv("CRF_FAC_K2") && atoi(getenv("CRF_FAC_K2"))) plan = {{1, false, 2}, {2, false}};   // (tests: two CUs per recursion for any T o LM graph)
+    else if (opt_on(kOpt_fac_k2)) plan = {{1, false, 2}, {2, false}};   // (tests: two CUs per recursion for any T o LM graph)
     else if (from_rcl) plan = {{1, false}, {2, false}};
     else if (no_rcl) plan = {{0, false}, {2, false}};
     else plan = {{0, true}, {1, false}, {0, false}, {1, false, 2}, {2, false}};   // level 0 only for graphs without long rows -- unless level 1 does
                                                                    // not take them; then two CUs per recursion (table geometry), then 512 threads
-    const bool no_k2 = getenv("CRF_FAC_NO_K2") && atoi(getenv("CRF_FAC_NO_K2"));
+    const bool no_k2 = opt_on(kOpt_fac_no_k2);
     bool long_bail = false;
     for (const Try &t : plan) {
         if (t.level == 0 && !t.short_only && plan.size() == 5 && !long_bail) continue;   // level 0 has been tried in full already
@@ -1574,7 +1574,7 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
                     if (dir == 0) {
                         for (int z = p0; z < p1; ++z) mine[(size_t)z] = peer[(size_t)z];
                         if (i == T - 1) { if (k == 0) for (int z = p0; z < p1; ++z) { mine[(size_t)R + z] = peer[(size_t)R + z]; mine[(size_t)2 * R + z] = peer[(size_t)2 * R + z]; } }
-                        else if (!(getenv("CRF_EMU_DROP_LIST") && atoi(getenv("CRF_EMU_DROP_LIST")))) for (int j = F.xlist_off[k]; j < F.xlist_off[k + 1]; ++j) {   // (negative control of the test)
+                        else if (!opt_on(kOpt_emu_drop_list)) for (int j = F.xlist_off[k]; j < F.xlist_off[k + 1]; ++j) {   // (negative control of the test)
                             const int en = C.xlist[(size_t)j], rid = en % R;
                             if (en < R || en >= 3 * R || rid < p0 || rid >= p1) return fail("a listed entry is not an L / A entry of the peer");
                             mine[(size_t)en] = peer[(size_t)en];
@@ -1618,7 +1618,7 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
                 }
                 tot += e[(size_t)t][(size_t)v] * sc;
             }
-        if (getenv("CRF_EMU_VERBOSE")) fprintf(stderr, "[emu] frame %d: pair-list mass %.12g, path mass %.12g\n", t, tot, out3[0]);
+        if (opt_on(kOpt_emu_verbose)) fprintf(stderr, "[emu] frame %d: pair-list mass %.12g, path mass %.12g\n", t, tot, out3[0]);
         if (!(std::fabs(tot - out3[0]) <= 1e-9 * std::fabs(out3[0]))) return fail("the grad pass's pair lists do not give the path mass at frame " + std::to_string(t));
     }
     return CRF_OK;

@@ -51,13 +51,18 @@ _lib.crf_timing_read.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
 _lib.crf_timing_read.restype = ctypes.c_int
 _lib.crf_stage_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
 _lib.crf_stage_i32.restype = ctypes.c_int
+_lib.crf_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_int]
+_lib.crf_debug_set.restype = ctypes.c_int
+_lib.crf_debug_unset.argtypes = [ctypes.c_char_p]
+_lib.crf_debug_unset.restype = ctypes.c_int
+_lib.crf_debug_list.restype = ctypes.c_char_p
 _lib.crf_last_error.restype = ctypes.c_char_p
 _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
     "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_debug_res_emulate", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
-    "crf_last_error", "crf_version",
+    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_error", "crf_version",
 )
 
 PROFILE_SLOTS = ("prep", "den_fwd_chain", "den_bwd_chain", "ctc_fwd_chain", "ctc_bwd_chain", "grad",
@@ -84,9 +89,54 @@ def _check(rc: int) -> None:
         raise RuntimeError(f"ctc_crf_hip error {rc}: {_lib.crf_last_error().decode()}")
 
 
+# Debug / experiment switches of tests and tools (include/ctc_crf_hip.h crf_debug_set): the LIBRARY never reads the
+# environment.  For the tools' convenience this binding applies CRF_DEBUG="name=value,name=value" once, at import.
+_DEBUG_SET: Dict[str, int] = {}
+
+
+def debug_set(key: str, value: Optional[int]) -> None:
+    """Set (value None: return to the default) one switch of crf_debug_list()."""
+    if value is None:
+        _check(_lib.crf_debug_unset(key.encode()))
+        _DEBUG_SET.pop(key, None)
+    else:
+        _check(_lib.crf_debug_set(key.encode(), int(value)))
+        _DEBUG_SET[key] = int(value)
+
+
+def debug_list() -> str:
+    return _lib.crf_debug_list().decode()
+
+
+class debug_opts:
+    """``with debug_opts(no_factored=1, bat_ul=16): ...`` -- switches set for the block, previous values restored after."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: _DEBUG_SET.get(k) for k in self.kw}
+        for k, v in self.kw.items():
+            debug_set(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            debug_set(k, v)
+
+
 # process-global graphs, one per device -- the reference keeps one graph per process in globals
-# indexed by DEVICE_HASH[cudaGetDevice()] (den_calculate.cu:263-273, 436-438)
+# indexed by DEVICE_HASH[cudaGetDevice()] (den_calculate.cu:263-273, 436-438).  Identified by a GENERATION number, not by
+# the handle's value: a later graph can be allocated at the address of one that was destroyed, and a context that compared
+# pointers would then take the newcomer for its own (and destroy it).
 _GRAPHS: Dict[int, int] = {}
+_GRAPH_GEN: Dict[int, int] = {}
+_gen_counter = 0
+
+
+def graph_generation(dev: int) -> Optional[int]:
+    """Generation number of the graph currently loaded on `dev` (None: none)."""
+    return _GRAPH_GEN.get(dev)
 
 
 def graph_dims(handle: int):
@@ -173,24 +223,28 @@ def init_env(fst_name: str, gpus: torch.Tensor) -> None:
         _check(_lib.crf_graph_create(os.fsencode(fst_name), dev, ctypes.byref(out)))
         if dev in _GRAPHS:  # the reference leaks on a second Init; we replace
             _lib.crf_graph_destroy(_vp(_GRAPHS.pop(dev)))
+        global _gen_counter
+        _gen_counter += 1
         _GRAPHS[dev] = out.value
+        _GRAPH_GEN[dev] = _gen_counter
 
 
 def release_env(gpus: torch.Tensor) -> None:
     """binding.cpp:58-63 ``release_env`` -> Release()."""
     for dev in [int(i) for i in gpus.tolist()]:
         h = _GRAPHS.pop(dev, None)
+        _GRAPH_GEN.pop(dev, None)
         if h is not None:
             _lib.crf_graph_destroy(_vp(h))
 
 
 def release_handles(handles: Dict[int, int]) -> None:
-    """Release exactly the graphs a CRFContext created: a device whose graph has been replaced since (a second
-    CRFContext on the same device) is left alone -- the replacement already destroyed the old tables."""
-    for dev, h in handles.items():
-        if _GRAPHS.get(dev) == h:
-            _GRAPHS.pop(dev)
-            _lib.crf_graph_destroy(_vp(h))
+    """Release exactly the graphs a CRFContext created ({device: generation}): a device whose graph has been replaced
+    since (a second CRFContext on the same device) is left alone -- the replacement already destroyed the old tables."""
+    for dev, gen in handles.items():
+        if _GRAPH_GEN.get(dev) == gen:
+            _GRAPH_GEN.pop(dev)
+            _lib.crf_graph_destroy(_vp(_GRAPHS.pop(dev)))
 
 
 def graph_for(device: torch.device) -> int:
@@ -262,10 +316,10 @@ def _h2d_async(src: torch.Tensor, dev: torch.device) -> torch.Tensor:
 
 _FUSED_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
-# Debug aid for the parity tests (CRF_DEBUG_POISON_WS=1): fill the workspace with NaN bit patterns before every call, so
+# Debug aid for the parity tests (set_debug_poison): fill the workspace with NaN bit patterns before every call, so
 # that a kernel reading a row before its producer has written it cannot pass by finding the previous call's values in the
 # block the caching allocator hands back.
-_POISON_WS = os.environ.get("CRF_DEBUG_POISON_WS", "0") not in ("", "0")
+_POISON_WS = False
 
 
 def set_debug_poison(on: bool) -> None:
@@ -371,3 +425,8 @@ def gpu_ctc(probs: torch.Tensor, grads: torch.Tensor, labels: torch.Tensor, labe
     _, g, ex = loss_fwd_bwd(probs.transpose(0, 1).contiguous(), labels, sizes, label_sizes, 0.0, -1.0, None, True)
     grads.copy_(g.transpose(0, 1))
     costs.copy_(ex["costs_ctc"].to(costs.device))
+
+
+for _kv in filter(None, os.environ.get("CRF_DEBUG", "").split(",")):   # tools only (see debug_set)
+    _k, _, _v = _kv.partition("=")
+    debug_set(_k.strip(), int(_v) if _v.strip() else 1)

@@ -158,13 +158,13 @@ class CRFContext:
         self._gpus = gpus_t
         # the graphs THIS context created: __del__ releases these and nothing else (a later context on the same
         # device replaces the graph; the reference's Release() would free whatever is current, den_calculate.cu:394-425)
-        self._handles = {int(i): core._GRAPHS[int(i)] for i in gpus}
+        self._handles = {int(i): core.graph_generation(int(i)) for i in gpus}   # {device: generation of the graph}
         self.den_lm = den_lm
 
     def owns_graph(self, idx: int) -> bool:
         """True while the graph this context loaded on device `idx` is still the device's current graph."""
-        h = getattr(self, '_handles', {}).get(idx)
-        return h is not None and core._GRAPHS.get(idx) == h
+        gen = getattr(self, '_handles', {}).get(idx)
+        return gen is not None and core.graph_generation(idx) == gen
 
     def __del__(self):
         if hasattr(self, '_handles'):

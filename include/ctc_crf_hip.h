@@ -172,6 +172,14 @@ int crf_profile_read(float *ms_out, int n);
  * values, 0 in a product build.  tools/timing_probe.py decodes them.  No reference counterpart. */
 int crf_timing_read(unsigned long long *out, int n);
 
+/* Debug / experiment switches of tests and tools (no reference counterpart).  The library NEVER reads the process
+ * environment: every switch is set here, by name, process-wide; crf_debug_unset returns it to its default.  Switches marked
+ * G are read when a graph is created, C per loss call, X when a (device, stream) context is first used;
+ * crf_debug_list() returns one "name: when  what" line per switch.  CRF_ERR_ARG for an unknown name. */
+int crf_debug_set(const char *key, int value);
+int crf_debug_unset(const char *key);
+const char *crf_debug_list(void);
+
 /* Message for the last non-zero status returned on this thread. */
 const char *crf_last_error(void);
 

@@ -10,6 +10,7 @@ import pytest
 from oracle import fst_io
 from cat_amd.den_lm import synth_den_lm
 from tests.conftest import ROOT
+from tests.util import crf_env
 
 
 def _declared_symbols():
@@ -112,13 +113,10 @@ def test_register_resident_layouts_host_only(tmp_path, golden_dir):
         assert st["res_K"] >= 1
         assert st["fac"] in (0, 1)
     # CRF_NO_FACTORED keeps the generic layout (read at graph creation)
-    os.environ["CRF_NO_FACTORED"] = "1"
-    try:
+    with crf_env(CRF_NO_FACTORED=1):
         h = core.compile_graph_host_only(p)
         assert core.graph_stats(h)["fac"] == 0
         core._lib.crf_graph_destroy(ctypes.c_void_p(h))
-    finally:
-        os.environ.pop("CRF_NO_FACTORED")
 
 
 def test_factored_layout_takes_an_estimated_ngram_graph(tmp_path):
@@ -171,9 +169,7 @@ def test_which_kernels_take_which_graph(tmp_path):
     core = ctc_crf._C
 
     def which(H, d, **env):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update({k: str(v) for k, v in env.items()})
-        try:
+        with crf_env(**env):
             p = os.path.join(str(tmp_path), f"g{H}_{d}.fst")
             if not os.path.exists(p):
                 synth_den_lm(72, H, d, 0, path=p)
@@ -182,12 +178,6 @@ def test_which_kernels_take_which_graph(tmp_path):
             k = core.den_kernels(h, 64, 1500, 72)
             core._lib.crf_graph_destroy(ctypes.c_void_p(h))
             return k, st
-        finally:
-            for k_, v in old.items():
-                if v is None:
-                    os.environ.pop(k_, None)
-                else:
-                    os.environ[k_] = v
 
     k, st = which(2048, 24)
     assert k == "factored" and st["fac"] == 1
@@ -219,20 +209,12 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
     core = ctc_crf._C
 
     def emu(path, T=5, **env):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update({k: str(v) for k, v in env.items()})
-        try:
+        with crf_env(**env):
             h = core.compile_graph_host_only(path)
             st = core.graph_stats(h)
             r = core.debug_fac_emulate(h, T, 7)
             core._lib.crf_graph_destroy(ctypes.c_void_p(h))
             return st["fac_geom"], r
-        finally:
-            for k_, v in old.items():
-                if v is None:
-                    os.environ.pop(k_, None)
-                else:
-                    os.environ[k_] = v
 
     def agree(r):
         # (backward: start weight x arc weight of the rowless states is ONE fp32 table constant -- a rounding of 6e-8 on those terms
@@ -294,20 +276,12 @@ def test_generic_resident_layout_emulated_on_the_host(tmp_path, golden_dir):
     core = ctc_crf._C
 
     def emu(path, T=4, **env):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update({k: str(v) for k, v in env.items()})
-        try:
+        with crf_env(**env):
             h = core.compile_graph_host_only(path)
             st = core.graph_stats(h)
             r = core.debug_res_emulate(h, T, 11)
             core._lib.crf_graph_destroy(ctypes.c_void_p(h))
             return st["res_K"], r
-        finally:
-            for k_, v in old.items():
-                if v is None:
-                    os.environ.pop(k_, None)
-                else:
-                    os.environ[k_] = v
 
     def agree(r):
         # (backward: start weight x arc weight of the rowless states is ONE fp32 table constant -- a rounding of 6e-8 on those terms
@@ -343,3 +317,54 @@ def test_generic_resident_layout_emulated_on_the_host(tmp_path, golden_dir):
     synth_den_lm(72, 3072, 24, seed=0, path=mid)
     K, r = emu(mid, T=3)
     assert K == 4 and agree(r)
+
+
+def test_generic_layout_that_does_not_fit_the_lds_takes_another_family(tmp_path):
+    """The generic register-resident kernels reserve two fixed 64 KiB state-vector buffers; a K = 1 layout with ~6.6 k rows and
+    V = 1000 classes needs more than the CU's 160 KiB with them.  Such a call must take the next kernel family (crf_den_kernels
+    != resident) instead of failing with 'graph too large' (round-2 advisor finding); a smaller V on the same graph still fits."""
+    import ctc_crf
+    core = ctc_crf._C
+    p = os.path.join(str(tmp_path), "v1000.fst")
+    synth_den_lm(1000, 3300, 5, 0, path=p)
+    with crf_env(CRF_NO_FACTORED=1):
+        h = core.compile_graph_host_only(p)
+        st = core.graph_stats(h)
+        assert st["S"] == 6601 and st["res_K"] == 1 and st["fac"] == 0
+        rows = max(st["res_fwd_rows"], st["res_bwd_rows"])
+        need = 2 * 65536 + 4 * (rows + 2 * ((1000 + 1 + 63) // 64 * 64) + 48)
+        assert need > 160 * 1024                                  # (the layout the finding was about)
+        assert core.den_kernels(h, 8, 100, 1000) != "resident"
+        core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+
+
+def test_debug_switches_are_set_by_name_not_from_the_environment(tmp_path):
+    """crf_debug_set / crf_debug_unset / crf_debug_list: the library's only switches; the process environment is never read."""
+    import ctc_crf
+    core = ctc_crf._C
+    names = [ln.split(":")[0] for ln in core.debug_list().splitlines() if ln]
+    assert "no_factored" in names and "bat_ul" in names and len(names) == len(set(names)) >= 30
+    with pytest.raises(RuntimeError):
+        core.debug_set("no_such_switch", 1)
+    p = os.path.join(str(tmp_path), "g.fst")
+    synth_den_lm(24, 64, 6, 0, path=p)
+
+    def fac():
+        h = core.compile_graph_host_only(p)
+        f = core.graph_stats(h)["fac"]
+        core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+        return f
+    os.environ["CRF_NO_FACTORED"] = "1"                            # (the round-2 spelling: must have no effect any more)
+    try:
+        assert fac() == 1
+    finally:
+        del os.environ["CRF_NO_FACTORED"]
+    core.debug_set("no_factored", 1)
+    try:
+        assert fac() == 0
+    finally:
+        core.debug_set("no_factored", None)
+    assert fac() == 1
+    src = open(os.path.join(ROOT, "cat_amd", "csrc", "crf_kernels.hip")).read() + open(os.path.join(ROOT, "cat_amd", "csrc", "fst_graph.cpp")).read() + \
+        open(os.path.join(ROOT, "cat_amd", "csrc", "res_layout.cpp")).read()
+    assert "getenv" not in src

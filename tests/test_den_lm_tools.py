@@ -118,7 +118,7 @@ def test_factoring_survives_openfst_style_rewrites(tmp_path):
     moved along the arcs -- determinizestar does not do this to an input-deterministic graph, but other OpenFst tools
     would): fst_graph.cpp regauge_pushed.  Host-only compile: no GPU needed."""
     from cat_amd.ctc_crf import _C
-    from tests.util import transform_graph
+    from tests.util import crf_env, transform_graph
 
     def stats(path):
         h = _C.compile_graph_host_only(path)
@@ -145,11 +145,13 @@ def test_factoring_survives_openfst_style_rewrites(tmp_path):
     assert s["regauged"] == 1 and s["fac"] == 1 and s["fac_matched_pairs"] == base["fac_matched_pairs"]
     assert s["fac_fwd_slots"] == base["fac_fwd_slots"] and s["fac_bwd_slots"] == base["fac_bwd_slots"]
     assert base["regauged"] == 0
-    os.environ["CRF_NO_REGAUGE"] = "1"
-    try:
+    with crf_env(CRF_REGAUGE_MINHASH=1):                    # the near-linear search graphs of millions of arcs take: same result
+        s2 = stats(q)
+    # (two states that share d rows collide in one of 12 min-hashes with probability 1 - (2 / (d + 2))^12: histories with one or
+    # two successors may be missed -- they then simply do not factor; exact for the graphs the search is meant for)
+    assert s2["regauged"] == 1 and s2["fac"] == 1 and 0.98 * base["fac_matched_pairs"] <= s2["fac_matched_pairs"] <= base["fac_matched_pairs"]
+    with crf_env(CRF_NO_REGAUGE=1):
         s = stats(q)
-    finally:
-        del os.environ["CRF_NO_REGAUGE"]
     assert s["regauged"] == 0 and (s["fac"] == 0 or s["fac_matched_pairs"] < base["fac_matched_pairs"]) and (s["fac"] == 1 or s["res_K"] >= 1)
 
 

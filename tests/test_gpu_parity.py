@@ -13,7 +13,7 @@ import torch
 
 import oracle
 from oracle import fst_io
-from tests.util import graph_to_file, make_batch, post_err, rel_err, small_synth
+from tests.util import crf_env, graph_to_file, make_batch, post_err, rel_err, small_synth
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -30,53 +30,31 @@ def crf():
 MODES = ["factored", "factored_rcl", "factored_k2", "resident", "streaming", "batch"]
 
 
-class _env:
-    def __init__(self, **kw):
-        self.kw = kw
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        os.environ.update({k: str(v) for k, v in self.kw.items()})
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+_env = crf_env   # (debug switches of the library, tests/util.py)
 
 
-class _mode:
-    """The denominator has three kernel families: factored register-resident (one CU per recursion; needs the
-    T o LM structure, else it falls back to the next), generic register-resident, and streaming (fallback for
-    graphs that do not fit registers).  CRF_NO_FACTORED / CRF_NO_RESIDENT are read when a graph is created."""
+class _mode(crf_env):
+    """The denominator has four kernel families: factored register-resident (one CU per recursion; needs the
+    T o LM structure, else it falls back to the next), generic register-resident, utterance-minor ("batch") and streaming
+    (fallbacks for graphs that do not fit registers).  no_factored / no_resident are read when a graph is created."""
 
     def __init__(self, mode):
         self.mode = mode
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in ("CRF_NO_RESIDENT", "CRF_NO_FACTORED", "CRF_NO_BATCH", "CRF_FAC_RCL", "CRF_FAC_NO_RCL", "CRF_FAC_K2")}
-        os.environ["CRF_NO_RESIDENT"] = "1" if self.mode in ("streaming", "batch") else "0"
-        os.environ["CRF_NO_FACTORED"] = "0" if self.mode.startswith("factored") else "1"
-        # "factored_rcl": the factored kernels' 768-thread variant with the row constants in an LDS table (what graphs with more
-        # than three slices of rows per wave take by themselves), forced for every graph with the T o LM structure
-        os.environ["CRF_FAC_RCL"] = "1" if self.mode == "factored_rcl" else "0"
-        os.environ["CRF_FAC_NO_RCL"] = "1" if self.mode == "factored_rc" else "0"   # row constants in registers even for long rows
-        # "factored_k2": the factored kernels over TWO compute units per recursion (what T o LM graphs of 120 k - 240 k arcs
-        # take by themselves), forced for every graph with the structure
-        os.environ["CRF_FAC_K2"] = "1" if self.mode == "factored_k2" else "0"
+        kw = dict(
+            CRF_NO_RESIDENT=mode in ("streaming", "batch"),
+            CRF_NO_FACTORED=not mode.startswith("factored"),
+            # "factored_rcl": the factored kernels' 768-thread variant with the row constants in an LDS table (what graphs with more
+            # than three slices of rows per wave take by themselves), forced for every graph with the T o LM structure
+            CRF_FAC_RCL=mode == "factored_rcl",
+            CRF_FAC_NO_RCL=mode == "factored_rc",      # row constants in registers even for long rows
+            # "factored_k2": the factored kernels over TWO compute units per recursion (what T o LM graphs of 120 k - 240 k arcs
+            # take by themselves), forced for every graph with the structure
+            CRF_FAC_K2=mode == "factored_k2")
         # "batch": the utterance-minor kernels (one launch per frame), what graphs that fit no register-resident layout
-        # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (CRF_NO_BATCH is read per call,
-        # so it stays set for the life of the test process's calls in this mode: see run_hip)
-        if self.mode in ("streaming", "batch"):
-            os.environ["CRF_NO_BATCH"] = "1" if self.mode == "streaming" else "0"
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (no_batch is read per call)
+        if mode in ("streaming", "batch"):
+            kw["CRF_NO_BATCH"] = mode == "streaming"
+        super().__init__(**kw)
 
 
 def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mode="factored"):

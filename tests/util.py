@@ -70,3 +70,21 @@ def transform_graph(g, path, seed=0, renumber=True, reorder=True, push=False):
     write_fst(path, S, int(perm[start]), src, dst, lab + 1, lab + 1, -w.astype(np.float32), -end2.astype(np.float32))
     from oracle import fst_io
     return fst_io.read_fst(path)
+
+
+class crf_env:
+    """``with crf_env(CRF_NO_FACTORED=1, CRF_BAT_UL=16): ...`` -- the library's debug switches (include/ctc_crf_hip.h
+    crf_debug_set; the library never reads the environment) under their historical upper-case names: CRF_X_Y is the switch
+    x_y.  Values are restored when the block ends."""
+
+    def __init__(self, **kw):
+        self.kw = {k[4:].lower() if k.startswith("CRF_") else k: int(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        from cat_amd.ctc_crf import _C
+        self._cm = _C.debug_opts(**self.kw)
+        self._cm.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        return self._cm.__exit__(*a)

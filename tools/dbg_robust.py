@@ -16,8 +16,7 @@ print("oracle", ref["loss"], ref["costs_den"], ref["costs_ctc"])
 core = ctc_crf._C
 for mode in ["factored", "resident", "streaming", "batch"]:
     for rob in ["", "0", "1"]:
-        if rob == "": os.environ.pop("CRF_ROBUST", None)
-        else: os.environ["CRF_ROBUST"] = rob
+        core.debug_set("robust", None if rob == "" else int(rob))
         with _mode(mode):
             ctx = ctc_crf.CRFContext(p, 0)
             st = core.graph_stats(core.graph_for(torch.device("cuda", 0)))

@@ -4,7 +4,7 @@ TAG=${1:-k2}
 OUT=gpurun_out; mkdir -p $OUT
 timeout 600 python -X faulthandler -m pytest tests/test_gpu_parity.py tests/test_gpu_callers.py -x -q -m gpu -k "k2 or two_cus" --timeout 300 2>&1 | grep -v amdgpu.ids | tail -8 | tee $OUT/k2_${TAG}_tests.txt
 for cfg in "2304 0" "3072 0" "3072 1" "4096 0" "4096 1"; do set -- $cfg
-  CRF_FAC_NO_K2=$2 timeout 200 python bench.py --no-cpu-baseline --histories $1 --fanout 24 --steps 5 --warmup 2 2>/dev/null | tail -1 | python -c "
+  CRF_DEBUG=fac_no_k2=$2 timeout 200 python bench.py --no-cpu-baseline --histories $1 --fanout 24 --steps 5 --warmup 2 2>/dev/null | tail -1 | python -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.read()); k=d['roofline']['kernels_ms']

@@ -3,7 +3,7 @@
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 for cfg in "1024 24 1" "1024 24 2" "1024 24 4" "512 24 1" "512 24 2" "512 24 4" "2048 24 2" "2048 24 4"; do
   set -- $cfg
-  CRF_RES_MINK=$3 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --histories $1 --fanout $2 > $OUT/kexp_$1_$2_$3.json 2> $OUT/kexp.err || tail -2 $OUT/kexp.err
+  CRF_DEBUG=res_mink=$3 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --histories $1 --fanout $2 > $OUT/kexp_$1_$2_$3.json 2> $OUT/kexp.err || tail -2 $OUT/kexp.err
   python - <<PY
 import json
 try:

@@ -19,12 +19,12 @@ PY
 LARGE="--histories 8192 --fanout 32 --steps 3 --warmup 1"
 run large $LARGE
 if [ "$2" == "sweep" ]; then
-  CRF_BAT_UL=64 run large_ul64 $LARGE
-  CRF_BAT_UL=16 run large_ul16 $LARGE
+  CRF_DEBUG=bat_ul=64 run large_ul64 $LARGE
+  CRF_DEBUG=bat_ul=16 run large_ul16 $LARGE
   ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_large_$TAG -o trace -- python $REPO/bench.py --no-cpu-baseline --histories 8192 --fanout 32 --steps 1 --warmup 1 > $OUT/prof_large_$TAG.log 2>&1; echo "rocprof rc=$?" )
   F=$(find $OUT/prof_large_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -8 "$F" | cut -c1-220
   find $OUT/prof_large_$TAG -name "*kernel_trace.csv" -size +8M -delete
 else
-  CRF_NO_BATCH=1 run large_streaming --histories 8192 --fanout 32 --steps 2 --warmup 1
+  CRF_DEBUG=no_batch=1 run large_streaming --histories 8192 --fanout 32 --steps 2 --warmup 1
 fi
 run c5 --B 8 --T 3000 --V 5000 --histories 32768 --fanout 64 --steps 2 --warmup 1

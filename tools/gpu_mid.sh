@@ -1,9 +1,9 @@
 #!/bin/bash
 # tools/gpu_mid.sh -- graphs between the benchmark graph and the large one (same generator, d = 24): which kernels take them, how
-# fast; "nores": the same with CRF_NO_RESIDENT=1 (utterance-minor kernels instead of the generic K-CU layout)
+# fast; "nores": the same with CRF_DEBUG=no_resident=1 (utterance-minor kernels instead of the generic K-CU layout)
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 for cfg in "3072 24 0" "3072 24 1" "4096 24 0" "4096 24 1" "6144 24 0"; do set -- $cfg
-  CRF_NO_RESIDENT=$3 timeout 300 python bench.py --no-cpu-baseline --histories $1 --fanout $2 --steps 5 --warmup 2 > $OUT/pt_mid_$1_$3.json 2> $OUT/pt_mid_$1_$3.err
+  CRF_DEBUG=no_resident=$3 timeout 300 python bench.py --no-cpu-baseline --histories $1 --fanout $2 --steps 5 --warmup 2 > $OUT/pt_mid_$1_$3.json 2> $OUT/pt_mid_$1_$3.err
   python - <<PY
 import json
 try:
