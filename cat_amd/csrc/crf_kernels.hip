@@ -91,7 +91,16 @@ struct LossParams {
     float *cost_alpha, *cost_beta, *cost_ctc;  // [B]
     int *invalid;                 // [B]
     int *redo;                    // [2][B] utterance whose scaled-fp32 denominator lost all its mass (forward / backward): redone by the robust kernels
-    int force_redo;               // CRF_ROBUST=1: every utterance takes the robust path
+    int force_redo;               // switch robust = 1: every utterance takes the robust path
+    // Numerator fallback.  The fp64 chains rescale a frame's vector by its maximum; a frame whose posterior mass sits more than
+    // ~650 nats below (max alpha) * (max beta) -- long utterances with many labels whose emissions do not follow the labels:
+    // T = 3000, L = 500 on random inputs -- has the products that matter at the bottom of the fp64 range (and beyond: 0 * inf).
+    // The grad kernels recognise such frames from the frame's exponents alone (ctc_frame_factor), contribute nothing for them
+    // and mark them; crf_robust_ctc_kernel redoes the marked utterances' chains in the log domain and
+    // crf_robust_ctc_fix_kernel adds the marked frames' posteriors.
+    int *redo_ctc;                // [B] 0 = fine, 1 = some frames marked in ctc_bad, 2 = the whole utterance (the forward chain lost its mass, or forced)
+    int *ctc_bad;                 // [B*T] marked frames (cleared by the prep kernel)
+    int force_redo_ctc;           // switches robust = 1 / robust_ctc = 1: every utterance's numerator takes the log-domain path
     int64_t gvec_stride;          // floats per utterance of `gvec`
     // outputs
     float *grad, *loss, *out_den, *out_beta, *out_ctc;
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < p.nclear; i += 256) __hip_atomic_store(p.clear + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (p.redo) for (int i = threadIdx.x; i < 2 * p.B; i += 256) p.redo[i] = p.force_redo;
+        if (p.redo_ctc) for (int i = threadIdx.x; i < p.B; i += 256) p.redo_ctc[i] = p.force_redo_ctc ? 2 : 0;
     }
     const int64_t f = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
     if (f >= (int64_t)p.B * p.T) return;
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
         ssum = gsum(ssum);
         if (sub == 0) { p.moff[f] = -logf(ssum); p.inv_s[f] = 1.f / ssum; }   // (moff == mx without fusion: same array)
     }
-    if (sub == 0) p.mx[f] = m;
+    if (sub == 0) { p.mx[f] = m; if (p.ctc_bad) p.ctc_bad[f] = 0; }
 }
 
 // crf_stage_i32: the integer metadata of a call (labels, lengths, offsets) come from the host; a kernel reads
@@ -648,6 +658,20 @@ __device__ __forceinline__ float to_log_d(double zs, int e, double mxs) {
     return zs > 0.0 ? (float)(log(zs) - (double)e * 0.6931471805599453 + mxs) : -INFINITY;
 }
 
+// The factor that turns the scaled products A~_t[s] * Bx~_t[s] of frame `bt` into posteriors, or 0 with the frame MARKED for the
+// log-domain fallback: A~ and Bx~ are rescaled to a maximum in [2^40, 2^41), so a factor beyond 2^900 means the entries that carry
+// the frame's mass are ~2^-900 below the maxima -- at the bottom of the fp64 range, where they are rounded away or flushed (and the
+// factor itself overflows: 0 * inf).  A frame that passes has every entry that matters to 1e-9 of the posterior as a normal number,
+// at this frame and -- mass never grows along a path -- at every frame before it.
+constexpr int kCtcSafeExp = 900;
+__device__ __forceinline__ double ctc_frame_factor(const LossParams &p, int b, int64_t bt, double invc, int ezc) {
+    const int e = ezc - p.ECA[bt] - p.ECB[bt];
+    if (e + ilogb(invc) > kCtcSafeExp) { p.ctc_bad[bt] = 1; p.redo_ctc[b] = 1; return 0.0; }
+    return ldexp(invc, e);
+}
+// scaled partition sum of the numerator as the grad kernels use it: 0 (= "contribute nothing") for an utterance that is redone whole
+__device__ __forceinline__ double ctc_zc_for_grad(const LossParams &p, int b) { return p.redo_ctc[b] == 2 ? 0.0 : p.ctc_zc[b]; }
+
 // NR = ctc states per thread actually needed (ceil((2L+1)/512) rounded up to 1, 2, 4, 8): a frame is ONE
 // in-order instruction stream per wave (~5 cycles per instruction, dependent or not), so the predicated-off
 // register iterations of a fixed NR = 8 were most of a frame's ~440 instructions for ordinary label lengths.
@@ -794,11 +818,12 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
     const double mxs = ctc_mx_total(p, b, lx, c.red, tid);
     if (tid == 0) {
         const double zc = Af[Sx - 1] + (Sx > 1 ? Af[Sx - 2] : 0.0);
-        const bool ok = zc > 0.0;
+        const bool ok = zc > 0.0 && zc < INFINITY;
         p.ctc_zc[b] = ok ? zc : 0.0;
         p.ctc_ez[b] = E;
         p.cost_ctc[b] = ok ? to_log_d(zc, E, mxs) : 0.f;
         p.invalid[b] = ok ? 0 : 1;
+        if (!ok) p.redo_ctc[b] = 2;   // a VALID label sequence whose scaled chain lost all its mass: the log-domain kernels decide
     }
 }
 
@@ -1652,6 +1677,13 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         constexpr int NP = PIPE > 0 ? PIPE : 1;
         [[maybe_unused]] f32x2 ga01[NP], ga23[NP], gb01[NP], gb23[NP];   // PIPE: two sets of gathered entries in rotation
         if constexpr (PIPE > 0) { CRF_RES_GATHER_N(ga01, ga23, A, xb, 0, NP); }   // the frame's first requests, ahead of its bookkeeping
+#ifdef CRF_EXP_GFIRST
+        // the first batch of gathers goes out BEFORE the frame's bookkeeping: right after the barrier every wave of the workgroup
+        // does ~50 instructions of scalar bookkeeping (and waits a whole LDS round trip for the frame maximum) while the LDS is idle
+        constexpr int NB0 = PIPE == 0 ? NB : 1;
+        [[maybe_unused]] f32x2 h01[NB0], h23[NB0];
+        if constexpr (PIPE == 0) { CRF_RES_GATHER_N(h01, h23, A, xb, 0, NB0); }
+#endif
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
         const int tpre = DIR == 0 ? t + 1 : t - 2;
         // (only the waves that hold emissions take part in the prefetch: the compiler waits for vmcnt(0) around these
@@ -1830,7 +1862,13 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             constexpr int nb = NB;
             if (c0 < nch_f) {
                 f32x2 g01[NB], g23[NB];
-                CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb);
+#ifdef CRF_EXP_GFIRST
+                if (c0 == 0) {
+#pragma unroll
+                    for (int ci = 0; ci < nb; ++ci) { g01[ci] = h01[ci]; g23[ci] = h23[ci]; }
+                } else
+#endif
+                { CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb); }
 #pragma unroll
                 for (int ci = 0; ci < nb; ++ci) {
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
@@ -2055,7 +2093,7 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
     int ez = 0, ezc = 0, Sx = 0;
     const int *ul = nullptr;
     if (do_den) { zs = p.den_zs[b]; ez = p.den_ez[b]; }
-    if (do_ctc) { zc = p.ctc_zc[b]; ezc = p.ctc_ez[b]; Sx = 2 * p.ly[b] + 1; ul = p.labels + p.lab_off[b]; }
+    if (do_ctc) { zc = ctc_zc_for_grad(p, b); ezc = p.ctc_ez[b]; Sx = 2 * p.ly[b] + 1; ul = p.labels + p.lab_off[b]; }
     const float inv = zs > 0.f ? 1.f / zs : 0.f;
     const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
 
@@ -2095,7 +2133,7 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
             __syncthreads();
             if (zc > 0.0) {
                 const double *Ar = p.CA + (bt0 + t) * p.Sc, *Br = p.CB + (bt0 + t) * p.Sc;
-                const double fc = ldexp(invc, ezc - p.ECA[bt0 + t] - p.ECB[bt0 + t]);
+                const double fc = ctc_frame_factor(p, b, bt0 + t, invc, ezc);
                 float blank = 0.f;
                 for (int s = tid; s < Sx; s += kGradThreads) {
                     const float pr = (float)(Ar[s] * Br[s] * fc);  // a posterior, in [0,1]
@@ -2363,7 +2401,7 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
     float *gc = lds;                          // [4][Vp] in rotation
     double *fcs = (double *)(gc + 4 * Vp);    // [kGCFrames]
     const int64_t bt0 = (int64_t)b * p.T;
-    const double zc = p.ctc_zc[b];
+    const double zc = ctc_zc_for_grad(p, b);
     const int ezc = p.ctc_ez[b], Sx = 2 * p.ly[b] + 1;
     const int *ul = p.labels + p.lab_off[b];
     const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
@@ -2376,7 +2414,7 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
         mylab[i] = (s < Sx && (s & 1)) ? ul[s >> 1] : 0;
     }
     if (tid < kGCFrames)
-        fcs[tid] = (t0 + tid < tl && zc > 0.0) ? ldexp(invc, ezc - p.ECA[bt0 + t0 + tid] - p.ECB[bt0 + t0 + tid]) : 0.0;
+        fcs[tid] = (t0 + tid < tl && zc > 0.0) ? ctc_frame_factor(p, b, bt0 + t0 + tid, invc, ezc) : 0.0;
     double an[REGS], bn[REGS];
     float rown[kGCVRegs];
 #define CRF_GC_FETCH(t)                                                                          \
@@ -3248,7 +3286,7 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParam
     double zc = 0.0;
     int ezc = 0, Sx = 0;
     const int *ul = nullptr;
-    if (do_ctc) { zc = p.ctc_zc[b]; ezc = p.ctc_ez[b]; Sx = 2 * p.ly[b] + 1; ul = p.labels + p.lab_off[b]; }
+    if (do_ctc) { zc = ctc_zc_for_grad(p, b); ezc = p.ctc_ez[b]; Sx = 2 * p.ly[b] + 1; ul = p.labels + p.lab_off[b]; }
     const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
     auto bmax = [&](double v) {
 #pragma unroll
@@ -3299,7 +3337,7 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParam
         const double nrm = bsum(part);
         if (do_ctc && zc > 0.0) {
             const double *Ar = p.CA + (bt0 + t) * p.Sc, *Bx = p.CB + (bt0 + t) * p.Sc;
-            const double fc = ldexp(invc, ezc - p.ECA[bt0 + t] - p.ECB[bt0 + t]);
+            const double fc = ctc_frame_factor(p, b, bt0 + t, invc, ezc);
             float blank = 0.f;
             for (int s = tid; s < Sx; s += kGradThreads) {
                 const float pr = (float)(Ar[s] * Bx[s] * fc);
@@ -3317,6 +3355,160 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParam
                 o -= (p.c_den - (zc > 0.0 ? p.c_ctc : 0.f)) * __expf(ld_x(p, (bt0 + t) * V + v) - (float)mx) * p.inv_s[bt0 + t];
             row[v] = o;
         }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Numerator fallback (LossParams::redo_ctc): the CTC recursions of the marked utterances in the LOG domain, fp64 -- the arithmetic
+// of the reference's numerator (gpu_ctc_kernels.h:87-458 works on log-probabilities with log_plus) at double width.  Block
+// x < B: forward chain of utterance x, log alpha_t[s] (emission included) into the CA rows and log p(labels | x) into the
+// utterance's cost; else the backward chain, log beta_t[s] (emission excluded) into the CB rows.  One barrier per frame, the
+// next frame's emissions requested a frame ahead.  Unmarked utterances leave at once.
+// LDS: A[2][Sxp] (double) | red[16] (double) | lab[Sxp] (int)   (same carve as the scaled chains)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
+    if (!(m > -INFINITY)) return -INFINITY;
+    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+}
+__global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const bool fwd = (int)blockIdx.x < p.B;
+    const int b = fwd ? (int)blockIdx.x : (int)blockIdx.x - p.B;
+    if (!p.redo_ctc[b]) return;
+    const int tid = threadIdx.x;
+    const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
+    const CtcLds c = ctc_carve(lds, Sxp);
+    double *A = c.A;
+    const int *lab = c.lab;
+    const int64_t bt0 = (int64_t)b * p.T;
+    if (!ctc_setup(p, b, c, L, lx, tid)) return;            // (not a valid label sequence: the scaled chain has said so)
+    constexpr int NR = kCtcRegs;
+    int mylab[NR];
+    bool skip[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int s = tid + i * kCtcThreads;
+        mylab[i] = s < Sx ? lab[s] : 0;
+        skip[i] = fwd ? (s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2])
+                      : ((s + 2 < Sx) && lab[s + 2] != 0 && lab[s + 2] != mylab[i]);
+    }
+    // log p_t[l'_s] = (x_t[l] - max_t) + offset_t (offset = the row maximum, or -log sum exp(x - max) with the fused log_softmax)
+    auto lp = [&](int t, int i) -> double {
+        return ((double)ld_x(p, (bt0 + t) * V + mylab[i]) - (double)p.mx[bt0 + t]) + (double)p.moff[bt0 + t];
+    };
+    double en[NR];
+    if (fwd) {
+        double *CArow = p.CA + bt0 * p.Sc;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int s = tid + i * kCtcThreads;
+            if (s < Sxp) {
+                const double v = (s < 2 && s < Sx) ? lp(0, i) : -INFINITY;
+                A[s] = v;
+                A[Sxp + s] = -INFINITY;
+                if (s < Sx) CArow[s] = v;
+            }
+            en[i] = (s < Sx && lx > 1) ? lp(1, i) : 0.0;
+        }
+        __syncthreads();
+        for (int t = 1; t < lx; ++t) {
+            const double *Ac = A + ((t - 1) & 1) * Sxp;
+            double *An = A + (t & 1) * Sxp;
+            CArow = p.CA + (bt0 + t) * p.Sc;
+            double e[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) { e[i] = en[i]; if (tid + i * kCtcThreads < Sx && t + 1 < lx) en[i] = lp(t + 1, i); }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int s = tid + i * kCtcThreads;
+                if (s < Sx) {
+                    const double v = lse3(Ac[s], s >= 1 ? Ac[s - 1] : -INFINITY, skip[i] ? Ac[s - 2] : -INFINITY) + e[i];
+                    An[s] = v;
+                    CArow[s] = v;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double *Af = A + ((lx - 1) & 1) * Sxp;
+            const double lz = lse3(Af[Sx - 1], Sx > 1 ? Af[Sx - 2] : -INFINITY, -INFINITY);
+            const bool ok = lz > -INFINITY && lz < INFINITY;
+            p.ctc_zc[b] = lz;                    // (from here on the LOG of the partition sum: read by crf_robust_ctc_fix_kernel only)
+            p.cost_ctc[b] = ok ? (float)lz : 0.f;
+            p.invalid[b] = ok ? 0 : 1;
+        }
+    } else {
+        // Y_t[s] = log(e_t[l'_s] Bx_t[s]) in LDS; Bx_t itself goes to the CB rows
+        double *CBrow = p.CB + (bt0 + lx - 1) * p.Sc;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int s = tid + i * kCtcThreads;
+            if (s < Sxp) {
+                const double bx = (s < Sx && s >= Sx - 2) ? 0.0 : -INFINITY;
+                A[s] = s < Sx ? bx + lp(lx - 1, i) : -INFINITY;
+                A[Sxp + s] = -INFINITY;
+                if (s < Sx) CBrow[s] = bx;
+            }
+            en[i] = (s < Sx && lx > 1) ? lp(lx - 2, i) : 0.0;
+        }
+        __syncthreads();
+        for (int k = 1; k < lx; ++k) {
+            const int t = lx - 1 - k;
+            const double *Yc = A + ((k - 1) & 1) * Sxp;
+            double *Yn = A + (k & 1) * Sxp;
+            CBrow = p.CB + (bt0 + t) * p.Sc;
+            double e[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) { e[i] = en[i]; if (tid + i * kCtcThreads < Sx && t >= 1) en[i] = lp(t - 1, i); }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int s = tid + i * kCtcThreads;
+                if (s < Sx) {
+                    const double bx = lse3(Yc[s], s + 1 < Sx ? Yc[s + 1] : -INFINITY, skip[i] ? Yc[s + 2] : -INFINITY);
+                    CBrow[s] = bx;
+                    Yn[s] = bx + e[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+// ... and the posteriors of the marked frames (all frames of an utterance redone whole), subtracted from the rows the grad pass
+// wrote without them: grad[b][t][v] -= c_ctc * sum_{s: l'_s = v} exp(log alpha_t[s] + log beta_t[s] - log Z).  grid (T / 16, B).
+__global__ __launch_bounds__(kGradThreads) void crf_robust_ctc_fix_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.y, V = p.V;
+    const int redo = p.redo_ctc[b];
+    if (!redo) return;
+    const double lz = p.ctc_zc[b];
+    if (!(lz > -INFINITY && lz < INFINITY) || p.invalid[b]) return;   // no alignment at all: the numerator contributes nothing
+    const int lx = p.lx[b], Sx = 2 * p.ly[b] + 1;
+    const int *ul = p.labels + p.lab_off[b];
+    const int64_t bt0 = (int64_t)b * p.T;
+    float *gc = lds;                                          // [Vp]
+    const int t0 = blockIdx.x * kGCFrames, t1 = min(t0 + kGCFrames, lx);
+    for (int t = t0; t < t1; ++t) {
+        if (redo != 2 && !p.ctc_bad[bt0 + t]) continue;      // (uniform)
+        for (int v = tid; v < V; v += kGradThreads) gc[v] = 0.f;
+        __syncthreads();
+        const double *Ar = p.CA + (bt0 + t) * p.Sc, *Bx = p.CB + (bt0 + t) * p.Sc;
+        float blank = 0.f;
+        for (int s = tid; s < Sx; s += kGradThreads) {
+            const float pr = (float)exp(Ar[s] + Bx[s] - lz);
+            if (s & 1) atomicAdd(&gc[ul[s >> 1]], pr);
+            else blank += pr;
+        }
+        blank = wave_sum(blank);
+        if (lane == 0) atomicAdd(&gc[0], blank);
+        __syncthreads();
+        float *row = p.grad + (bt0 + t) * V;
+        // (an utterance redone whole went through the grad pass as "no numerator": with the fused log_softmax its softmax term
+        // was taken with the factor c_den instead of c_den - c_ctc)
+        const float ks = (redo == 2 && p.fused) ? p.c_ctc * pow2f(-kEpExp) * p.inv_s[bt0 + t] : 0.f;
+        for (int v = tid; v < V; v += kGradThreads) row[v] += ks * p.ep[(bt0 + t) * V + v] - p.c_ctc * gc[v];
         __syncthreads();
     }
 }
@@ -3356,7 +3548,7 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
 // host side
 // ---------------------------------------------------------------------------------------------
 struct WsLayout {
-    int64_t off_ep, off_mx, off_moff, off_invs, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_xch, off_row0, total;
+    int64_t off_ep, off_mx, off_moff, off_invs, off_Q, off_BP, off_EQ, off_EB, off_CA, off_CB, off_ECA, off_ECB, off_pb, off_cbad, off_xch, off_row0, total;
     int64_t xch_bytes;
     int64_t Rq, Rb;
     bool res, gv, fac;
@@ -3429,6 +3621,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_ECA = o; o = al(o + B * T * 4);
     w.off_ECB = o; o = al(o + B * T * 4);
     w.off_pb = o; o = al(o + 32 * B * 8);
+    w.off_cbad = o; o = al(o + B * T * 4);   // frames of the numerator marked for the log-domain fallback
     // tagged granules [2 slots] of both directions, then one XCD-id word per CU of every recursion
     w.xch_bytes = (w.res && !w.fac && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8)
                 : (w.fac && h->dev.fac.K > 1) ? al((B * 2 * ((int64_t)h->dev.fac.f.G + h->dev.fac.b.G) + 2 * B * kResMaxK) * 8) : 0;
@@ -3599,6 +3792,7 @@ struct Prof {
     bool made = false, used[8]{};
 };
 static thread_local Prof g_prof;
+static thread_local const char *g_den_kernel = "";   // template instantiation of the denominator recursions' kernel in the last call (crf_last_den_kernel)
 static void prof_mark(int slot, bool stop, hipStream_t st) {
     if (!g_prof.on) return;
     if (!g_prof.made) {
@@ -3615,6 +3809,7 @@ static int launch_den_pair(const LossParams &p, size_t lds, hipStream_t st) {
     static LdsMark mark;
     int rc;
     if ((rc = ensure_lds((const void *)crf_den_pair_kernel<GV>, lds, mark, "den pair"))) return rc;
+    g_den_kernel = GV ? "crf_den_pair_kernel<true>" : "crf_den_pair_kernel<false>";
     prof_mark(1, false, st); prof_mark(2, false, st);
     hipLaunchKernelGGL((crf_den_pair_kernel<GV>), dim3((unsigned)(2 * p.B)), dim3(kChainThreads), lds, st, p);
     prof_mark(1, true, st); prof_mark(2, true, st);
@@ -3663,6 +3858,7 @@ static int launch_res_pair(const LossParams &lp, size_t lds, int b0, int nb, hip
     static LdsMark mark;
     int rc;
     if ((rc = ensure_lds((const void *)crf_res_pair_kernel, lds, mark, "res pair"))) return rc;
+    g_den_kernel = "crf_res_pair_kernel";
     const ResParams pf = res_params(lp, 0, b0), pb = res_params(lp, 1, b0);
     hipLaunchKernelGGL(crf_res_pair_kernel, dim3((unsigned)(2 * nb * lp.g.res.K)), dim3(kResThreads), lds, st, pf, pb);
     hipError_t e;
@@ -3718,6 +3914,7 @@ static int launch_fac2_pair(const LossParams &lp, size_t lds, hipStream_t st, in
     FacParams pb = fac_params(lp, 1, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
     pf.b0 = pb.b0 = b0; pf.nbu = pb.nbu = nbu;
     auto *k = crf_fac2_pair_kernel<kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B>;
+        g_den_kernel = "crf_fac2_pair_kernel<768,20,4,4>";
     int rc;
     if ((rc = ensure_lds((const void *)k, lds, mk, "fac2 pair"))) return rc;
     hipLaunchKernelGGL(k, dim3((unsigned)(2 * nbu * 2)), dim3(kFac3Threads), lds, st, pf, pb);
@@ -3740,30 +3937,37 @@ static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int
     const int pipe = opt(kOpt_fac_pipe, kFacPipeDefault);   // software-pipelined gather batches (fac_chain_body)
     if (g3 && pipe > 0 && F.rcl) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true, CRF_FAC_PIPE_N>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,20,4,4,true,true,pipe>" : "crf_fac_pair_kernel<false,768,20,4,4,true,true,pipe>";
         if ((rc = ensure_lds((const void *)k, lds, m3lp, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else if (g3 && pipe > 0 && ml) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, false, CRF_FAC_PIPE_N>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,false,pipe>" : "crf_fac_pair_kernel<false,768,21,4,4,true,false,pipe>";
         if ((rc = ensure_lds((const void *)k, lds, m3mp, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else if (g3 && pipe > 0) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, false, false, CRF_FAC_PIPE_N>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,false,false,pipe>" : "crf_fac_pair_kernel<false,768,21,4,4,false,false,pipe>";
         if ((rc = ensure_lds((const void *)k, lds, m3p, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else if (g3 && F.rcl) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,20,4,4,true,true,0>" : "crf_fac_pair_kernel<false,768,20,4,4,true,true,0>";
         if ((rc = ensure_lds((const void *)k, lds, m3l, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else if (g3 && ml) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,false,0>" : "crf_fac_pair_kernel<false,768,21,4,4,true,false,0>";
         if ((rc = ensure_lds((const void *)k, lds, m3m, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else if (g3) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, false>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,false,false,0>" : "crf_fac_pair_kernel<false,768,21,4,4,false,false,0>";
         if ((rc = ensure_lds((const void *)k, lds, m3, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else {
         auto *k = crf_fac_pair_kernel<FLAG, kResThreads, kResNCH, kResBatch, kResBatch, true>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,512,30,6,6,true,false,0>" : "crf_fac_pair_kernel<false,512,30,6,6,true,false,0>";
         if ((rc = ensure_lds((const void *)k, lds, m5, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kResThreads), lds, st, pf, pb);
     }
@@ -3883,10 +4087,13 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     float *pb = (float *)(p.cb_mxs + B);
     p.cb_part = pb + 8 * B; p.cb_F = (int *)(pb + 8 * B + (int64_t)kResMaxK * B);
     p.redo = (int *)(pb + 16 * B);   // [2][B]
+    p.redo_ctc = (int *)(pb + 18 * B);   // [B]
+    p.ctc_bad = (int *)(base + w.off_cbad);
     // CRF_ROBUST: 0 = never run the robust fallback, 1 = every utterance takes it (tests, or "safe mode"); default: the
     // utterances the fast kernels flag
     const int robust_env = opt(kOpt_robust, -1);   // (read per call: tests switch it)
     p.force_redo = (den && robust_env == 1) ? 1 : 0;
+    p.force_redo_ctc = (ctc && (robust_env == 1 || opt_on(kOpt_robust_ctc))) ? 1 : 0;
     p.xch = (unsigned long long *)(base + w.off_xch);
     p.err = (int *)(base + w.off_xch + w.xch_bytes);
     p.Row0 = (float *)(base + w.off_row0);
@@ -4142,6 +4349,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         CRF_BAT_UL(crf_batch_transpose_kernel, dim3((unsigned)((V + 63) / 64), (unsigned)T, ngrp), bp);
         hipLaunchKernelGGL(crf_batch_init_kernel, dim3((unsigned)(((int64_t)bp.SX * w.Bp + kBatThreads - 1) / kBatThreads)), dim3(kBatThreads), 0, stream, bp);
         LAUNCH_CHECK("crf_batch_init_kernel");
+        g_den_kernel = w.UL == 64 ? (bfac ? "crf_batch_frame_kernel<64,4,true>" : "crf_batch_frame_kernel<64,4,false>")
+                     : w.UL == 32 ? (bfac ? "crf_batch_frame_kernel<32,4,true>" : "crf_batch_frame_kernel<32,4,false>")
+                     : w.UL == 16 ? (bfac ? "crf_batch_frame_kernel<16,4,true>" : "crf_batch_frame_kernel<16,4,false>")
+                     : (bfac ? "crf_batch_frame_kernel<8,4,true>" : "crf_batch_frame_kernel<8,4,false>");
         for (int j = 0; j <= (int)T; ++j) {
             bp.j = j;
             switch (w.UL) {   // (4: batches of gathers in flight per wave; 2 measured 6 % slower, 8 needs more registers than a wave has)
@@ -4280,6 +4491,17 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         hipLaunchKernelGGL(crf_robust_grad_kernel, dim3(16, (unsigned)B), dim3(kGradThreads), lg, stream, p);
         LAUNCH_CHECK("crf_robust_grad_kernel");
     }
+    if (ctc && robust_env != 0) {
+        // Numerator fallback: utterances with frames the grad pass marked (or whose scaled chain lost its mass) redo their chains
+        // in the log domain; the others' workgroups leave at once -- two near-empty launches per call.
+        static LdsMark mrc;
+        if ((rc = ensure_lds((const void *)crf_robust_ctc_kernel, lds_ctc, mrc, "robust ctc"))) return rc;
+        hipLaunchKernelGGL(crf_robust_ctc_kernel, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, stream, p);
+        LAUNCH_CHECK("crf_robust_ctc_kernel");
+        hipLaunchKernelGGL(crf_robust_ctc_fix_kernel, dim3((unsigned)((T + kGCFrames - 1) / kGCFrames), (unsigned)B), dim3(kGradThreads),
+                           (size_t)rup64((int)V) * sizeof(float), stream, p);
+        LAUNCH_CHECK("crf_robust_ctc_fix_kernel");
+    }
     prof_mark(6, false, stream);
     hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
     prof_mark(6, true, stream);
@@ -4310,6 +4532,8 @@ int crf_timing_read(unsigned long long *out, int n) {
     return 0;  // not a timing build
 #endif
 }
+
+const char *crf_last_den_kernel(void) { return g_den_kernel; }
 
 void crf_profile_enable(int on) { g_prof.on = on != 0; if (!on) g_prof.have = false; }
 

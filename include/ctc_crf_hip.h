@@ -165,6 +165,10 @@ int crf_loss_fwd_bwd_logits(const crf_graph *g, const void *logits_dev, int dtyp
  *   [4] ctc backward chain  [5] grad  [6] finalize  [7] whole call (first launch .. last launch)
  * (-1 for kernels that were not launched).  Returns the number of slots written. */
 void crf_profile_enable(int on);
+/* The template instantiation of the kernel that ran the denominator recursions in this thread's last call, e.g.
+ * "crf_fac_pair_kernel<true,768,21,4,4,false,false,0>" (the prefix of the name rocprofv3 reports; "pipe" in the last place =
+ * the software-pipelined variant): bench.py keys its committed PMC traffic numbers by workload AND by this string. */
+const char *crf_last_den_kernel(void);
 int crf_profile_read(float *ms_out, int n);
 
 /* Diagnostics, timing builds only (CRF_BUILD_DEFS=-DCRF_TIMING python -m cat_amd.build --force): copies

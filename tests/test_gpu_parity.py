@@ -493,6 +493,72 @@ def test_underflow_fallback_forbidden_argmax(crf, tmp_path, mode):
         assert rel_err(grad[b], ref["grad"][b]) <= TOL
 
 
+@pytest.mark.parametrize("mode", ["factored", "resident", "batch"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_numerator_fallback_forced(crf, tmp_path, mode, fused):
+    """robust_ctc = 1: EVERY utterance's numerator is redone by the log-domain kernels (crf_robust_ctc_kernel + the fix pass)
+    behind the grad pass, which then treats it as absent; ordinary inputs, ragged lengths, an empty label sequence and an invalid
+    one (L + repeats > T) riding along; loss, per-utterance costs and the gradient against the fp64 oracle -- also behind the fused
+    log_softmax, whose softmax term depends on whether the numerator counts."""
+    g, p = small_synth(tmp_path, 12, 40, 6, 5)
+    B, T, V = 5, 37, 12
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=8, ragged=True)
+    lab = [list(labels[sum(ly[:i]):sum(ly[:i + 1])]) for i in range(B)]
+    lab[3] = []                                            # no labels: the all-blank path
+    lab[4] = [3] * 25                                      # 25 labels + 24 repeats > lx: invalid (gpu_ctc.h:166-174)
+    ly = np.array([len(x) for x in lab], dtype=np.int32)
+    labels = np.array([v for x in lab for v in x], dtype=np.int32)
+    assert ly[4] * 2 - 1 > lx[4]
+    with _env(CRF_ROBUST_CTC=1), _mode(mode):
+        ctx = crf.CRFContext(p, 0)
+        if fused:
+            raw = torch.tensor(np.random.default_rng(3).normal(size=(B, T, V)) * 2.0, dtype=torch.float32)
+            logp = raw.log_softmax(-1).numpy()
+            x = raw.cuda().requires_grad_(True)
+        else:
+            logp = logits
+            x = torch.tensor(logits, device="cuda:0", requires_grad=True)
+        loss = crf.CTC_CRF_LOSS(lamb=0.1, fuse_log_softmax=fused)(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly))
+        loss.backward()
+        got, grad = float(loss.item()), x.grad.cpu().numpy()
+        _, gc, ex = crf._C.loss_fwd_bwd(torch.tensor(logp, device="cuda:0"), torch.tensor(labels), torch.tensor(lx), torch.tensor(ly),
+                                        0.0, -1.0, None, True)
+        del ctx
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logp, labels, lx, ly, lamb=0.1)
+    gref, cref, valid = oracle.ctc(logp, labels, lx, ly)
+    assert list(valid) == [1, 1, 1, 1, 0] and list(ex["invalid"].cpu().numpy()) == [0, 0, 0, 0, 1]
+    assert np.allclose(ex["costs_ctc"].cpu().numpy()[:4], cref[:4], rtol=TOL, atol=0)
+    assert rel_err(gc.cpu().numpy(), gref) <= TOL
+    assert abs(got - ref["loss"]) <= TOL * abs(ref["loss"])
+    gexp = ref["grad"].astype(np.float64)
+    if fused:                                              # chain rule of log_softmax
+        gexp = gexp - np.exp(logp.astype(np.float64)) * gexp.sum(-1, keepdims=True)
+    assert rel_err(grad, gexp) <= TOL
+
+
+@pytest.mark.parametrize("T,L", [(2400, 400), (3000, 500)])
+def test_numerator_long_utterances_with_many_labels(crf, T, L):
+    """T = 3000 frames, L = 500 labels (BASELINE config #5's utterance shape; ly = lx // 6 as bench.py draws them) on inputs that do
+    not follow the labels: in the middle of such an utterance the posterior mass lies hundreds of nats below (max alpha)(max beta) --
+    beyond what the chains' per-frame rescaling keeps in fp64 (round 3 finding: 0 * inf = NaN gradients from frame ~800 on).  The
+    grad pass marks those frames and the log-domain kernels redo them; a short utterance in the same batch stays on the fast path."""
+    rng = np.random.default_rng(T)
+    V = 72
+    x = torch.tensor(rng.normal(size=(2, T, V)) * 2.0, dtype=torch.float32).log_softmax(-1)
+    ly = np.array([L, 40], dtype=np.int32)
+    lx = np.array([T, 300], dtype=np.int32)
+    labels = rng.integers(1, V, size=int(ly.sum())).astype(np.int32)
+    gref, cref, valid = oracle.ctc(x.numpy(), labels, lx, ly)
+    assert valid.all() and np.isfinite(gref).all()
+    _, g, ex = crf._C.loss_fwd_bwd(x.cuda(), torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
+    g = g.cpu().numpy()
+    assert np.isfinite(g).all()
+    assert np.allclose(ex["costs_ctc"].cpu().numpy(), cref, rtol=TOL, atol=0) and int(ex["invalid"].sum().item()) == 0
+    for b in range(2):
+        assert rel_err(g[b], gref[b]) <= TOL, b
+        assert np.allclose(g[b, :lx[b]].sum(-1), 1.0, atol=1e-4)      # every frame's posteriors sum to one
+
+
 def test_numerator_extreme_range(crf):
     """Forced alignments through labels ~400 nats below the row max: the numerator runs in fp64
     (range e^+-700) exactly so that this matches the log-domain reference semantics."""
