@@ -329,8 +329,7 @@ void set_error(const std::string &msg);
     X(gd_full_grid,     "C  stage launches of the grad pass as full grids")                                                  \
     X(ctc_after,        "C  0 / 1: numerator chains beside / after the denominator recursions")                              \
     X(serial_chains,    "C  everything on the caller's stream")                                                              \
-    X(no_side_stream,   "X  no side stream for this context")                                                                \
-    X(fac_pipe,         "C  factored recursions: 0 = gather batches drained one by one, 2 = software-pipelined batches of 2 chunks")
+    X(no_side_stream,   "X  no side stream for this context")
 
 enum Opt : int {
 #define CRF_OPT_ENUM(name, doc) kOpt_##name,

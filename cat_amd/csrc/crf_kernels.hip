@@ -1466,7 +1466,7 @@ struct FacParams {
 // also published as {frame tag, value} granules (res_chain_body's protocol: the data is the flag), and after its last chunk the
 // CU fetches the peer's entries into its own vector before the frame barrier.  Table geometry (RL) only, one copy of the
 // gathered entries, no stages (2 B x 2 workgroups are every CU of the device: nothing runs beside the recursions).
-template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML, bool RL, bool K2 = false, int PIPE = 0>
+template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML, bool RL, bool K2 = false>
 __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, const int b, const int k = 0) {
     static_assert(!K2 || (RL && !FLAG), "two CUs per recursion: table geometry, no stage flags");
     constexpr int NW = NTH / kWave;
@@ -1485,7 +1485,6 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     constexpr int NCHA = IMP ? kFac3ArcCh : NCH;             // chunk slots that hold arcs
     constexpr int RCW = NCHA * 6;                            // first row-constant word
     static_assert(NCHA % NB == 0, "chunks per thread must be a multiple of the batch");
-    static_assert(PIPE == 0 || NCHA % (PIPE > 0 ? PIPE : 1) == 0, "chunks per thread must be a multiple of the pipelined batch");
 
     const FacDirDev &L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1674,16 +1673,6 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #endif
         const char *xb = (const char *)lds + par * XB;
         char *xnb = (char *)lds + (1 - par) * XB;
-        constexpr int NP = PIPE > 0 ? PIPE : 1;
-        [[maybe_unused]] f32x2 ga01[NP], ga23[NP], gb01[NP], gb23[NP];   // PIPE: two sets of gathered entries in rotation
-        if constexpr (PIPE > 0) { CRF_RES_GATHER_N(ga01, ga23, A, xb, 0, NP); }   // the frame's first requests, ahead of its bookkeeping
-#ifdef CRF_EXP_GFIRST
-        // the first batch of gathers goes out BEFORE the frame's bookkeeping: right after the barrier every wave of the workgroup
-        // does ~50 instructions of scalar bookkeeping (and waits a whole LDS round trip for the frame maximum) while the LDS is idle
-        constexpr int NB0 = PIPE == 0 ? NB : 1;
-        [[maybe_unused]] f32x2 h01[NB0], h23[NB0];
-        if constexpr (PIPE == 0) { CRF_RES_GATHER_N(h01, h23, A, xb, 0, NB0); }
-#endif
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
         const int tpre = DIR == 0 ? t + 1 : t - 2;
         // (only the waves that hold emissions take part in the prefetch: the compiler waits for vmcnt(0) around these
@@ -1856,51 +1845,18 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             acc = f32x2{0.f, 0.f};
             r4 += kWave * 4u;
         };
-        if constexpr (PIPE == 0) {
 #pragma unroll
         for (int c0 = 0; c0 < NCHA; c0 += NB) {
             constexpr int nb = NB;
             if (c0 < nch_f) {
                 f32x2 g01[NB], g23[NB];
-#ifdef CRF_EXP_GFIRST
-                if (c0 == 0) {
-#pragma unroll
-                    for (int ci = 0; ci < nb; ++ci) { g01[ci] = h01[ci]; g23[ci] = h23[ci]; }
-                } else
-#endif
-                { CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb); }
+                CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb);
 #pragma unroll
                 for (int ci = 0; ci < nb; ++ci) {
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
                     if (ends_f >> (c0 + ci) & 1u) row_end((unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u)));
                 }
             }
-        }
-        } else {
-        // PIPE: the gathers of batch k + 1 are REQUESTED before the products of batch k are summed (two register sets in
-        // rotation, batches of PIPE chunks): without it a wave drains its LDS queue at every batch end -- address adds, requests
-        // and a full LDS round trip before the next FMA, five times per frame -- and the frame is a chain of such round trips
-        // (a wave's ~480 instructions take 3 200 - 4 300 cycles, in-kernel stamps).  lgkmcnt counts 15 at most, so batches of 2
-        // chunks (8 + 8 gathers in flight) are what the waits can express exactly.
-        // Control flow is a CHAIN (one exit per batch, no joins between a request and its use): the wait-count pass merges
-        // the states of the paths that meet at a join to the strictest one, and a conditional request ahead of a join made every
-        // later wait a full drain.  So the next batch is requested unconditionally while the current one is active (unused chunk
-        // slots hold offset 0 / weight 0: at most one batch of 4 * PIPE wasted gathers per wave), and the first batch at the frame top.
-        if (0 < nch_f) {
-#pragma unroll
-            for (int kb = 0; kb < NCHA / NP; ++kb) {
-                const int c0 = kb * NP;
-                if (kb + 1 < NCHA / NP) {
-                    if (kb & 1) { CRF_RES_GATHER_N(ga01, ga23, A, xb, c0 + NP, NP); } else { CRF_RES_GATHER_N(gb01, gb23, A, xb, c0 + NP, NP); }
-                }
-#pragma unroll
-                for (int ci = 0; ci < NP; ++ci) {
-                    if (kb & 1) { CRF_RES_CHUNK_ACC(acc, gb01, gb23, A, c0 + ci, ci); } else { CRF_RES_CHUNK_ACC(acc, ga01, ga23, A, c0 + ci, ci); }
-                    if (ends_f >> (c0 + ci) & 1u) row_end((unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u)));
-                }
-                if (!(c0 + NP < nch_f)) break;
-            }
-        }
         }
         CRF_TM(tm_on, tm_i + 2);
 #ifdef CRF_TIMING
@@ -2014,13 +1970,12 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 // guaranteed inside a training process (HIP maps all streams of a process onto GPU_MAX_HW_QUEUES = 4 queues; with
 // RCCL's and torch's streams around, the recursions were observed to run one after the other: 5.3 instead of 3.25 ms).
 // NBF / NBB: chunks gathered per batch, forward / backward.
-// PIPE > 0: software-pipelined gathers in batches of PIPE chunks (fac_chain_body)
-template <bool FLAG, int NTH, int NCH, int NBF, int NBB, bool ML, bool RL = false, int PIPE = 0>
+template <bool FLAG, int NTH, int NCH, int NBF, int NBB, bool ML, bool RL = false>
 __global__ __launch_bounds__(NTH) void crf_fac_pair_kernel(FacParams pf, FacParams pb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = pf.B;
-    if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML, RL, false, PIPE>(pf, lds, (int)blockIdx.x);
-    else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML, RL, false, PIPE>(pb, lds, (int)blockIdx.x - B);
+    if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML, RL>(pf, lds, (int)blockIdx.x);
+    else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - B);
 }
 // ... with TWO CUs per recursion: 2 * nbu * 2 workgroups for the utterances [b0, b0 + nbu), forward recursions first; the
 // two CUs of a recursion 8 block ids apart (block x is observed on XCD x % 8: one L2 for the hand-off; a matter of speed only)
@@ -3875,13 +3830,6 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     return (size_t)2 * rup64(L.G) * 4 + table +
            ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }
-#ifndef CRF_FAC_PIPE_DEFAULT
-#define CRF_FAC_PIPE_DEFAULT 0
-#endif
-#ifndef CRF_FAC_PIPE_N
-#define CRF_FAC_PIPE_N 2
-#endif
-constexpr int kFacPipeDefault = CRF_FAC_PIPE_DEFAULT;   // crf_debug_set("fac_pipe", ...) overrides
 #ifndef CRF_FAC3_NB_F
 #define CRF_FAC3_NB_F 4
 #endif
@@ -3927,47 +3875,31 @@ static int launch_fac2_pair(const LossParams &lp, size_t lds, hipStream_t st, in
 template <bool FLAG>
 static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *fstate, float *bstate,
                            int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
-    static LdsMark m3, m3m, m3l, m5, m3p, m3mp, m3lp;
+    static LdsMark m3, m3m, m3l, m5;
     const FacDev &F = lp.g.fac;
     const bool g3 = F.threads == kFac3Threads, ml = F.multilane != 0;
     const FacParams pf = fac_params(lp, 0, started, i0, i1, fstate, nb, bound, stage_cnt);
     const FacParams pb = fac_params(lp, 1, started, i0, i1, bstate, nb, bound, stage_cnt);
     const dim3 grid((unsigned)(2 * lp.B));
     int rc;
-    const int pipe = opt(kOpt_fac_pipe, kFacPipeDefault);   // software-pipelined gather batches (fac_chain_body)
-    if (g3 && pipe > 0 && F.rcl) {
-        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true, CRF_FAC_PIPE_N>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,20,4,4,true,true,pipe>" : "crf_fac_pair_kernel<false,768,20,4,4,true,true,pipe>";
-        if ((rc = ensure_lds((const void *)k, lds, m3lp, "fac pair"))) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
-    } else if (g3 && pipe > 0 && ml) {
-        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, false, CRF_FAC_PIPE_N>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,false,pipe>" : "crf_fac_pair_kernel<false,768,21,4,4,true,false,pipe>";
-        if ((rc = ensure_lds((const void *)k, lds, m3mp, "fac pair"))) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
-    } else if (g3 && pipe > 0) {
-        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, false, false, CRF_FAC_PIPE_N>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,false,false,pipe>" : "crf_fac_pair_kernel<false,768,21,4,4,false,false,pipe>";
-        if ((rc = ensure_lds((const void *)k, lds, m3p, "fac pair"))) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
-    } else if (g3 && F.rcl) {
+    if (g3 && F.rcl) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,20,4,4,true,true,0>" : "crf_fac_pair_kernel<false,768,20,4,4,true,true,0>";
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,20,4,4,true,true>" : "crf_fac_pair_kernel<false,768,20,4,4,true,true>";
         if ((rc = ensure_lds((const void *)k, lds, m3l, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else if (g3 && ml) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,false,0>" : "crf_fac_pair_kernel<false,768,21,4,4,true,false,0>";
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,false>" : "crf_fac_pair_kernel<false,768,21,4,4,true,false>";
         if ((rc = ensure_lds((const void *)k, lds, m3m, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else if (g3) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, false>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,false,false,0>" : "crf_fac_pair_kernel<false,768,21,4,4,false,false,0>";
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,false,false>" : "crf_fac_pair_kernel<false,768,21,4,4,false,false>";
         if ((rc = ensure_lds((const void *)k, lds, m3, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else {
         auto *k = crf_fac_pair_kernel<FLAG, kResThreads, kResNCH, kResBatch, kResBatch, true>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,512,30,6,6,true,false,0>" : "crf_fac_pair_kernel<false,512,30,6,6,true,false,0>";
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,512,30,6,6,true,false>" : "crf_fac_pair_kernel<false,512,30,6,6,true,false>";
         if ((rc = ensure_lds((const void *)k, lds, m5, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kResThreads), lds, st, pf, pb);
     }

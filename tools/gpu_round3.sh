@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/gpu_round2.sh TAG [what...] -- one gpurun call of round 2.  what: tests bench hwq prof pmc points (default: tests bench hwq prof)
+# tools/gpu_round3.sh TAG [what...] -- one gpurun call of round 2.  what: tests bench hwq prof pmc points (default: tests bench hwq prof)
 TAG=${1:-r2a}; shift
 WHAT=${@:-tests bench hwq prof}
 OUT=$PWD/gpurun_out; mkdir -p $OUT

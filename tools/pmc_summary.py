@@ -1,9 +1,9 @@
 """tools/pmc_summary.py TAG -- condense the rocprofv3 outputs of tools/gpu_round.sh + tools/gpu_prof.sh
 (gpurun_out/) into the small summaries kept under profiles/:
 
-    profiles/round2_<TAG>_bench.json          the bench line (with cpu_baseline)
-    profiles/round2_<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary
-    profiles/round2_<TAG>_pmc.json            per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch) and SQ counters
+    profiles/round3_<TAG>_bench.json          the bench line (with cpu_baseline)
+    profiles/round3_<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary
+    profiles/round3_<TAG>_pmc.json            per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch) and SQ counters
     profiles/pmc_traffic.json                 HBM bytes per launch of every loss kernel + the whole-path ratio, KEYED BY
                                               WORKLOAD (read by bench.py; another workload prints traffic: null)
 """
@@ -40,10 +40,10 @@ def counters(tag, what):
 def main():
     tag = sys.argv[1]
     os.makedirs(PROF, exist_ok=True)
-    shutil.copy(os.path.join(OUT, f"bench_{tag}.json"), os.path.join(PROF, f"round2_{tag}_bench.json"))
+    shutil.copy(os.path.join(OUT, f"bench_{tag}.json"), os.path.join(PROF, f"round3_{tag}_bench.json"))
     ks = glob.glob(os.path.join(OUT, f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
-        shutil.copy(ks[0], os.path.join(PROF, f"round2_{tag}_kernel_stats.csv"))
+        shutil.copy(ks[0], os.path.join(PROF, f"round3_{tag}_kernel_stats.csv"))
     traffic, sq = {}, {}
     fe, wr, s = counters(tag, "fetch"), counters(tag, "write"), counters(tag, "sq")
     def nsteps(acc, what):   # calls of the loss in that profiling pass = launches of the finalize kernel
@@ -74,7 +74,7 @@ def main():
                 "stream (MI355X_MICROARCH.md HBM section): the grad kernels' row reads are such streams.",
         "traffic": traffic, "sq": sq,
     }
-    json.dump(doc, open(os.path.join(PROF, f"round2_{tag}_pmc.json"), "w"), indent=1)
+    json.dump(doc, open(os.path.join(PROF, f"round3_{tag}_pmc.json"), "w"), indent=1)
     # bytes per call of the loss, per kernel.  FETCH_SIZE is doubled for the kernels whose reads are wide (16 B / lane)
     # coalesced streams (MI355X_MICROARCH.md, HBM section): the grad pass reading the Q / BP / CA / CB rows.
     bench = json.load(open(os.path.join(OUT, f"bench_{tag}.json")))
@@ -90,9 +90,13 @@ def main():
         kernels[short] = kernels.get(short, 0) + byts
         total += byts
     alg = bench["roofline"]["den_fwd_bwd"]["bytes"] + bench["roofline"]["den_fwd_bwd"]["bytes_num"]
-    tr = {"workload": key, "kernels": kernels,
+    # the denominator recursions' kernel as the library names it (crf_last_den_kernel): rocprofv3's demangled name without
+    # "void crf::", blanks and the argument list -- bench.py prints `traffic` only for a call that ran THIS instantiation
+    den = [k for k in traffic if any(n in k for n in ("crf_fac_pair_kernel", "crf_fac2_pair_kernel", "crf_res_pair_kernel", "crf_batch_frame_kernel", "crf_den_pair_kernel"))]
+    den_kernel = den[0].replace("void ", "").replace("crf::", "").split("(")[0].replace(" ", "") if len(den) == 1 else None
+    tr = {"workload": key, "den_kernel": den_kernel, "kernels": kernels,
           "whole_path": {"pmc_bytes_per_call": total, "algorithmic_bytes": alg, "ratio": round(total / max(1, alg), 3)},
-          "source": f"profiles/round2_{tag}_pmc.json: (FETCH_SIZE [x2 for the grad kernels' 16-byte row streams] + WRITE_SIZE) * 1024 bytes "
+          "source": f"profiles/round3_{tag}_pmc.json: (FETCH_SIZE [x2 for the grad kernels' 16-byte row streams] + WRITE_SIZE) * 1024 bytes "
                     "per call of the loss, every launch of a kernel summed"}
     json.dump(tr, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(tr, indent=1))
