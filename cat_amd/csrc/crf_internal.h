@@ -329,7 +329,8 @@ void set_error(const std::string &msg);
     X(gd_full_grid,     "C  stage launches of the grad pass as full grids")                                                  \
     X(ctc_after,        "C  0 / 1: numerator chains beside / after the denominator recursions")                              \
     X(serial_chains,    "C  everything on the caller's stream")                                                              \
-    X(no_side_stream,   "X  no side stream for this context")
+    X(no_side_stream,   "X  no side stream for this context")                                                                \
+    X(fac_pair2,        "C  factored recursions with TWO utterances per workgroup: 1 = for any batch, 0 = never (default: batches above CUs / 2)")
 
 enum Opt : int {
 #define CRF_OPT_ENUM(name, doc) kOpt_##name,

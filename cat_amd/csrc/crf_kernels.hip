@@ -80,6 +80,7 @@ struct LossParams {
     int *err;                     // [1] set if an exchange timed out
     int *clear; int nclear;       // words the prep kernel zeroes (error word, start and stage counters of the factored schedule)
     float *Row0;                  // [B][Rb] spare rows (b_0 of the resident backward recursion)
+    float *dump; int dump_stride; // two utterances per workgroup (fac_chain_body2): [2][ceil(B / 2)][dump_stride] dump rows
     float *gvec;                  // streaming kernels, graphs too large for LDS: [B][3*Sp + 4*Pr] state vectors in global memory
     int grad_stage;               // crf_grad_kernel: 1 = stage the Q / BP rows in LDS, 0 = gather them from global memory
     int *EQ, *EB;                 // [B*T] their binary exponents
@@ -1453,6 +1454,9 @@ struct FacParams {
     int xlist_off[3];
     unsigned long long *xch;
     int *err;
+    // two utterances per workgroup (fac_chain_body2): pairs of this launch, rows that take the stores of an utterance that has ended
+    int npair, dump_stride;
+    float *dump;                // [2 directions][npair][dump_stride]
 };
 
 // FLAG: publish stage flags and store rows write-through (one instantiation per use: the frame loop has no
@@ -1482,9 +1486,9 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     static_assert(!RL || NTH == kFac3Threads, "the row-constant table goes with the 768-thread geometry");
     constexpr bool IMP = NTH == kFac3Threads;                // entries of a row lie where its row id says
     constexpr bool RC = IMP && !RL;
-    constexpr int NCHA = IMP ? kFac3ArcCh : NCH;             // chunk slots that hold arcs
+    constexpr int NCHA = RC ? kFac3ArcCh : NCH;              // chunk slots that hold arcs (RC: the last slot holds the row constants)
     constexpr int RCW = NCHA * 6;                            // first row-constant word
-    static_assert(NCHA % NB == 0, "chunks per thread must be a multiple of the batch");
+    static_assert(!RC || NCH == kFac3NCH, "row constants in registers: 20 chunks of arcs + the constants' slot");
 
     const FacDirDev &L = p.L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1847,7 +1851,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         };
 #pragma unroll
         for (int c0 = 0; c0 < NCHA; c0 += NB) {
-            constexpr int nb = NB;
+            const int nb = NCHA - c0 < NB ? NCHA - c0 : NB;   // (the last batch may be short: 21 chunks in batches of 4)
             if (c0 < nch_f) {
                 f32x2 g01[NB], g23[NB];
                 CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb);
@@ -1964,6 +1968,386 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     }
 }
 
+// =============================================================================================
+// TWO UTTERANCES per workgroup (throughput mode: batches above CUs / 4 utterances per GPU).  Same layout tables, same arithmetic,
+// same rows in memory as fac_chain_body -- bit for bit -- but the state vector is [entry][2 utterances] (float2): ONE address
+// computation and ONE ds_read_b64 (the LDS cycles of a ds_read_b32) gather an entry for both, the weight is shared in its register,
+// the product is one v_pk_fma_f32 whose two lanes are the two utterances.  Per arc and utterance that is half an address
+// instruction, half an LDS instruction and half a packed FMA, against 1 + 1 + 1/2 with one utterance per workgroup; the price is
+// two row epilogues per slice and twice the frame's bookkeeping (two scales, two exponents, two row pointers).  A pair runs
+// max(lx0, lx1) frames: the shorter utterance's sums are taken when it ends (its half of the vector then holds garbage nobody
+// reads, its row stores go to a dump row).  768-thread geometries only (row constants in registers or in the LDS table).
+// LDS: X2[2][Gp] float2 | row table (RL: as fac_chain_body; RC backward: the two extra-arc weights per row) | EP2[2][Vp] float2 |
+//      wm[3][2][4] | red
+// =============================================================================================
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ f32x2 lds_ld2(unsigned a) { return *(const __attribute__((address_space(3))) f32x2 *)(uintptr_t)a; }
+__device__ __forceinline__ float lds_ld1(unsigned a) { return *(const __attribute__((address_space(3))) float *)(uintptr_t)a; }
+__device__ __forceinline__ void lds_st2(unsigned a, f32x2 v) { *(__attribute__((address_space(3))) f32x2 *)(uintptr_t)a = v; }
+// address of entry (16-bit byte offset of the one-utterance layout, low / high half of `w`) in a float2 vector at LDS address `base`
+__device__ __forceinline__ unsigned addr2_lo(unsigned w, unsigned base) { unsigned r; asm("v_mad_u32_u16 %0, %1, 2, %2" : "=v"(r) : "v"(w), "s"(base)); return r; }
+__device__ __forceinline__ unsigned addr2_hi(unsigned w, unsigned base) { unsigned r; asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(w), "s"(base)); return r; }
+
+template <int DIR, bool FLAG, int NCH, int NB, bool ML, bool RL>
+__device__ __forceinline__ void fac_chain_body2(const FacParams &p, float *lds, const int pair) {
+    constexpr int NTH = kFac3Threads, NW = NTH / kWave;
+    constexpr bool RC = !RL;
+    constexpr int NCHA = RC ? kFac3ArcCh : NCH;
+    constexpr int RCW = NCHA * 6;
+    static_assert(!RC || NCH == kFac3NCH, "row constants in registers: 20 chunks of arcs + the constants' slot");
+    const FacDirDev &L = p.L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int V = p.V, G = L.G, R = L.R;
+    const int bu[2] = {2 * pair, 2 * pair + 1};
+    const bool real1 = bu[1] < p.B;                          // (an odd batch: the last pair's second utterance does not exist)
+    const int lxu[2] = {p.lx[bu[0]], real1 ? p.lx[bu[1]] : 0};
+    const unsigned dup2 = 2u * (unsigned)L.dup;
+    const int Vp = rup64(V + 1), Gp = rup64(G);
+    const unsigned XB2 = (unsigned)Gp * 8u;                  // bytes per state vector
+    constexpr int kRowB = RL ? (DIR == 0 ? 8 : 16) : 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char *)lds;   // LDS address of the carve
+    f32x2 *X2 = (f32x2 *)lds;                                // [2][Gp]
+    char *RMc = (char *)(X2 + 2 * Gp);
+    const size_t tbytes = RL ? (size_t)(R + 64) * kRowB : (DIR == 1 ? (size_t)R * 8 : (size_t)0);
+    f32x2 *EP2 = (f32x2 *)(RMc + tbytes);                    // [2][Vp]
+    float *wm = (float *)(EP2 + 2 * Vp);                     // [3][2][4]
+    double *red = (double *)(wm + 24);
+    const unsigned rm0 = lds0 + 2u * XB2, ep0 = rm0 + (unsigned)tbytes, EB2 = (unsigned)Vp * 8u;
+    if (tid == 0 && p.started) atomicAdd(p.started, 1);
+
+    unsigned A[(NCH * 6)];
+    unsigned rc00 = 0, rc01 = 0, rc10 = 0, rc11 = 0, rc20 = 0, rc21 = 0;
+    {
+        const unsigned *src = L.arcs + tid;
+#pragma unroll
+        for (int i = 0; i < (RC ? RCW : NCH * 6); ++i) A[i] = src[(size_t)i * NTH];
+        if (RC) {
+            rc00 = src[(size_t)(RCW + 0) * NTH]; rc01 = src[(size_t)(RCW + 1) * NTH];
+            rc10 = src[(size_t)(RCW + 2) * NTH]; rc11 = src[(size_t)(RCW + 3) * NTH];
+            rc20 = src[(size_t)(RCW + 4) * NTH]; rc21 = src[(size_t)(RCW + 5) * NTH];
+        }
+    }
+    const uint4 wi = L.wave_info[wave];
+    const unsigned ends = __builtin_amdgcn_readfirstlane(wi.x);
+    const int nch = __builtin_amdgcn_readfirstlane(wi.y);
+    const int row0 = __builtin_amdgcn_readfirstlane(wi.z);
+    const unsigned lgbits = __builtin_amdgcn_readfirstlane(wi.w);
+    if (RL) {
+        if (DIR == 0) {
+            uint2 *RT = (uint2 *)RMc;
+            for (int r = tid; r < R; r += NTH) {
+                const int4 m = p.frow_meta[r];
+                RT[r] = uint2{(((unsigned)m.x >> 16) * 4u) | (((unsigned)m.w * 4u) << 16), (unsigned)m.z};
+            }
+        } else {
+            uint4 *RT = (uint4 *)RMc;
+            for (int r = tid; r < R; r += NTH) {
+                const int4 m = p.brow_meta[r];
+                const unsigned l0 = (unsigned)m.w & 0xffffu, l1 = (unsigned)m.w >> 16;
+                RT[r] = uint4{(unsigned)m.x, ((l0 == 0xffffu ? (unsigned)V : l0) * 4u) | (((l1 == 0xffffu ? (unsigned)V : l1) * 4u) << 16), (unsigned)m.y, (unsigned)m.z};
+            }
+        }
+    } else if (DIR == 1) {
+        f32x2 *RW = (f32x2 *)RMc;
+        for (int r = tid; r < R; r += NTH) { const int4 m = p.brow_meta[r]; RW[r] = f32x2{__int_as_float(m.y), __int_as_float(m.z)}; }
+        auto fix = [&](unsigned w) {
+            const unsigned l0 = w & 0xffffu, l1 = w >> 16;
+            return (l0 == 0xffffu ? (unsigned)V * 4u : l0) | ((l1 == 0xffffu ? (unsigned)V * 4u : l1) << 16);
+        };
+        rc01 = fix(rc01); rc11 = fix(rc11); rc21 = fix(rc21);
+    }
+    const int64_t bt0u[2] = {(int64_t)bu[0] * p.T, (int64_t)bu[1] * p.T};
+    const float *ep_b[2] = {p.ep + bt0u[0] * V, p.ep + (real1 ? bt0u[1] : bt0u[0]) * V};
+    float *Out_b[2] = {p.Out + bt0u[0] * p.Rout, p.Out + (real1 ? bt0u[1] : bt0u[0]) * p.Rout};
+    int *Eo_b[2] = {p.Eout + bt0u[0], p.Eout + (real1 ? bt0u[1] : bt0u[0])};
+    float *dump = p.dump + ((size_t)DIR * p.npair + pair) * (size_t)p.dump_stride;   // rows of an utterance that has ended
+    int E[2] = {kScaleExp, kScaleExp};
+    float zpart[2] = {0.f, 0.f};
+    for (int s = tid; s < 2 * Gp; s += NTH) X2[s] = f32x2{0.f, 0.f};
+    if (tid < 2) EP2[tid * Vp + V] = f32x2{0.f, 0.f};
+    if (tid < 24) wm[tid] = 0.f;                             // [3 frames][2 utterances][4 rows of 16 lanes]
+    const bool rowlead = (lane & 15) == 0;
+    int sr = 0;
+    for (int v = tid; v < V; v += NTH) {
+        f32x2 e0{0.f, 0.f}, e1{0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int lx = lxu[u];
+            if (lx <= 0) continue;
+            if (DIR == 0) e0[u] = ep_b[u][v];                                             // e'_0
+            else { e0[u] = ep_b[u][(unsigned)(lx - 1) * (unsigned)V + v]; if (lx >= 2) e1[u] = ep_b[u][(unsigned)(lx - 2) * (unsigned)V + v]; }
+        }
+        EP2[v] = e0;
+        if (DIR == 1) EP2[Vp + v] = e1;
+    }
+    __syncthreads();
+    {
+        f32x2 m0{0.f, 0.f};
+        if (DIR == 0) {
+            for (int s = tid; s < G; s += NTH) { const float v = p.x_start[s] * pow2f(kScaleExp); X2[s] = f32x2{v, v}; m0.x = fmaxf(m0.x, v); }
+            m0.y = m0.x;
+        } else {
+            for (int z = tid; z < G; z += NTH) {
+                const int l = p.z_lab[z];
+                const f32x2 e = EP2[l < 0 ? V : l];
+                const float ze = p.z_end[z] * pow2f(kScaleExp);
+                const f32x2 v{lxu[0] > 0 ? e.x * ze : 0.f, lxu[1] > 0 ? e.y * ze : 0.f};
+                X2[z] = v; m0.x = fmaxf(m0.x, v.x); m0.y = fmaxf(m0.y, v.y);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !real1) continue;
+                if (lxu[u] > 0) {
+                    float *BProw = Out_b[u] + (unsigned)(lxu[u] - 1) * (unsigned)p.Rout;
+                    for (int r = tid; r < 2 * R; r += NTH) BProw[r] = p.brow_end[r] * pow2f(kScaleExp);
+                    if (tid == 0) Eo_b[u][lxu[u] - 1] = E[u];
+                } else {
+                    for (int r = tid; r < 2 * R; r += NTH) zpart[u] += p.brow_start[r] * p.brow_end[r] * pow2f(kScaleExp);
+                }
+            }
+        }
+        m0.x = row_max16(m0.x); m0.y = row_max16(m0.y);
+        if (rowlead) { lds_fmax(wm + (lane >> 4), m0.x); lds_fmax(wm + 4 + (lane >> 4), m0.y); }
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    int next_stage = 1;
+    int next_bound = (FLAG && p.nb > 1) ? p.bound[1] : 0x7fffffff;
+    const int nreal = real1 ? 2 : 1;
+    auto publish_stage = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.stage_cnt + next_stage, nreal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ++next_stage;
+        next_bound = next_stage < p.nb ? p.bound[next_stage] : 0x7fffffff;
+    };
+    const bool pre_w = wave * kWave < V;
+    f32x2 last_sc{1.f, 1.f};
+    f32x2 epn[kEpRegsR] = {};
+    // one frame; `act`: bit u = utterance u has not ended (its rows, exponents and emissions are real)
+    auto frame = [&](const int par, const int i, const int act) __attribute__((always_inline)) {
+        if (FLAG && i == next_bound) publish_stage();
+        const unsigned xb = lds0 + (unsigned)par * XB2, xnb = lds0 + (unsigned)(1 - par) * XB2;
+        const unsigned epu = ep0 + (unsigned)(DIR == 0 ? par : 1 - par) * EB2;
+        int tu[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) tu[u] = DIR == 0 ? i : lxu[u] - 1 - i;
+        bool pre[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pre[u] = pre_w && (act >> u & 1) && (DIR == 0 ? (tu[u] + 1 < lxu[u]) : (tu[u] >= 2));
+            if (pre[u]) {
+                const float *er = ep_b[u] + (unsigned)(DIR == 0 ? tu[u] + 1 : tu[u] - 2) * (unsigned)V;
+#pragma unroll
+                for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; if (v < V) epn[q][u] = er[v]; }
+            }
+        }
+        const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;
+        const int4 ma = *(const int4 *)(wm + sr * 8), mb = *(const int4 *)(wm + sr * 8 + 4);
+        const int ksc0 = rescale_exp_bits((unsigned)__builtin_amdgcn_readfirstlane(max(max(ma.x, ma.y), max(ma.z, ma.w))));
+        const int ksc1 = rescale_exp_bits((unsigned)__builtin_amdgcn_readfirstlane(max(max(mb.x, mb.y), max(mb.z, mb.w))));
+        if (wave == 0 && lane < 8) wm[sz * 8 + lane] = 0.f;
+        const f32x2 sc{pow2f(ksc0), pow2f(ksc1)};
+        if (DIR == 1) last_sc = sc;
+        float *Orow[2];
+        const int ksc[2] = {ksc0, ksc1};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool on = act >> u & 1;
+            if (DIR == 0) {
+                E[u] += ksc[u];
+                if (tid == 0 && on) Eo_b[u][tu[u]] = E[u];
+                E[u] += kEpExp;
+                Orow[u] = on ? Out_b[u] + (unsigned)tu[u] * (unsigned)p.Rout : dump;
+            } else {
+                E[u] += ksc[u] + kEpExp;
+                if (tid == 0 && on && tu[u] > 0) Eo_b[u][tu[u] - 1] = E[u];
+                Orow[u] = !on ? dump : tu[u] > 0 ? Out_b[u] + (unsigned)(tu[u] - 1) * (unsigned)p.Rout : p.Row0 + (int64_t)bu[u] * p.Rout;
+            }
+        }
+        unsigned ends_f = ends;
+        int nch_f = nch;
+        asm volatile("" : "+s"(ends_f), "+s"(nch_f));
+        f32x2 acc{0.f, 0.f}, accb{0.f, 0.f};
+        f32x2 mymax{0.f, 0.f};
+        unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
+        typedef std::conditional_t<DIR == 0, uint2, uint4> rct_t;
+        [[maybe_unused]] rct_t kc{};
+        if constexpr (RL) kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * r4);
+        auto row_end = [&](const unsigned ks) __attribute__((always_inline)) {
+            f32x2 tot = acc + accb;
+            if constexpr (ML) {
+                const unsigned lg = ks < 10u ? (lgbits >> (3u * ks)) & 7u : 0u;
+                if (lg) {
+#define CRF_DPP_ADD2(ctrl) { tot.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot.x), ctrl, 0xf, 0xf, false)); \
+                             tot.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot.y), ctrl, 0xf, 0xf, false)); }
+                    CRF_DPP_ADD2(0xB1);
+                    if (lg >= 2) CRF_DPP_ADD2(0x4E);
+                    if (lg >= 3) CRF_DPP_ADD2(0x141);
+                    if (lg >= 4) CRF_DPP_ADD2(0x140);
+#undef CRF_DPP_ADD2
+                    if (lg >= 5) { tot.x += __shfl_xor(tot.x, 16, 64); tot.y += __shfl_xor(tot.y, 16, 64); }
+                    if (lg >= 6) { tot.x += __shfl_xor(tot.x, 32, 64); tot.y += __shfl_xor(tot.y, 32, 64); }
+                }
+            }
+            unsigned k0, k1;
+            [[maybe_unused]] f32x2 wrl{};
+            if constexpr (RC) {
+                const unsigned s0 = 0u - (unsigned)(ks == 0), s1 = 0u - (unsigned)(ks == 1), s2 = 0u - (unsigned)(ks >= 2);
+                k0 = (rc00 & s0) | (rc10 & s1) | (rc20 & s2);
+                k1 = (rc01 & s0) | (rc11 & s1) | (rc21 & s2);
+            } else {
+                k0 = kc.x; k1 = kc.y;
+                if constexpr (DIR == 1) wrl = f32x2{__uint_as_float(kc.z), __uint_as_float(kc.w)};
+                kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * (r4 + kWave * 4u));
+            }
+            if (DIR == 0) {   // k0 = main label | tail label << 16 (byte offsets of a float row), k1 = tail weight; U, L, A at rid, R + rid, 2R + rid
+                const f32x2 uold = lds_ld2(xb + 2u * r4);
+                const f32x2 em = lds_ld2(epu + 2u * (k0 & 0xffffu)), et = lds_ld2(epu + 2u * (k0 >> 16));
+                const f32x2 rv = tot * sc;
+                const f32x2 qt = __uint_as_float(k1) * uold * sc;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (FLAG) {
+                        __hip_atomic_store((unsigned *)((char *)Orow[u] + r4), __float_as_uint(rv[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store((unsigned *)((char *)Orow[u] + r4 + 4u * (unsigned)R), __float_as_uint(qt[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        *(float *)((char *)Orow[u] + r4) = rv[u];
+                        *(float *)((char *)Orow[u] + r4 + 4u * (unsigned)R) = qt[u];
+                    }
+                }
+                const f32x2 Lp = em * rv, Ap = et * qt, Up = Ap + Lp;
+                lds_st2(xnb + 2u * r4, Up);
+                lds_st2(xnb + 2u * r4 + dup2, Up);
+                lds_st2(xnb + 2u * r4 + 8u * (unsigned)R, Lp);
+                lds_st2(xnb + 2u * r4 + 16u * (unsigned)R, Ap);
+                mymax.x = __int_as_float(max(__float_as_int(mymax.x), __float_as_int(Up.x)));
+                mymax.y = __int_as_float(max(__float_as_int(mymax.y), __float_as_int(Up.y)));
+            } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16 (byte offsets of a float row)
+                const f32x2 z0 = lds_ld2(xb + 2u * (k0 & 0xffffu)), z1 = lds_ld2(xb + 2u * (k0 >> 16));
+                const f32x2 e0 = lds_ld2(epu + 2u * (k1 & 0xffffu)), e1 = lds_ld2(epu + 2u * (k1 >> 16));
+                const f32x2 w01 = RL ? wrl : *(const f32x2 *)(RMc + 2u * r4);
+                f32x2 bx, by;                                     // b_t of the row's two states, per utterance
+                bx = __builtin_elementwise_fma(f32x2{w01.x, w01.x}, z0, tot) * sc;
+                by = __builtin_elementwise_fma(f32x2{w01.y, w01.y}, z1, tot) * sc;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (FLAG)
+                        __hip_atomic_store((unsigned long long *)((char *)Orow[u] + 2u * r4),
+                                           (unsigned long long)__float_as_uint(bx[u]) | ((unsigned long long)__float_as_uint(by[u]) << 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        *(f32x2 *)((char *)Orow[u] + 2u * r4) = f32x2{bx[u], by[u]};
+                }
+                const f32x2 zx = e0 * bx, zy = e1 * by;           // z_{t-1} of the pairs entering them
+                lds_st2(xnb + 4u * r4, zx);
+                lds_st2(xnb + 4u * r4 + 8u, zy);
+                lds_st2(xnb + 4u * r4 + dup2, zx);
+                lds_st2(xnb + 4u * r4 + dup2 + 8u, zy);
+                mymax.x = __int_as_float(max(__float_as_int(mymax.x), max(__float_as_int(zx.x), __float_as_int(zy.x))));
+                mymax.y = __int_as_float(max(__float_as_int(mymax.y), max(__float_as_int(zx.y), __float_as_int(zy.y))));
+            }
+            acc = f32x2{0.f, 0.f}; accb = f32x2{0.f, 0.f};
+            r4 += kWave * 4u;
+        };
+#pragma unroll
+        for (int c0 = 0; c0 < NCHA; c0 += NB) {
+            const int nb = NCHA - c0 < NB ? NCHA - c0 : NB;
+            if (c0 < nch_f) {
+                f32x2 g[NB][4];
+#pragma unroll
+                for (int ci = 0; ci < nb; ++ci) {
+                    const unsigned i01 = A[6 * (c0 + ci)], i23 = A[6 * (c0 + ci) + 1];
+                    g[ci][0] = lds_ld2(addr2_lo(i01, xb)); g[ci][1] = lds_ld2(addr2_hi(i01, xb));
+                    g[ci][2] = lds_ld2(addr2_lo(i23, xb)); g[ci][3] = lds_ld2(addr2_hi(i23, xb));
+                }
+#pragma unroll
+                for (int ci = 0; ci < nb; ++ci) {
+                    const int c = c0 + ci;
+                    // the weights stay the register PAIRS the one-utterance kernel multiplies with; a packed FMA takes one half of a
+                    // pair for both of its lanes (op_sel) -- a splat built in C makes the compiler keep a second register per weight
+                    // alive across the whole kernel (400 spilled registers).  The one-utterance kernel sums (a0 w0 + a2 w2) and
+                    // (a1 w1 + a3 w3) in the two lanes of its packed FMA and adds the two at the row's end: the same two chains here,
+                    // per utterance -- the results are bit-identical
+                    f32x2 w01, w23;
+                    w01.x = __uint_as_float(A[6 * c + 2]); w01.y = __uint_as_float(A[6 * c + 3]);
+                    w23.x = __uint_as_float(A[6 * c + 4]); w23.y = __uint_as_float(A[6 * c + 5]);
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(g[ci][0]), "v"(w01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(accb) : "v"(g[ci][1]), "v"(w01));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(g[ci][2]), "v"(w23));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(accb) : "v"(g[ci][3]), "v"(w23));
+                    if (ends_f >> c & 1u) row_end((unsigned)__builtin_popcount(ends_f & ((1u << c) - 1u)));
+                }
+            }
+        }
+        mymax.x = row_max16(mymax.x); mymax.y = row_max16(mymax.y);
+        if (rowlead) { lds_fmax(wm + sw * 8 + (lane >> 4), mymax.x); lds_fmax(wm + sw * 8 + 4 + (lane >> 4), mymax.y); }
+        sr = sw;
+        if (pre[0] | pre[1]) {
+            f32x2 *EPw = EP2 + (DIR == 0 ? 1 - par : par) * Vp;
+#pragma unroll
+            for (int q = 0; q < kEpRegsR; ++q) {
+                const int v = tid + q * NTH;
+                if (v < V) {   // (an utterance that is not prefetched keeps its old emissions: never read again, or read by garbage only)
+                    if (pre[0] && pre[1]) EPw[v] = epn[q];
+                    else if (pre[0]) ((float *)(EPw + v))[0] = epn[q].x;
+                    else ((float *)(EPw + v))[1] = epn[q].y;
+                }
+            }
+        }
+        sync_lds();
+    };
+    // sums of an utterance that has just ended (forward: its logZ; backward: its part of the backward logZ)
+    auto finish = [&](const int u, const int nfr) __attribute__((always_inline)) {
+        if (u == 1 && !real1) return;
+        const int b = bu[u], lx = lxu[u];
+        if (DIR == 0) {
+            const f32x2 *Xf = X2 + (nfr & 1) * Gp;
+            float part = 0.f;
+            for (int s = tid; s < G; s += NTH) part += Xf[s][u] * p.x_end[s];
+            const float zs = res_block_sum<NW>(part, (float *)red, tid);
+            const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
+            if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E[u]; p.cost_alpha[b] = to_log(zs, E[u], mxs); if (!(zs > 0.f && zs < INFINITY)) p.redo[b] = 1; }
+        } else {
+            float zp = zpart[u];
+            if (lx > 0) {
+                __syncthreads();  // drains vmcnt: this workgroup's own stores to the spare row are visible to it
+                const float *r0 = p.Row0 + (int64_t)b * p.Rout;
+                for (int r = tid; r < 2 * R; r += NTH) zp += p.brow_start[r] * r0[r];
+                const f32x2 *Xl = X2 + ((lx - 1) & 1) * Gp;     // the vector the utterance's last frame read
+                for (int a = tid; a < p.nbx; a += NTH) zp += p.bx_w[a] * Xl[p.bx_idx[a]][u] * last_sc[u];
+            } else if (tid == 0) zp += p.bx_se * pow2f(kScaleExp);
+            const float zb = res_block_sum<NW>(zp, (float *)red, tid);
+            const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
+            if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E[u]; p.cb_mxs[b] = mxs; if (!(zb > 0.f && zb < INFINITY)) p.redo[p.B + b] = 1; }
+        }
+    };
+    const int us = lxu[1] < lxu[0] ? 1 : 0, ul = 1 - us;      // the utterance that ends first / last
+    const int lmin = lxu[us], lmax = lxu[ul];
+    if (lmin == 0) finish(us, 0);                             // an empty utterance: its sums come from the untouched start vector
+    // ONE call site of the frame (the loop body is ~10 KB of code; the 64 KiB instruction cache is shared by two CUs): three runs of
+    // the same loop -- frame 0 of the forward recursion alone (the entries no row produces, the start state, are cleared before their
+    // buffer becomes the source again: see fac_chain_body), the frames with both utterances, the frames of the longer one alone
+    int i = 0;
+#pragma clang loop unroll(disable)
+    for (int seg = 0; seg < 3; ++seg) {
+        const int iend = seg == 0 ? (DIR == 0 ? min(lmax, 1) : 0) : seg == 1 ? lmin : lmax;
+#pragma clang loop unroll(disable)
+        for (; i < iend; ++i) frame(i & 1, i, i < lmin ? 3 : (1 << ul));
+        if (seg == 0 && DIR == 0 && lmax > 0) {
+            for (int s = tid; s < G; s += NTH) if (p.x_start[s] != 0.f) X2[s] = f32x2{0.f, 0.f};
+            sync_lds();
+        }
+        if (seg == 1 && lmin > 0 && lmin < lmax) finish(us, lmin);
+    }
+    if (FLAG)
+        while (next_stage < p.nb) publish_stage();
+    if (lmin > 0 && lmin == lmax) finish(us, lmin);
+    finish(ul, lmax);
+}
+
 // Both recursions of every utterance as ONE grid of 2B workgroups (block x < B: forward recursion of utterance x,
 // else the backward recursion of utterance x - B).  One launch on one stream: the two directions used to be two
 // kernels on two streams, which ran side by side only while those streams sat on different hardware queues -- not
@@ -1976,6 +2360,14 @@ __global__ __launch_bounds__(NTH) void crf_fac_pair_kernel(FacParams pf, FacPara
     const int B = pf.B;
     if ((int)blockIdx.x < B) fac_chain_body<0, FLAG, NTH, NCH, NBF, ML, RL>(pf, lds, (int)blockIdx.x);
     else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - B);
+}
+// ... with TWO UTTERANCES per workgroup: 2 * ceil(B / 2) workgroups, forward recursions first
+template <bool FLAG, int NCH, int NBF, int NBB, bool ML, bool RL>
+__global__ __launch_bounds__(kFac3Threads) void crf_fac_pair2_kernel(FacParams pf, FacParams pb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int np = pf.npair;
+    if ((int)blockIdx.x < np) fac_chain_body2<0, FLAG, NCH, NBF, ML, RL>(pf, lds, (int)blockIdx.x);
+    else fac_chain_body2<1, FLAG, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - np);
 }
 // ... with TWO CUs per recursion: 2 * nbu * 2 workgroups for the utterances [b0, b0 + nbu), forward recursions first; the
 // two CUs of a recursion 8 block ids apart (block x is observed on XCD x % 8: one L2 for the hand-off; a matter of speed only)
@@ -3322,10 +3714,14 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParam
 // next frame's emissions requested a frame ahead.  Unmarked utterances leave at once.
 // LDS: A[2][Sxp] (double) | red[16] (double) | lab[Sxp] (int)   (same carve as the scaled chains)
 // ---------------------------------------------------------------------------------------------
+// log(e^a + e^b + e^c): the maximum in fp64, the correction log(1 + ...) in [0, ln 3] with the hardware's fp32 exp / log (absolute
+// error ~1e-7 per step; what all states of a frame have in common cancels in the posteriors, the rest is a random walk of ~5e-6
+// over 3 000 frames) -- a software fp64 exp / log made the chain 1.8 us per frame, 2.7 ms for T = 1500
 __device__ __forceinline__ double lse3(double a, double b, double c) {
     const double m = fmax(a, fmax(b, c));
     if (!(m > -INFINITY)) return -INFINITY;
-    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+    const float s = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
+    return m + (double)__logf(s);
 }
 __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -3509,7 +3905,7 @@ struct WsLayout {
     bool res, gv, fac;
     bool bat; int UL; int64_t Bp, off_ept, off_Af, off_Zb, off_bsm;   // utterance-minor layout (large graphs)
     bool gv_robust;              // the robust fallback kernels keep their vectors in global memory too
-    int64_t off_gvec, off_state, state_stride, gvec_stride;
+    int64_t off_gvec, off_state, state_stride, gvec_stride, off_dump, dump_stride;
 };
 static int64_t al(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -3593,6 +3989,9 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     // factored recursions launched in segments park their state vector + exponent here: [2 dir][B][stride]
     w.state_stride = w.fac ? rup64(std::max(h->dev.fac.f.G, h->dev.fac.b.G)) + 64 : 0;
     w.off_state = o; o = al(o + 2 * B * w.state_stride * 4);
+    // two utterances per workgroup: one dump row per (direction, pair) for the row stores of an utterance that has ended
+    w.dump_stride = w.fac ? al(std::max(w.Rq, w.Rb)) : 0;
+    w.off_dump = o; o = al(o + (w.fac ? 2 * ((B + 1) / 2) * w.dump_stride * 4 : 0));
     w.total = o;
     return w;
 }
@@ -3830,6 +4229,31 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
     return (size_t)2 * rup64(L.G) * 4 + table +
            ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }
+// ... of the two-utterance kernels (fac_chain_body2): float2 state vectors and emission rows, the same row table
+static size_t fac2u_lds_bytes(const HostGraph *h, int V, int dir) {
+    const FacDev &F = h->dev.fac;
+    const FacDirDev &L = dir == 0 ? F.f : F.b;
+    const size_t table = F.rcl ? (size_t)(L.R + 64) * (dir == 0 ? 8 : 16) : (dir == 1 ? (size_t)L.R * 8 : (size_t)0);
+    return (size_t)2 * rup64(L.G) * 8 + table + (size_t)2 * rup64(V + 1) * 8 + 24 * 4 + (kFac3Threads / kWave) * 8 + 64;
+}
+// Two utterances per workgroup?  For batches whose one-utterance grid (2 B workgroups) is larger than the device: switch
+// fac_pair2 = 1 forces it for any batch, 0 forbids it.  768-thread geometries on one CU per recursion only, and both vectors must fit the LDS twice over.
+static bool use_fac_pair2(const HostGraph *h, int64_t B, int64_t V, int ncu) {
+    const FacDev &F = h->dev.fac;
+    const int sw = opt(kOpt_fac_pair2, -1);
+    if (sw == 0 || !F.ok || F.K != 1 || F.threads != kFac3Threads) return false;
+    if (std::max(fac2u_lds_bytes(h, (int)V, 0), fac2u_lds_bytes(h, (int)V, 1)) > (size_t)160 * 1024) return false;
+    // Measured (B per GPU, metric graph, one box): the pair kernel's frame is 3.65 us against 1.98 us for one utterance -- its row
+    // epilogues and bookkeeping double while 126 of a thread's 168 registers hold arcs, and the compiler keeps only 4 - 8 of a batch's
+    // gathers in flight -- so it wins only where the one-utterance grid no longer fits the device at once (2 B > CUs):
+    // B = 256: 10.1 against 10.5 ms per step; B = 128: 5.9 against 5.3; B = 96: 5.7 against 4.4.
+    return sw == 1 || 2 * B > ncu;
+}
+#ifndef CRF_FAC3_NB2
+#define CRF_FAC3_NB2 2      // chunks gathered per batch by the two-utterance kernels (8 ds_read_b64 = 16 registers in flight)
+#endif
+#define CRF_STR_(x) #x
+#define CRF_STR(x) CRF_STR_(x)
 #ifndef CRF_FAC3_NB_F
 #define CRF_FAC3_NB_F 4
 #endif
@@ -3851,6 +4275,7 @@ static FacParams fac_params(const LossParams &lp, int dir, int *started, int i0,
     p.den_zs = lp.den_zs; p.cost_alpha = lp.cost_alpha; p.den_ez = lp.den_ez;
     p.brow_meta = F.brow_meta; p.z_lab = F.z_lab; p.z_end = F.z_end; p.brow_start = F.brow_start; p.brow_end = F.brow_end;
     p.cb_part = lp.cb_part; p.cb_mxs = lp.cb_mxs; p.cb_F = lp.cb_F; p.redo = lp.redo;
+    p.npair = (lp.B + 1) / 2; p.dump = lp.dump; p.dump_stride = lp.dump_stride;
     p.K = F.K; p.b0 = 0; p.nbu = lp.B; p.Gf = F.f.G; p.Gb = F.b.G; p.xch = lp.xch; p.err = lp.err; p.xlist = F.xlist; for (int k = 0; k < 3; ++k) p.xlist_off[k] = F.xlist_off[k];
     return p;
 }
@@ -3861,8 +4286,8 @@ static int launch_fac2_pair(const LossParams &lp, size_t lds, hipStream_t st, in
     FacParams pf = fac_params(lp, 0, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
     FacParams pb = fac_params(lp, 1, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
     pf.b0 = pb.b0 = b0; pf.nbu = pb.nbu = nbu;
-    auto *k = crf_fac2_pair_kernel<kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B>;
-        g_den_kernel = "crf_fac2_pair_kernel<768,20,4,4>";
+    auto *k = crf_fac2_pair_kernel<kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B>;
+        g_den_kernel = "crf_fac2_pair_kernel<768,21,4,4>";
     int rc;
     if ((rc = ensure_lds((const void *)k, lds, mk, "fac2 pair"))) return rc;
     hipLaunchKernelGGL(k, dim3((unsigned)(2 * nbu * 2)), dim3(kFac3Threads), lds, st, pf, pb);
@@ -3882,9 +4307,15 @@ static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int
     const FacParams pb = fac_params(lp, 1, started, i0, i1, bstate, nb, bound, stage_cnt);
     const dim3 grid((unsigned)(2 * lp.B));
     int rc;
-    if (g3 && F.rcl) {
-        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,20,4,4,true,true>" : "crf_fac_pair_kernel<false,768,20,4,4,true,true>";
+    if (g3 && F.rcl && !ml) {
+        static LdsMark m3ln;
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, false, true>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,false,true>" : "crf_fac_pair_kernel<false,768,21,4,4,false,true>";
+        if ((rc = ensure_lds((const void *)k, lds, m3ln, "fac pair"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else if (g3 && F.rcl) {
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true>;
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,true>" : "crf_fac_pair_kernel<false,768,21,4,4,true,true>";
         if ((rc = ensure_lds((const void *)k, lds, m3l, "fac pair"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else if (g3 && ml) {
@@ -3905,6 +4336,42 @@ static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int
     }
     hipError_t e;
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac_pair_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return CRF_OK;
+}
+
+// ... two utterances per workgroup: 2 * ceil(B / 2) workgroups
+template <bool FLAG>
+static int launch_fac_pair2(const LossParams &lp, size_t lds, hipStream_t st, int *started, int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
+    static LdsMark m2, m2m, m2l, m2ln;
+    const FacDev &F = lp.g.fac;
+    const bool ml = F.multilane != 0;
+    const FacParams pf = fac_params(lp, 0, started, 0, lp.T, nullptr, nb, bound, stage_cnt);
+    const FacParams pb = fac_params(lp, 1, started, 0, lp.T, nullptr, nb, bound, stage_cnt);
+    const dim3 grid((unsigned)(2 * pf.npair));
+    int rc;
+    if (F.rcl && !ml) {
+        auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, false, true>;
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,true>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,true>";
+        if ((rc = ensure_lds((const void *)k, lds, m2ln, "fac pair2"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else if (F.rcl) {
+        auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, true, true>;
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,true>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,true>";
+        if ((rc = ensure_lds((const void *)k, lds, m2l, "fac pair2"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else if (ml) {
+        auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, true, false>;
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,false>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,false>";
+        if ((rc = ensure_lds((const void *)k, lds, m2m, "fac pair2"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    } else {
+        auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, false, false>;
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,false>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,false>";
+        if ((rc = ensure_lds((const void *)k, lds, m2, "fac pair2"))) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
+    }
+    hipError_t e;
+    if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac_pair2_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
 }
 
@@ -4029,6 +4496,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.xch = (unsigned long long *)(base + w.off_xch);
     p.err = (int *)(base + w.off_xch + w.xch_bytes);
     p.Row0 = (float *)(base + w.off_row0);
+    p.dump = (float *)(base + w.off_dump); p.dump_stride = (int)w.dump_stride;
     p.gvec = (float *)(base + w.off_gvec);
     p.gvec_stride = w.gvec_stride;
     p.den_zs = pb; p.den_ez = (int *)(pb + B); p.ctc_ez = (int *)(pb + 2 * B);
@@ -4092,7 +4560,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
     const bool gd_wide = den && (w.Rq > 4 * kGDRowRegs * kGDThreads || w.Rb > 4 * kGDRowRegs * kGDThreads);   // 512-thread grad workgroups
     const bool fast_den = den && w.Rq <= 8 * kGDRowRegs * kGDThreads && w.Rb <= 8 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
-                          gnc <= 2 * kGDThreads && V <= kGDEpRegs * kGDThreads && !opt_on(kOpt_no_fast_grad);
+                          gnc <= 4 * kGDThreads && V <= kGDEpRegs * kGDThreads && !opt_on(kOpt_no_fast_grad);
     // numerator half of the grad pass: streaming kernel when the vocabulary fits its registers
     const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
                           !opt_on(kOpt_no_fast_grad);
@@ -4112,7 +4580,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const bool segmode = use_segments.load() || opt_on(kOpt_segments);
     const int stages_env = opt(kOpt_stages, 0);
     const int pieces = stages_env > 0 ? stages_env : (segmode ? 4 : 12);   // measured: 4 / 8 / 12 pieces -> call 4.06 / 3.98 / 3.93 ms (flags)
-    const bool staged = fac && h->dev.fac.K == 1 && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && 2 * B <= ncu_dev / 2;
+    // two utterances per workgroup (use_fac_pair2): the den grid is 2 * ceil(B / 2) workgroups instead of 2 B
+    const bool pair2 = fac && !segmode && use_fac_pair2(h, B, V, ncu_dev);   // (no segment relaunches in that kernel)
+    const int64_t den_wgs = pair2 ? 2 * ((B + 1) / 2) : 2 * B;
+    const bool staged = fac && h->dev.fac.K == 1 && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && den_wgs <= ncu_dev / 2;
     // Stage bounds.  Nothing can be released before the two recursions have met, so the first stage ends at half of
     // the frames or later; after that a piece of `piece` iterations releases 2 * piece / 16 frame blocks per
     // utterance.  The grad pass has half of the chip and is bandwidth-bound there (~2 TB/s against the 2.2 TB/s the
@@ -4147,7 +4618,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.gd_nb = nstage + 1;
     for (int k = 0; k <= nstage && k < 16; ++k) p.gd_bound[k] = bound[k];
     float *fstate = (float *)(base + w.off_state), *bstate = fstate + B * w.state_stride;
-    const size_t lds_fac = fac ? std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1)) : 0;
+    const size_t lds_fac = !fac ? 0 : pair2 ? std::max(fac2u_lds_bytes(h, (int)V, 0), fac2u_lds_bytes(h, (int)V, 1))
+                                              : std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1));
     const size_t lds_ctc = chain_lds_bytes(h, (int)V, Sc, 2);
 
     const dim3 ggrid((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B);
@@ -4163,7 +4635,12 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         }
         static LdsMark set1, set2, set3, set5;
         int r2;
-        if (gd_wide) {   // rows of more than 5120 floats: 512 threads per workgroup (one chunk per thread up to 512 chunks)
+        if (gnc > 2 * kGDThreads) {   // more than 512 label chunks (graphs over hundreds of classes: V = 500 has ~8 pairs per label,
+                                      // one chunk each): 512 threads with two chunks each
+            static LdsMark set6;
+            if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<2, 2, 2 * kGDThreads>, l, set6, "grad den"))) return r2;
+            hipLaunchKernelGGL((crf_grad_den_kernel<2, 2, 2 * kGDThreads>), gg, dim3(2 * kGDThreads), l, st, p);
+        } else if (gd_wide) {   // rows of more than 5120 floats: 512 threads per workgroup (one chunk per thread up to 512 chunks)
             if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<1, 2, 2 * kGDThreads>, l, set5, "grad den"))) return r2;
             hipLaunchKernelGGL((crf_grad_den_kernel<1, 2, 2 * kGDThreads>), gg, dim3(2 * kGDThreads), l, st, p);
         } else if (gnc <= kGDThreads && V <= kGDThreads) {   // small vocabulary
@@ -4202,6 +4679,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         if (fac && h->dev.fac.K > 1) {
             const int grp = std::max(1, ncu_dev / 4);
             for (int b0 = 0; b0 < (int)B && !r2; b0 += grp) r2 = launch_fac2_pair(p, lds_fac, st, b0, std::min(grp, (int)B - b0));
+        } else if (fac && pair2) {
+            r2 = launch_fac_pair2<false>(p, lds_fac, st, started);
         } else if (fac) {
             r2 = launch_fac_pair<false>(p, lds_fac, st, started, 0, (int)T, fstate, bstate);
         } else if (res) {
@@ -4318,7 +4797,9 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // grad half (writes -c_ctc * gamma_ctc), then the den half of the grad pass stage by stage (adds gamma_den).
         if ((rc = fork_side())) return rc;
         prof_mark(1, false, stream); prof_mark(2, false, stream);
-        if (!segmode) {
+        if (pair2) {
+            if ((rc = launch_fac_pair2<true>(p, lds_fac, stream, started, nstage + 1, bound, cx->flags + 16))) return rc;
+        } else if (!segmode) {
             if ((rc = launch_fac_pair<true>(p, lds_fac, stream, started, 0, (int)T, fstate, bstate, nstage + 1, bound, cx->flags + 16))) return rc;
         } else {
             for (int k = 0; k < nstage; ++k) {
@@ -4328,7 +4809,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         }
         prof_mark(1, true, stream); prof_mark(2, true, stream);
         // hold the numerator back (briefly, bounded) until the den workgroups have their CUs
-        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, side, started, 2 * (int)B);
+        hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, side, started, (int)den_wgs);
         if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
         prof_mark(5, false, side);
         if ((rc = launch_grad_ctc(0, side))) return rc;
@@ -4355,8 +4836,27 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // workgroups own every CU (register-resident layouts with 2B (x K) >= CUs): then the numerator recursions run
         // beside the DEN HALF of the grad pass instead (HBM-bound, small workgroups that share CUs happily).
         const int ctc_after_env = opt(kOpt_ctc_after, -1);
-        const bool after = ctc_after_env >= 0 ? ctc_after_env != 0 : (res && (fac || h->dev.res.K > 1));
-        if (!after) {
+        // (factored, one CU per recursion: the den grid leaves ncu - den_wgs CUs free -- B = 96: 64 of them -- and the numerator
+        // chains, four workgroups to a CU, run there beside it, behind the start gate so that the den workgroups get their CUs first)
+        const bool fac1 = fac && h->dev.fac.K == 1;
+        const bool after = ctc_after_env >= 0 ? ctc_after_env != 0 : fac1 ? den_wgs >= ncu_dev : (res && h->dev.res.K > 1);
+        if (!after && fac1 && have_flags) {
+            if ((rc = fork_side())) return rc;
+            if ((rc = launch_den(stream))) return rc;
+            hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, side, started, (int)den_wgs);
+            if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
+            if ((rc = join_side())) return rc;
+            prof_mark(5, false, stream);
+            if (fast_den) {
+                if ((rc = launch_grad_den(stream, 0))) return rc;
+                if ((rc = launch_grad_ctc(2, stream))) return rc;
+            } else {
+                p.grad_phase = 0;
+                hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, stream, p);
+                LAUNCH_CHECK("crf_grad_kernel");
+            }
+            prof_mark(5, true, stream);
+        } else if (!after) {
             if ((rc = fork_side())) return rc;
             if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
             if ((rc = launch_den(stream))) return rc;

@@ -29,7 +29,9 @@ constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3NC
 // ... and 768 threads with the row constants in an LDS table that the kernel reads one slice AHEAD (crf_kernels.hip, RL): any
 // number of slices per wave up to the ten that the 3-bit fields of wave_info.w hold -- graphs with many short rows (a den_lm
 // estimated from text: 4 000 rows = 63 slices at 100 k arcs) keep three waves per SIMD instead of falling to 512 threads
-constexpr Geom kGeomFac3L{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3ArcCh * 6, 10, 1};
+// (all 21 chunk slots hold arcs here: the 21st is free of row constants -- 5 % more arc slots, which is what keeps a 104 k-arc
+// graph with a few rows of 150 - 230 arcs, V = 143 ... 500 classes, on ONE CU per recursion)
+constexpr Geom kGeomFac3L{kFac3Threads, kFac3Threads / kWave, kFac3NCH, kFac3NCH * 6, 10, 1};
 
 struct DirOut {
     std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
@@ -1497,7 +1499,7 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
                     const unsigned ends = wi.x, lgbits = wi.w;
                     const int nch = (int)wi.y;
                     int row = (int)wi.z, slice = 0;
-                    if (nch > (implicit ? kFac3ArcCh : words / 6)) return fail("a wave uses more chunks than the geometry has");
+                    if (nch > (rcregs ? kFac3ArcCh : words / 6)) return fail("a wave uses more chunks than the geometry has");
                     double acc[kWave];
                     for (double &x : acc) x = 0.0;
                     for (int c = 0; c < nch; ++c) {

@@ -254,3 +254,51 @@ def test_arc_streams_of_the_utterance_minor_kernels(tmp_path, golden_dir, UL):
         assert r["arc_records"] <= 2 * st["A"]
     st, r = check(os.path.join(golden_dir, "den_lm_fixture.fst"), 4)
     assert r["arc_records"] > 0
+
+
+def test_estimator_on_a_hand_worked_count_table():
+    """The estimator's rule, pinned on a table worked by hand (cat/utils/tool/prep_den_lm.sh:40-51 calls Kaldi's
+    ``chain-est-phone-lm --ngram-order=N --no-prune-ngram-order=M --num-extra-lm-states=K``, which is not in this image:
+    equivalence with it stays UNPINNED).  order N = 3, no-prune order M = 2, K = 2 extra states, tokens {1, 2, 3}:
+
+        transcripts            1 2 3 | 1 2 3 | 1 2 1 | 2 3 | 3 1 2 3 | 2 1
+
+    1. Histories (up to N - 1 = 2 tokens) in front of every position, the end included, with their frequencies
+         ():6  (1):4  (2):2  (3):1  (1,2):4  (2,3):4  (2,1):2  (3,1):1
+    2. Kept states: every history shorter than M = 2 tokens -- (), (1), (2), (3) -- plus the K = 2 most frequent longer ones
+       (ties in lexicographic order): (1,2) and (2,3); suffix-closed already.  (2,1) and (3,1) fall back to their longest kept
+       suffix (1).
+    3. Counts collected by running the transcripts through that automaton (0 = end of sentence):
+         ()    : 1 x3, 2 x2, 3 x1                  total 6
+         (1)   : 2 x4 (from 1 2 3, 1 2 3, 1 2 1 and 3 1 2 3: the last one arrives in (1) from (3,1)), end x2 (1 2 1 and 2 1)   total 6
+         (2)   : 1 x1 (2 1), 3 x1 (2 3)            total 2
+         (3)   : 1 x1                              total 1
+         (1,2) : 3 x3, 1 x1                        total 4
+         (2,3) : end x4                            total 4
+    4. Maximum-likelihood probabilities, no smoothing, no back-off arcs; a token leads to the longest kept suffix of
+       (history + token): 1 after (1,2) -> (2,1) is not kept -> state (1); 3 after (1,2) -> (2,3)."""
+    seqs = [(1, 2, 3), (1, 2, 3), (1, 2, 1), (2, 3), (3, 1, 2, 3), (2, 1)]
+    lm = den_lm.estimate_token_lm(seqs, 4, ngram_order=3, no_prune_ngram_order=2, num_extra_states=2)
+    assert lm["histories"] == [(), (1,), (2,), (3,), (1, 2), (2, 3)] and lm["start"] == 0 and lm["num_states"] == 6
+    L = math.log
+    want_arcs = [
+        [(1, 1, L(3 / 6)), (2, 2, L(2 / 6)), (3, 3, L(1 / 6))],     # ()
+        [(2, 4, L(4 / 6))],                                         # (1)
+        [(1, 1, L(1 / 2)), (3, 5, L(1 / 2))],                       # (2)
+        [(1, 1, 0.0)],                                              # (3)
+        [(1, 1, L(1 / 4)), (3, 5, L(3 / 4))],                       # (1,2)
+        [],                                                         # (2,3)
+    ]
+    want_final = [-math.inf, L(2 / 6), -math.inf, -math.inf, -math.inf, 0.0]
+    for got, want in zip(lm["arcs"], want_arcs):
+        assert [(t, n) for t, n, _ in got] == [(t, n) for t, n, _ in want]
+        assert np.allclose([w for _, _, w in got], [w for _, _, w in want], rtol=0, atol=1e-12)
+    assert np.allclose(lm["final"], want_final, rtol=0, atol=1e-12)
+    assert lm["tok_in"] == [-1, 1, 2, 3, 2, 3]
+    # every transcript is accepted with exactly the product of those probabilities
+    for s in seqs:
+        st, lp = 0, 0.0
+        for t in s:
+            (nxt, w), = [(n, w) for tt, n, w in lm["arcs"][st] if tt == t]
+            st, lp = nxt, lp + w
+        assert math.isfinite(lp + lm["final"][st])

@@ -27,7 +27,7 @@ def crf():
     return ctc_crf
 
 
-MODES = ["factored", "factored_rcl", "factored_k2", "resident", "streaming", "batch"]
+MODES = ["factored", "factored_rcl", "factored_k2", "factored_pair2", "resident", "streaming", "batch"]
 
 
 _env = crf_env   # (debug switches of the library, tests/util.py)
@@ -49,7 +49,10 @@ class _mode(crf_env):
             CRF_FAC_NO_RCL=mode == "factored_rc",      # row constants in registers even for long rows
             # "factored_k2": the factored kernels over TWO compute units per recursion (what T o LM graphs of 120 k - 240 k arcs
             # take by themselves), forced for every graph with the structure
-            CRF_FAC_K2=mode == "factored_k2")
+            CRF_FAC_K2=mode == "factored_k2",
+            # "factored_pair2": the factored kernels with TWO utterances per workgroup (what batches above CUs / 4 utterances take by
+            # themselves), forced for any batch; 0 otherwise, so that the other modes test the one-utterance kernels at any batch size
+            CRF_FAC_PAIR2=mode == "factored_pair2")
         # "batch": the utterance-minor kernels (one launch per frame), what graphs that fit no register-resident layout
         # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (no_batch is read per call)
         if mode in ("streaming", "batch"):
@@ -166,6 +169,53 @@ def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
+@pytest.mark.parametrize("geom", ["factored_pair2", "pair2_rcl"])
+@pytest.mark.parametrize("B", [1, 2, 7, 16])
+def test_two_utterances_per_workgroup(crf, tmp_path, geom, B):
+    """The two-utterance kernels (float2 state vectors, one gather for both utterances) do, per utterance, the arithmetic of the
+    one-utterance kernels in the same order (the costs come out bit-identical; the row epilogues' multiply-adds are contracted
+    differently by the compiler, so the rows agree to rounding) -- on ragged pairs (the shorter utterance's sums are taken when it
+    ends, its rows go to a dump row afterwards), with an empty utterance, a one-frame utterance, an odd batch (the last pair has one
+    utterance), with the row constants in registers and in the LDS table; and within 1e-4 of the fp64 oracle."""
+    g, p = small_synth(tmp_path, 24, 96, 8, 13)
+    T, V = 53, 24
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=B, ragged=True)
+    lx = np.array(lx); ly = np.array(ly)
+    lab = [list(labels[sum(ly[:i]):sum(ly[:i + 1])]) for i in range(B)]
+    if B >= 7:
+        lx[2], lab[2] = 0, []                               # an empty utterance (partner of utterance 3)
+        lx[5], lab[5] = 1, lab[5][:1]                       # a one-frame utterance (partner of utterance 4, full length: ends 52 frames earlier)
+    ly = np.array([len(x) for x in lab], dtype=np.int32)
+    labels = np.array([v for x in lab for v in x], dtype=np.int32)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1, size_average=False)
+    outs = {}
+    for pair in (0, 1):
+        with _mode("factored_rcl" if geom == "pair2_rcl" else "factored"), _env(CRF_FAC_PAIR2=pair):
+            ctx = crf.CRFContext(p, 0)
+            x = torch.tensor(logits, device="cuda:0")
+            crf._C.set_debug_poison(True)
+            try:
+                loss, grad, ex = crf._C.loss_fwd_bwd(x, torch.tensor(labels), torch.tensor(lx.astype(np.int32)), torch.tensor(ly), 1.0, 1.1,
+                                                     crf._C.graph_for(x.device), True)
+                torch.cuda.synchronize()
+            finally:
+                crf._C.set_debug_poison(False)
+            kern = crf._C.last_den_kernel()
+            assert kern.startswith("crf_fac_pair2_kernel") == bool(pair), kern
+            outs[pair] = (float(loss.item()), grad.cpu().numpy(), {k: v.cpu().numpy() for k, v in ex.items()})
+            del ctx
+    (l0, g0, e0), (l1, g1, e1) = outs[0], outs[1]
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    for k in ("costs_alpha", "costs_beta", "costs_ctc"):
+        assert np.allclose(e0[k], e1[k], rtol=1e-6, atol=0), k
+    assert rel_err(g1, g0) <= 2e-6
+    assert np.allclose(e1["costs_alpha"], e1["costs_beta"], rtol=3e-5, atol=0)
+    assert abs(l1 - ref["loss"]) <= TOL * abs(ref["loss"])
+    for b in range(B):
+        if lx[b] > 0:
+            assert rel_err(g1[b], ref["grad"][b]) <= TOL, b
+
+
 @pytest.mark.parametrize("B", [16, 21, 70])
 def test_factored_layout_over_two_cus(crf, tmp_path, B):
     """The factored kernels with TWO compute units per recursion (fac_geom 3; forced here, graphs of 120 k - 240 k arcs take it by
@@ -261,7 +311,7 @@ def test_fused_log_softmax(crf, tmp_path, mode, dtype):
     del ctx
 
 
-@pytest.mark.parametrize("mode,V", [("factored", 40), ("factored_rc", 40), ("factored_k2", 40), ("resident", 40), ("streaming", 40), ("factored", 150), ("factored_rc", 150), ("factored_k2", 150)])
+@pytest.mark.parametrize("mode,V", [("factored", 40), ("factored_rc", 40), ("factored_k2", 40), ("resident", 40), ("streaming", 40), ("factored", 150), ("factored_rc", 150), ("factored_k2", 150), ("factored_pair2", 40), ("factored_pair2", 150)])
 def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
     """A den_lm ESTIMATED from text (cat_amd.den_lm.prep_den_lm) has the in-degree profile of a real
     n-gram LM: the low-order history states are entered from hundreds of states.  The factored layout cuts such rows

@@ -11,7 +11,7 @@ which = int(sys.argv[2]) if len(sys.argv) > 2 else -2          # a call in the m
 a, b = fin[which - 1] + 1, fin[which]
 call = ks[a:b + 1]
 t0 = call[0][0]
-chain_end = max(e for s, e, n in call if "chain_kernel" in n and "fac" in n or "res_chain" in n)
+chain_end = max(e for s, e, n in call if any(k in n for k in ("fac_pair", "fac2_pair", "fac_pair2", "res_pair", "den_pair", "batch_frame")))
 def short(n):
     n = n.replace("crf::", "").split("(")[0]
     return n[:60]
