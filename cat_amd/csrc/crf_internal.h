@@ -50,6 +50,10 @@ constexpr int kResMaxK = 4;
 constexpr int kFac3Threads = 768;
 constexpr int kFac3NCH = 21;       // chunk slots (6 words each) per thread: 20 hold arcs, the last holds row constants
 constexpr int kFac3ArcCh = 20;     // chunks of arcs per thread
+#ifndef CRF_FAC3L_NCH
+#define CRF_FAC3L_NCH 21
+#endif
+constexpr int kFac3LNCH = CRF_FAC3L_NCH;   // chunks of arcs per thread with the row constants in the LDS table (all 21 slots hold arcs)
 constexpr int kFac3MaxSl = 3;      // slices (row epilogues) per wave: two words of row constants each, at word kFac3ArcCh * 6 on
 
 struct ResDirDev {

@@ -2181,15 +2181,20 @@ __device__ __forceinline__ void fac_chain_body2(const FacParams &p, float *lds, 
             if constexpr (ML) {
                 const unsigned lg = ks < 10u ? (lgbits >> (3u * ks)) & 7u : 0u;
                 if (lg) {
-#define CRF_DPP_ADD2(ctrl) { tot.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot.x), ctrl, 0xf, 0xf, false)); \
-                             tot.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot.y), ctrl, 0xf, 0xf, false)); }
+                    // (two scalars, not the halves of the float2: with the DPP source a sub-register of a 64-bit tuple the compiler's
+                    // DPP combiner took the OTHER half as source -- v_add_f32_dpp v7, v6, v7 -- found by the parity tests)
+                    float tx = tot.x, ty = tot.y;
+                    asm volatile("" : "+v"(tx), "+v"(ty));
+#define CRF_DPP_ADD2(ctrl) { tx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tx), ctrl, 0xf, 0xf, false)); \
+                             ty += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ty), ctrl, 0xf, 0xf, false)); }
                     CRF_DPP_ADD2(0xB1);
                     if (lg >= 2) CRF_DPP_ADD2(0x4E);
                     if (lg >= 3) CRF_DPP_ADD2(0x141);
                     if (lg >= 4) CRF_DPP_ADD2(0x140);
 #undef CRF_DPP_ADD2
-                    if (lg >= 5) { tot.x += __shfl_xor(tot.x, 16, 64); tot.y += __shfl_xor(tot.y, 16, 64); }
-                    if (lg >= 6) { tot.x += __shfl_xor(tot.x, 32, 64); tot.y += __shfl_xor(tot.y, 32, 64); }
+                    if (lg >= 5) { tx += __shfl_xor(tx, 16, 64); ty += __shfl_xor(ty, 16, 64); }
+                    if (lg >= 6) { tx += __shfl_xor(tx, 32, 64); ty += __shfl_xor(ty, 32, 64); }
+                    tot = f32x2{tx, ty};
                 }
             }
             unsigned k0, k1;
@@ -3727,7 +3732,8 @@ __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const bool fwd = (int)blockIdx.x < p.B;
     const int b = fwd ? (int)blockIdx.x : (int)blockIdx.x - p.B;
-    if (!p.redo_ctc[b]) return;
+    const int redo = p.redo_ctc[b];
+    if (redo != 1 && redo != 2) return;                     // (3: already redone by an earlier pass of this call)
     const int tid = threadIdx.x;
     const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
     const CtcLds c = ctc_carve(lds, Sxp);
@@ -3745,42 +3751,68 @@ __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams 
         skip[i] = fwd ? (s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2])
                       : ((s + 2 < Sx) && lab[s + 2] != 0 && lab[s + 2] != mylab[i]);
     }
-    // log p_t[l'_s] = (x_t[l] - max_t) + offset_t (offset = the row maximum, or -log sum exp(x - max) with the fused log_softmax)
-    auto lp = [&](int t, int i) -> double {
+    // log p_t[l'_s] = (x_t[l] - max_t) + offset_t (offset = the row maximum, or -log sum exp(x - max) with the fused log_softmax).
+    // Emissions are fetched in BATCHES of kCtcPF frames into two alternating register sets, as in the scaled chains: one wait on
+    // global memory per batch, for loads issued a batch ago (a wait per frame ties the frame to the memory latency: 1.2 us), and the
+    // frame barrier orders LDS only.
+    float lr[2][kCtcPF][NR];
+    double of[2][kCtcPF];
+    auto fetch = [&](auto SET, const int t0, const int dt) __attribute__((always_inline)) {   // frames t0, t0 + dt, ...
+        constexpr int st = decltype(SET)::value;
+#pragma unroll
+        for (int f = 0; f < kCtcPF; ++f) {
+            const int t = t0 + f * dt;
+            if (t >= 0 && t < lx) {
+                of[st][f] = (double)p.moff[bt0 + t] - (double)p.mx[bt0 + t];
+#pragma unroll
+                for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? ld_x(p, (bt0 + t) * V + mylab[i]) : 0.f;
+            }
+        }
+    };
+    auto lp0 = [&](int t, int i) -> double {   // (set-up frames only)
         return ((double)ld_x(p, (bt0 + t) * V + mylab[i]) - (double)p.mx[bt0 + t]) + (double)p.moff[bt0 + t];
     };
-    double en[NR];
     if (fwd) {
         double *CArow = p.CA + bt0 * p.Sc;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
-                const double v = (s < 2 && s < Sx) ? lp(0, i) : -INFINITY;
+                const double v = (s < 2 && s < Sx) ? lp0(0, i) : -INFINITY;
                 A[s] = v;
                 A[Sxp + s] = -INFINITY;
                 if (s < Sx) CArow[s] = v;
             }
-            en[i] = (s < Sx && lx > 1) ? lp(1, i) : 0.0;
         }
         __syncthreads();
-        for (int t = 1; t < lx; ++t) {
-            const double *Ac = A + ((t - 1) & 1) * Sxp;
-            double *An = A + (t & 1) * Sxp;
-            CArow = p.CA + (bt0 + t) * p.Sc;
-            double e[NR];
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        auto batch = [&](auto SET, const int tb) __attribute__((always_inline)) {
+            constexpr int st = decltype(SET)::value;
+            fetch(std::integral_constant<int, 1 - st>{}, tb + kCtcPF, 1);   // the next batch, requested before this one is used
 #pragma unroll
-            for (int i = 0; i < NR; ++i) { e[i] = en[i]; if (tid + i * kCtcThreads < Sx && t + 1 < lx) en[i] = lp(t + 1, i); }
+            for (int f = 0; f < kCtcPF; ++f) {
+                const int t = tb + f;
+                if (t < lx) {
+                    const double *Ac = A + ((t - 1) & 1) * Sxp;
+                    double *An = A + (t & 1) * Sxp;
+                    double *row = p.CA + (bt0 + t) * p.Sc;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int s = tid + i * kCtcThreads;
-                if (s < Sx) {
-                    const double v = lse3(Ac[s], s >= 1 ? Ac[s - 1] : -INFINITY, skip[i] ? Ac[s - 2] : -INFINITY) + e[i];
-                    An[s] = v;
-                    CArow[s] = v;
+                    for (int i = 0; i < NR; ++i) {
+                        const int s = tid + i * kCtcThreads;
+                        if (s < Sx) {
+                            const double v = lse3(Ac[s], s >= 1 ? Ac[s - 1] : -INFINITY, skip[i] ? Ac[s - 2] : -INFINITY) + ((double)lr[st][f][i] + of[st][f]);
+                            An[s] = v;
+                            row[s] = v;
+                        }
+                    }
+                    sync_lds();
                 }
             }
-            __syncthreads();
+        };
+        fetch(I0{}, 1, 1);
+        for (int tb = 1; tb < lx; tb += 2 * kCtcPF) {
+            batch(I0{}, tb);
+            if (tb + kCtcPF < lx) batch(I1{}, tb + kCtcPF);
         }
         if (tid == 0) {
             const double *Af = A + ((lx - 1) & 1) * Sxp;
@@ -3798,31 +3830,41 @@ __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams 
             const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
                 const double bx = (s < Sx && s >= Sx - 2) ? 0.0 : -INFINITY;
-                A[s] = s < Sx ? bx + lp(lx - 1, i) : -INFINITY;
+                A[s] = s < Sx ? bx + lp0(lx - 1, i) : -INFINITY;
                 A[Sxp + s] = -INFINITY;
                 if (s < Sx) CBrow[s] = bx;
             }
-            en[i] = (s < Sx && lx > 1) ? lp(lx - 2, i) : 0.0;
         }
         __syncthreads();
-        for (int k = 1; k < lx; ++k) {
-            const int t = lx - 1 - k;
-            const double *Yc = A + ((k - 1) & 1) * Sxp;
-            double *Yn = A + (k & 1) * Sxp;
-            CBrow = p.CB + (bt0 + t) * p.Sc;
-            double e[NR];
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        auto batch = [&](auto SET, const int kb) __attribute__((always_inline)) {
+            constexpr int st = decltype(SET)::value;
+            fetch(std::integral_constant<int, 1 - st>{}, lx - 1 - (kb + kCtcPF), -1);
 #pragma unroll
-            for (int i = 0; i < NR; ++i) { e[i] = en[i]; if (tid + i * kCtcThreads < Sx && t >= 1) en[i] = lp(t - 1, i); }
+            for (int f = 0; f < kCtcPF; ++f) {
+                const int k = kb + f;
+                if (k < lx) {
+                    const int t = lx - 1 - k;
+                    const double *Yc = A + ((k - 1) & 1) * Sxp;
+                    double *Yn = A + (k & 1) * Sxp;
+                    double *row = p.CB + (bt0 + t) * p.Sc;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int s = tid + i * kCtcThreads;
-                if (s < Sx) {
-                    const double bx = lse3(Yc[s], s + 1 < Sx ? Yc[s + 1] : -INFINITY, skip[i] ? Yc[s + 2] : -INFINITY);
-                    CBrow[s] = bx;
-                    Yn[s] = bx + e[i];
+                    for (int i = 0; i < NR; ++i) {
+                        const int s = tid + i * kCtcThreads;
+                        if (s < Sx) {
+                            const double bx = lse3(Yc[s], s + 1 < Sx ? Yc[s + 1] : -INFINITY, skip[i] ? Yc[s + 2] : -INFINITY);
+                            row[s] = bx;
+                            Yn[s] = bx + ((double)lr[st][f][i] + of[st][f]);
+                        }
+                    }
+                    sync_lds();
                 }
             }
-            __syncthreads();
+        };
+        fetch(I0{}, lx - 2, -1);
+        for (int kb = 1; kb < lx; kb += 2 * kCtcPF) {
+            batch(I0{}, kb);
+            if (kb + kCtcPF < lx) batch(I1{}, kb + kCtcPF);
         }
     }
 }
@@ -4286,8 +4328,8 @@ static int launch_fac2_pair(const LossParams &lp, size_t lds, hipStream_t st, in
     FacParams pf = fac_params(lp, 0, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
     FacParams pb = fac_params(lp, 1, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
     pf.b0 = pb.b0 = b0; pf.nbu = pb.nbu = nbu;
-    auto *k = crf_fac2_pair_kernel<kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B>;
-        g_den_kernel = "crf_fac2_pair_kernel<768,21,4,4>";
+    auto *k = crf_fac2_pair_kernel<kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B>;
+        g_den_kernel = "crf_fac2_pair_kernel<768,20,4,4>";
     int rc;
     if ((rc = ensure_lds((const void *)k, lds, mk, "fac2 pair"))) return rc;
     hipLaunchKernelGGL(k, dim3((unsigned)(2 * nbu * 2)), dim3(kFac3Threads), lds, st, pf, pb);
@@ -4300,25 +4342,28 @@ static int launch_fac2_pair(const LossParams &lp, size_t lds, hipStream_t st, in
 template <bool FLAG>
 static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int *started, int i0, int i1, float *fstate, float *bstate,
                            int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
-    static LdsMark m3, m3m, m3l, m5;
+    static LdsMark m3, m3m, m5;
     const FacDev &F = lp.g.fac;
     const bool g3 = F.threads == kFac3Threads, ml = F.multilane != 0;
     const FacParams pf = fac_params(lp, 0, started, i0, i1, fstate, nb, bound, stage_cnt);
     const FacParams pb = fac_params(lp, 1, started, i0, i1, bstate, nb, bound, stage_cnt);
     const dim3 grid((unsigned)(2 * lp.B));
     int rc;
-    if (g3 && F.rcl && !ml) {
-        static LdsMark m3ln;
-        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, false, true>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,false,true>" : "crf_fac_pair_kernel<false,768,21,4,4,false,true>";
-        if ((rc = ensure_lds((const void *)k, lds, m3ln, "fac pair"))) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
-    } else if (g3 && F.rcl) {
-        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true, true>;
-        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,true>" : "crf_fac_pair_kernel<false,768,21,4,4,true,true>";
-        if ((rc = ensure_lds((const void *)k, lds, m3l, "fac pair"))) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
-    } else if (g3 && ml) {
+#define CRF_LAUNCH_RL(NCH_, ML_, NAME_, MARK_)                                                                                   \
+    {                                                                                                                           \
+        static LdsMark MARK_;                                                                                                   \
+        auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, NCH_, CRF_FAC3_NB_F, CRF_FAC3_NB_B, ML_, true>;                       \
+        g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768," NAME_ ",true>" : "crf_fac_pair_kernel<false,768," NAME_ ",true>"; \
+        if ((rc = ensure_lds((const void *)k, lds, MARK_, "fac pair"))) return rc;                                              \
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);                                                       \
+    }
+    // row constants in the LDS table: 20 chunks of arcs per thread (F.rcl == 1), or all 21 slots (== 2: graphs that need them)
+    if (g3 && F.rcl == 1 && !ml) CRF_LAUNCH_RL(kFac3ArcCh, false, "20,4,4,false", mk20n)
+    else if (g3 && F.rcl == 1) CRF_LAUNCH_RL(kFac3ArcCh, true, "20,4,4,true", mk20m)
+    else if (g3 && F.rcl == 2 && !ml) CRF_LAUNCH_RL(kFac3LNCH, false, "21,4,4,false", mk21n)
+    else if (g3 && F.rcl == 2) CRF_LAUNCH_RL(kFac3LNCH, true, "21,4,4,true", mk21m)
+#undef CRF_LAUNCH_RL
+    else if (g3 && ml) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true>;
         g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,false>" : "crf_fac_pair_kernel<false,768,21,4,4,true,false>";
         if ((rc = ensure_lds((const void *)k, lds, m3m, "fac pair"))) return rc;
@@ -4342,24 +4387,27 @@ static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int
 // ... two utterances per workgroup: 2 * ceil(B / 2) workgroups
 template <bool FLAG>
 static int launch_fac_pair2(const LossParams &lp, size_t lds, hipStream_t st, int *started, int nb = 0, const int *bound = nullptr, int *stage_cnt = nullptr) {
-    static LdsMark m2, m2m, m2l, m2ln;
+    static LdsMark m2, m2m;
     const FacDev &F = lp.g.fac;
     const bool ml = F.multilane != 0;
     const FacParams pf = fac_params(lp, 0, started, 0, lp.T, nullptr, nb, bound, stage_cnt);
     const FacParams pb = fac_params(lp, 1, started, 0, lp.T, nullptr, nb, bound, stage_cnt);
     const dim3 grid((unsigned)(2 * pf.npair));
     int rc;
-    if (F.rcl && !ml) {
-        auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, false, true>;
-        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,true>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,true>";
-        if ((rc = ensure_lds((const void *)k, lds, m2ln, "fac pair2"))) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
-    } else if (F.rcl) {
-        auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, true, true>;
-        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,true>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,true>";
-        if ((rc = ensure_lds((const void *)k, lds, m2l, "fac pair2"))) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
-    } else if (ml) {
+#define CRF_LAUNCH_RL2(NCH_, ML_, NAME_, MARK_)                                                                                 \
+    {                                                                                                                           \
+        static LdsMark MARK_;                                                                                                   \
+        auto *k = crf_fac_pair2_kernel<FLAG, NCH_, CRF_FAC3_NB2, CRF_FAC3_NB2, ML_, true>;                                      \
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true," NAME_ ",true>" : "crf_fac_pair2_kernel<false," NAME_ ",true>";       \
+        if ((rc = ensure_lds((const void *)k, lds, MARK_, "fac pair2"))) return rc;                                             \
+        hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);                                                       \
+    }
+    if (F.rcl == 1 && !ml) CRF_LAUNCH_RL2(kFac3ArcCh, false, "20," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false", mp20n)
+    else if (F.rcl == 1) CRF_LAUNCH_RL2(kFac3ArcCh, true, "20," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true", mp20m)
+    else if (F.rcl == 2 && !ml) CRF_LAUNCH_RL2(kFac3LNCH, false, "21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false", mp21n)
+    else if (F.rcl == 2) CRF_LAUNCH_RL2(kFac3LNCH, true, "21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true", mp21m)
+#undef CRF_LAUNCH_RL2
+    else if (ml) {
         auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, true, false>;
         g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,false>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,false>";
         if ((rc = ensure_lds((const void *)k, lds, m2m, "fac pair2"))) return rc;

@@ -1175,15 +1175,16 @@ int crf_graph_dims(const crf_graph *g, int64_t *S, int64_t *A, int64_t *P, int64
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
     if (!g || !g->h || !out) { crf::set_error("null argument"); return CRF_ERR_ARG; }
     const crf::HostGraph *h = g->h;
-    const int64_t v[25] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
+    const int64_t v[26] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
                            h->fwd_conflicts, h->bwd_conflicts, (int64_t)h->max_in_deg * 100000 + h->max_out_deg,
                            h->res_stats.K, h->res_stats.slots_f, h->res_stats.slots_b, h->res_stats.conflicts_f,
                            h->res_stats.conflicts_b, (int64_t)h->dev.res.f.R * 100000 + h->dev.res.b.R,
                            h->fac_stats.ok, h->fac_stats.matched, (int64_t)h->regauged, h->fac_stats.tail,
                            h->fac_stats.slots_f, h->fac_stats.slots_b, h->fac_stats.fused,
                            h->fac_stats.Gf * 100000 + h->fac_stats.Gb,
-                           h->fac_stats.ok ? (h->dev.fac.threads != crf::kFac3Threads ? 2 : h->dev.fac.K > 1 ? 3 : h->dev.fac.rcl ? 1 : 0) : -1};
-    for (int i = 0; i < n && i < 25; ++i) out[i] = v[i];
+                           h->fac_stats.ok ? (h->dev.fac.threads != crf::kFac3Threads ? 2 : h->dev.fac.K > 1 ? 3 : h->dev.fac.rcl ? 1 : 0) : -1,
+                           h->fac_stats.ok ? (h->dev.fac.threads != crf::kFac3Threads ? crf::kResNCH : h->dev.fac.rcl == 2 ? crf::kFac3LNCH : crf::kFac3ArcCh) : 0};
+    for (int i = 0; i < n && i < 26; ++i) out[i] = v[i];
     return CRF_OK;
 }
 

@@ -29,9 +29,12 @@ constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3NC
 // ... and 768 threads with the row constants in an LDS table that the kernel reads one slice AHEAD (crf_kernels.hip, RL): any
 // number of slices per wave up to the ten that the 3-bit fields of wave_info.w hold -- graphs with many short rows (a den_lm
 // estimated from text: 4 000 rows = 63 slices at 100 k arcs) keep three waves per SIMD instead of falling to 512 threads
-// (all 21 chunk slots hold arcs here: the 21st is free of row constants -- 5 % more arc slots, which is what keeps a 104 k-arc
-// graph with a few rows of 150 - 230 arcs, V = 143 ... 500 classes, on ONE CU per recursion)
-constexpr Geom kGeomFac3L{kFac3Threads, kFac3Threads / kWave, kFac3NCH, kFac3NCH * 6, 10, 1};
+constexpr Geom kGeomFac3L{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3ArcCh * 6, 10, 1};
+// ... the same with ALL 21 chunk slots holding arcs (no row constants in the 21st): 5 % more arc slots, which is what keeps a
+// 104 k-arc graph with a few rows of 150 - 500 arcs (V = 143 ... 500 classes) on ONE CU per recursion.  Tried only when the
+// 20-chunk table geometry does not take the graph: measured 0.13 - 0.3 us per frame slower on the graphs that fit both
+// (S = 513: 2.04 -> 2.52 ms, estimated S = 1 212: 2.04 -> 2.48 ms)
+constexpr Geom kGeomFac3L21{kFac3Threads, kFac3Threads / kWave, kFac3LNCH, kFac3LNCH * 6, 10, 1};
 
 struct DirOut {
     std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
@@ -1047,8 +1050,9 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // Geometry: 768 threads (3 waves per SIMD at <= 168 VGPRs; 20 chunks of arcs and the constants of up to 3 rows per
     // thread) when both directions fit it, else 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces
     // the latter.
-    const Geom *gm = level == 0 ? &kGeomFac3 : level == 1 ? &kGeomFac3L : &kGeomFac512;
-    const bool allow3 = level < 2;                // a larger geometry is left to try
+    const bool lvl_table = level == 1 || level == 3;   // row constants in the LDS table: 20 chunks of arcs per thread (1) or 21 (3)
+    const Geom *gm = level == 0 ? &kGeomFac3 : level == 1 ? &kGeomFac3L : level == 3 ? &kGeomFac3L21 : &kGeomFac512;
+    const bool allow3 = level != 2;               // a larger geometry is left to try
     const bool rcregs = level == 0;               // row constants in registers
     const bool implicit = gm->maxsl > 0;   // entries numbered by row id, row constants in registers (below)
     // entries (512-thread layout): [U of every pair][sink][L of every pair][A of every pair][plain states]
@@ -1370,9 +1374,9 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         // direction again without it.  (level 1: the forward table has 8 bytes per row, and both have 64 rows of slack.)
         const int V0 = std::max(max_lab + 1, 256);
         const size_t tail = ((size_t)2 * ((V0 + 1 + 63) / 64 * 64) + 4 * (size_t)gm->waves + 16) * 4 + 256;
-        auto need = [&](int G, int R, int rb) { return (size_t)2 * ((G + 63) / 64 * 64) * 4 + (size_t)(R + (level == 1 ? 64 : 0)) * rb + tail; };
+        auto need = [&](int G, int R, int rb) { return (size_t)2 * ((G + 63) / 64 * 64) * 4 + (size_t)(R + (lvl_table ? 64 : 0)) * rb + tail; };
         auto cu_rows = [&](const DirOut &o) { int m = 0; for (int k = 0; k < K; ++k) m = std::max(m, o.cu_row_off[(size_t)k + 1] - o.cu_row_off[(size_t)k]); return m; };   // (two CUs: a CU's table holds its own rows)
-        const bool f_ok = need(Gf, K > 1 ? cu_rows(fo) : Rf, level == 1 ? 8 : 16) <= (size_t)160 * 1024, b_ok = need(Gb, K > 1 ? cu_rows(bo) : Rb, 16) <= (size_t)160 * 1024;
+        const bool f_ok = need(Gf, K > 1 ? cu_rows(fo) : Rf, lvl_table ? 8 : 16) <= (size_t)160 * 1024, b_ok = need(Gb, K > 1 ? cu_rows(bo) : Rb, 16) <= (size_t)160 * 1024;
         if (!f_ok || !b_ok) {
             int m = dup_mask;
             if (!f_ok && !no_dupf) m &= ~1;
@@ -1386,7 +1390,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     for (auto &wi : fo.wave_info) if (wi.w) F.multilane = 1;
     for (auto &wi : bo.wave_info) if (wi.w) F.multilane = 1;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
-    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads; F.rcl = level == 1; F.K = K;
+    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads; F.rcl = level == 1 ? 1 : level == 3 ? 2 : 0; F.K = K;
     for (int k = 0; k < 3; ++k) F.xlist_off[k] = xlist_off[k];
     for (int k = 0; k <= 2; ++k) { F.f.cu_row[k] = fo.cu_row_off[(size_t)std::min(k, K)]; F.b.cu_row[k] = bo.cu_row_off[(size_t)std::min(k, K)]; }
     int rc;
@@ -1423,14 +1427,15 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     std::vector<Try> plan;
     if (!want3) plan = {{2, false}};
     else if (opt_on(kOpt_fac_k2)) plan = {{1, false, 2}, {2, false}};   // (tests: two CUs per recursion for any T o LM graph)
-    else if (from_rcl) plan = {{1, false}, {2, false}};
+    else if (opt(kOpt_fac_rcl, 0) == 2) plan = {{3, false}, {2, false}};   // (tests: the 21-chunk table geometry for any T o LM graph)
+    else if (from_rcl) plan = {{1, false}, {3, false}, {2, false}};
     else if (no_rcl) plan = {{0, false}, {2, false}};
-    else plan = {{0, true}, {1, false}, {0, false}, {1, false, 2}, {2, false}};   // level 0 only for graphs without long rows -- unless level 1 does
+    else plan = {{0, true}, {1, false}, {0, false}, {3, false}, {1, false, 2}, {2, false}};   // level 0 only for graphs without long rows -- unless level 1 does
                                                                    // not take them; then two CUs per recursion (table geometry), then 512 threads
     const bool no_k2 = opt_on(kOpt_fac_no_k2);
     bool long_bail = false;
     for (const Try &t : plan) {
-        if (t.level == 0 && !t.short_only && plan.size() == 5 && !long_bail) continue;   // level 0 has been tried in full already
+        if (t.level == 0 && !t.short_only && plan.size() == 6 && !long_bail) continue;   // level 0 has been tried in full already
         if (t.K > 1 && no_k2) continue;
         bool retry = false;
         int mask = 3, nm = 3;
