@@ -130,6 +130,7 @@ struct FacDev {
     // grad pass
     const int *gq, *gb, *chunk_off, *lab_chunk_off;
     int NC;
+    int chunk_cap;             // entries per chunk at most: kChunk, or 8 for graphs with few pairs per label (crf_grad_den_kernel<..., 8>)
     int Rq;                    // Q row stride = 2*Rf: main rows, then the tail row of each main row
     int Rbp;                   // BP row stride = 2*Rb
 };

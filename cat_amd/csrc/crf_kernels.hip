@@ -102,6 +102,10 @@ struct LossParams {
     int *redo_ctc;                // [B] 0 = fine, 1 = some frames marked in ctc_bad, 2 = the whole utterance (the forward chain lost its mass, or forced)
     int *ctc_bad;                 // [B*T] marked frames (cleared by the prep kernel)
     int force_redo_ctc;           // switches robust = 1 / robust_ctc = 1: every utterance's numerator takes the log-domain path
+    int *ctc_logdom;              // [B] 0, or the pass (1 = right behind the numerator's grad half, beside the denominator recursions of the
+                                  // staged schedule; 2 = end of the call) in which the log-domain kernels redid the utterance: its CA / CB
+                                  // rows and ctc_zc then hold LOGARITHMS
+    int ctc_pass;                 // the pass of this launch of the log-domain kernels
     int64_t gvec_stride;          // floats per utterance of `gvec`
     // outputs
     float *grad, *loss, *out_den, *out_beta, *out_ctc;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < p.nclear; i += 256) __hip_atomic_store(p.clear + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (p.redo) for (int i = threadIdx.x; i < 2 * p.B; i += 256) p.redo[i] = p.force_redo;
-        if (p.redo_ctc) for (int i = threadIdx.x; i < p.B; i += 256) p.redo_ctc[i] = p.force_redo_ctc ? 2 : 0;
+        if (p.redo_ctc) for (int i = threadIdx.x; i < p.B; i += 256) { p.redo_ctc[i] = p.force_redo_ctc ? 2 : 0; p.ctc_logdom[i] = 0; }
     }
     const int64_t f = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
     if (f >= (int64_t)p.B * p.T) return;
@@ -2523,7 +2527,9 @@ constexpr int kGDEpRegs = 4;                                      // V <= 4*256
 // exponents are read once per workgroup, and the barriers are LDS-only (sync_lds) -- __syncthreads()
 // would drain vmcnt, i.e. wait for the prefetch it has just issued (that alone was ~2/3 of this kernel).
 // NT threads: 256, or 512 for graphs whose rows do not fit 256 threads' prefetch registers (5 float4 each per row)
-template <int NCPT, int EPR, int NT = kGDThreads>
+// CH: entries per chunk the index registers hold (kChunk; 8 for graphs with few pairs per label -- V = 500: ~8 -- whose chunk lists the
+// graph compiler cuts at 8: a chunk of 32 slots with 8 pairs spends three quarters of its gathers on padding)
+template <int NCPT, int EPR, int NT = kGDThreads, int CH = kChunk>
 __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
@@ -2570,7 +2576,8 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
         if (mine != p.gd_stage) return;
     }
 
-    unsigned idx[NCPT][kChunk];
+    unsigned idx[NCPT][CH];
+    constexpr int HS = CH < 16 ? CH : 16;
     {
         // unconditional (clamped) loads, selected afterwards: predicated loads were issued one at a time,
         // 32 L2 round trips in a row before the first frame
@@ -2581,16 +2588,16 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
             const int j0 = c < NC ? p.gchunk[c] : 0;
             const int clen = c < NC ? p.gchunk[c + 1] - j0 : 0;
 #pragma unroll
-            for (int h = 0; h < kChunk; h += 16) {   // in two halves: 64 loads in flight were the register peak of the kernel
-                unsigned short gqv[16], gbv[16];
+            for (int h = 0; h < CH; h += HS) {   // in halves of 16: 64 loads in flight were the register peak of the kernel
+                unsigned short gqv[HS], gbv[HS];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
+                for (int j = 0; j < HS; ++j) {
                     const int jj = min(j0 + h + j, nlist - 1);
                     gqv[j] = (unsigned short)p.gq[jj];
                     gbv[j] = (unsigned short)p.gb[jj];
                 }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) idx[i][h + j] = h + j < clen ? ((unsigned)gqv[j] | (unsigned)gbv[j] << 16) : (unsigned)Rq;
+                for (int j = 0; j < HS; ++j) idx[i][h + j] = h + j < clen ? ((unsigned)gqv[j] | (unsigned)gbv[j] << 16) : (unsigned)Rq;
             }
         }
     }
@@ -2666,7 +2673,7 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
         for (int i = 0; i < NCPT; ++i) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int j = 0; j < kChunk; j += 2) {  // padding pairs read Qs[Rq] = 0 (times Bs[0])
+            for (int j = 0; j < CH; j += 2) {  // padding pairs read Qs[Rq] = 0 (times Bs[0])
                 s0 = fmaf(Qs[idx[i][j] & 0xffffu], Bs[idx[i][j] >> 16], s0);
                 s1 = fmaf(Qs[idx[i][j + 1] & 0xffffu], Bs[idx[i][j + 1] >> 16], s1);
             }
@@ -3639,6 +3646,11 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParam
     int ezc = 0, Sx = 0;
     const int *ul = nullptr;
     if (do_ctc) { zc = ctc_zc_for_grad(p, b); ezc = p.ctc_ez[b]; Sx = 2 * p.ly[b] + 1; ul = p.labels + p.lab_off[b]; }
+    // an utterance whose numerator the log-domain kernels have redone already (pass 1, beside the recursions): CA / CB hold logarithms
+    const bool logdom = do_ctc && p.ctc_logdom[b] != 0;
+    const double lzc = logdom ? p.ctc_zc[b] : 0.0;
+    const bool logok = logdom && lzc > -INFINITY && lzc < INFINITY && !p.invalid[b];
+    if (logdom) zc = logok ? 1.0 : 0.0;                      // (only its sign is used below)
     const double invc = zc > 0.0 ? 1.0 / zc : 0.0;
     auto bmax = [&](double v) {
 #pragma unroll
@@ -3689,10 +3701,10 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParam
         const double nrm = bsum(part);
         if (do_ctc && zc > 0.0) {
             const double *Ar = p.CA + (bt0 + t) * p.Sc, *Bx = p.CB + (bt0 + t) * p.Sc;
-            const double fc = ctc_frame_factor(p, b, bt0 + t, invc, ezc);
+            const double fc = logdom ? 0.0 : ctc_frame_factor(p, b, bt0 + t, invc, ezc);
             float blank = 0.f;
             for (int s = tid; s < Sx; s += kGradThreads) {
-                const float pr = (float)(Ar[s] * Bx[s] * fc);
+                const float pr = logdom ? (float)exp(Ar[s] + Bx[s] - lzc) : (float)(Ar[s] * Bx[s] * fc);
                 if (s & 1) atomicAdd(&gc[ul[s >> 1]], pr);
                 else blank += pr;
             }
@@ -3732,8 +3744,8 @@ __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const bool fwd = (int)blockIdx.x < p.B;
     const int b = fwd ? (int)blockIdx.x : (int)blockIdx.x - p.B;
-    const int redo = p.redo_ctc[b];
-    if (redo != 1 && redo != 2) return;                     // (3: already redone by an earlier pass of this call)
+    const int redo = p.redo_ctc[b], done = p.ctc_logdom[b];
+    if (!redo || (done != 0 && done != p.ctc_pass)) return;   // not marked, or redone by an earlier pass of this call
     const int tid = threadIdx.x;
     const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
     const CtcLds c = ctc_carve(lds, Sxp);
@@ -3818,9 +3830,10 @@ __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams 
             const double *Af = A + ((lx - 1) & 1) * Sxp;
             const double lz = lse3(Af[Sx - 1], Sx > 1 ? Af[Sx - 2] : -INFINITY, -INFINITY);
             const bool ok = lz > -INFINITY && lz < INFINITY;
-            p.ctc_zc[b] = lz;                    // (from here on the LOG of the partition sum: read by crf_robust_ctc_fix_kernel only)
+            p.ctc_zc[b] = lz;                    // (from here on the LOG of the partition sum)
             p.cost_ctc[b] = ok ? (float)lz : 0.f;
             p.invalid[b] = ok ? 0 : 1;
+            p.ctc_logdom[b] = p.ctc_pass;        // (the backward workgroup of this pass may start later: it lets its own pass through)
         }
     } else {
         // Y_t[s] = log(e_t[l'_s] Bx_t[s]) in LDS; Bx_t itself goes to the CB rows
@@ -3875,7 +3888,7 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_ctc_fix_kernel(LossPa
     const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.y, V = p.V;
     const int redo = p.redo_ctc[b];
-    if (!redo) return;
+    if (!redo || p.ctc_logdom[b] != p.ctc_pass) return;      // not marked, or fixed by an earlier pass (or not a valid label sequence)
     const double lz = p.ctc_zc[b];
     if (!(lz > -INFINITY && lz < INFINITY) || p.invalid[b]) return;   // no alignment at all: the numerator contributes nothing
     const int lx = p.lx[b], Sx = 2 * p.ly[b] + 1;
@@ -4535,6 +4548,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.cb_part = pb + 8 * B; p.cb_F = (int *)(pb + 8 * B + (int64_t)kResMaxK * B);
     p.redo = (int *)(pb + 16 * B);   // [2][B]
     p.redo_ctc = (int *)(pb + 18 * B);   // [B]
+    p.ctc_logdom = (int *)(pb + 19 * B); // [B]
     p.ctc_bad = (int *)(base + w.off_cbad);
     // CRF_ROBUST: 0 = never run the robust fallback, 1 = every utterance takes it (tests, or "safe mode"); default: the
     // utterances the fast kernels flag
@@ -4606,6 +4620,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     // The denominator half of the grad pass has a streaming kernel (index pairs in registers, rows
     // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
     const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
+    const int gcap = fac ? h->dev.fac.chunk_cap : kChunk;       // entries per chunk of the grad pass's pair lists
     const bool gd_wide = den && (w.Rq > 4 * kGDRowRegs * kGDThreads || w.Rb > 4 * kGDRowRegs * kGDThreads);   // 512-thread grad workgroups
     const bool fast_den = den && w.Rq <= 8 * kGDRowRegs * kGDThreads && w.Rb <= 8 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
                           gnc <= 4 * kGDThreads && V <= kGDEpRegs * kGDThreads && !opt_on(kOpt_no_fast_grad);
@@ -4683,7 +4698,11 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         }
         static LdsMark set1, set2, set3, set5;
         int r2;
-        if (gnc > 2 * kGDThreads) {   // more than 512 label chunks (graphs over hundreds of classes: V = 500 has ~8 pairs per label,
+        if (gcap == 8) {              // chunk lists cut at 8 entries (many labels with few pairs each): 512 threads, two chunks each
+            static LdsMark set7;
+            if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<2, 2, 2 * kGDThreads, 8>, l, set7, "grad den"))) return r2;
+            hipLaunchKernelGGL((crf_grad_den_kernel<2, 2, 2 * kGDThreads, 8>), gg, dim3(2 * kGDThreads), l, st, p);
+        } else if (gnc > 2 * kGDThreads) {   // more than 512 label chunks (graphs over hundreds of classes: V = 500 has ~8 pairs per label,
                                       // one chunk each): 512 threads with two chunks each
             static LdsMark set6;
             if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<2, 2, 2 * kGDThreads>, l, set6, "grad den"))) return r2;
@@ -4717,6 +4736,23 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             hipLaunchKernelGGL(crf_grad_kernel, ggrid, dim3(kGradThreads), lds_grad, st, p);
         }
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_grad(ctc): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+        return CRF_OK;
+    };
+    // Numerator fallback: utterances with frames the grad pass marked (or whose scaled chain lost its mass) redo their chains in the
+    // log domain, then the marked frames' posteriors are subtracted from the rows; the other utterances' workgroups leave at once --
+    // two near-empty launches.  Pass 1 runs right behind the numerator's grad half on the side stream of the staged schedule, i.e.
+    // BESIDE the denominator recursions (V = 500: 1.2 ms that followed the call's last grad launch); pass 2 at the end of every call
+    // takes what is marked and was not redone in pass 1.
+    auto launch_robust_ctc = [&](hipStream_t st, int pass) -> int {
+        static LdsMark mrc;
+        int r2;
+        if ((r2 = ensure_lds((const void *)crf_robust_ctc_kernel, lds_ctc, mrc, "robust ctc"))) return r2;
+        p.ctc_pass = pass;
+        hipLaunchKernelGGL(crf_robust_ctc_kernel, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, st, p);
+        if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_robust_ctc_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+        hipLaunchKernelGGL(crf_robust_ctc_fix_kernel, dim3((unsigned)((T + kGCFrames - 1) / kGCFrames), (unsigned)B), dim3(kGradThreads),
+                           (size_t)rup64((int)V) * sizeof(float), st, p);
+        if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_robust_ctc_fix_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
     };
     // the denominator recursions of the whole batch on `st` (every layout; both directions per launch)
@@ -4861,6 +4897,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
         prof_mark(5, false, side);
         if ((rc = launch_grad_ctc(0, side))) return rc;
+        if (robust_env != 0 && (rc = launch_robust_ctc(side, 1))) return rc;
         p.grad_den_acc = 1;
         for (int k = 0; k < nstage; ++k) {
             if (!segmode) {
@@ -4971,17 +5008,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         hipLaunchKernelGGL(crf_robust_grad_kernel, dim3(16, (unsigned)B), dim3(kGradThreads), lg, stream, p);
         LAUNCH_CHECK("crf_robust_grad_kernel");
     }
-    if (ctc && robust_env != 0) {
-        // Numerator fallback: utterances with frames the grad pass marked (or whose scaled chain lost its mass) redo their chains
-        // in the log domain; the others' workgroups leave at once -- two near-empty launches per call.
-        static LdsMark mrc;
-        if ((rc = ensure_lds((const void *)crf_robust_ctc_kernel, lds_ctc, mrc, "robust ctc"))) return rc;
-        hipLaunchKernelGGL(crf_robust_ctc_kernel, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, stream, p);
-        LAUNCH_CHECK("crf_robust_ctc_kernel");
-        hipLaunchKernelGGL(crf_robust_ctc_fix_kernel, dim3((unsigned)((T + kGCFrames - 1) / kGCFrames), (unsigned)B), dim3(kGradThreads),
-                           (size_t)rup64((int)V) * sizeof(float), stream, p);
-        LAUNCH_CHECK("crf_robust_ctc_fix_kernel");
-    }
+    if (ctc && robust_env != 0 && (rc = launch_robust_ctc(stream, 2))) return rc;   // (what pass 1 has not seen, or every marked utterance)
     prof_mark(6, false, stream);
     hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
     prof_mark(6, true, stream);

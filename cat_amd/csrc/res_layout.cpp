@@ -1348,13 +1348,22 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // ---- 5. grad pass list: one (Q position, BP position) per pair, label-sorted (pairs already are), chunked
     std::vector<int> gq, gb, gchunk{0}, glab((size_t)max_lab + 2, 0);
     for (int p = 0; p < P; ++p) { gq.push_back(fpos[p]); gb.push_back(zpos[pair_dst[p]]); }
+    // Chunks of at most `cap` entries within one label: kChunk = 32, or 8 when the labels have few pairs each (hundreds of classes
+    // over a graph of this size: V = 500 -> ~8 pairs per label): the grad kernel's threads walk every slot of a chunk, and chunks of
+    // 32 slots a quarter full spend most of their gathers on padding.  (8 only when the chunk count then fits 512 threads x 2.)
+    int cap = kChunk;
+    auto count_chunks = [&](int c_) { int n = 0, r = 0; for (int v = 0; v <= max_lab; ++v) { int e = r; while (e < P && pair_lab[e] == v) ++e; n += (e - r + c_ - 1) / c_; r = e; } return n; };
+    {
+        const int n32 = count_chunks(kChunk), n8 = count_chunks(8);
+        if (n32 > 0 && (int64_t)P * 5 < (int64_t)n32 * kChunk * 2 && n8 <= 1024) cap = 8;   // chunks of 32 would be less than 40 % full
+    }
     {
         int r = 0;
         for (int v = 0; v <= max_lab; ++v) {
             glab[v] = (int)gchunk.size() - 1;
             int e = r;
             while (e < P && pair_lab[e] == v) ++e;
-            for (int c = r; c < e; c += kChunk) gchunk.push_back(std::min(e, c + kChunk));
+            for (int c = r; c < e; c += cap) gchunk.push_back(std::min(e, c + cap));
             r = e;
         }
         glab[(size_t)max_lab + 1] = (int)gchunk.size() - 1;
@@ -1390,7 +1399,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     for (auto &wi : fo.wave_info) if (wi.w) F.multilane = 1;
     for (auto &wi : bo.wave_info) if (wi.w) F.multilane = 1;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
-    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.threads = gm->threads; F.rcl = level == 1 ? 1 : level == 3 ? 2 : 0; F.K = K;
+    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.chunk_cap = cap; F.threads = gm->threads; F.rcl = level == 1 ? 1 : level == 3 ? 2 : 0; F.K = K;
     for (int k = 0; k < 3; ++k) F.xlist_off[k] = xlist_off[k];
     for (int k = 0; k <= 2; ++k) { F.f.cu_row[k] = fo.cu_row_off[(size_t)std::min(k, K)]; F.b.cu_row[k] = bo.cu_row_off[(size_t)std::min(k, K)]; }
     int rc;
