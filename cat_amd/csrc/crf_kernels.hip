@@ -3740,6 +3740,9 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
     const float s = __expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m));
     return m + (double)__logf(s);
 }
+// NR = ctc states per thread actually needed (1, 2, 4, 8 <- the batch's longest label sequence), as for the scaled chains: the
+// predicated-off iterations of a fixed NR = 8 are most of a frame's instructions for ordinary label lengths
+template <int NR>
 __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const bool fwd = (int)blockIdx.x < p.B;
@@ -3753,7 +3756,6 @@ __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams 
     const int *lab = c.lab;
     const int64_t bt0 = (int64_t)b * p.T;
     if (!ctc_setup(p, b, c, L, lx, tid)) return;            // (not a valid label sequence: the scaled chain has said so)
-    constexpr int NR = kCtcRegs;
     int mylab[NR];
     bool skip[NR];
 #pragma unroll
@@ -4744,11 +4746,20 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     // BESIDE the denominator recursions (V = 500: 1.2 ms that followed the call's last grad launch); pass 2 at the end of every call
     // takes what is marked and was not redone in pass 1.
     auto launch_robust_ctc = [&](hipStream_t st, int pass) -> int {
-        static LdsMark mrc;
+        static LdsMark mrc[4];
         int r2;
-        if ((r2 = ensure_lds((const void *)crf_robust_ctc_kernel, lds_ctc, mrc, "robust ctc"))) return r2;
+        const int64_t ni = (2 * max_label_len + 1 + kCtcThreads - 1) / kCtcThreads;
+        const int nri = ni <= 1 ? 0 : ni <= 2 ? 1 : ni <= 4 ? 2 : 3;
+        const void *fn = nri == 0 ? (const void *)crf_robust_ctc_kernel<1> : nri == 1 ? (const void *)crf_robust_ctc_kernel<2>
+                       : nri == 2 ? (const void *)crf_robust_ctc_kernel<4> : (const void *)crf_robust_ctc_kernel<kCtcRegs>;
+        if ((r2 = ensure_lds(fn, lds_ctc, mrc[nri], "robust ctc"))) return r2;
         p.ctc_pass = pass;
-        hipLaunchKernelGGL(crf_robust_ctc_kernel, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, st, p);
+        switch (nri) {
+            case 0: hipLaunchKernelGGL(crf_robust_ctc_kernel<1>, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, st, p); break;
+            case 1: hipLaunchKernelGGL(crf_robust_ctc_kernel<2>, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, st, p); break;
+            case 2: hipLaunchKernelGGL(crf_robust_ctc_kernel<4>, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, st, p); break;
+            default: hipLaunchKernelGGL(crf_robust_ctc_kernel<kCtcRegs>, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, st, p); break;
+        }
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_robust_ctc_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         hipLaunchKernelGGL(crf_robust_ctc_fix_kernel, dim3((unsigned)((T + kGCFrames - 1) / kGCFrames), (unsigned)B), dim3(kGradThreads),
                            (size_t)rup64((int)V) * sizeof(float), st, p);
