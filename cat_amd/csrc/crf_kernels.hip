@@ -106,6 +106,8 @@ struct LossParams {
                                   // staged schedule; 2 = end of the call) in which the log-domain kernels redid the utterance: its CA / CB
                                   // rows and ctc_zc then hold LOGARITHMS
     int ctc_pass;                 // the pass of this launch of the log-domain kernels
+    int *ctc_seen;                // host-visible word: the number of the last call in which an utterance took the log-domain chains
+    int call_id;                  // this call's number (per context)
     int64_t gvec_stride;          // floats per utterance of `gvec`
     // outputs
     float *grad, *loss, *out_den, *out_beta, *out_ctc;
@@ -3756,6 +3758,7 @@ __global__ __launch_bounds__(kCtcThreads) void crf_robust_ctc_kernel(LossParams 
     const int *lab = c.lab;
     const int64_t bt0 = (int64_t)b * p.T;
     if (!ctc_setup(p, b, c, L, lx, tid)) return;            // (not a valid label sequence: the scaled chain has said so)
+    if (fwd && tid == 0 && p.ctc_seen) __hip_atomic_store(p.ctc_seen, p.call_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int mylab[NR];
     bool skip[NR];
 #pragma unroll
@@ -4084,6 +4087,10 @@ struct DevCtx {
     int dev = 0;
     hipStream_t owner{};
     hipStream_t side{};       // null: no side stream that runs beside the owner was found -> everything on the owner's stream
+    hipStream_t aux{};        // a third stream that runs beside the owner's (numerator fallback chains beside the grad stages), or null
+    hipEvent_t ev_a{}, ev_b{};
+    int *seen = nullptr;      // pinned host word the log-domain numerator chains write the call number to (read without a sync: a hint)
+    int call_id = 0;
     hipEvent_t fork{}, join{}, ev[kMaxStages]{}, evb[kMaxStages]{};
     int *flags = nullptr;     // fine-grained (uncached, cross-XCD coherent) words: [0] error word, [1] start counter, [16..32) stage counters
     bool warned = false;
@@ -4133,7 +4140,8 @@ static int get_ctx(hipStream_t owner, DevCtx **out) {
     // context; the owner's stream is drained first so that both probe kernels start at once).  CRF_NO_SIDE_STREAM=1
     // skips it (everything then runs on the caller's stream, one kernel after the other).
     const bool want_side = !opt_on(kOpt_no_side_stream);
-    if (want_side && c->flags) {
+    const bool trust = opt_on(kOpt_trust_side);   // (counter passes of a profiler run one kernel at a time: the probe cannot succeed there)
+    if (want_side && c->flags && !trust) {
         (void)hipStreamSynchronize(owner);
         for (int tries = 0; tries < 6 && !c->side; ++tries) {
             hipStream_t cand{};
@@ -4155,6 +4163,27 @@ static int get_ctx(hipStream_t owner, DevCtx **out) {
                         "the loss runs its kernels one after the other on the caller's stream -- correct, but slower; "
                         "raise GPU_MAX_HW_QUEUES before the HIP runtime starts\n");
         c->warned = true;
+    }
+    // A third stream for work that may take long beside the staged grad pass (the numerator's log-domain chains): it must not sit
+    // behind the owner's stream (the den grid), which is all the probe asks; sharing a queue with the side stream only delays it.
+    if (c->side && c->flags && !trust && !opt_on(kOpt_no_aux_stream) &&
+        hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess) {
+        (void)hipStreamSynchronize(owner);
+        for (int tries = 0; tries < 4 && !c->aux; ++tries) {
+            hipStream_t cand{};
+            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            int res[4] = {0, 0, 0, 0};
+            bool ran = hipMemset(c->flags, 0, sizeof(res)) == hipSuccess;
+            hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, owner, c->flags, 0, 1);
+            hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, cand, c->flags, 1, 0);
+            ran = ran && hipStreamSynchronize(cand) == hipSuccess && hipStreamSynchronize(owner) == hipSuccess &&
+                  hipMemcpy(res, c->flags, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess;
+            if (ran && res[2] == 1 && res[3] == 1) c->aux = cand;
+            else { (void)hipGetLastError(); (void)hipStreamDestroy(cand); }
+        }
+        void *hp = nullptr;
+        if (c->aux && hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { c->seen = (int *)hp; *c->seen = 0; }
+        else (void)hipGetLastError();
     }
     g_ctxs.push_back(c);
     *out = c;
@@ -4203,6 +4232,7 @@ struct Prof {
     bool made = false, used[8]{};
 };
 static thread_local Prof g_prof;
+static thread_local int g_call_streams = 1;          // crf_last_call_streams
 static thread_local const char *g_den_kernel = "";   // template instantiation of the denominator recursions' kernel in the last call (crf_last_den_kernel)
 static void prof_mark(int slot, bool stop, hipStream_t st) {
     if (!g_prof.on) return;
@@ -4585,6 +4615,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     // error word, start counter and stage counters live in fine-grained memory (get_ctx); the prep kernel clears them
     const bool have_flags = cx->flags != nullptr;
     p.clear = nullptr; p.nclear = 0;
+    p.call_id = ++cx->call_id; p.ctc_seen = cx->seen;
+    g_call_streams = 1;
     if (have_flags) { p.err = cx->flags; p.clear = cx->flags; p.nclear = 64; }
     for (bool &u : g_prof.used) u = false;
     prof_mark(7, false, stream);
@@ -4606,6 +4638,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             set_error(std::string("fork: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
         }
         forked = side_used = true;
+        if (g_call_streams < 2) g_call_streams = 2;
         return CRF_OK;
     };
     auto join_side = [&]() -> int {   // the caller's stream continues behind everything queued on the side stream so far
@@ -4745,7 +4778,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     // two near-empty launches.  Pass 1 runs right behind the numerator's grad half on the side stream of the staged schedule, i.e.
     // BESIDE the denominator recursions (V = 500: 1.2 ms that followed the call's last grad launch); pass 2 at the end of every call
     // takes what is marked and was not redone in pass 1.
-    auto launch_robust_ctc = [&](hipStream_t st, int pass) -> int {
+    auto launch_robust_ctc_chains = [&](hipStream_t st, int pass) -> int {
         static LdsMark mrc[4];
         int r2;
         const int64_t ni = (2 * max_label_len + 1 + kCtcThreads - 1) / kCtcThreads;
@@ -4761,10 +4794,18 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             default: hipLaunchKernelGGL(crf_robust_ctc_kernel<kCtcRegs>, dim3((unsigned)(2 * B)), dim3(kCtcThreads), lds_ctc, st, p); break;
         }
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_robust_ctc_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+        return CRF_OK;
+    };
+    auto launch_robust_ctc_fix = [&](hipStream_t st, int pass) -> int {
+        p.ctc_pass = pass;
         hipLaunchKernelGGL(crf_robust_ctc_fix_kernel, dim3((unsigned)((T + kGCFrames - 1) / kGCFrames), (unsigned)B), dim3(kGradThreads),
                            (size_t)rup64((int)V) * sizeof(float), st, p);
         if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_robust_ctc_fix_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
         return CRF_OK;
+    };
+    auto launch_robust_ctc = [&](hipStream_t st, int pass) -> int {
+        const int r2 = launch_robust_ctc_chains(st, pass);
+        return r2 ? r2 : launch_robust_ctc_fix(st, pass);
     };
     // the denominator recursions of the whole batch on `st` (every layout; both directions per launch)
     auto launch_den = [&](hipStream_t st) -> int {
@@ -4908,7 +4949,29 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
         prof_mark(5, false, side);
         if ((rc = launch_grad_ctc(0, side))) return rc;
-        if (robust_env != 0 && (rc = launch_robust_ctc(side, 1))) return rc;
+        // Numerator fallback, pass 1.  The chains of the marked utterances can take as long as the scaled ones did (T = 3 000, L = 500,
+        // every utterance marked: 3 ms): on the third stream they run beside the grad stages instead of in front of them, and the
+        // marked frames' posteriors are subtracted behind the last stage (the stages ADD gamma_den: the order does not matter).
+        // Enqueued BEFORE the stage waits of the side stream: whatever hardware queues the three streams share, the chains' packets
+        // precede the wait for their event.
+        bool aux_fix = false;
+        if (robust_env != 0) {
+            // (the third stream costs the call ~20 us of event traffic whether or not an utterance is marked -- B = 64, T = 1 500: 3.172 ->
+            // 3.192 ms -- so it is taken when one of this context's last 16 calls ran the log-domain chains: they write the call's
+            // number to a pinned host word, read here without any synchronisation; `aux_stream` 1 / 0 forces it on / off)
+            const int aux_env = opt(kOpt_aux_stream, -1);
+            const int seen = cx->seen ? *(volatile int *)cx->seen : 0;
+            const bool want_aux = aux_env >= 0 ? aux_env != 0 : (seen > 0 && p.call_id - seen <= 16);
+            if (cx->aux && want_aux && hipEventRecord(cx->ev_a, side) == hipSuccess && hipStreamWaitEvent(cx->aux, cx->ev_a, 0) == hipSuccess) {
+                if ((rc = launch_robust_ctc_chains(cx->aux, 1))) return rc;
+                if ((e = hipEventRecord(cx->ev_b, cx->aux)) != hipSuccess) { set_error(std::string("hipEventRecord(aux): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+                aux_fix = true;
+                g_call_streams = 3;
+            } else {
+                (void)hipGetLastError();
+                if ((rc = launch_robust_ctc(side, 1))) return rc;
+            }
+        }
         p.grad_den_acc = 1;
         for (int k = 0; k < nstage; ++k) {
             if (!segmode) {
@@ -4924,6 +4987,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
                 set_error(std::string("hipStreamWaitEvent(segment): ") + hipGetErrorString(e)); return CRF_ERR_HIP;
             }
             if ((rc = launch_grad_den(side, k + 1))) return rc;
+        }
+        if (aux_fix) {
+            if ((e = hipStreamWaitEvent(side, cx->ev_b, 0)) != hipSuccess) { set_error(std::string("hipStreamWaitEvent(aux): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+            if ((rc = launch_robust_ctc_fix(side, 1))) return rc;
         }
         prof_mark(5, true, side);
         if ((rc = join_side())) return rc;   // the last grad launch is behind every stage of the recursions
@@ -5052,6 +5119,7 @@ int crf_timing_read(unsigned long long *out, int n) {
 }
 
 const char *crf_last_den_kernel(void) { return g_den_kernel; }
+int crf_last_call_streams(void) { return g_call_streams; }
 
 void crf_profile_enable(int on) { g_prof.on = on != 0; if (!on) g_prof.have = false; }
 

@@ -58,12 +58,13 @@ _lib.crf_debug_unset.restype = ctypes.c_int
 _lib.crf_debug_list.restype = ctypes.c_char_p
 _lib.crf_last_error.restype = ctypes.c_char_p
 _lib.crf_last_den_kernel.restype = ctypes.c_char_p
+_lib.crf_last_call_streams.restype = ctypes.c_int
 _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
     "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_debug_res_emulate", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
-    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_error", "crf_version",
+    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_call_streams", "crf_last_error", "crf_version",
 )
 
 PROFILE_SLOTS = ("prep", "den_fwd_chain", "den_bwd_chain", "ctc_fwd_chain", "ctc_bwd_chain", "grad",
@@ -84,6 +85,11 @@ def profile_read() -> Dict[str, float]:
 def last_den_kernel() -> str:
     """Template instantiation of the denominator recursions' kernel in this thread's last call (include/ctc_crf_hip.h)."""
     return _lib.crf_last_den_kernel().decode()
+
+
+def last_call_streams() -> int:
+    """1 / 2 / 3: streams this thread's last call put work on (caller's, + side stream, + third stream)."""
+    return int(_lib.crf_last_call_streams())
 
 
 def version() -> str:

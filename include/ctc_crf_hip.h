@@ -167,9 +167,12 @@ int crf_loss_fwd_bwd_logits(const crf_graph *g, const void *logits_dev, int dtyp
  * (-1 for kernels that were not launched).  Returns the number of slots written. */
 void crf_profile_enable(int on);
 /* The template instantiation of the kernel that ran the denominator recursions in this thread's last call, e.g.
- * "crf_fac_pair_kernel<true,768,21,4,4,false,false,0>" (the prefix of the name rocprofv3 reports; "pipe" in the last place =
- * the software-pipelined variant): bench.py keys its committed PMC traffic numbers by workload AND by this string. */
+ * "crf_fac_pair_kernel<true,768,21,4,4,false,false>" (the prefix of the name rocprofv3 reports): bench.py keys its committed PMC
+ * traffic numbers by workload AND by this string. */
 const char *crf_last_den_kernel(void);
+/* Streams this thread's last call put work on: 1 = the caller's only, 2 = + the context's side stream, 3 = + its third stream
+ * (the numerator's log-domain fallback chains beside the staged grad pass: taken when a recent call of the context needed them). */
+int crf_last_call_streams(void);
 int crf_profile_read(float *ms_out, int n);
 
 /* Diagnostics, timing builds only (CRF_BUILD_DEFS=-DCRF_TIMING python -m cat_amd.build --force): copies

@@ -586,6 +586,45 @@ def test_numerator_fallback_forced(crf, tmp_path, mode, fused):
     assert rel_err(grad, gexp) <= TOL
 
 
+def test_numerator_fallback_on_the_third_stream(crf, tmp_path):
+    """The staged schedule moves the log-domain numerator chains to the context's third stream -- beside the grad stages instead of
+    in front of them, the marked frames' posteriors subtracted behind the last stage -- once a recent call of the context needed
+    them (a pinned host word the chains write, read without a sync).  Four calls with every utterance marked (robust_ctc = 1): the
+    first runs them in front of the stages, the following ones on the third stream; each against the fp64 oracle; then the switch
+    `aux_stream` 0 / 1 forces either form."""
+    g, p = small_synth(tmp_path, 12, 40, 6, 5)
+    B, T, V = 6, 96, 12
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=11, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    core = crf._C
+
+    def call():
+        x = torch.tensor(logits, device="cuda:0", requires_grad=True)
+        loss = crf.CTC_CRF_LOSS(lamb=0.1)(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly))
+        streams = core.last_call_streams()
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss.item()) - ref["loss"]) <= TOL * abs(ref["loss"])
+        assert rel_err(x.grad.cpu().numpy(), ref["grad"]) <= TOL
+        return streams
+
+    with _env(CRF_ROBUST_CTC=1), _mode("factored"):
+        ctx = crf.CRFContext(p, 0)
+        seen = [call() for _ in range(4)]
+        if seen[0] >= 2:                                       # (a context without a side stream runs everything in order)
+            assert seen[0] in (2, 3) and seen[-1] == 3, seen   # (earlier calls of this process may have marked utterances already)
+            with _env(CRF_AUX_STREAM=0):
+                assert call() == 2
+            with _env(CRF_AUX_STREAM=1):
+                assert call() == 3
+        del ctx
+    with _mode("factored"):                                    # nothing marked, nothing remembered beyond 16 calls: two streams
+        ctx = crf.CRFContext(p, 0)
+        seen = [call() for _ in range(18)]
+        assert seen[-1] <= 2, seen
+        del ctx
+
+
 @pytest.mark.parametrize("T,L", [(2400, 400), (3000, 500)])
 def test_numerator_long_utterances_with_many_labels(crf, T, L):
     """T = 3000 frames, L = 500 labels (BASELINE config #5's utterance shape; ly = lx // 6 as bench.py draws them) on inputs that do
