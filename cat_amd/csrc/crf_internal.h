@@ -326,6 +326,7 @@ void set_error(const std::string &msg);
     X(no_batch,         "C  streaming kernels instead of the utterance-minor ones")                                          \
     X(robust,           "C  0: never run the robust fallbacks, 1: every utterance takes them (denominator and numerator)")  \
     X(robust_ctc,       "C  1: every utterance's numerator takes the log-domain fallback")                                  \
+    X(ctc_tilt,         "C  numerator chains: strength of the tilt in percent (default 100, 0 = plain chains)")                \
     X(no_fast_grad,     "C  generic grad kernel instead of the streaming grad kernels")                                      \
     X(no_overlap,       "C  no staged grad pass beside the recursions")                                                      \
     X(segments,         "C  staged schedule by relaunching the recursions per stage (events) instead of stream-level waits") \

@@ -106,6 +106,7 @@ struct LossParams {
                                   // staged schedule; 2 = end of the call) in which the log-domain kernels redid the utterance: its CA / CB
                                   // rows and ctc_zc then hold LOGARITHMS
     int ctc_pass;                 // the pass of this launch of the log-domain kernels
+    int ctc_tilt;                 // percent of the numerator chains' tilt (ctc_rho): 100 by default, 0 = none
     int *ctc_seen;                // host-visible word: the number of the last call in which an utterance took the log-domain chains
     int call_id;                  // this call's number (per context)
     int64_t gvec_stride;          // floats per utterance of `gvec`
@@ -655,6 +656,37 @@ __device__ __forceinline__ bool ctc_setup(const LossParams &p, int b, const CtcL
     __syncthreads();
     return lx > 0 && L + repeats <= lx;
 }
+// Tilt of the numerator chains.  The two chains are stored as A'_t[s] = A_t[s] rho^s and Bx'_t[s] = Bx_t[s] rho^(Sx-1-s): the
+// recursions keep their form with the factors rho, rho^2 on the transitions that advance by one, two states (both directions), the
+// products A' Bx' are the posteriors' numerators times the constant rho^(Sx-1), which the chain's own end sum Z' = A'[Sx-1] +
+// rho A'[Sx-2] carries too -- EXACT for any rho > 0; log Z = log Z' - (Sx-1) log rho.  What rho buys is range: each chain is
+// rescaled by its own maximum, and with diffuse emissions (an untrained network, a large output layer) the free forward mass runs
+// ahead at ~0.8 states per frame whatever the labels need (Sx / lx), the backward mass likewise from the other end, so the states
+// that carry a frame's posterior sit e^-0.8 per frame of the utterance's middle below both maxima: beyond fp64 from T ~ 1 600 on
+// (frames marked for the log-domain chains; T = 3 000 / L = 500: every utterance).  rho_u solves "mean advance of the tilted free
+// chain = Sx / lx" for uniform emissions ((rho + rho^2) / (1 + rho + rho^2 / 2): a state passes mass to itself, the next, and --
+// half of the states -- the one after); a peaked network's chains follow the alignment by themselves and a tilt would only cost
+// range where the alignment leaves the diagonal, so the tilt's strength is (1 - mean_t max_v p_t[v]).  Both chains' workgroups
+// compute rho from the same inputs by the same instructions (it must be the same number, bit for bit).
+__device__ __forceinline__ double ctc_rho(const LossParams &p, int b, int Sx, int lx, double *red, int tid) {
+    if (p.ctc_tilt <= 0 || Sx < 2 || lx < 1) return 1.0;
+    double part = 0.0;
+    for (int t = tid; t < lx; t += kCtcThreads) part += exp((double)p.moff[(int64_t)b * p.T + t]);   // max_v p_t[v] (the offset IS its log)
+    part = wave_sum_d(part);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < kCtcWaves; ++i) sum += red[i];
+    __syncthreads();
+    const double c = fmin(1.0, fmax(0.0, sum / (double)lx));
+    const double r = fmin(0.79, (double)Sx / (double)lx);   // (0.8 = the untilted chain's own speed: rho_u = 1)
+    const double a2 = 1.0 - 0.5 * r, a1 = 1.0 - r;
+    const double rho_u = (-a1 + sqrt(a1 * a1 + 4.0 * r * a2)) / (2.0 * a2);
+    const double theta = -log(rho_u) * (1.0 - c) * (double)p.ctc_tilt * 0.01;
+    return fmin(1.0, fmax(0x1p-8, exp(-theta)));
+}
 __device__ __forceinline__ double frame_max_d(const double *wm) {
     double m = wm[0];
 #pragma unroll
@@ -708,6 +740,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         skip[i] = s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2];
     }
     int E = kScaleExpD;
+    const double rho = ctc_rho(p, b, Sx, lx, c.red, tid), rho2 = rho * rho;
     // The frame maximum used for the (exact, power-of-two) rescale is taken from the values as they are
     // WRITTEN: one barrier per frame instead of a separate reduction pass plus barrier.
     {   // t = 0 (gpu_ctc_kernels.h:146-152)
@@ -719,7 +752,7 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         for (int i = 0; i < NR; ++i) {
             const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
-                const double v = (s < 2 && s < Sx) ? exp_scaled_d(ld_x(p, lr0 + mylab[i]) - m0) * pow2d(kScaleExpD) : 0.0;
+                const double v = (s < 2 && s < Sx) ? exp_scaled_d(ld_x(p, lr0 + mylab[i]) - m0) * pow2d(kScaleExpD) * (s == 1 ? rho : 1.0) : 0.0;
                 A[s] = v;
                 A[Sxp + s] = 0.0;
                 if (s < Sx) CArow[s] = v;
@@ -790,8 +823,8 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
             const int s = tid + i * kCtcThreads;
             if (s < Sx) {
                 double a = Ac[s];
-                if (s >= 1) a += Ac[s - 1];
-                if (skip[i]) a += Ac[s - 2];
+                if (s >= 1) a = fma(rho, Ac[s - 1], a);
+                if (skip[i]) a = fma(rho2, Ac[s - 2], a);
                 const double v = sc * em[i] * a;
                 An[s] = v;
                 CArow[s] = v;
@@ -824,11 +857,11 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
     const double *Af = A + ((lx - 1) & 1) * Sxp;
     const double mxs = ctc_mx_total(p, b, lx, c.red, tid);
     if (tid == 0) {
-        const double zc = Af[Sx - 1] + (Sx > 1 ? Af[Sx - 2] : 0.0);
+        const double zc = Af[Sx - 1] + (Sx > 1 ? rho * Af[Sx - 2] : 0.0);   // Z' (ctc_rho)
         const bool ok = zc > 0.0 && zc < INFINITY;
         p.ctc_zc[b] = ok ? zc : 0.0;
         p.ctc_ez[b] = E;
-        p.cost_ctc[b] = ok ? to_log_d(zc, E, mxs) : 0.f;
+        p.cost_ctc[b] = ok ? (float)(log(zc) - (double)E * 0.6931471805599453 + mxs - (double)(Sx - 1) * log(rho)) : 0.f;
         p.invalid[b] = ok ? 0 : 1;
         if (!ok) p.redo_ctc[b] = 2;   // a VALID label sequence whose scaled chain lost all its mass: the log-domain kernels decide
     }
@@ -855,6 +888,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         skip[i] = (s + 2 < Sx) && lab[s + 2] != 0 && lab[s + 2] != mylab[i];
     }
     int F_ = kScaleExpD;
+    const double rho = ctc_rho(p, b, Sx, lx, c.red, tid), rho2 = rho * rho;
     {   // t = lx-1
         const int64_t lr0 = (bt0 + lx - 1) * V;
         const float ml = p.mx[bt0 + lx - 1];
@@ -864,7 +898,7 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         for (int i = 0; i < NR; ++i) {
             const int s = tid + i * kCtcThreads;
             if (s < Sxp) {
-                const double bx = (s < Sx && s >= Sx - 2) ? pow2d(kScaleExpD) : 0.0;
+                const double bx = (s < Sx && s >= Sx - 2) ? pow2d(kScaleExpD) * (s == Sx - 2 ? rho : 1.0) : 0.0;
                 const double y = s < Sx ? exp_scaled_d(ld_x(p, lr0 + mylab[i]) - ml) * bx : 0.0;
                 Y[s] = y;
                 Y[Sxp + s] = 0.0;
@@ -926,8 +960,8 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
             const int s = tid + q * kCtcThreads;
             if (s < Sx) {
                 double a = Yc[s];
-                if (s + 1 < Sx) a += Yc[s + 1];
-                if (skip[q]) a += Yc[s + 2];
+                if (s + 1 < Sx) a = fma(rho, Yc[s + 1], a);
+                if (skip[q]) a = fma(rho2, Yc[s + 2], a);
                 const double bx = sc * a;
                 const double y = em[q] * bx;
                 CBrow[s] = bx;
@@ -4587,6 +4621,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const int robust_env = opt(kOpt_robust, -1);   // (read per call: tests switch it)
     p.force_redo = (den && robust_env == 1) ? 1 : 0;
     p.force_redo_ctc = (ctc && (robust_env == 1 || opt_on(kOpt_robust_ctc))) ? 1 : 0;
+    p.ctc_tilt = std::min(400, std::max(0, opt(kOpt_ctc_tilt, 100)));
     p.xch = (unsigned long long *)(base + w.off_xch);
     p.err = (int *)(base + w.off_xch + w.xch_bytes);
     p.Row0 = (float *)(base + w.off_row0);

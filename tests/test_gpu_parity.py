@@ -625,27 +625,57 @@ def test_numerator_fallback_on_the_third_stream(crf, tmp_path):
         del ctx
 
 
-@pytest.mark.parametrize("T,L", [(2400, 400), (3000, 500)])
-def test_numerator_long_utterances_with_many_labels(crf, T, L):
+@pytest.mark.parametrize("switches", [{}, {"CRF_ROBUST": 0}, {"CRF_CTC_TILT": 0}], ids=["default", "tilt_alone", "fallback_alone"])
+@pytest.mark.parametrize("T,L,sigma", [(2400, 400, 2.0), (3000, 500, 2.0), (3000, 500, 1.0), (3000, 60, 1.0)])
+def test_numerator_long_utterances_with_many_labels(crf, T, L, sigma, switches):
     """T = 3000 frames, L = 500 labels (BASELINE config #5's utterance shape; ly = lx // 6 as bench.py draws them) on inputs that do
     not follow the labels: in the middle of such an utterance the posterior mass lies hundreds of nats below (max alpha)(max beta) --
-    beyond what the chains' per-frame rescaling keeps in fp64 (round 3 finding: 0 * inf = NaN gradients from frame ~800 on).  The
-    grad pass marks those frames and the log-domain kernels redo them; a short utterance in the same batch stays on the fast path."""
+    beyond what the chains' per-frame rescaling keeps in fp64 (round 3 finding: 0 * inf = NaN gradients from frame ~800 on).  Two
+    devices, each sufficient here: the chains are TILTED (ctc_rho: the free mass of either chain moves at the speed the labels need;
+    `tilt_alone` = fallback kernels switched off: no frame may be marked), and frames that still leave the range are marked by the grad
+    pass and redone by the log-domain kernels (`fallback_alone` = plain chains, as before the tilt).  A short utterance rides along."""
     rng = np.random.default_rng(T)
     V = 72
-    x = torch.tensor(rng.normal(size=(2, T, V)) * 2.0, dtype=torch.float32).log_softmax(-1)
+    x = torch.tensor(rng.normal(size=(2, T, V)) * sigma, dtype=torch.float32).log_softmax(-1)
     ly = np.array([L, 40], dtype=np.int32)
     lx = np.array([T, 300], dtype=np.int32)
     labels = rng.integers(1, V, size=int(ly.sum())).astype(np.int32)
     gref, cref, valid = oracle.ctc(x.numpy(), labels, lx, ly)
     assert valid.all() and np.isfinite(gref).all()
-    _, g, ex = crf._C.loss_fwd_bwd(x.cuda(), torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
+    with _env(**switches):
+        _, g, ex = crf._C.loss_fwd_bwd(x.cuda(), torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
     g = g.cpu().numpy()
     assert np.isfinite(g).all()
     assert np.allclose(ex["costs_ctc"].cpu().numpy(), cref, rtol=TOL, atol=0) and int(ex["invalid"].sum().item()) == 0
     for b in range(2):
         assert rel_err(g[b], gref[b]) <= TOL, b
         assert np.allclose(g[b, :lx[b]].sum(-1), 1.0, atol=1e-4)      # every frame's posteriors sum to one
+
+
+@pytest.mark.parametrize("boost", [6.0, 3.0, 1.5])
+def test_numerator_tilt_with_an_off_diagonal_alignment(crf, boost):
+    """The tilt of the numerator chains assumes nothing about the inputs -- any rho is exact -- but it spends range where the
+    alignment leaves the straight line from (0, 0) to (T, 2L + 1).  Here every label sits in the first 40 % of a long utterance
+    (then blanks to the end: up to ~450 states off the diagonal) and the network output favours that alignment by `boost` nats over
+    N(0, 1) noise: strongly (weak tilt), moderately, barely (nearly the full tilt against a far-off alignment: what does not fit the
+    range is marked and redone in the log domain).  Loss term and gradient against the fp64 oracle."""
+    rng = np.random.default_rng(int(boost * 10))
+    T, L, V = 2400, 400, 72
+    labels = rng.integers(1, V, size=L).astype(np.int32)
+    ali = np.zeros(T, dtype=np.int64)                       # label, blank, label, blank, ... from frame 0; blanks after frame 2L
+    ali[0:2 * L:2] = labels
+    raw = rng.normal(size=(1, T, V))
+    raw[0, np.arange(T), ali] += boost
+    x = torch.tensor(raw, dtype=torch.float32).log_softmax(-1)
+    lx, ly = np.array([T], dtype=np.int32), np.array([L], dtype=np.int32)
+    gref, cref, valid = oracle.ctc(x.numpy(), labels, lx, ly)
+    assert valid.all() and np.isfinite(gref).all()
+    _, g, ex = crf._C.loss_fwd_bwd(x.cuda(), torch.tensor(labels), torch.tensor(lx), torch.tensor(ly), 0.0, -1.0, None, True)
+    g = g.cpu().numpy()
+    assert np.isfinite(g).all() and int(ex["invalid"].sum().item()) == 0
+    assert np.allclose(ex["costs_ctc"].cpu().numpy(), cref, rtol=TOL, atol=0)
+    assert rel_err(g[0], gref[0]) <= TOL
+    assert np.allclose(g[0].sum(-1), 1.0, atol=1e-4)
 
 
 def test_numerator_extreme_range(crf):
