@@ -330,6 +330,7 @@ void set_error(const std::string &msg);
     X(no_fast_grad,     "C  generic grad kernel instead of the streaming grad kernels")                                      \
     X(no_overlap,       "C  no staged grad pass beside the recursions")                                                      \
     X(segments,         "C  staged schedule by relaunching the recursions per stage (events) instead of stream-level waits") \
+    X(stage_fill,       "C  staged schedule for den grids of up to this percent of the CUs (default 75)")                     \
     X(stages,           "C  number of grad stages")                                                                          \
     X(piece,            "C  iterations per grad stage")                                                                      \
     X(gd_full_grid,     "C  stage launches of the grad pass as full grids")                                                  \

@@ -4716,7 +4716,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     // two utterances per workgroup (use_fac_pair2): the den grid is 2 * ceil(B / 2) workgroups instead of 2 B
     const bool pair2 = fac && !segmode && use_fac_pair2(h, B, V, ncu_dev);   // (no segment relaunches in that kernel)
     const int64_t den_wgs = pair2 ? 2 * ((B + 1) / 2) : 2 * B;
-    const bool staged = fac && h->dev.fac.K == 1 && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && den_wgs <= ncu_dev / 2;
+    const bool staged = fac && h->dev.fac.K == 1 && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && den_wgs * 100 <= (int64_t)ncu_dev * opt(kOpt_stage_fill, 75);   // (B = 80: 4.16 -> 3.56 ms, B = 96: 4.37 -> 4.26, B = 112 at 90 %: 5.33 -> 5.57)
     // Stage bounds.  Nothing can be released before the two recursions have met, so the first stage ends at half of
     // the frames or later; after that a piece of `piece` iterations releases 2 * piece / 16 frame blocks per
     // utterance.  The grad pass has half of the chip and is bandwidth-bound there (~2 TB/s against the 2.2 TB/s the

@@ -31,15 +31,16 @@ def _slice(logits, labels, lx, ly, idx):
     return logits[idx], lab.astype(np.int32), lx[idx], ly[idx]
 
 
-@pytest.mark.parametrize("H,geom", [(2048, 0), (3072, 3)])
-def test_metric_shape_vs_oracle_poisoned(crf, tmp_path_factory, H, geom):
+@pytest.mark.parametrize("H,geom,B,T", [(2048, 0, 64, 1500), (3072, 3, 64, 1500), (2048, 0, 96, 700)])
+def test_metric_shape_vs_oracle_poisoned(crf, tmp_path_factory, H, geom, B, T):
     """H = 2048: the benchmark graph (one CU per recursion, staged grad pass).  H = 3072 (S = 6 145, 156 k arcs): the same
     shape on the factored layout over TWO CUs per recursion -- 256 workgroups = every CU of the device, the products
-    handed over through L2 every frame, which only a full-size batch exercises."""
+    handed over through L2 every frame, which only a full-size batch exercises.  B = 96: the staged schedule with the den grid on
+    three quarters of the device (192 workgroups; numerator chains and grad stages share the 64 CUs left)."""
     from cat_amd.den_lm import synth_den_lm
     p = os.path.join(str(tmp_path_factory.mktemp("denlm")), "den_lm_v72.fst")
     g = synth_den_lm(72, H, 24, 0, path=p)
-    B, T, V, lamb = 64, 1500, 72, 0.1
+    V, lamb = 72, 0.1
     core = crf._C
     ctx = crf.CRFContext(p, 0)
     st = core.graph_stats(core.graph_for(torch.device("cuda", 0)))
