@@ -2556,7 +2556,10 @@ __global__ __launch_bounds__(kGradThreads) void crf_grad_kernel(LossParams p) {
 // re-read from L2 for every frame and doubled its traffic; the rows of frame t+1 are prefetched into
 // registers while frame t is reduced out of LDS.  HBM-bound: two coalesced rows per frame.
 // ---------------------------------------------------------------------------------------------
-constexpr int kGDThreads = 256, kGDFrames = 16, kGDRowRegs = 5;   // rows of up to 5*256 float4 = 5120 floats
+#ifndef CRF_GD_FRAMES
+#define CRF_GD_FRAMES 16
+#endif
+constexpr int kGDThreads = 256, kGDFrames = CRF_GD_FRAMES, kGDRowRegs = 5;   // rows of up to 5*256 float4 = 5120 floats
 constexpr int kGDEpRegs = 4;                                      // V <= 4*256
 // Nothing in the frame loop may wait on global memory except for data requested a whole frame earlier:
 // the rows AND the emission row of frame t+1 are requested while frame t is reduced, the per-frame
@@ -4736,8 +4739,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             piece = ((int)T - half + nshort - 1) / nshort;
             piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
         } else {
-            piece = 8 * kGDFrames;
-            while ((kMaxStages - 2) * piece < (int)T - half && piece < (int)T) piece += 8 * kGDFrames;   // the stage counters cover T - half
+            piece = 128;
+            while ((kMaxStages - 2) * piece < (int)T - half && piece < (int)T) piece += 128;   // the stage counters cover T - half
             const int piece_env = opt(kOpt_piece, 0);
             if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
             const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
