@@ -24,6 +24,7 @@ run T3000 --T 3000 --steps 10
 run small --histories 256 --fanout 16
 run B256 --B 256 --steps 5
 run B96 --B 96 --steps 10
+run B80 --B 80 --steps 10
 run V143 --V 143
 run V217 --V 217 --lamb 0.01
 run V500 --V 500

@@ -6,3 +6,4 @@ timeout 2400 python -m pytest tests -m gpu -q -x --timeout 1500 > $OUT/pytest_$T
 timeout 600 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$?"; cut -c1-700 $OUT/bench_$TAG.json
 bash tools/gpu_prof.sh $TAG 2>&1 | grep -v amdgpu.ids | tail -25
 bash tools/gpu_points.sh $TAG 2>&1 | grep -v amdgpu.ids
+(timeout 300 python tools/soak.py 600; timeout 300 python tools/soak.py 300 3072) > $OUT/soak_$TAG.txt 2>&1; tail -3 $OUT/soak_$TAG.txt

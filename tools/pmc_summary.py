@@ -102,6 +102,17 @@ def main():
     print(json.dumps(tr, indent=1))
     for k, v in traffic.items():
         print(k[:60], v)
+    # the rest of the evidence run: points, the GPU suite's summary, soak, estimated graphs, the 1-rank torchrun line
+    for f in sorted(glob.glob(os.path.join(OUT, f"pt_{tag}_*.json"))):
+        if os.path.getsize(f) > 0:
+            shutil.copy(f, os.path.join(PROF, f"round3_{tag}_point_" + os.path.basename(f)[len(f"pt_{tag}_"):]))
+    for src, dst in ((f"pt_{tag}_estimated.txt", f"round3_{tag}_point_estimated.txt"), (f"soak_{tag}.txt", f"round3_{tag}_soak.txt"),
+                     (f"torchrun1_{tag}.json", f"round3_{tag}_torchrun_1rank.json")):
+        if os.path.exists(os.path.join(OUT, src)):
+            shutil.copy(os.path.join(OUT, src), os.path.join(PROF, dst))
+    log = os.path.join(OUT, f"pytest_{tag}.log")
+    if os.path.exists(log):
+        open(os.path.join(PROF, f"round3_{tag}_pytest_gpu.txt"), "w").write("".join(open(log).readlines()[-12:]))
 
 
 if __name__ == "__main__":
