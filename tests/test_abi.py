@@ -252,6 +252,14 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
     synth_den_lm(72, 3072, 24, seed=0, path=mid)
     g, r = emu(mid, T=3)
     assert g == 3 and agree(r)
+    v217 = os.path.join(str(tmp_path), "v217.fst")             # the benchmark LM over 217 classes: rows of up to ~500 arcs on several lanes;
+    synth_den_lm(217, 2048, 24, seed=0, path=v217)              # fits ONE CU only with all 21 chunk slots holding arcs (table geometry)
+    with crf_env():
+        h = core.compile_graph_host_only(v217)
+        st = core.graph_stats(h)
+        r = core.debug_fac_emulate(h, 3, 7)
+        core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+    assert st["fac_geom"] == 1 and st["fac_chunks"] == 21 and agree(r), (st["fac_geom"], st["fac_chunks"], r)
     from tests.util import transform_graph                       # renumbered, reordered, weight-pushed (re-gauged by the compiler), long rows
     from oracle import fst_io
     wide = os.path.join(str(tmp_path), "wide.fst")
