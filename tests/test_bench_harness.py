@@ -38,3 +38,18 @@ def test_one_rank_nccl_with_ddp_stand_in():
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["event_blocks"]["median_ms_per_step"] > 0
     assert d["ddp_head"]["value"] > 0 and d["ddp_head"]["gradient_bytes_per_step"] == 4 * d["ddp_head"]["parameters"]
     assert "DDP" in d["ddp_head"]["model"]
+
+
+def test_committed_pmc_traffic_belongs_to_the_default_bench_line():
+    """profiles/pmc_traffic.json (tools/pmc_summary.py) is what bench.py quotes as `roofline.traffic`: it must be keyed by the
+    DEFAULT bench workload and by the kernel instantiation the timed (staged) schedule runs -- a file captured on another
+    workload or on the serial schedule's instantiation would make every default bench line print `traffic: null` -- and the
+    dominant kernel's bytes must be its algorithmic bytes, not some other kernel's."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert d["workload"] == "B64_T1500_V72_S4097_A103791_full"
+    assert d["den_kernel"].startswith("crf_fac_pair_kernel<true,768,")
+    alg = 2 * (64 * 1500 * (4 * 72 + 4 * 4097) + 12 * 103791 + 12 * 4097)
+    assert 0.95 * alg <= d["kernels"]["crf_fac_pair_kernel"] <= 1.25 * alg
+    assert 1.0 < d["whole_path"]["ratio"] < 3.0
+    src = d["source"].split(":")[0]
+    assert os.path.exists(os.path.join(ROOT, src)), src
