@@ -4670,6 +4670,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     static LdsMark lds_mark_grad;
     if ((rc = ensure_lds((const void *)crf_grad_kernel, lds_grad, lds_mark_grad, "grad"))) return rc;
     bool forked = false, side_used = false;
+    bool ctc_pass1 = false;   // the numerator's log-domain fallback has run in this call (staged schedule)
     auto fork_side = [&]() -> int {   // the side stream starts behind everything queued on the caller's stream so far
         if (serial || forked) return CRF_OK;
         if ((e = hipEventRecord(cx->fork, stream)) != hipSuccess || (e = hipStreamWaitEvent(side, cx->fork, 0)) != hipSuccess) {
@@ -4993,6 +4994,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // Enqueued BEFORE the stage waits of the side stream: whatever hardware queues the three streams share, the chains' packets
         // precede the wait for their event.
         bool aux_fix = false;
+        ctc_pass1 = robust_env != 0;
         if (robust_env != 0) {
             // (the third stream costs the call ~20 us of event traffic whether or not an utterance is marked -- B = 64, T = 1 500: 3.172 ->
             // 3.192 ms -- so it is taken when one of this context's last 16 calls ran the log-domain chains: they write the call's
@@ -5124,7 +5126,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         hipLaunchKernelGGL(crf_robust_grad_kernel, dim3(16, (unsigned)B), dim3(kGradThreads), lg, stream, p);
         LAUNCH_CHECK("crf_robust_grad_kernel");
     }
-    if (ctc && robust_env != 0 && (rc = launch_robust_ctc(stream, 2))) return rc;   // (what pass 1 has not seen, or every marked utterance)
+    // (the staged schedule's pass 1 ran behind the only kernel that marks frames: nothing is left for a second pass there)
+    if (ctc && robust_env != 0 && !ctc_pass1 && (rc = launch_robust_ctc(stream, 2))) return rc;
     prof_mark(6, false, stream);
     hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
     prof_mark(6, true, stream);
