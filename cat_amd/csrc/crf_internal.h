@@ -54,6 +54,10 @@ constexpr int kFac3ArcCh = 20;     // chunks of arcs per thread
 #define CRF_FAC3L_NCH 21
 #endif
 constexpr int kFac3LNCH = CRF_FAC3L_NCH;   // chunks of arcs per thread with the row constants in the LDS table (all 21 slots hold arcs)
+#ifndef CRF_FAC4_NCH
+#define CRF_FAC4_NCH 15
+#endif
+constexpr int kFac4Threads = 1024, kFac4NCH = CRF_FAC4_NCH;   // four waves per SIMD at <= 128 VGPRs, chunks of arcs per thread, row constants in the LDS table (the planner's first choice)
 constexpr int kFac3MaxSl = 3;      // slices (row epilogues) per wave: two words of row constants each, at word kFac3ArcCh * 6 on
 
 struct ResDirDev {
@@ -303,7 +307,7 @@ void set_error(const std::string &msg);
     X(fac_no_rcl,       "G  factored layout: row constants in registers even for graphs with long rows")                     \
     X(fac_k2,           "G  factored layout over TWO CUs per recursion (fac_geom 3) for every T o LM graph")                 \
     X(fac_no_k2,        "G  never two CUs per recursion: graphs of 120 k - 240 k arcs take the generic layout")              \
-    X(fac_threads,      "G  512: the 512-thread geometry of the factored layout")                                            \
+    X(fac_threads,      "G  512 / 768 / 1024: that geometry of the factored layout (default: 1024 threads first, then the 768-thread geometries, then 512)")                                            \
     X(fac_no_dup,       "G  factored layout: no second copy of the gathered entries")                                        \
     X(fac_bank_shift,   "G  factored layout: bank distance of the second copy (default 5)")                                  \
     X(res_mink,         "G  generic layout: at least this many CUs per recursion")                                           \

@@ -1523,8 +1523,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     // slice AHEAD (the next slice's constants are requested in the epilogue of this one and arrive behind its gathers), so an
     // epilogue is still one round trip, a wave may finish any number of slices per frame, and no select between registers
     // is needed (with three slices that select is ~10 VALU instructions per epilogue).  For graphs with many short rows.
-    static_assert(!RL || NTH == kFac3Threads, "the row-constant table goes with the 768-thread geometry");
-    constexpr bool IMP = NTH == kFac3Threads;                // entries of a row lie where its row id says
+    static_assert(!RL || NTH != kResThreads, "the row-constant table goes with the 768- and 1024-thread geometries");
+    constexpr bool IMP = NTH != kResThreads;                 // entries of a row lie where its row id says
     constexpr bool RC = IMP && !RL;
     constexpr int NCHA = RC ? kFac3ArcCh : NCH;              // chunk slots that hold arcs (RC: the last slot holds the row constants)
     constexpr int RCW = NCHA * 6;                            // first row-constant word
@@ -4373,6 +4373,9 @@ static bool use_fac_pair2(const HostGraph *h, int64_t B, int64_t V, int ncu) {
     // B = 256: 10.1 against 10.5 ms per step; B = 128: 5.9 against 5.3; B = 96: 5.7 against 4.4.
     return sw == 1 || 2 * B > ncu;
 }
+#ifndef CRF_FAC4_NB
+#define CRF_FAC4_NB 3       // chunks gathered per batch by the 1024-thread kernels
+#endif
 #ifndef CRF_FAC3_NB2
 #define CRF_FAC3_NB2 2      // chunks gathered per batch by the two-utterance kernels (8 ds_read_b64 = 16 registers in flight)
 #endif
@@ -4445,6 +4448,20 @@ static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int
     else if (g3 && F.rcl == 2 && !ml) CRF_LAUNCH_RL(kFac3LNCH, false, "21,4,4,false", mk21n)
     else if (g3 && F.rcl == 2) CRF_LAUNCH_RL(kFac3LNCH, true, "21,4,4,true", mk21m)
 #undef CRF_LAUNCH_RL
+    else if (F.threads == kFac4Threads) {   // 1024 threads: four waves per SIMD (the planner's first choice)
+        static LdsMark m4n, m4m;
+        if (ml) {
+            auto *k = crf_fac_pair_kernel<FLAG, kFac4Threads, kFac4NCH, CRF_FAC4_NB, CRF_FAC4_NB, true, true>;
+            g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,1024," CRF_STR(CRF_FAC4_NCH) "," CRF_STR(CRF_FAC4_NB) "," CRF_STR(CRF_FAC4_NB) ",true,true>" : "crf_fac_pair_kernel<false,1024," CRF_STR(CRF_FAC4_NCH) "," CRF_STR(CRF_FAC4_NB) "," CRF_STR(CRF_FAC4_NB) ",true,true>";
+            if ((rc = ensure_lds((const void *)k, lds, m4m, "fac pair"))) return rc;
+            hipLaunchKernelGGL(k, grid, dim3(kFac4Threads), lds, st, pf, pb);
+        } else {
+            auto *k = crf_fac_pair_kernel<FLAG, kFac4Threads, kFac4NCH, CRF_FAC4_NB, CRF_FAC4_NB, false, true>;
+            g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,1024," CRF_STR(CRF_FAC4_NCH) "," CRF_STR(CRF_FAC4_NB) "," CRF_STR(CRF_FAC4_NB) ",false,true>" : "crf_fac_pair_kernel<false,1024," CRF_STR(CRF_FAC4_NCH) "," CRF_STR(CRF_FAC4_NB) "," CRF_STR(CRF_FAC4_NB) ",false,true>";
+            if ((rc = ensure_lds((const void *)k, lds, m4n, "fac pair"))) return rc;
+            hipLaunchKernelGGL(k, grid, dim3(kFac4Threads), lds, st, pf, pb);
+        }
+    }
     else if (g3 && ml) {
         auto *k = crf_fac_pair_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB_F, CRF_FAC3_NB_B, true>;
         g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,768,21,4,4,true,false>" : "crf_fac_pair_kernel<false,768,21,4,4,true,false>";

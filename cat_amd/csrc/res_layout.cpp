@@ -36,6 +36,10 @@ constexpr Geom kGeomFac3L{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3A
 // (S = 513: 2.04 -> 2.52 ms, estimated S = 1 212: 2.04 -> 2.48 ms)
 constexpr Geom kGeomFac3L21{kFac3Threads, kFac3Threads / kWave, kFac3LNCH, kFac3LNCH * 6, 10, 1};
 
+// 1024 threads (four waves per SIMD at <= 128 VGPRs), 15 chunks of arcs per thread, row constants in the LDS table: as many arc
+// slots as 768 x 20, and as many registers per wave left beside the arcs (128 - 90 against 168 - 126)
+constexpr Geom kGeomFac4L{kFac4Threads, kFac4Threads / kWave, kFac4NCH, kFac4NCH * 6, 10, 1};
+
 struct DirOut {
     std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
     std::vector<uint4> wave_info; // [K][kResWaves]
@@ -106,16 +110,21 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
         const int kEpiCost = opt(kOpt_res_epi, 4);  // slice end, in chunks
         std::vector<int> wave_of(nsl, -1), load(gm.waves, 0), cnt(gm.waves, 0);
         bool packed = true;
-        for (int j = 0; j < nsl && packed; ++j) {
-            int best = -1;
-            for (int w = 0; w < gm.waves; ++w) {
-                if (load[w] + len[j] > gm.nch || (gm.maxsl && cnt[w] >= gm.maxsl)) continue;
-                // with a limit on the slices per wave: longest-first onto the LEAST loaded wave (best fit fills a
-                // wave's slice count with long slices and strands the short ones)
-                if (best < 0 || (gm.maxsl ? load[w] < load[best] : load[w] > load[best])) best = w;
+        for (int strategy = 0; strategy < 2; ++strategy) {   // (second try: best fit also where the slices per wave are limited -- tight bins)
+            packed = true;
+            std::fill(wave_of.begin(), wave_of.end(), -1); std::fill(load.begin(), load.end(), 0); std::fill(cnt.begin(), cnt.end(), 0);
+            for (int j = 0; j < nsl && packed; ++j) {
+                int best = -1;
+                for (int w = 0; w < gm.waves; ++w) {
+                    if (load[w] + len[j] > gm.nch || (gm.maxsl && cnt[w] >= gm.maxsl)) continue;
+                    // with a limit on the slices per wave: longest-first onto the LEAST loaded wave (best fit fills a
+                    // wave's slice count with long slices and strands the short ones)
+                    if (best < 0 || ((gm.maxsl && strategy == 0) ? load[w] < load[best] : load[w] > load[best])) best = w;
+                }
+                if (best < 0) { packed = false; break; }
+                wave_of[j] = best; load[best] += len[j]; cnt[best]++;
             }
-            if (best < 0) { packed = false; break; }
-            wave_of[j] = best; load[best] += len[j]; cnt[best]++;
+            if (packed || !gm.maxsl) break;
         }
         std::vector<std::vector<int>> lists(gm.waves);
         std::vector<int> cost(gm.waves, 0);
@@ -1050,8 +1059,8 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // Geometry: 768 threads (3 waves per SIMD at <= 168 VGPRs; 20 chunks of arcs and the constants of up to 3 rows per
     // thread) when both directions fit it, else 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces
     // the latter.
-    const bool lvl_table = level == 1 || level == 3;   // row constants in the LDS table: 20 chunks of arcs per thread (1) or 21 (3)
-    const Geom *gm = level == 0 ? &kGeomFac3 : level == 1 ? &kGeomFac3L : level == 3 ? &kGeomFac3L21 : &kGeomFac512;
+    const bool lvl_table = level == 1 || level == 3 || level == 4;   // row constants in the LDS table: 20 chunks of arcs per thread (1) or 21 (3)
+    const Geom *gm = level == 0 ? &kGeomFac3 : level == 1 ? &kGeomFac3L : level == 3 ? &kGeomFac3L21 : level == 4 ? &kGeomFac4L : &kGeomFac512;
     const bool allow3 = level != 2;               // a larger geometry is left to try
     const bool rcregs = level == 0;               // row constants in registers
     const bool implicit = gm->maxsl > 0;   // entries numbered by row id, row constants in registers (below)
@@ -1399,7 +1408,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     for (auto &wi : fo.wave_info) if (wi.w) F.multilane = 1;
     for (auto &wi : bo.wave_info) if (wi.w) F.multilane = 1;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
-    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.chunk_cap = cap; F.threads = gm->threads; F.rcl = level == 1 ? 1 : level == 3 ? 2 : 0; F.K = K;
+    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.chunk_cap = cap; F.threads = gm->threads; F.rcl = level == 1 ? 1 : level == 3 ? 2 : level == 4 ? 1 : 0; F.K = K;
     for (int k = 0; k < 3; ++k) F.xlist_off[k] = xlist_off[k];
     for (int k = 0; k <= 2; ++k) { F.f.cu_row[k] = fo.cu_row_off[(size_t)std::min(k, K)]; F.b.cu_row[k] = bo.cu_row_off[(size_t)std::min(k, K)]; }
     int rc;
@@ -1428,23 +1437,31 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     // 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces the latter.
     // ... then 768 threads with the row constants in LDS (any number of slices per wave; CRF_FAC_RCL=1 starts there,
     // CRF_FAC_NO_RCL=1 skips it).  Each geometry first with the second copy of the gathered entries, then without it in the direction(s) that do not fit.
-    const bool want3 = !(opt(kOpt_fac_threads, 0) == 512);
+    const int thr = opt(kOpt_fac_threads, 0);          // 0: the planner's order; 512 / 768 / 1024: that geometry (first)
     const bool no_rcl = opt_on(kOpt_fac_no_rcl);
     const bool from_rcl = opt_on(kOpt_fac_rcl);
     int rc = CRF_OK;
     struct Try { int level; bool short_only; int K = 1; };
     std::vector<Try> plan;
-    if (!want3) plan = {{2, false}};
+    bool dflt = false;
+    if (thr == 512) plan = {{2, false}};
     else if (opt_on(kOpt_fac_k2)) plan = {{1, false, 2}, {2, false}};   // (tests: two CUs per recursion for any T o LM graph)
     else if (opt(kOpt_fac_rcl, 0) == 2) plan = {{3, false}, {2, false}};   // (tests: the 21-chunk table geometry for any T o LM graph)
     else if (from_rcl) plan = {{1, false}, {3, false}, {2, false}};
     else if (no_rcl) plan = {{0, false}, {2, false}};
-    else plan = {{0, true}, {1, false}, {0, false}, {3, false}, {1, false, 2}, {2, false}};   // level 0 only for graphs without long rows -- unless level 1 does
-                                                                   // not take them; then two CUs per recursion (table geometry), then 512 threads
+    else {
+        // 768 threads: level 0 (row constants in registers) only for graphs without long rows -- unless level 1 (LDS table) does not
+        // take them; then the 21-chunk table geometry, two CUs per recursion (table geometry), 512 threads.  In front of all of
+        // them since round 3: 1024 threads x 15 chunks with the table (level 4: four waves per SIMD at 128 VGPRs -- the same
+        // registers per wave are left beside the arcs as at 768 x 21 -- measured 2 - 6 % faster on every graph that fits it)
+        plan = {{0, true}, {1, false}, {0, false}, {3, false}, {1, false, 2}, {2, false}};
+        dflt = true;
+        if (thr != 768) plan.insert(plan.begin(), Try{4, false});
+    }
     const bool no_k2 = opt_on(kOpt_fac_no_k2);
     bool long_bail = false;
     for (const Try &t : plan) {
-        if (t.level == 0 && !t.short_only && plan.size() == 6 && !long_bail) continue;   // level 0 has been tried in full already
+        if (t.level == 0 && !t.short_only && dflt && !long_bail) continue;   // level 0 has been tried in full already
         if (t.K > 1 && no_k2) continue;
         bool retry = false;
         int mask = 3, nm = 3;
@@ -1473,7 +1490,7 @@ int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out
     if (!F.ok || C.words == 0) { set_error("no factored layout"); return CRF_ERR_UNSUPPORTED; }
     auto fail = [&](const std::string &why) { set_error("factored layout emulation: " + why); return CRF_ERR_ARG; };
     const int S = (int)h->S, V = h->dev.max_label + 1, NTH = F.threads, NW = NTH / kWave, K = F.K, words = C.words;
-    const bool implicit = NTH == kFac3Threads, rcregs = implicit && !F.rcl;
+    const bool implicit = NTH != kResThreads, rcregs = implicit && !F.rcl;
     uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
     auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return 0.5 + (double)(rng % 1000003) / 1000003.0; };
     std::vector<std::vector<double>> e((size_t)T, std::vector<double>((size_t)V + 1, 0.0));   // e[t][V] = 0: "no label"

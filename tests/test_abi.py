@@ -235,8 +235,8 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
     est = os.path.join(str(tmp_path), "est.fst")
     den_lm.prep_den_lm(seqs, V, est, 4, 3, 150)
     for path in (small, os.path.join(golden_dir, "den_lm_fixture.fst"), est):
-        for env, geom in (({}, (0, 1)), ({"CRF_FAC_NO_RCL": 1}, (0,)), ({"CRF_FAC_RCL": 1}, (1,)), ({"CRF_FAC_K2": 1}, (3,)), ({"CRF_FAC_THREADS": 512}, (2,)),
-                          ({"CRF_FAC_NO_DUP": 1}, (0, 1))):
+        for env, geom in (({}, (4,)), ({"CRF_FAC_THREADS": 768}, (0, 1)), ({"CRF_FAC_NO_RCL": 1}, (0,)), ({"CRF_FAC_RCL": 1}, (1,)), ({"CRF_FAC_K2": 1}, (3,)),
+                          ({"CRF_FAC_THREADS": 512}, (2,)), ({"CRF_FAC_NO_DUP": 1}, (4,)), ({"CRF_FAC_NO_DUP": 1, "CRF_FAC_THREADS": 768}, (0, 1))):
             g, r = emu(path, **env)
             assert g in geom and agree(r), (path, env, g, r)
     try:                                                          # negative control: NaN sums, or the emulator's own checks object
@@ -247,14 +247,18 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
     bench = os.path.join(str(tmp_path), "bench.fst")
     synth_den_lm(72, 2048, 24, seed=0, path=bench)
     g, r = emu(bench, T=3)
-    assert g == 0 and agree(r)
+    assert g == 4 and agree(r)                                    # 1024 threads x 15 chunks: the planner's first choice
+    g, r = emu(bench, T=3, CRF_FAC_THREADS=768)
+    assert g == 0 and agree(r)                                    # 768 threads, row constants in registers (round 2's default)
     mid = os.path.join(str(tmp_path), "mid.fst")
     synth_den_lm(72, 3072, 24, seed=0, path=mid)
     g, r = emu(mid, T=3)
     assert g == 3 and agree(r)
     v217 = os.path.join(str(tmp_path), "v217.fst")             # the benchmark LM over 217 classes: rows of up to ~500 arcs on several lanes;
-    synth_den_lm(217, 2048, 24, seed=0, path=v217)              # fits ONE CU only with all 21 chunk slots holding arcs (table geometry)
-    with crf_env():
+    synth_den_lm(217, 2048, 24, seed=0, path=v217)              # at 768 threads it fits ONE CU only with all 21 chunk slots holding arcs
+    g, r = emu(v217, T=3)
+    assert g == 4 and agree(r)                                    # (the 1024-thread geometry takes it too)
+    with crf_env(CRF_FAC_THREADS=768):
         h = core.compile_graph_host_only(v217)
         st = core.graph_stats(h)
         r = core.debug_fac_emulate(h, 3, 7)

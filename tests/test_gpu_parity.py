@@ -27,7 +27,7 @@ def crf():
     return ctc_crf
 
 
-MODES = ["factored", "factored_rcl", "factored_k2", "factored_pair2", "resident", "streaming", "batch"]
+MODES = ["factored", "factored_768", "factored_rcl", "factored_k2", "factored_pair2", "resident", "streaming", "batch"]
 
 
 _env = crf_env   # (debug switches of the library, tests/util.py)
@@ -52,7 +52,10 @@ class _mode(crf_env):
             CRF_FAC_K2=mode == "factored_k2",
             # "factored_pair2": the factored kernels with TWO utterances per workgroup (what batches above CUs / 4 utterances take by
             # themselves), forced for any batch; 0 otherwise, so that the other modes test the one-utterance kernels at any batch size
-            CRF_FAC_PAIR2=mode == "factored_pair2")
+            CRF_FAC_PAIR2=mode == "factored_pair2",
+            # "factored": the planner's own order (1024 threads x 15 chunks first since round 3); "factored_768": the 768-thread
+            # geometries first (row constants in registers where the rows allow), which is also what the two-utterance kernels need
+            CRF_FAC_THREADS=768 if mode in ("factored_768", "factored_pair2") else 0)
         # "batch": the utterance-minor kernels (one launch per frame), what graphs that fit no register-resident layout
         # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (no_batch is read per call)
         if mode in ("streaming", "batch"):
@@ -68,6 +71,8 @@ def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mo
             assert st["res_K"] == 0 and st["fac"] == 0
         if mode == "resident":
             assert st["fac"] == 0
+        if mode == "factored_768" and st["fac"]:
+            assert st["fac_geom"] != 4
         if mode == "factored_rcl" and st["fac"]:
             assert st["fac_geom"] in (1, 2)                      # (2: neither 768-thread geometry took the graph)
         if mode == "factored_k2" and st["fac"]:
@@ -190,7 +195,7 @@ def test_two_utterances_per_workgroup(crf, tmp_path, geom, B):
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1, size_average=False)
     outs = {}
     for pair in (0, 1):
-        with _mode("factored_rcl" if geom == "pair2_rcl" else "factored"), _env(CRF_FAC_PAIR2=pair):
+        with _mode("factored_rcl" if geom == "pair2_rcl" else "factored_768"), _env(CRF_FAC_PAIR2=pair):
             ctx = crf.CRFContext(p, 0)
             x = torch.tensor(logits, device="cuda:0")
             crf._C.set_debug_poison(True)
@@ -345,7 +350,7 @@ def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
             ctx = crf.CRFContext(p, 0)
         st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
         # rows that are still longer than a lane's 80 arcs after the factorisation: the LDS-table variant by default
-        assert st["fac"] == 1 and (st["fac_geom"] == 0 if mode == "factored_rc" else st["fac_geom"] == 3 if mode == "factored_k2" else st["fac_geom"] in (0, 1))
+        assert st["fac"] == 1 and (st["fac_geom"] == 0 if mode == "factored_rc" else st["fac_geom"] == 3 if mode == "factored_k2" else st["fac_geom"] in (0, 1, 4))
         del ctx
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
@@ -383,7 +388,7 @@ def test_estimated_den_lm_with_many_rows(crf, tmp_path):
     ctx = crf.CRFContext(p, 0)
     st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
     del ctx
-    assert st["fac"] == 1 and st["fac_geom"] == 1
+    assert st["fac"] == 1 and st["fac_geom"] in (1, 4)            # a table geometry: 1024 threads, or 768 where that does not take the graph
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
 
