@@ -1104,6 +1104,14 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             else fsub[i].push_back({ent[s], a[u].second});
         }
     }
+    if (level == 4) {
+        // 1024 threads: measured faster (2 - 6 %) on graphs whose rows fit a lane or nearly all do (V = 217 / 500: 3 - 8 % of the arcs
+        // in longer rows), SLOWER on den_lm estimated from text, where most arcs sit in rows of hundreds of arcs on many lanes
+        // (S = 3 006: 2.51 -> 2.64 ms per step, S = 6 836: 4.83 -> 5.26): those keep the 768-thread geometries
+        size_t long_arcs = 0, all_arcs = 0;
+        for (auto &r : fsub) { all_arcs += r.size(); if (chunks_of(r.size()) > gm->nch) long_arcs += r.size(); }
+        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * 5 > all_arcs) { *retry_next = true; return CRF_OK; }
+    }
     if (short_only)   // graphs with rows longer than a lane's registers (every den_lm estimated from text) run 2-3 % faster with the
         for (auto &r : fsub)   // row constants in the LDS table (level 1; measured): leave them to it
             if (chunks_of(r.size()) > gm->nch) { if (long_bail) *long_bail = true; *retry_next = true; return CRF_OK; }
