@@ -47,7 +47,7 @@ def test_committed_pmc_traffic_belongs_to_the_default_bench_line():
     dominant kernel's bytes must be its algorithmic bytes, not some other kernel's."""
     d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     assert d["workload"] == "B64_T1500_V72_S4097_A103791_full"
-    assert d["den_kernel"].startswith("crf_fac_pair_kernel<true,768,")
+    assert d["den_kernel"].startswith("crf_fac_pair_kernel<true,1024,")
     alg = 2 * (64 * 1500 * (4 * 72 + 4 * 4097) + 12 * 103791 + 12 * 4097)
     assert 0.95 * alg <= d["kernels"]["crf_fac_pair_kernel"] <= 1.25 * alg
     assert 1.0 < d["whole_path"]["ratio"] < 3.0
