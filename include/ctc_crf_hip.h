@@ -70,9 +70,10 @@ int crf_graph_dims(const crf_graph *g, int64_t *num_states, int64_t *num_arcs, i
  * out[16..23] = factored layout (one CU per recursion, T o LM structure): available (0/1), matched state pairs,
  * weights re-gauged (0/1), single-gather (tail) rows, forward / backward arc slots, fused backward rows, Gf*100000 + Gb;
  * out[24] = geometry of the factored kernels: 0 = 768 threads, row constants in registers (at most 3 slices of rows per wave),
- * 1 = 768 threads, row constants in an LDS table, 2 = 512 threads, 3 = as 1 over TWO compute units per recursion; -1 = no
- * factored layout; out[25] = chunks of four arcs per thread in that geometry (20; 21 = the table geometry with all chunk slots
- * holding arcs, taken by graphs that do not fit 20; 30 with 512 threads).
+ * 1 = 768 threads, row constants in an LDS table, 2 = 512 threads, 3 = as 1 over TWO compute units per recursion, 4 = 1024
+ * threads with the table (four waves per SIMD: the planner's first choice); -1 = no factored layout; out[25] = chunks of four
+ * arcs per thread in that geometry (20; 21 = the 768-thread table geometry with all chunk slots holding arcs, taken by graphs
+ * that do not fit 20; 15 with 1024 threads; 30 with 512 threads).
  * A graph created with device < 0 is compiled on the host
  * only (no GPU needed) and can be used with crf_graph_dims / crf_graph_stats / crf_graph_destroy. */
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n);
