@@ -4376,6 +4376,9 @@ static bool use_fac_pair2(const HostGraph *h, int64_t B, int64_t V, int ncu) {
 #ifndef CRF_FAC4_NB
 #define CRF_FAC4_NB 3       // chunks gathered per batch by the 1024-thread kernels
 #endif
+#ifndef CRF_FAC4_NB_ML
+#define CRF_FAC4_NB_ML 2    // ... with multi-lane rows: the butterfly's registers make batches of 3 spill (V = 217: recursions 3.32 -> 3.02 ms)
+#endif
 #ifndef CRF_FAC3_NB2
 #define CRF_FAC3_NB2 2      // chunks gathered per batch by the two-utterance kernels (8 ds_read_b64 = 16 registers in flight)
 #endif
@@ -4451,8 +4454,8 @@ static int launch_fac_pair(const LossParams &lp, size_t lds, hipStream_t st, int
     else if (F.threads == kFac4Threads) {   // 1024 threads: four waves per SIMD (the planner's first choice)
         static LdsMark m4n, m4m;
         if (ml) {
-            auto *k = crf_fac_pair_kernel<FLAG, kFac4Threads, kFac4NCH, CRF_FAC4_NB, CRF_FAC4_NB, true, true>;
-            g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,1024," CRF_STR(CRF_FAC4_NCH) "," CRF_STR(CRF_FAC4_NB) "," CRF_STR(CRF_FAC4_NB) ",true,true>" : "crf_fac_pair_kernel<false,1024," CRF_STR(CRF_FAC4_NCH) "," CRF_STR(CRF_FAC4_NB) "," CRF_STR(CRF_FAC4_NB) ",true,true>";
+            auto *k = crf_fac_pair_kernel<FLAG, kFac4Threads, kFac4NCH, CRF_FAC4_NB_ML, CRF_FAC4_NB_ML, true, true>;
+            g_den_kernel = FLAG ? "crf_fac_pair_kernel<true,1024," CRF_STR(CRF_FAC4_NCH) "," CRF_STR(CRF_FAC4_NB_ML) "," CRF_STR(CRF_FAC4_NB_ML) ",true,true>" : "crf_fac_pair_kernel<false,1024," CRF_STR(CRF_FAC4_NCH) "," CRF_STR(CRF_FAC4_NB_ML) "," CRF_STR(CRF_FAC4_NB_ML) ",true,true>";
             if ((rc = ensure_lds((const void *)k, lds, m4m, "fac pair"))) return rc;
             hipLaunchKernelGGL(k, grid, dim3(kFac4Threads), lds, st, pf, pb);
         } else {
