@@ -1701,7 +1701,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     };
     const bool pre_w = wave * kWave < V;                     // this wave holds emissions
     float last_sc = 1.f;                                     // scale of the last frame (rowless states, after the loop)
-    float epn[kEpRegsR] = {};                               // next emission row, in flight across the frame (waves that hold emissions only)
+    constexpr int EPR = NTH >= 2 * kResThreads ? 1 : kEpRegsR;   // (V <= 2 * 512 everywhere: use_factored)
+    float epn[EPR] = {};                                    // next emission row, in flight across the frame (waves that hold emissions only)
     // this utterance's emissions, rows and exponents (the frame loop adds 32-bit offsets: one s_mul instead of a 64-bit product per address)
     const float *ep_b = p.ep + bt0 * V;
     float *Out_b = p.Out + bt0 * p.Rout;
@@ -1725,7 +1726,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         if (pre) {
             const float *er = ep_b + (unsigned)tpre * (unsigned)V;   // (32-bit products: B * T * max(V, Rout) floats per utterance < 2^32, checked by the host)
 #pragma unroll
-            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; if (v < V) epn[q] = er[v]; }
+            for (int q = 0; q < EPR; ++q) { const int v = tid + q * NTH; if (v < V) epn[q] = er[v]; }
         }
         const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
         const int4 m4 = *(const int4 *)(wm + sr * 4);          // (non-negative floats: their bits order like integers)
@@ -1937,7 +1938,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         if (pre) {
             float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;
 #pragma unroll
-            for (int q = 0; q < kEpRegsR; ++q) { const int v = tid + q * NTH; if (v < V) EPw[v] = epn[q]; }
+            for (int q = 0; q < EPR; ++q) { const int v = tid + q * NTH; if (v < V) EPw[v] = epn[q]; }
         }
         CRF_TM(tm_on, tm_i + 3);
         sync_lds();
@@ -4374,7 +4375,7 @@ static bool use_fac_pair2(const HostGraph *h, int64_t B, int64_t V, int ncu) {
     return sw == 1 || 2 * B > ncu;
 }
 #ifndef CRF_FAC4_NB
-#define CRF_FAC4_NB 3       // chunks gathered per batch by the 1024-thread kernels
+#define CRF_FAC4_NB 2       // chunks gathered per batch by the 1024-thread kernels (3: one weight pair spills INSIDE the frame loop, behind a vmcnt(0))
 #endif
 #ifndef CRF_FAC4_NB_ML
 #define CRF_FAC4_NB_ML 2    // ... with multi-lane rows: the butterfly's registers make batches of 3 spill (V = 217: recursions 3.32 -> 3.02 ms)
