@@ -193,6 +193,10 @@ def main():
 
     dt = timed(step, args.steps, args.warmup)
     loss_val = float(step().item())
+    # a timing of a call whose gradient is NaN is not a measurement (round 3 found T = 3000 points of rounds 1 - 2 that were)
+    assert np.isfinite(loss_val) and bool(torch.isfinite(x.grad).all().item()), "non-finite loss or gradient at this bench point"
+    side_stream, call_streams = ctc_crf._C.last_side_stream(), ctc_crf._C.last_call_streams()
+    workspace_bytes = int(ctc_crf._C._lib.crf_workspace_bytes(ctc_crf._C.graph_for(dev), B, T, V, int(max(ly))))
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
@@ -323,8 +327,9 @@ def main():
             crit(lp, labels_t, lx_t, ly_t).backward()
 
         dt2 = timed(ddp_step, args.ddp_steps, 2)
+        assert all(bool(torch.isfinite(p.grad).all().item()) for p in model.parameters() if p.grad is not None), "non-finite gradient behind the DDP head"
         ddp_info = {"value": round(world * B * args.ddp_steps / dt2, 2), "ms_per_step": round(dt2 / args.ddp_steps * 1e3, 4),
-                    "steps": args.ddp_steps, "parameters": nparam, "gradient_bytes_per_step": 4 * nparam,
+                    "steps": args.ddp_steps, "parameters": nparam, "den_kernel": ctc_crf._C.last_den_kernel(), "call_streams": ctc_crf._C.last_call_streams(), "gradient_bytes_per_step": 4 * nparam,
                     "model": f"Linear(80->1024) + {args.ddp_layers} x residual MLP(1024->4096->1024) + Linear(1024->{V}), bf16 autocast, "
                              "log_softmax + CTC_CRF_LOSS in fp32" + (", torch DDP (bucket 100 MB), gradients all-reduced by RCCL" if use_dist else ", no DDP (single process)")}
         del model, feats
@@ -369,7 +374,9 @@ def main():
                                        "whole batch, one launch per frame)" if batch_path else "streaming"),
                        "global_batch": world * B, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
                        "world_size": world, "devices": devices},
-            "loss": round(loss_val, 6),
+            "loss": round(loss_val, 6), "grad_finite": True,
+            "schedule": {"call_streams": call_streams, "side_stream": side_stream, "rccl_initialised": bool(use_dist and not share)},
+            "workspace_bytes": workspace_bytes,
             "event_blocks": event_blocks,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -342,6 +342,7 @@ void set_error(const std::string &msg);
     X(serial_chains,    "C  everything on the caller's stream")                                                              \
     X(no_side_stream,   "X  no side stream for this context")                                                                \
     X(trust_side,       "X  take a side stream without probing that it runs beside the caller's (profiler counter passes)")  \
+    X(side_kind,        "X  side stream candidates of one kind only: 1 plain, 2 high priority, 3 low priority, 4 CU-masked")  \
     X(aux_stream,       "C  numerator fallback chains on the third stream: 1 always, 0 never (default: when a recent call needed them)")  \
     X(no_aux_stream,    "X  no third stream for this context (numerator fallback chains in front of the grad stages)")      \
     X(fac_pair2,        "C  factored recursions with TWO utterances per workgroup: 1 = for any batch, 0 = never (default: batches above CUs / 2)")

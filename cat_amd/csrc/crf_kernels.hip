@@ -4132,22 +4132,91 @@ struct DevCtx {
     hipEvent_t fork{}, join{}, ev[kMaxStages]{}, evb[kMaxStages]{};
     int *flags = nullptr;     // fine-grained (uncached, cross-XCD coherent) words: [0] error word, [1] start counter, [16..32) stage counters
     bool warned = false;
+    int side_kind = 0, side_tries = 0;   // find_beside: what kind of stream the side stream is, how many candidates were probed
+    char side_desc[96] = "none";
 };
 static std::mutex g_ctx_mu;
 static std::vector<DevCtx *> g_ctxs;
 
 // Do two streams run side by side?  HIP maps every stream of the process onto GPU_MAX_HW_QUEUES (default 4) hardware
 // queues; two streams on one queue run their kernels one after the other.  Two single-wave kernels shake hands through
-// fine-grained memory: each raises its flag and waits (bounded, ~0.5 ms) for the other's.  Both see the other only if
+// fine-grained memory: each raises its flag and waits (bounded, ~5 ms) for the other's.  Both see the other only if
 // they were resident at the same time.
 __global__ void crf_probe_kernel(int *flags, int me, int other) {
     __hip_atomic_store(flags + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int saw = 0;
-    for (int spins = 0; spins < 400 && !saw; ++spins) {
+    for (int spins = 0; spins < 2500 && !saw; ++spins) {   // ~2 us per spin: bounded at ~5 ms
         saw = __hip_atomic_load(flags + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (!saw) __builtin_amdgcn_s_sleep(64);
     }
     __hip_atomic_store(flags + 2 + me, saw ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// A stream that runs BESIDE `owner`, or null.  HIP (ROCclr) gives every stream one of GPU_MAX_HW_QUEUES (default 4) HSA queues PER
+// PRIORITY -- a new stream takes the queue with the fewest users -- and a stream created with a CU mask gets a queue of its own.
+// In a trainer process the pools are crowded before this library is loaded (torch's stream pool: 32 streams per priority as soon as
+// c10d asks for one; RCCL's own), so the least-used queue may well be the owner's, and a candidate that is destroyed gives its
+// slot back: the next one lands on the same queue again (rounds 2 - 3 probed six candidates that way and found all six behind the
+// owner in every process that had initialised RCCL).  Hence: failed candidates stay alive until one passes -- each pushes the
+// next one to another queue --, then the other priorities' pools (low first: the side stream's work is the filler, the owner's den
+// grid is the critical path), then a CU-masked stream with every CU enabled.  Switch `side_kind` (1 plain, 2 high, 3 low, 4 masked)
+// restricts the search to one kind.
+enum { kSideNone = 0, kSidePlain, kSideHigh, kSideLow, kSideMask };
+static const char *const kSideNames[] = {"none", "plain", "priority-high", "priority-low", "cu-mask"};
+static hipStream_t make_candidate(int kind, int dev) {
+    hipStream_t s{};
+    hipError_t e = hipErrorInvalidValue;
+    if (kind == kSidePlain) {
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    } else if (kind == kSideHigh || kind == kSideLow) {
+        int least = 0, greatest = 0;   // (numerically lower = higher priority)
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, kind == kSideHigh ? greatest : least);
+    } else if (kind == kSideMask) {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) {
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
+            if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
+            e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+        }
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
+static bool runs_beside(hipStream_t owner, hipStream_t cand, int *flags) {
+    int res[4] = {0, 0, 0, 0};
+    // (a first launch on a new stream may pay for its queue's set-up: get that out of the way, or the owner's probe kernel
+    // gives up before the candidate's has started -- the kernel below shakes hands with itself)
+    hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, cand, flags + 8, 0, 0);
+    bool ran = hipStreamSynchronize(cand) == hipSuccess && hipMemset(flags, 0, sizeof(res)) == hipSuccess;
+    hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, owner, flags, 0, 1);
+    hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, cand, flags, 1, 0);
+    ran = ran && hipStreamSynchronize(cand) == hipSuccess && hipStreamSynchronize(owner) == hipSuccess &&
+          hipMemcpy(res, flags, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ran) (void)hipGetLastError();
+    return ran && res[2] == 1 && res[3] == 1;
+}
+static hipStream_t find_beside(hipStream_t owner, int *flags, int dev, int *kind_out, int *tries_out) {
+    static const struct { int kind, count; } plan[] = {{kSidePlain, 8}, {kSideLow, 2}, {kSideHigh, 2}, {kSideMask, 1}};
+    const int only = opt(kOpt_side_kind, 0);
+    std::vector<hipStream_t> failed;
+    hipStream_t found{};
+    int tries = 0;
+    for (const auto &ph : plan) {
+        if (only > 0 && ph.kind != only) continue;
+        for (int i = 0; i < ph.count && !found; ++i) {
+            hipStream_t cand = make_candidate(ph.kind, dev);
+            if (!cand) break;
+            ++tries;
+            if (runs_beside(owner, cand, flags)) { found = cand; *kind_out = ph.kind; }
+            else failed.push_back(cand);
+        }
+        if (found) break;
+    }
+    for (hipStream_t s : failed) (void)hipStreamDestroy(s);
+    *tries_out = tries;
+    if (!found) *kind_out = kSideNone;
+    return found;
 }
 
 static int get_ctx(hipStream_t owner, DevCtx **out) {
@@ -4174,32 +4243,24 @@ static int get_ctx(hipStream_t owner, DevCtx **out) {
         (void)hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->evb[i], hipEventDisableTiming);
     }
-    // The side stream: the first of a few candidates that demonstrably runs beside the owner's stream (once per
-    // context; the owner's stream is drained first so that both probe kernels start at once).  CRF_NO_SIDE_STREAM=1
-    // skips it (everything then runs on the caller's stream, one kernel after the other).
+    // The side stream: the first candidate that demonstrably runs beside the owner's stream (once per context; the owner's
+    // stream is drained first so that both probe kernels start at once).  find_beside() keeps the candidates that failed
+    // alive until one passes, and tries streams of other priorities (queue pools of their own) and a CU-masked stream (a
+    // queue of its own) when no plain stream does.  Switch `no_side_stream` skips it (everything then runs on the caller's
+    // stream, one kernel after the other).
     const bool want_side = !opt_on(kOpt_no_side_stream);
     const bool trust = opt_on(kOpt_trust_side);   // (counter passes of a profiler run one kernel at a time: the probe cannot succeed there)
     if (want_side && c->flags && !trust) {
         (void)hipStreamSynchronize(owner);
-        for (int tries = 0; tries < 6 && !c->side; ++tries) {
-            hipStream_t cand{};
-            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
-            int res[4] = {0, 0, 0, 0};
-            bool ran = hipMemset(c->flags, 0, sizeof(res)) == hipSuccess;
-            hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, owner, c->flags, 0, 1);
-            hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, cand, c->flags, 1, 0);
-            ran = ran && hipStreamSynchronize(cand) == hipSuccess && hipStreamSynchronize(owner) == hipSuccess &&
-                  hipMemcpy(res, c->flags, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess;
-            if (ran && res[2] == 1 && res[3] == 1) c->side = cand;
-            else { (void)hipGetLastError(); (void)hipStreamDestroy(cand); }
-        }
+        c->side = find_beside(owner, c->flags, dev, &c->side_kind, &c->side_tries);
     } else if (want_side) {   // no fine-grained memory for the probe: take a stream on trust
         if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->side = nullptr; }
+        c->side_kind = c->side ? kSidePlain : kSideNone;
     }
     if (want_side && !c->side && !c->warned) {
-        fprintf(stderr, "[ctc_crf_hip] no stream of this process runs beside the caller's stream (all hardware queues shared?): "
-                        "the loss runs its kernels one after the other on the caller's stream -- correct, but slower; "
-                        "raise GPU_MAX_HW_QUEUES before the HIP runtime starts\n");
+        fprintf(stderr, "[ctc_crf_hip] no stream of this process runs beside the caller's stream (%d candidates probed: plain, other "
+                        "priorities, CU-masked): the loss runs its kernels one after the other on the caller's stream -- correct, but slower\n",
+                c->side_tries);
         c->warned = true;
     }
     // A third stream for work that may take long beside the staged grad pass (the numerator's log-domain chains): it must not sit
@@ -4207,22 +4268,13 @@ static int get_ctx(hipStream_t owner, DevCtx **out) {
     if (c->side && c->flags && !trust && !opt_on(kOpt_no_aux_stream) &&
         hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess) {
         (void)hipStreamSynchronize(owner);
-        for (int tries = 0; tries < 4 && !c->aux; ++tries) {
-            hipStream_t cand{};
-            if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
-            int res[4] = {0, 0, 0, 0};
-            bool ran = hipMemset(c->flags, 0, sizeof(res)) == hipSuccess;
-            hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, owner, c->flags, 0, 1);
-            hipLaunchKernelGGL(crf_probe_kernel, dim3(1), dim3(1), 0, cand, c->flags, 1, 0);
-            ran = ran && hipStreamSynchronize(cand) == hipSuccess && hipStreamSynchronize(owner) == hipSuccess &&
-                  hipMemcpy(res, c->flags, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess;
-            if (ran && res[2] == 1 && res[3] == 1) c->aux = cand;
-            else { (void)hipGetLastError(); (void)hipStreamDestroy(cand); }
-        }
+        int kind = 0, tries = 0;
+        c->aux = find_beside(owner, c->flags, dev, &kind, &tries);
         void *hp = nullptr;
         if (c->aux && hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { c->seen = (int *)hp; *c->seen = 0; }
         else (void)hipGetLastError();
     }
+    snprintf(c->side_desc, sizeof(c->side_desc), "%s (candidate %d)%s", kSideNames[c->side_kind], c->side_tries, c->aux ? " + third stream" : "");
     g_ctxs.push_back(c);
     *out = c;
     return CRF_OK;
@@ -4271,6 +4323,7 @@ struct Prof {
 };
 static thread_local Prof g_prof;
 static thread_local int g_call_streams = 1;          // crf_last_call_streams
+static thread_local const char *g_side_desc = "none";   // crf_last_side_stream
 static thread_local const char *g_den_kernel = "";   // template instantiation of the denominator recursions' kernel in the last call (crf_last_den_kernel)
 static void prof_mark(int slot, bool stop, hipStream_t st) {
     if (!g_prof.on) return;
@@ -4676,6 +4729,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.clear = nullptr; p.nclear = 0;
     p.call_id = ++cx->call_id; p.ctc_seen = cx->seen;
     g_call_streams = 1;
+    g_side_desc = cx->side_desc;
     if (have_flags) { p.err = cx->flags; p.clear = cx->flags; p.nclear = 64; }
     for (bool &u : g_prof.used) u = false;
     prof_mark(7, false, stream);
@@ -5030,7 +5084,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
                 g_call_streams = 3;
             } else {
                 (void)hipGetLastError();
-                if ((rc = launch_robust_ctc(side, 1))) return rc;
+                if ((rc = launch_robust_ctc_chains(side, 1))) return rc;
             }
         }
         p.grad_den_acc = 1;
@@ -5049,10 +5103,11 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             }
             if ((rc = launch_grad_den(side, k + 1))) return rc;
         }
-        if (aux_fix) {
-            if ((e = hipStreamWaitEvent(side, cx->ev_b, 0)) != hipSuccess) { set_error(std::string("hipStreamWaitEvent(aux): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
-            if ((rc = launch_robust_ctc_fix(side, 1))) return rc;
-        }
+        // The marked frames' posteriors are subtracted at ONE place whichever stream ran the chains -- behind the last stage -- so that
+        // the order of the float additions into `grad` (and with it every bit of the gradient) does not depend on the unsynchronised
+        // hint above (round-3 advisor: with the chains on the side stream the subtraction used to precede the stages).
+        if (aux_fix && (e = hipStreamWaitEvent(side, cx->ev_b, 0)) != hipSuccess) { set_error(std::string("hipStreamWaitEvent(aux): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+        if (ctc_pass1 && (rc = launch_robust_ctc_fix(side, 1))) return rc;
         prof_mark(5, true, side);
         if ((rc = join_side())) return rc;   // the last grad launch is behind every stage of the recursions
     } else if (den && ctc && !serial) {
@@ -5182,6 +5237,7 @@ int crf_timing_read(unsigned long long *out, int n) {
 
 const char *crf_last_den_kernel(void) { return g_den_kernel; }
 int crf_last_call_streams(void) { return g_call_streams; }
+const char *crf_last_side_stream(void) { return g_side_desc; }
 
 void crf_profile_enable(int on) { g_prof.on = on != 0; if (!on) g_prof.have = false; }
 

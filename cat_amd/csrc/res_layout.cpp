@@ -1296,6 +1296,11 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     }
     Rows bsub(brow.size());
     for (size_t i = 0; i < brow.size(); ++i) bsub[i] = brow[i].arcs;   // pair ids for now; lengths are all placement needs
+    if (level == 4) {   // (the same test as on the forward rows above: a graph whose BACKWARD rows are mostly multi-lane keeps 768 threads too)
+        size_t long_arcs = 0, all_arcs = 0;
+        for (auto &r : bsub) { all_arcs += r.size(); if (chunks_of(r.size()) > gm->nch) long_arcs += r.size(); }
+        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * 5 > all_arcs) { *retry_next = true; return CRF_OK; }
+    }
     if (short_only)
         for (auto &r : bsub)
             if (chunks_of(r.size()) > gm->nch) { if (long_bail) *long_bail = true; *retry_next = true; return CRF_OK; }

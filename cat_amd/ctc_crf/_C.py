@@ -6,6 +6,7 @@ and every call goes through the C ABI of include/ctc_crf_hip.h.
 """
 import ctypes
 import os
+import sys
 import threading
 from typing import Dict, Optional
 
@@ -59,12 +60,13 @@ _lib.crf_debug_list.restype = ctypes.c_char_p
 _lib.crf_last_error.restype = ctypes.c_char_p
 _lib.crf_last_den_kernel.restype = ctypes.c_char_p
 _lib.crf_last_call_streams.restype = ctypes.c_int
+_lib.crf_last_side_stream.restype = ctypes.c_char_p
 _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
     "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_debug_res_emulate", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
-    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_call_streams", "crf_last_error", "crf_version",
+    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_call_streams", "crf_last_side_stream", "crf_last_error", "crf_version",
 )
 
 PROFILE_SLOTS = ("prep", "den_fwd_chain", "den_bwd_chain", "ctc_fwd_chain", "ctc_bwd_chain", "grad",
@@ -90,6 +92,11 @@ def last_den_kernel() -> str:
 def last_call_streams() -> int:
     """1 / 2 / 3: streams this thread's last call put work on (caller's, + side stream, + third stream)."""
     return int(_lib.crf_last_call_streams())
+
+
+def last_side_stream() -> str:
+    """Kind of the side stream of the last call's context and how many candidates were probed (include/ctc_crf_hip.h)."""
+    return _lib.crf_last_side_stream().decode()
 
 
 def version() -> str:
@@ -441,4 +448,8 @@ def gpu_ctc(probs: torch.Tensor, grads: torch.Tensor, labels: torch.Tensor, labe
 
 for _kv in filter(None, os.environ.get("CRF_DEBUG", "").split(",")):   # tools only (see debug_set)
     _k, _, _v = _kv.partition("=")
-    debug_set(_k.strip(), int(_v) if _v.strip() else 1)
+    try:                                                                # a stray or stale CRF_DEBUG must not break `import ctc_crf`
+        debug_set(_k.strip(), int(_v) if _v.strip() else 1)
+        print(f"[ctc_crf] CRF_DEBUG: switch {_k.strip()} = {_DEBUG_SET[_k.strip()]} (tools / tests only: changes product behaviour)", file=sys.stderr)
+    except (ValueError, RuntimeError) as _e:
+        print(f"[ctc_crf] CRF_DEBUG: ignored {_kv!r}: {_e}", file=sys.stderr)

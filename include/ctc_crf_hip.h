@@ -174,6 +174,11 @@ const char *crf_last_den_kernel(void);
 /* Streams this thread's last call put work on: 1 = the caller's only, 2 = + the context's side stream, 3 = + its third stream
  * (the numerator's log-domain fallback chains beside the staged grad pass: taken when a recent call of the context needed them). */
 int crf_last_call_streams(void);
+/* What the side stream of the (device, caller stream) context of this thread's last call is: "plain (candidate 2)", "priority-low
+ * (candidate 9)", "cu-mask (candidate 13) + third stream", "none (candidate 13)" -- the kind of stream that was found to run
+ * beside the caller's and how many candidates had been probed by then (crf_kernels.hip find_beside).  The reference runs everything
+ * on the caller's stream (binding.cpp:75,102) and has nothing to report. */
+const char *crf_last_side_stream(void);
 int crf_profile_read(float *ms_out, int n);
 
 /* Diagnostics, timing builds only (CRF_BUILD_DEFS=-DCRF_TIMING python -m cat_amd.build --force): copies

@@ -72,6 +72,25 @@ def den(g: Dict, logits: np.ndarray, lx: np.ndarray, precision: str = "f64"):
     return grad, ca, cb
 
 
+def den_alpha(g: Dict, logits: np.ndarray, lx: np.ndarray, precision: str = "f64"):
+    """Debug entry: gpu_den restatement + its forward table in the layout of the reference's `alpha` buffer, [B, T+1, S] float64
+    (row lx[b] with end_weight added, as alpha_last_kernel leaves it; rows beyond lx[b] NaN)."""
+    lib = _load()
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    B, T, V = logits.shape
+    lx = np.ascontiguousarray(lx, dtype=np.int32)
+    grad = np.zeros((B, T, V), dtype=np.float32)
+    ca = np.zeros(B, dtype=np.float64)
+    cb = np.zeros(B, dtype=np.float64)
+    alpha = np.full((B, T + 1, int(g["S"])), np.nan, dtype=np.float64)
+    keep, ga = _graph_args(g)
+    fn = getattr(lib, f"oracle_den_alpha_{precision}")
+    rc = fn(*ga, _p(logits, ctypes.c_float), B, T, V, _p(lx, ctypes.c_int), _p(grad, ctypes.c_float),
+            _p(ca, ctypes.c_double), _p(cb, ctypes.c_double), _p(alpha, ctypes.c_double))
+    assert rc == 0
+    return grad, ca, cb, alpha
+
+
 def ctc(logits: np.ndarray, labels: np.ndarray, lx: np.ndarray, ly: np.ndarray, precision: str = "f64"):
     """gpu_ctc restatement on [B,T,V] log-probs -> (grad_ctc [B,T,V], costs_ctc[B] (+loglike), valid[B])."""
     lib = _load()

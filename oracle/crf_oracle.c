@@ -104,7 +104,7 @@ static void graph_free(graph_t *g) {
  * LSE_s(beta_0[s]+start_w[s]); the reference reads state 0 only, :255-261).
  * ------------------------------------------------------------------------------------------ */
 static int den_one(const graph_t *g, const float *logits, int T, int V, int lx, float *grad,
-                   double *lz_alpha, double *lz_beta) {
+                   double *lz_alpha, double *lz_beta, double *alpha_out) {
     const int S = g->S;
     (void)T;
     real *alpha = malloc(sizeof(real) * (size_t)(lx + 1) * (size_t)S);
@@ -131,6 +131,12 @@ static int den_one(const graph_t *g, const float *logits, int T, int V, int lx, 
     real lz = NEG_INF;
     for (int s = 0; s < S; ++s) lz = log_plus(lz, alpha[(size_t)lx * S + s] + g->end_w[s]);
     *lz_alpha = (double)lz;
+    /* debug entry oracle_den_alpha: the table as the reference leaves it in its `alpha` buffer -- rows 0..lx, row lx
+     * with end_weight added in place by alpha_last_kernel :105-119; rows beyond lx are never written (:86). */
+    if (alpha_out) {
+        for (size_t i = 0; i < (size_t)(lx + 1) * S; ++i) alpha_out[i] = (double)alpha[i];
+        for (int s = 0; s < S; ++s) alpha_out[(size_t)lx * S + s] = (double)(alpha[(size_t)lx * S + s] + g->end_w[s]);
+    }
 
     /* beta_last_kernel :163-175 */
     for (int s = 0; s < S; ++s) beta[(size_t)(lx % 2) * S + s] = g->end_w[s];
@@ -253,7 +259,26 @@ int FN(oracle_den)(int S, int A, const int *src, const int *dst, const int *lab,
 #pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
     for (int b = 0; b < B; ++b)
         err |= den_one(&g, logits + (size_t)b * T * V, T, V, lx[b], grad_den + (size_t)b * T * V,
-                       costs_alpha + b, costs_beta + b);
+                       costs_alpha + b, costs_beta + b, NULL);
+    graph_free(&g);
+    return err;
+}
+
+/* Debug entry (tests only): oracle_den plus the forward table in the layout of the reference's `alpha` buffer,
+ * [B][T+1][S] (den_calculate.cu:70, 88-89: alpha[b * S * (T+1) + t * S + s]), as double; rows t > lx[b] are left
+ * untouched.  The reference fills each entry with a SERIAL loop over the state's in-arcs (:96-100), in the order
+ * graph_build reproduces, so its table is deterministic and comparable entry by entry. */
+int FN(oracle_den_alpha)(int S, int A, const int *src, const int *dst, const int *lab, const float *w,
+                         const float *start_w, const float *end_w, const float *logits, int B, int T,
+                         int V, const int *lx, float *grad_den, double *costs_alpha, double *costs_beta,
+                         double *alpha_out) {
+    graph_t g; graph_build(&g, S, A, src, dst, lab, w, start_w, end_w);
+    memset(grad_den, 0, sizeof(float) * (size_t)B * T * V);
+    int err = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
+    for (int b = 0; b < B; ++b)
+        err |= den_one(&g, logits + (size_t)b * T * V, T, V, lx[b], grad_den + (size_t)b * T * V,
+                       costs_alpha + b, costs_beta + b, alpha_out + (size_t)b * (T + 1) * S);
     graph_free(&g);
     return err;
 }
