@@ -1462,6 +1462,9 @@ __global__ __launch_bounds__(kResThreads) void crf_res_pair_kernel(ResParams pf,
 //             extra arc (BP positions / z entries 2*rid, 2*rid + 1).
 // LDS: V0 | V1 (two state vectors of Gp floats) | row metadata int4[R] | EP[2][Vp] | wm | red
 // =============================================================================================
+#ifndef CRF_X_EARLY
+#define CRF_X_EARLY 1       // fac_chain_body: the frame's scale / exponent bookkeeping behind the first batch of gathers (0: in front of it)
+#endif
 struct FacParams {
     FacDirDev L;
     int B, T, V, Rout, NT, Rf;
@@ -1722,6 +1725,12 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         const int tpre = DIR == 0 ? t + 1 : t - 2;
         // (only the waves that hold emissions take part in the prefetch: the compiler waits for vmcnt(0) around these
         // loads -- i.e. for the acknowledgement of the previous frame's row stores -- and the other waves need not)
+        // The frame's side jobs belong to a few waves -- the emission prefetch to the waves that hold emissions, the exponent store
+        // and the clearing of the maximum words to wave 0 -- and are tested as UNIFORM, UNLIKELY conditions: the other waves fall
+        // through.  (As lane conditions they were exec-masked blocks that every other wave JUMPED over, ~32 cycles of instruction
+        // refetch per taken branch and wave, six of them before the frame's first gather: tools/ubench_issue.py.)
+        // (NOT the prefetch: as a cold block its register -- live across the whole frame -- is what the allocator spills first, and a
+        // reload from scratch waits for vmcnt(0), i.e. for the frame's row stores: the S = 513 graph went from 1.84 to 2.35 ms)
         const bool pre = pre_w && (DIR == 0 ? (t + 1 < lx) : (t >= 2));
         if (pre) {
             const float *er = ep_b + (unsigned)tpre * (unsigned)V;   // (32-bit products: B * T * max(V, Rout) floats per utterance < 2^32, checked by the host)
@@ -1730,21 +1739,34 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         }
         const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
         const int4 m4 = *(const int4 *)(wm + sr * 4);          // (non-negative floats: their bits order like integers)
-        const int ksc = rescale_exp_bits((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
-        if (wave == 0 && lane < 4) wm[sz * 4 + lane] = 0.f;
-        const float sc = pow2f(ksc);
-        if (DIR == 1) last_sc = sc;
-        float *Orow;
-        if (DIR == 0) {
-            E += ksc;
-            if (tid == 0 && lead) Eo_b[t] = E;
-            E += kEpExp;
-            Orow = Out_b + (unsigned)t * (unsigned)p.Rout;
-        } else {
-            E += ksc + kEpExp;
-            if (t > 0 && tid == 0 && lead) Eo_b[t - 1] = E;
-            Orow = t > 0 ? Out_b + (unsigned)(t - 1) * (unsigned)p.Rout : p.Row0 + (int64_t)b * p.Rout;
-        }
+        // The frame's scale and exponent are worked out BEHIND the first batch of gathers (EARLY: the batch loop calls `bookkeeping`
+        // once its first gathers are requested -- they need nothing but the vector; the scale enters in the row epilogues only):
+        // with the scale first, every wave of the workgroup sat out one LDS round trip right after the frame barrier, the LDS idle.
+        float sc = 1.f;
+        float *Orow = nullptr;
+        auto bookkeeping = [&]() __attribute__((always_inline)) {
+            const int ksc = rescale_exp_bits((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
+            sc = pow2f(ksc);
+            if (DIR == 1) last_sc = sc;
+            if (DIR == 0) {
+                E += ksc;
+                if (__builtin_expect(wave == 0, 0)) {
+                    if (lane < 4) wm[sz * 4 + lane] = 0.f;
+                    if (tid == 0 && lead) Eo_b[t] = E;
+                }
+                E += kEpExp;
+                Orow = Out_b + (unsigned)t * (unsigned)p.Rout;
+            } else {
+                E += ksc + kEpExp;
+                if (__builtin_expect(wave == 0, 0)) {
+                    if (lane < 4) wm[sz * 4 + lane] = 0.f;
+                    if (t > 0 && tid == 0 && lead) Eo_b[t - 1] = E;
+                }
+                Orow = t > 0 ? Out_b + (unsigned)(t - 1) * (unsigned)p.Rout : p.Row0 + (int64_t)b * p.Rout;
+            }
+        };
+        constexpr bool EARLY = CRF_X_EARLY != 0 && !K2;
+        if constexpr (!EARLY) bookkeeping();
         unsigned ends_f = ends;
         int nch_f = nch;
         asm volatile("" : "+s"(ends_f), "+s"(nch_f));
@@ -1893,13 +1915,19 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #pragma unroll
         for (int c0 = 0; c0 < NCHA; c0 += NB) {
             const int nb = NCHA - c0 < NB ? NCHA - c0 : NB;   // (the last batch may be short: 21 chunks in batches of 4)
-            if (c0 < nch_f) {
+            // (EARLY: the first batch is gathered by every wave -- the slots of a wave without arcs hold padding, offset 0 and weight 0)
+            if ((EARLY && c0 == 0) || c0 < nch_f) {
                 f32x2 g01[NB], g23[NB];
                 CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb);
+                if constexpr (EARLY) { if (c0 == 0) bookkeeping(); }
 #pragma unroll
                 for (int ci = 0; ci < nb; ++ci) {
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
-                    if (ends_f >> (c0 + ci) & 1u) row_end((unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u)));
+                    // (a row ends after 2 - 3 of a wave's 15 chunks: the test is laid out so that the common path falls through --
+                    // a taken branch costs a wave ~32 cycles of instruction refetch, tools/ubench_issue.py.  With a probability, not
+                    // "never": blocks the allocator believes cold are where it spills, and a reload from scratch waits for
+                    // vmcnt(0), i.e. for the acknowledgement of the frame's write-through row stores)
+                    if (__builtin_expect_with_probability((ends_f >> (c0 + ci) & 1u) != 0u, 0, 0.8)) row_end((unsigned)__builtin_popcount(ends_f & ((1u << (c0 + ci)) - 1u)));
                 }
             }
         }
@@ -1941,6 +1969,9 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             for (int q = 0; q < EPR; ++q) { const int v = tid + q * NTH; if (v < V) EPw[v] = epn[q]; }
         }
         CRF_TM(tm_on, tm_i + 3);
+#ifdef CRF_TIMING
+        if (b == 3 && i >= 150 && i < 158) CRF_TM(true, 15360 + (DIR * 16 + wave) * 8 + (i - 150));   // this wave's arrival at the frame barrier
+#endif
         sync_lds();
         CRF_TM(tm_on, tm_i + 4);
     };

@@ -57,7 +57,7 @@ def main():
             v = [rows[f + 1][0] - rows[f][0] for f in range(127)]
             print(f"   {'frame total':32s} median {statistics.median(v):8.0f} cyc")
     print("per-wave compute time (cycles, median of 8 frames) vs chunks / slices of the wave:")
-    nw = 12 if fac else 8
+    nw = {4: 16, 2: 8}.get(_C.graph_stats(_C.graph_for(dev)).get("fac_geom"), 12) if fac else 8   # 1024 / 512 / 768 threads
     for d, dn in enumerate(("fwd", "bwd")):
         for k in range(1 if fac else 2):
             line = []
@@ -67,6 +67,12 @@ def main():
                 v = [tm[o + f] - st[f] for f in range(8)]
                 line.append(f"w{w}: {statistics.median(v):5.0f} ({tm[o + 8]:2d}ch,{tm[o + 9]:2d}sl)")
             print(f"   den {dn} CU {k}: " + "  ".join(line))
+            if fac:   # arrival at the frame barrier (after the wave maximum and, in the waves that hold emissions, their staging)
+                line = []
+                for w in range(nw):
+                    v = [tm[15360 + (d * 16 + w) * 8 + f] - st[f] for f in range(8)]
+                    line.append(f"w{w}: {statistics.median(v):5.0f}")
+                print(f"   den {dn} arrival at the barrier: " + "  ".join(line))
     rows = [[tm[14336 + f * 8 + j] for j in range(6)] for f in range(128)]
     if rows[0][0]:
         print("ctc forward, utterance 3, wave 0:")
