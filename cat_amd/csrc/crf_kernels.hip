@@ -1462,6 +1462,13 @@ __global__ __launch_bounds__(kResThreads) void crf_res_pair_kernel(ResParams pf,
 //             extra arc (BP positions / z entries 2*rid, 2*rid + 1).
 // LDS: V0 | V1 (two state vectors of Gp floats) | row metadata int4[R] | EP[2][Vp] | wm | red
 // =============================================================================================
+#ifndef CRF_X_ROWMAX
+#define CRF_X_ROWMAX 0      // fac_chain_body: ds_max_f32 of the frame maximum per row end instead of once in the frame's tail (A/B switch)
+#endif
+#ifndef CRF_X_PRIO
+#define CRF_X_PRIO 2        // fac_chain_body: issue priority by progress through the frame's chunks: 0 off, 1 steps at 1/4, 1/2, 3/4 of the
+                            // chunks, 2 at 1/2, 3/4, 7/8 (product), 3 at 1/8, 1/4, 1/2 -- profiles/round4_ab_setprio_by_progress.txt
+#endif
 #ifndef CRF_X_EARLY
 #define CRF_X_EARLY 1       // fac_chain_body: the frame's scale / exponent bookkeeping behind the first batch of gathers (0: in front of it)
 #endif
@@ -1766,6 +1773,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             }
         };
         constexpr bool EARLY = CRF_X_EARLY != 0 && !K2;
+        constexpr bool ROWMAX = CRF_X_ROWMAX != 0 && IMP && !K2;   // the frame maximum is fed from the row epilogues, not from the frame's tail
         if constexpr (!EARLY) bookkeeping();
         unsigned ends_f = ends;
         int nch_f = nch;
@@ -1838,7 +1846,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                         gu64 *gs = (gu64 *)((char *)slot + 2u * r4);
                         res_publish(gs, 0, tag, Up, same_l2); res_publish(gs, R, tag, Lp, same_l2); res_publish(gs, 2 * R, tag, Ap, same_l2);
                     }
-                    mymax = __int_as_float(max(__float_as_int(mymax), __float_as_int(Up)));   // (non-negative: bits order like integers; fmaxf canonicalises first)
+                    if constexpr (ROWMAX) { const float m_ = row_max16(Up); if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), m_); }
+                    else mymax = __int_as_float(max(__float_as_int(mymax), __float_as_int(Up)));   // (non-negative: bits order like integers; fmaxf canonicalises first)
                 } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16
                     const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
                     const float e0 = *(const float *)((const char *)EPu + (k1 & 0xffffu)), e1 = *(const float *)((const char *)EPu + (k1 >> 16));
@@ -1863,7 +1872,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                         gu64 *gs = (gu64 *)((char *)slot + 4u * r4);
                         res_publish(gs, 0, tag, zv.x, same_l2); res_publish(gs, 1, tag, zv.y, same_l2);
                     }
-                    mymax = __int_as_float(max(__float_as_int(mymax), max(__float_as_int(zv.x), __float_as_int(zv.y))));
+                    if constexpr (ROWMAX) { const float m_ = row_max16(__int_as_float(max(__float_as_int(zv.x), __float_as_int(zv.y)))); if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), m_); }
+                    else mymax = __int_as_float(max(__float_as_int(mymax), max(__float_as_int(zv.x), __float_as_int(zv.y))));
                 }
             } else {
             const int4 m = *(const int4 *)(RMc + 4u * r4);
@@ -1915,6 +1925,21 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #pragma unroll
         for (int c0 = 0; c0 < NCHA; c0 += NB) {
             const int nb = NCHA - c0 < NB ? NCHA - c0 : NB;   // (the last batch may be short: 21 chunks in batches of 4)
+#if CRF_X_PRIO
+            // least progress first: a wave's issue priority (s_setprio) falls as it advances through its chunks, so that the four
+            // waves of a SIMD reach the frame barrier together.  Without it the SIMD issues its OLDEST wave first: in the timing
+            // build the oldest waves were through their chunks at 2 560 cycles and the youngest -- alone on their SIMDs at the end,
+            // one wave's latency hiding -- at 4 140 of a 4 700-cycle frame; with it 3 050 ... 3 790 of 4 350.  (Round 2 had tried
+            // STATIC priorities for the younger waves: slower.)
+            {
+                constexpr int f1 = CRF_X_PRIO == 2 ? 4 : CRF_X_PRIO == 3 ? 1 : 2, f2 = CRF_X_PRIO == 2 ? 6 : CRF_X_PRIO == 3 ? 2 : 4, f3 = CRF_X_PRIO == 2 ? 7 : CRF_X_PRIO == 3 ? 4 : 6;   // eighths of the chunks
+                constexpr int q1 = (f1 * NCHA / 8 + NB - 1) / NB * NB, q2 = (f2 * NCHA / 8 + NB - 1) / NB * NB, q3 = (f3 * NCHA / 8 + NB - 1) / NB * NB;
+                if (c0 == 0) __builtin_amdgcn_s_setprio(3);
+                else if (c0 == q1) __builtin_amdgcn_s_setprio(2);
+                else if (c0 == q2) __builtin_amdgcn_s_setprio(1);
+                else if (c0 == q3) __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             // (EARLY: the first batch is gathered by every wave -- the slots of a wave without arcs hold padding, offset 0 and weight 0)
             if ((EARLY && c0 == 0) || c0 < nch_f) {
                 f32x2 g01[NB], g23[NB];
@@ -1960,8 +1985,10 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             }
             mymax = fmaxf(mymax, fm);
         }
-        mymax = row_max16(mymax);
-        if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), mymax);
+        if constexpr (!ROWMAX) {   // (ROWMAX: every row end has sent its maximum already -- no reduction and no LDS round trip in front of the barrier)
+            mymax = row_max16(mymax);
+            if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), mymax);
+        }
         sr = sw;
         if (pre) {
             float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;

@@ -915,9 +915,8 @@ def test_denominator_vs_reference_kernels(crf, tmp_path, hist, fan, B, T, tol_re
     oracle within 1e-5 * max(1, |alpha|) of the reference's at T = 120 (3e-5 at T = 500, where the reference's own fp32 drift is
     1.4e-5 of |alpha| ~ 1500), the same -inf pattern (a wrong arc order, an off-by-one frame or a
     mis-read label moves entries by O(1)), and the fp32 build of the oracle -- the reference's arithmetic type, same
-    operation order, only the libm differs from the device's -- closer still.  The gradient of the fp32 oracle must be
-    CLOSER to the reference's gradient than the fp64 oracle's is: the restatement follows the reference's arithmetic, not
-    just its mathematics."""
+    operation order, only the libm differs from the device's -- within 2e-6 (a few ulp): the restatement follows the
+    reference's arithmetic, not just its mathematics."""
     g, p = small_synth(tmp_path, 72, hist, fan, 4 if hist == 256 else 0)
     logits, _, lx, _ = make_batch(g, B, T, 72, seed=4, ragged=True)
     gref, cref, aref = _ref_den(p, logits, lx)
@@ -936,11 +935,16 @@ def test_denominator_vs_reference_kernels(crf, tmp_path, hist, fan, B, T, tol_re
         worst64 = max(worst64, float((np.abs(o64[m] - r[m]) / scale).max()))
         worst32 = max(worst32, float((np.abs(o32[m] - r[m]) / scale).max()))
     print(f"alpha table vs the reference's, max |d| / max(1, |alpha|): fp64 oracle {worst64:.2e}, fp32 oracle {worst32:.2e}")
-    assert worst64 <= tol_alpha and worst32 <= tol_alpha and worst32 <= worst64
-    # --- gradients: the fp32 oracle is the closer restatement of the reference's arithmetic ---
+    # measured on the GPU box (round 4): T = 120: fp64 1.8e-6, fp32 1.3e-7; T = 500: fp64 1.4e-5, fp32 2.1e-7 -- the fp32 build of the
+    # oracle reproduces the reference's table to a few ulp (same operations in the same order; only libm's expf / log1pf differ
+    # from the device's), which is what pins the restatement's arc order, frame indexing and label look-ups on the reference
+    assert worst64 <= tol_alpha and worst32 <= 2e-6 and worst32 <= worst64
+    # --- gradients: the reference accumulates them with CAS log-adds into 32 striped slots (den_calculate.cu:37-49, 221-223), in an
+    # order that changes from run to run, so neither build of the oracle is "the same arithmetic" there: both sit at the
+    # reference's own fp32 noise (measured 1.4e-2 / 1.5e-2 at T = 500) and are held to the bound the reference itself is held to
     e32_ref, e64_ref = rel_err(g32, gref), rel_err(gor, gref)
     print(f"gradient vs the reference's: fp32 oracle {e32_ref:.2e}, fp64 oracle {e64_ref:.2e}")
-    assert e32_ref <= e64_ref
+    assert e32_ref <= tol_ref and e64_ref <= tol_ref
     core = crf._C
     ctx = crf.CRFContext(p, 0)
     x = torch.tensor(logits, device="cuda:0")
