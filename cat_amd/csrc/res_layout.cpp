@@ -56,7 +56,7 @@ inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / 
 // Step 1: decide where every row lives (CU, wave, slice, lane) from the row LENGTHS only.
 struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; int ord; int lg = 0; };   // ord: number of the slice within its wave;
                                                       // lg > 0: every row of the slice is cut into 2^lg pieces on 2^lg adjacent lanes
-bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm, int piece) {
+bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm, int piece, bool spread = false) {
     o->arcs.assign((size_t)K * gm.words * gm.threads, 0u);
     o->wave_info.assign((size_t)K * gm.waves, uint4{0u, 0u, 0u, 0u});
     o->rid_of_row.assign(rows.size(), -1);
@@ -81,7 +81,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
             auto lg_of = [&](int r) {
                 int lg = 0;
                 const int n = chunks_of(rows[r].size());
-                if (!gm.multilane || n <= gm.nch) return 0;
+                if (!gm.multilane || n <= (spread ? piece : gm.nch)) return 0;   // (spread: rows that would fit a lane are cut too -- place_rows, small graphs)
                 // pieces of at most `piece` chunks (place_rows tries several sizes)
                 while (lg < 6 && (n + (1 << lg) - 1) / (1 << lg) > piece) ++lg;
                 return lg;
@@ -268,7 +268,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
 // per row: four rows per epilogue), long pieces mean fewer slices and fewer padding rows but may not pack at all.  The cost
 // model (chunks + kEpiCost per slice, busiest SIMD) follows the measured frame time closely (den_lm of 40 000 sentences:
 // model 1.40 x the benchmark graph's frame, measured 1.38 x), so try a few sizes and keep the cheapest packing.
-bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm = kGeomRes) {
+static bool place_rows_sized(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm) {
     const int half = (gm.nch + 1) / 2;
     bool any_long = false;
     if (gm.multilane)
@@ -287,6 +287,28 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
     if (!have) return false;
     *o = std::move(best);
     *slices = std::move(best_slices);
+    return true;
+}
+bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm = kGeomRes) {
+    if (!place_rows_sized(rows, row_cu, K, o, slices, gm)) return false;
+    // SMALL graphs (fewer slices than waves: most waves of the workgroup would have no rows at all while a few walk 10 - 15
+    // chunks one batch after the other -- S = 513: 5 slices on 16 waves, 1.15 us per frame of which the arcs need a quarter):
+    // cut the rows into 2 or 4 pieces on adjacent lanes although they would fit one, so that every wave has a short list.
+    // What a frame then costs is no longer the busiest SIMD's sum but one wave's serial chain (a batch of gathers is an LDS
+    // round trip: ~70 cycles per chunk for a wave alone on its SIMD against ~49 per chunk of a saturated SIMD's sum,
+    // tools/ubench_issue.py): compare max(5 x busiest SIMD, 7 x heaviest wave).
+    if (gm.multilane && K == 1 && opt(kOpt_res_piece, 0) <= 0 && !opt_on(kOpt_res_no_spread) && (int)slices->size() < gm.waves) {
+        auto frame_est = [](const DirOut &d) { return std::max<int64_t>((int64_t)d.simd_cost * 5, (int64_t)d.est_cost * 7); };
+        int maxlen = 1;
+        for (auto &r : rows) maxlen = std::max(maxlen, std::min(gm.nch, chunks_of(r.size())));
+        for (int div : {2, 4}) {
+            const int piece = std::max(2, (maxlen + div - 1) / div);
+            DirOut cand;
+            std::vector<SliceAt> cs;
+            if (!place_rows_piece(rows, row_cu, K, &cand, &cs, gm, piece, true)) continue;
+            if (frame_est(cand) < frame_est(*o)) { *o = std::move(cand); *slices = std::move(cs); }
+        }
+    }
     return true;
 }
 
