@@ -2761,7 +2761,7 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
         for (int q = 0; q < EPR; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
     }
     sync_lds();
-    [[maybe_unused]] const bool tm_on = blockIdx.x == 40 && blockIdx.y == 3 && tid < 64;
+    [[maybe_unused]] const bool tm_on = blk == 46 && blockIdx.y == 3 && tid < 64;   // (T = 1500: a block of the first stage, the middle of utterance 3)
     for (int t = t0; t < tl; ++t) {
         CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
         float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;

@@ -1132,7 +1132,11 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         // (S = 3 006: 2.51 -> 2.64 ms per step, S = 6 836: 4.83 -> 5.26): those keep the 768-thread geometries
         size_t long_arcs = 0, all_arcs = 0;
         for (auto &r : fsub) { all_arcs += r.size(); if (chunks_of(r.size()) > gm->nch) long_arcs += r.size(); }
-        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * 5 > all_arcs) { *retry_next = true; return CRF_OK; }
+        if (opt_on(kOpt_verbose)) fprintf(stderr, "[fac_layout] 1024 threads: %zu of %zu forward arcs in rows longer than a lane\n", long_arcs, all_arcs);
+        // (round 4, with issue priorities by progress: S = 3 006 -- 14.9 k of 20.5 k forward arcs in such rows -- is now FASTER on 1024
+        // threads, recursions 2.28 -> 2.13 ms; S = 6 836 -- 27.3 k of 49.0 k -- still slower, 3.41 -> 3.51: the share alone does not
+        // decide, the number of multi-lane slices a wave has to finish per frame does)
+        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * 5 > all_arcs && long_arcs > 20000) { *retry_next = true; return CRF_OK; }
     }
     if (short_only)   // graphs with rows longer than a lane's registers (every den_lm estimated from text) run 2-3 % faster with the
         for (auto &r : fsub)   // row constants in the LDS table (level 1; measured): leave them to it
@@ -1321,7 +1325,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (level == 4) {   // (the same test as on the forward rows above: a graph whose BACKWARD rows are mostly multi-lane keeps 768 threads too)
         size_t long_arcs = 0, all_arcs = 0;
         for (auto &r : bsub) { all_arcs += r.size(); if (chunks_of(r.size()) > gm->nch) long_arcs += r.size(); }
-        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * 5 > all_arcs) { *retry_next = true; return CRF_OK; }
+        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * 5 > all_arcs && long_arcs > 20000) { *retry_next = true; return CRF_OK; }
     }
     if (short_only)
         for (auto &r : bsub)

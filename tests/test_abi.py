@@ -234,9 +234,26 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
         seqs.append(sq)
     est = os.path.join(str(tmp_path), "est.fst")
     den_lm.prep_den_lm(seqs, V, est, 4, 3, 150)
-    # the planner's own choice: 1024 threads x 15 chunks (geometry 4) unless most of the arcs sit in rows longer than a lane -- a den_lm
-    # estimated from text -- which keep the 768-thread table geometry (measured slower on 1024 threads: DESIGN.md section 2)
-    assert emu(small)[0] == 4 and emu(est)[0] == 1
+    # the planner's own choice: 1024 threads x 15 chunks (geometry 4) unless MOST of a LARGE graph's arcs sit in rows longer than a
+    # lane (more than a fifth and more than 20 000 of them: a den_lm estimated from a large corpus), which keeps the 768-thread table
+    # geometry -- measured in round 4: S = 3 006 (14.9 k such arcs) faster on 1024 threads, S = 6 836 (27.3 k) slower
+    assert emu(small)[0] == 4 and emu(est)[0] == 4
+
+    def corpus(V, n, seed):                                       # the same second-order source, sampled in bulk (40 000 sentences in a second)
+        rng = np.random.default_rng(seed)
+        cum = np.cumsum(rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V)), axis=-1)
+        out = []
+        for L, u in zip(rng.integers(10, 40, size=n), rng.random((n, 40))):
+            sq, a, b = [], 0, 0
+            for k in range(int(L)):
+                c = 1 + min(int(np.searchsorted(cum[a, b], u[k])), V - 2); sq.append(c); a, b = b, c
+            out.append(sq)
+        return out
+
+    big = os.path.join(str(tmp_path), "est_big.fst")
+    den_lm.prep_den_lm(corpus(72, 40000, 0), 72, big, 4, 3, 2000)
+    g, r = emu(big, T=3)
+    assert g == 1 and agree(r)                                    # tens of thousands of arcs in multi-lane rows: 768 threads, table geometry
     for path in (small, os.path.join(golden_dir, "den_lm_fixture.fst"), est):
         for env, geom in (({}, (4, 1)), ({"CRF_FAC_THREADS": 1024}, (4,)), ({"CRF_FAC_THREADS": 768}, (0, 1)), ({"CRF_FAC_NO_RCL": 1}, (0,)), ({"CRF_FAC_RCL": 1}, (1,)), ({"CRF_FAC_K2": 1}, (3,)),
                           ({"CRF_FAC_THREADS": 512}, (2,)), ({"CRF_FAC_NO_DUP": 1}, (4, 1)), ({"CRF_FAC_NO_DUP": 1, "CRF_FAC_THREADS": 768}, (0, 1))):
