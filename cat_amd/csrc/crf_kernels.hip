@@ -4528,11 +4528,19 @@ static int launch_fac2_pair(const LossParams &lp, size_t lds, hipStream_t st, in
     FacParams pf = fac_params(lp, 0, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
     FacParams pb = fac_params(lp, 1, nullptr, 0, lp.T, nullptr, 0, nullptr, nullptr);
     pf.b0 = pb.b0 = b0; pf.nbu = pb.nbu = nbu;
-    auto *k = crf_fac2_pair_kernel<kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B>;
-        g_den_kernel = "crf_fac2_pair_kernel<768,20,4,4>";
     int rc;
-    if ((rc = ensure_lds((const void *)k, lds, mk, "fac2 pair"))) return rc;
-    hipLaunchKernelGGL(k, dim3((unsigned)(2 * nbu * 2)), dim3(kFac3Threads), lds, st, pf, pb);
+    if (lp.g.fac.threads == kFac4Threads) {   // 1024 threads x 15 chunks, four waves per SIMD (round 4)
+        static LdsMark mk4;
+        auto *k4 = crf_fac2_pair_kernel<kFac4Threads, kFac4NCH, CRF_FAC4_NB_ML, CRF_FAC4_NB_ML>;
+        g_den_kernel = "crf_fac2_pair_kernel<1024,15," CRF_STR(CRF_FAC4_NB_ML) "," CRF_STR(CRF_FAC4_NB_ML) ">";
+        if ((rc = ensure_lds((const void *)k4, lds, mk4, "fac2 pair"))) return rc;
+        hipLaunchKernelGGL(k4, dim3((unsigned)(2 * nbu * 2)), dim3(kFac4Threads), lds, st, pf, pb);
+    } else {
+        auto *k = crf_fac2_pair_kernel<kFac3Threads, kFac3ArcCh, CRF_FAC3_NB_F, CRF_FAC3_NB_B>;
+        g_den_kernel = "crf_fac2_pair_kernel<768,20,4,4>";
+        if ((rc = ensure_lds((const void *)k, lds, mk, "fac2 pair"))) return rc;
+        hipLaunchKernelGGL(k, dim3((unsigned)(2 * nbu * 2)), dim3(kFac3Threads), lds, st, pf, pb);
+    }
     hipError_t e;
     if ((e = hipGetLastError()) != hipSuccess) { set_error(std::string("crf_fac2_pair_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;

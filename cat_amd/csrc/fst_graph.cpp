@@ -1182,7 +1182,7 @@ int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
                            h->fac_stats.ok, h->fac_stats.matched, (int64_t)h->regauged, h->fac_stats.tail,
                            h->fac_stats.slots_f, h->fac_stats.slots_b, h->fac_stats.fused,
                            h->fac_stats.Gf * 100000 + h->fac_stats.Gb,
-                           h->fac_stats.ok ? (h->dev.fac.threads == crf::kFac4Threads ? 4 : h->dev.fac.threads != crf::kFac3Threads ? 2 : h->dev.fac.K > 1 ? 3 : h->dev.fac.rcl ? 1 : 0) : -1,
+                           h->fac_stats.ok ? (h->dev.fac.threads == crf::kFac4Threads ? (h->dev.fac.K > 1 ? 5 : 4) : h->dev.fac.threads != crf::kFac3Threads ? 2 : h->dev.fac.K > 1 ? 3 : h->dev.fac.rcl ? 1 : 0) : -1,
                            h->fac_stats.ok ? (h->dev.fac.threads == crf::kFac4Threads ? crf::kFac4NCH : h->dev.fac.threads != crf::kFac3Threads ? crf::kResNCH : h->dev.fac.rcl == 2 ? crf::kFac3LNCH : crf::kFac3ArcCh) : 0};
     for (int i = 0; i < n && i < 26; ++i) out[i] = v[i];
     return CRF_OK;

@@ -1484,7 +1484,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
     std::vector<Try> plan;
     bool dflt = false;
     if (thr == 512) plan = {{2, false}};
-    else if (opt_on(kOpt_fac_k2)) plan = {{1, false, 2}, {2, false}};   // (tests: two CUs per recursion for any T o LM graph)
+    else if (opt_on(kOpt_fac_k2)) plan = thr == 1024 ? std::vector<Try>{{4, false, 2}, {2, false}} : std::vector<Try>{{1, false, 2}, {2, false}};   // (tests: two CUs per recursion for any T o LM graph; with fac_threads = 1024 on that geometry)
     else if (opt(kOpt_fac_rcl, 0) == 2) plan = {{3, false}, {2, false}};   // (tests: the 21-chunk table geometry for any T o LM graph)
     else if (from_rcl) plan = {{1, false}, {3, false}, {2, false}};
     else if (no_rcl) plan = {{0, false}, {2, false}};
@@ -1493,6 +1493,9 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         // take them; then the 21-chunk table geometry, two CUs per recursion (table geometry), 512 threads.  In front of all of
         // them since round 3: 1024 threads x 15 chunks with the table (level 4: four waves per SIMD at 128 VGPRs -- the same
         // registers per wave are left beside the arcs as at 768 x 21 -- measured 2 - 6 % faster on every graph that fits it)
+        // (Two CUs per recursion stay on 768 threads: built on 1024 x 15 in round 4 -- `fac_k2` with `fac_threads` = 1024, geometry 5 --
+        // and measured SLOWER, H = 3 072 / 4 096 recursions 4.13 -> 4.31 / 5.84 -> 6.3 ms: the hand-off's polls and granule stores are per
+        // wave, and there are a third more waves.)
         plan = {{0, true}, {1, false}, {0, false}, {3, false}, {1, false, 2}, {2, false}};
         dflt = true;
         if (thr != 768) plan.insert(plan.begin(), Try{4, false});

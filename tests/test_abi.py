@@ -255,7 +255,7 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
     g, r = emu(big, T=3)
     assert g == 1 and agree(r)                                    # tens of thousands of arcs in multi-lane rows: 768 threads, table geometry
     for path in (small, os.path.join(golden_dir, "den_lm_fixture.fst"), est):
-        for env, geom in (({}, (4, 1)), ({"CRF_FAC_THREADS": 1024}, (4,)), ({"CRF_FAC_THREADS": 768}, (0, 1)), ({"CRF_FAC_NO_RCL": 1}, (0,)), ({"CRF_FAC_RCL": 1}, (1,)), ({"CRF_FAC_K2": 1}, (3,)),
+        for env, geom in (({}, (4, 1)), ({"CRF_FAC_THREADS": 1024}, (4,)), ({"CRF_FAC_THREADS": 768}, (0, 1)), ({"CRF_FAC_NO_RCL": 1}, (0,)), ({"CRF_FAC_RCL": 1}, (1,)), ({"CRF_FAC_K2": 1}, (3,)), ({"CRF_FAC_K2": 1, "CRF_FAC_THREADS": 1024}, (5,)),
                           ({"CRF_FAC_THREADS": 512}, (2,)), ({"CRF_FAC_NO_DUP": 1}, (4, 1)), ({"CRF_FAC_NO_DUP": 1, "CRF_FAC_THREADS": 768}, (0, 1))):
             g, r = emu(path, **env)
             assert g in geom and agree(r), (path, env, g, r)
@@ -273,7 +273,9 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
     mid = os.path.join(str(tmp_path), "mid.fst")
     synth_den_lm(72, 3072, 24, seed=0, path=mid)
     g, r = emu(mid, T=3)
-    assert g == 3 and agree(r)
+    assert g == 3 and agree(r)                                    # two CUs per recursion, 768 threads each (the planner's choice)
+    g, r = emu(mid, T=3, CRF_FAC_THREADS=1024, CRF_FAC_K2=1)
+    assert g == 5 and agree(r)                                    # ... 1024 threads each (round 4: built, measured slower, on request only)
     v217 = os.path.join(str(tmp_path), "v217.fst")             # the benchmark LM over 217 classes: rows of up to ~500 arcs on several lanes;
     synth_den_lm(217, 2048, 24, seed=0, path=v217)              # at 768 threads it fits ONE CU only with all 21 chunk slots holding arcs
     g, r = emu(v217, T=3)

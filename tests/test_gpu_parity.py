@@ -27,7 +27,7 @@ def crf():
     return ctc_crf
 
 
-MODES = ["factored", "factored_768", "factored_rcl", "factored_k2", "factored_pair2", "resident", "streaming", "batch"]
+MODES = ["factored", "factored_768", "factored_rcl", "factored_k2", "factored_k2_1024", "factored_pair2", "resident", "streaming", "batch"]
 
 
 _env = crf_env   # (debug switches of the library, tests/util.py)
@@ -49,13 +49,14 @@ class _mode(crf_env):
             CRF_FAC_NO_RCL=mode == "factored_rc",      # row constants in registers even for long rows
             # "factored_k2": the factored kernels over TWO compute units per recursion (what T o LM graphs of 120 k - 240 k arcs
             # take by themselves), forced for every graph with the structure
-            CRF_FAC_K2=mode == "factored_k2",
+            # ("factored_k2_1024": the same on the 1024-thread geometry -- built in round 4, slower, on request only)
+            CRF_FAC_K2=mode in ("factored_k2", "factored_k2_1024"),
             # "factored_pair2": the factored kernels with TWO utterances per workgroup (what batches above CUs / 4 utterances take by
             # themselves), forced for any batch; 0 otherwise, so that the other modes test the one-utterance kernels at any batch size
             CRF_FAC_PAIR2=mode == "factored_pair2",
             # "factored": the planner's own order (1024 threads x 15 chunks first since round 3); "factored_768": the 768-thread
             # geometries first (row constants in registers where the rows allow), which is also what the two-utterance kernels need
-            CRF_FAC_THREADS=768 if mode in ("factored_768", "factored_pair2") else 0)
+            CRF_FAC_THREADS=768 if mode in ("factored_768", "factored_pair2") else 1024 if mode == "factored_k2_1024" else 0)
         # "batch": the utterance-minor kernels (one launch per frame), what graphs that fit no register-resident layout
         # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (no_batch is read per call)
         if mode in ("streaming", "batch"):
@@ -77,6 +78,8 @@ def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mo
             assert st["fac_geom"] in (1, 2)                      # (2: neither 768-thread geometry took the graph)
         if mode == "factored_k2" and st["fac"]:
             assert st["fac_geom"] in (3, 2)
+        if mode == "factored_k2_1024" and st["fac"]:
+            assert st["fac_geom"] in (5, 2)
         x = torch.tensor(logits, device="cuda:0", requires_grad=True)
         crit = crf.CTC_CRF_LOSS(lamb=lamb, size_average=size_average)
         loss = crit(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32),
@@ -238,7 +241,7 @@ def test_factored_layout_over_two_cus(crf, tmp_path, B):
         ctx = crf.CRFContext(p, 0)
         st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
         del ctx
-    assert st["fac"] == 1 and st["fac_geom"] == 3
+    assert st["fac"] == 1 and st["fac_geom"] in (3, 5)
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     assert rel_err(grad, ref["grad"]) <= TOL
     for b in range(B):
