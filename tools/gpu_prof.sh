@@ -16,4 +16,4 @@ find $OUT/prof_$TAG $OUT/pmc_*_$TAG -name "*kernel_trace.csv" -size +2M -delete
 ls -la $OUT/pmc_fetch_$TAG $OUT/pmc_sq_$TAG 2>/dev/null | head
 cd $REPO
 # single-rank torchrun smoke of the N>1 code path (NCCL init, DDP head) -- the driver runs N=2,4,8 on an 8-GPU node
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/torchrun1_$TAG.json 2> $OUT/torchrun1_$TAG.err; echo "torchrun rc=$?"; tail -c 600 $OUT/torchrun1_$TAG.json
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --ddp-head > $OUT/torchrun1_$TAG.json 2> $OUT/torchrun1_$TAG.err; echo "torchrun rc=$?"; tail -c 600 $OUT/torchrun1_$TAG.json

@@ -1,9 +1,9 @@
-"""tools/pmc_summary.py TAG -- condense the rocprofv3 outputs of tools/gpu_round4.sh (gpu_prof.sh)
-(gpurun_out/) into the small summaries kept under profiles/:
+"""tools/pmc_summary.py TAG [ROUND] -- condense the rocprofv3 outputs of tools/gpu_round4.sh (gpu_prof.sh)
+(gpurun_out/) into the small summaries kept under profiles/ (ROUND: file name prefix, default "round4"):
 
-    profiles/round3_<TAG>_bench.json          the bench line (with cpu_baseline)
-    profiles/round3_<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary
-    profiles/round3_<TAG>_pmc.json            per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch) and SQ counters
+    profiles/<ROUND>_<TAG>_bench.json          the bench line (with cpu_baseline)
+    profiles/<ROUND>_<TAG>_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary
+    profiles/<ROUND>_<TAG>_pmc.json            per-kernel FETCH_SIZE / WRITE_SIZE (KB per launch) and SQ counters
     profiles/pmc_traffic.json                 HBM bytes per launch of every loss kernel + the whole-path ratio, KEYED BY
                                               WORKLOAD (read by bench.py; another workload prints traffic: null)
 """
@@ -18,6 +18,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "round4"
 
 
 def counters(tag, what):
@@ -40,10 +41,10 @@ def counters(tag, what):
 def main():
     tag = sys.argv[1]
     os.makedirs(PROF, exist_ok=True)
-    shutil.copy(os.path.join(OUT, f"bench_{tag}.json"), os.path.join(PROF, f"round3_{tag}_bench.json"))
+    shutil.copy(os.path.join(OUT, f"bench_{tag}.json"), os.path.join(PROF, f"{ROUND}_{tag}_bench.json"))
     ks = glob.glob(os.path.join(OUT, f"prof_{tag}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
-        shutil.copy(ks[0], os.path.join(PROF, f"round3_{tag}_kernel_stats.csv"))
+        shutil.copy(ks[0], os.path.join(PROF, f"{ROUND}_{tag}_kernel_stats.csv"))
     traffic, sq = {}, {}
     fe, wr, s = counters(tag, "fetch"), counters(tag, "write"), counters(tag, "sq")
     def nsteps(acc, what):   # calls of the loss in that profiling pass = launches of the finalize kernel
@@ -74,7 +75,7 @@ def main():
                 "stream (MI355X_MICROARCH.md HBM section): the grad kernels' row reads are such streams.",
         "traffic": traffic, "sq": sq,
     }
-    json.dump(doc, open(os.path.join(PROF, f"round3_{tag}_pmc.json"), "w"), indent=1)
+    json.dump(doc, open(os.path.join(PROF, f"{ROUND}_{tag}_pmc.json"), "w"), indent=1)
     # bytes per call of the loss, per kernel.  FETCH_SIZE is doubled for the kernels whose reads are wide (16 B / lane)
     # coalesced streams (MI355X_MICROARCH.md, HBM section): the grad pass reading the Q / BP / CA / CB rows.
     bench = json.load(open(os.path.join(OUT, f"bench_{tag}.json")))
@@ -96,7 +97,7 @@ def main():
     den_kernel = den[0].replace("void ", "").replace("crf::", "").split("(")[0].replace(" ", "") if len(den) == 1 else None
     tr = {"workload": key, "den_kernel": den_kernel, "kernels": kernels,
           "whole_path": {"pmc_bytes_per_call": total, "algorithmic_bytes": alg, "ratio": round(total / max(1, alg), 3)},
-          "source": f"profiles/round3_{tag}_pmc.json: (FETCH_SIZE [x2 for the grad kernels' 16-byte row streams] + WRITE_SIZE) * 1024 bytes "
+          "source": f"profiles/{ROUND}_{tag}_pmc.json: (FETCH_SIZE [x2 for the grad kernels' 16-byte row streams] + WRITE_SIZE) * 1024 bytes "
                     "per call of the loss, every launch of a kernel summed"}
     json.dump(tr, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(tr, indent=1))
@@ -105,14 +106,14 @@ def main():
     # the rest of the evidence run: points, the GPU suite's summary, soak, estimated graphs, the 1-rank torchrun line
     for f in sorted(glob.glob(os.path.join(OUT, f"pt_{tag}_*.json"))):
         if os.path.getsize(f) > 0:
-            shutil.copy(f, os.path.join(PROF, f"round3_{tag}_point_" + os.path.basename(f)[len(f"pt_{tag}_"):]))
-    for src, dst in ((f"pt_{tag}_estimated.txt", f"round3_{tag}_point_estimated.txt"), (f"soak_{tag}.txt", f"round3_{tag}_soak.txt"),
-                     (f"torchrun1_{tag}.json", f"round3_{tag}_torchrun_1rank.json")):
+            shutil.copy(f, os.path.join(PROF, f"{ROUND}_{tag}_point_" + os.path.basename(f)[len(f"pt_{tag}_"):]))
+    for src, dst in ((f"pt_{tag}_estimated.txt", f"{ROUND}_{tag}_point_estimated.txt"), (f"soak_{tag}.txt", f"{ROUND}_{tag}_soak.txt"),
+                     (f"torchrun1_{tag}.json", f"{ROUND}_{tag}_torchrun_1rank.json")):
         if os.path.exists(os.path.join(OUT, src)):
             shutil.copy(os.path.join(OUT, src), os.path.join(PROF, dst))
     log = os.path.join(OUT, f"pytest_{tag}.log")
     if os.path.exists(log):
-        open(os.path.join(PROF, f"round3_{tag}_pytest_gpu.txt"), "w").write("".join(open(log).readlines()[-12:]))
+        open(os.path.join(PROF, f"{ROUND}_{tag}_pytest_gpu.txt"), "w").write("".join(open(log).readlines()[-12:]))
 
 
 if __name__ == "__main__":
