@@ -228,6 +228,13 @@ __device__ __forceinline__ int rescale_exp_bits(unsigned bits) {
     const int k = kScaleExp + 127 - (int)((bits >> 23) & 0xffu);
     return k < -100 ? -100 : (k > 100 ? 100 : k);
 }
+// ... for a value the caller KNOWS to be wave-uniform (an SGPR): the clamp as s_max / s_min.  The compiler selects v_med3_i32 for the
+// C form above even on uniform operands, which costs the frame loops a VALU instruction and three VGPRs (the two bounds and the result).
+__device__ __forceinline__ int rescale_exp_bits_uniform(unsigned bits) {
+    int k = kScaleExp + 127 - (int)((bits >> 23) & 0xffu);
+    asm("s_max_i32 %0, %0, %1\n\ts_min_i32 %0, %0, %2" : "+s"(k) : "s"(-100), "s"(100) : "scc");
+    return bits == 0u ? 0 : k;
+}
 
 // ---------------------------------------------------------------------------------------------
 // prep: e[b][t][v] = exp(logp[b][t][v] - max_v) * 2^kEpExp, mx[b][t] = max_v   (one wave per frame)
@@ -1752,7 +1759,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         float sc = 1.f;
         float *Orow = nullptr;
         auto bookkeeping = [&]() __attribute__((always_inline)) {
-            const int ksc = rescale_exp_bits((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
+            const int ksc = rescale_exp_bits_uniform((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
             sc = pow2f(ksc);
             if (DIR == 1) last_sc = sc;
             if (DIR == 0) {
