@@ -178,6 +178,27 @@ def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
 
 
 @pytest.mark.parametrize("geom", ["factored_pair2", "pair2_rcl"])
+def test_default_kernel_for_a_batch_beyond_the_device(crf, tmp_path):
+    """Which kernel a batch with 2 B workgroups > CUs takes BY DEFAULT (round-3 advisor: the docs said "the two-utterance kernel" while
+    the planner's first geometry, 1024 threads, has none).  Pinned: on the planner's own layout the one-utterance kernel (in rounds
+    of the device); with the 768-thread geometries (`fac_threads` = 768) the two-utterance kernel; both within 1e-4 of the oracle."""
+    g, p = small_synth(tmp_path, 24, 96, 8, 13)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    B, T, V = ncu // 2 + 3, 21, 24
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=5, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    for thr, want in ((0, "crf_fac_pair_kernel<"), (768, "crf_fac_pair2_kernel<")):
+        with _env(CRF_FAC_THREADS=thr):
+            ctx = crf.CRFContext(p, 0)
+            x = torch.tensor(logits, device="cuda:0", requires_grad=True)
+            loss = crf.CTC_CRF_LOSS(lamb=0.1)(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly))
+            loss.backward()
+            kern = crf._C.last_den_kernel()
+            assert kern.startswith(want), (thr, kern)
+            assert abs(loss.item() - ref["loss"]) <= TOL * abs(ref["loss"]) and rel_err(x.grad.cpu().numpy(), ref["grad"]) <= TOL
+            del ctx
+
+
 @pytest.mark.parametrize("B", [1, 2, 7, 16])
 def test_two_utterances_per_workgroup(crf, tmp_path, geom, B):
     """The two-utterance kernels (float2 state vectors, one gather for both utterances) do, per utterance, the arithmetic of the
