@@ -1469,6 +1469,9 @@ __global__ __launch_bounds__(kResThreads) void crf_res_pair_kernel(ResParams pf,
 //             extra arc (BP positions / z entries 2*rid, 2*rid + 1).
 // LDS: V0 | V1 (two state vectors of Gp floats) | row metadata int4[R] | EP[2][Vp] | wm | red
 // =============================================================================================
+#ifndef CRF_X_GDEARLY
+#define CRF_X_GDEARLY 1     // crf_grad_den_kernel: the rows of frame t+2 are requested right behind the staging of frame t+1 (0: at the top of frame t+1)
+#endif
 #ifndef CRF_X_ROWMAX
 #define CRF_X_ROWMAX 0      // fac_chain_body: ds_max_f32 of the frame maximum per row end instead of once in the frame's tail (A/B switch)
 #endif
@@ -2761,75 +2764,153 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
         if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];                                                        \
     }
     float erc[EPR], rwc[EPR];
-    if (t0 < tl) {
-        CRF_GD_FETCH(t0);
-        CRF_GD_STAGE();
+    // (one chunk and one emission register per thread only -- the kernel of graphs over <= 256 classes with <= 256 label chunks: V = 72 step 2.89 -> 2.865 ms;
+    // with the larger register sets of the other instantiations the same reordering was 4 % SLOWER at V = 217 / 500: profiles/round4_ab_grad_pass_variants.txt)
+    constexpr bool GDE = CRF_X_GDEARLY != 0 && NCPT == 1 && EPR == 1;
+    if constexpr (GDE) {
+        // Round 4: the rows of frame t+2 are requested as soon as frame t+1's have left the registers for the LDS (behind the first barrier of
+        // frame t) instead of at the top of frame t+1 -- a normalise-and-store phase and a barrier earlier.  The timing build had shown the
+        // pass waiting ~1 800 of a frame's 8 600 cycles for rows requested only ~4 000 cycles before (issue 2 000 -- the requests queue --,
+        // gathers 2 000): memory latency under load is ~2.4 us.  The emission / grad-row registers get a third set (cur, next, in flight).
+        float erx[EPR], rwx[EPR];   // frame t+1's emissions and grad row, landed (ern / rwn: in flight for t+2)
+        if (t0 < tl) {
+            CRF_GD_FETCH(t0);
+            CRF_GD_STAGE();
 #pragma unroll
-        for (int q = 0; q < EPR; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
-    }
-    sync_lds();
-    [[maybe_unused]] const bool tm_on = blk == 46 && blockIdx.y == 3 && tid < 64;   // (T = 1500: a block of the first stage, the middle of utterance 3)
-    for (int t = t0; t < tl; ++t) {
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
-        float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
-        if (t + 1 < tl) CRF_GD_FETCH(t + 1);   // lands while frame t is reduced
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 1);
+            for (int q = 0; q < EPR; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
+            if (t0 + 1 < tl) CRF_GD_FETCH(t0 + 1);
+        }
+        sync_lds();
+        [[maybe_unused]] const bool tm_on = blk == 46 && blockIdx.y == 3 && tid < 64;   // (T = 1500: a block of the first stage, the middle of utterance 3)
+        for (int t = t0; t < tl; ++t) {
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
+            float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 1);
 #pragma unroll
-        for (int i = 0; i < NCPT; ++i) {
-            float s0 = 0.f, s1 = 0.f;
+            for (int i = 0; i < NCPT; ++i) {
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int j = 0; j < CH; j += 2) {  // padding pairs read Qs[Rq] = 0 (times Bs[0])
-                s0 = fmaf(Qs[idx[i][j] & 0xffffu], Bs[idx[i][j] >> 16], s0);
-                s1 = fmaf(Qs[idx[i][j + 1] & 0xffffu], Bs[idx[i][j + 1] >> 16], s1);
+                for (int j = 0; j < CH; j += 2) {  // padding pairs read Qs[Rq] = 0 (times Bs[0])
+                    s0 = fmaf(Qs[idx[i][j] & 0xffffu], Bs[idx[i][j] >> 16], s0);
+                    s1 = fmaf(Qs[idx[i][j + 1] & 0xffffu], Bs[idx[i][j + 1] >> 16], s1);
+                }
+                float sv = s0 + s1;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {   // suffix sums within the label segment: lane gets sum over [lane, segment end]
+                    const float o = __shfl_down(sv, 1 << j, 64);
+                    if (segm[i] >> j & 1u) sv += o;
+                }
+                if (!(segm[i] >> 31)) atomicAdd(&gsum[clab[i]], sv);
             }
-            float sv = s0 + s1;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {   // suffix sums within the label segment: lane gets sum over [lane, segment end]
-                const float o = __shfl_down(sv, 1 << j, 64);
-                if (segm[i] >> j & 1u) sv += o;
+            for (int q = 0; q < EPR; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
+                const int v = tid + q * NT;
+                if (v < V) gzero[v] = 0.f;
             }
-            if (!(segm[i] >> 31)) atomicAdd(&gsum[clab[i]], sv);
+            if (tid == 0) nrm[(t + 2) & 3] = 0.f;
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 2);
+            sync_lds();                             // every gather of frame t is done: the row buffers are free
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 3);
+            if (t + 1 < tl) {
+                CRF_GD_STAGE();                     // (the compiler's vmcnt wait in front of these LDS writes: the rows of frame t+1 -- and frame t-1's row store)
+#pragma unroll
+                for (int q = 0; q < EPR; ++q) { erx[q] = ern[q]; rwx[q] = rwn[q]; }
+                if (t + 2 < tl) CRF_GD_FETCH(t + 2);
+            }
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 4);
+            float u[EPR], part = 0.f;
+#pragma unroll
+            for (int q = 0; q < EPR; ++q) {
+                const int v = tid + q * NT;
+                u[q] = v < V ? (erc[q] * pow2f(-kEpExp)) * gsum[v] : 0.f;
+                part += u[q];
+            }
+            part = wave_sum(part);
+            if ((tid & 63) == 0 && part != 0.f) atomicAdd(&nrm[t & 3], part);
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
+            sync_lds();                             // rows of frame t+1 visible, normaliser complete
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 6);
+            const float nv = nrm[t & 3];
+            const float inv = nv > 0.f ? p.c_den / nv : 0.f;
+            float *row = p.grad + (bt0 + t) * V;
+#pragma unroll
+            for (int q = 0; q < EPR; ++q) {
+                const int v = tid + q * NT;
+                if (v < V) row[v] = rwc[q] + u[q] * inv;   // rwc = 0 unless accumulating onto the numerator half
+                erc[q] = erx[q]; rwc[q] = rwx[q];
+            }
         }
+    } else {
+        if (t0 < tl) {
+            CRF_GD_FETCH(t0);
+            CRF_GD_STAGE();
 #pragma unroll
-        for (int q = 0; q < EPR; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
-            const int v = tid + q * NT;
-            if (v < V) gzero[v] = 0.f;
+            for (int q = 0; q < EPR; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
         }
-        if (tid == 0) nrm[(t + 2) & 3] = 0.f;
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 2);
-        sync_lds();                             // every gather of frame t is done: the row buffers are free
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 3);
-        // Stage frame t+1 BEFORE this frame's stores are issued: the vmcnt wait in front of the LDS writes
-        // then covers loads only (vmcnt counts in order; behind the stores it would also wait for their
-        // acknowledgement).
-        if (t + 1 < tl) CRF_GD_STAGE();
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 4);
-        // gamma[t][v] = u_v / sum_v u_v with u_v = e'_t[v] * (label sum): the posteriors of a frame sum to 1, so
-        // the frame normalises itself -- no logZ, no per-frame exponents, hence no dependence on the END of the
-        // recursions (the pass runs beside them).  e' is taken without its 2^kEpExp (range: label sums reach 2^50).
-        float u[EPR], part = 0.f;
+        sync_lds();
+        [[maybe_unused]] const bool tm_on = blk == 46 && blockIdx.y == 3 && tid < 64;   // (T = 1500: a block of the first stage, the middle of utterance 3)
+        for (int t = t0; t < tl; ++t) {
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
+            float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
+            if (t + 1 < tl) CRF_GD_FETCH(t + 1);   // lands while frame t is reduced
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 1);
 #pragma unroll
-        for (int q = 0; q < EPR; ++q) {
-            const int v = tid + q * NT;
-            u[q] = v < V ? (erc[q] * pow2f(-kEpExp)) * gsum[v] : 0.f;
-            part += u[q];
-            erc[q] = ern[q];
-        }
-        float rw[EPR];
+            for (int i = 0; i < NCPT; ++i) {
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int q = 0; q < EPR; ++q) { rw[q] = rwc[q]; rwc[q] = rwn[q]; }
-        part = wave_sum(part);
-        if ((tid & 63) == 0 && part != 0.f) atomicAdd(&nrm[t & 3], part);
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
-        sync_lds();                             // rows of frame t+1 visible, normaliser complete
-        CRF_TM(tm_on, 8192 + (t - t0) * 8 + 6);
-        const float nv = nrm[t & 3];
-        const float inv = nv > 0.f ? p.c_den / nv : 0.f;
-        float *row = p.grad + (bt0 + t) * V;
+                for (int j = 0; j < CH; j += 2) {  // padding pairs read Qs[Rq] = 0 (times Bs[0])
+                    s0 = fmaf(Qs[idx[i][j] & 0xffffu], Bs[idx[i][j] >> 16], s0);
+                    s1 = fmaf(Qs[idx[i][j + 1] & 0xffffu], Bs[idx[i][j + 1] >> 16], s1);
+                }
+                float sv = s0 + s1;
 #pragma unroll
-        for (int q = 0; q < EPR; ++q) {
-            const int v = tid + q * NT;
-            if (v < V) row[v] = rw[q] + u[q] * inv;   // rw = 0 unless accumulating onto the numerator half
+                for (int j = 0; j < 6; ++j) {   // suffix sums within the label segment: lane gets sum over [lane, segment end]
+                    const float o = __shfl_down(sv, 1 << j, 64);
+                    if (segm[i] >> j & 1u) sv += o;
+                }
+                if (!(segm[i] >> 31)) atomicAdd(&gsum[clab[i]], sv);
+            }
+#pragma unroll
+            for (int q = 0; q < EPR; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
+                const int v = tid + q * NT;
+                if (v < V) gzero[v] = 0.f;
+            }
+            if (tid == 0) nrm[(t + 2) & 3] = 0.f;
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 2);
+            sync_lds();                             // every gather of frame t is done: the row buffers are free
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 3);
+            // Stage frame t+1 BEFORE this frame's stores are issued: the vmcnt wait in front of the LDS writes
+            // then covers loads only (vmcnt counts in order; behind the stores it would also wait for their
+            // acknowledgement).
+            if (t + 1 < tl) CRF_GD_STAGE();
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 4);
+            // gamma[t][v] = u_v / sum_v u_v with u_v = e'_t[v] * (label sum): the posteriors of a frame sum to 1, so
+            // the frame normalises itself -- no logZ, no per-frame exponents, hence no dependence on the END of the
+            // recursions (the pass runs beside them).  e' is taken without its 2^kEpExp (range: label sums reach 2^50).
+            float u[EPR], part = 0.f;
+#pragma unroll
+            for (int q = 0; q < EPR; ++q) {
+                const int v = tid + q * NT;
+                u[q] = v < V ? (erc[q] * pow2f(-kEpExp)) * gsum[v] : 0.f;
+                part += u[q];
+                erc[q] = ern[q];
+            }
+            float rw[EPR];
+#pragma unroll
+            for (int q = 0; q < EPR; ++q) { rw[q] = rwc[q]; rwc[q] = rwn[q]; }
+            part = wave_sum(part);
+            if ((tid & 63) == 0 && part != 0.f) atomicAdd(&nrm[t & 3], part);
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
+            sync_lds();                             // rows of frame t+1 visible, normaliser complete
+            CRF_TM(tm_on, 8192 + (t - t0) * 8 + 6);
+            const float nv = nrm[t & 3];
+            const float inv = nv > 0.f ? p.c_den / nv : 0.f;
+            float *row = p.grad + (bt0 + t) * V;
+#pragma unroll
+            for (int q = 0; q < EPR; ++q) {
+                const int v = tid + q * NT;
+                if (v < V) row[v] = rw[q] + u[q] * inv;   // rw = 0 unless accumulating onto the numerator half
+            }
         }
     }
 #undef CRF_GD_STAGE

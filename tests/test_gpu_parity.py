@@ -177,7 +177,6 @@ def test_batch_kernels_utterance_groups(crf, tmp_path, B, ul):
         assert np.all(grad[b, lx[b]:] == 0.0)
 
 
-@pytest.mark.parametrize("geom", ["factored_pair2", "pair2_rcl"])
 def test_default_kernel_for_a_batch_beyond_the_device(crf, tmp_path):
     """Which kernel a batch with 2 B workgroups > CUs takes BY DEFAULT (round-3 advisor: the docs said "the two-utterance kernel" while
     the planner's first geometry, 1024 threads, has none).  Pinned: on the planner's own layout the one-utterance kernel (in rounds
@@ -199,6 +198,7 @@ def test_default_kernel_for_a_batch_beyond_the_device(crf, tmp_path):
             del ctx
 
 
+@pytest.mark.parametrize("geom", ["factored_pair2", "pair2_rcl"])
 @pytest.mark.parametrize("B", [1, 2, 7, 16])
 def test_two_utterances_per_workgroup(crf, tmp_path, geom, B):
     """The two-utterance kernels (float2 state vectors, one gather for both utterances) do, per utterance, the arithmetic of the
