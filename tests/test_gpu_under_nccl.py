@@ -17,6 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _run(launcher, port, extra=()):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -31,9 +38,10 @@ def _run(launcher, port, extra=()):
 
 @pytest.mark.parametrize("how", ["python", "torchrun"])
 def test_staged_schedule_in_a_ddp_trainer_process(how):
+    port = _free_port()
     launcher = [sys.executable] if how == "python" else \
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29541"]
-    rec, err = _run(launcher, 29537 if how == "python" else 29541)
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    rec, err = _run(launcher, port)
     print(rec)
     assert rec["nccl"] and rec["busy_streams"] == 8
     assert rec["den_kernel"].startswith("crf_fac_pair_kernel<true"), rec         # the staged schedule's instantiation
@@ -45,7 +53,7 @@ def test_staged_schedule_in_a_ddp_trainer_process(how):
 
 def test_serial_schedule_is_still_correct():
     """... and the schedule a process without any usable side stream would get (forced) is the same numbers."""
-    env_extra = dict(os.environ, CRF_DEBUG="no_side_stream=1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29539")
+    env_extra = dict(os.environ, CRF_DEBUG="no_side_stream=1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     cmd = [sys.executable, os.path.join(ROOT, "tools", "nccl_probe.py"), "--streams", "2", "--B", "8", "--T", "300", "--steps", "3", "--check"]
     r = subprocess.run(cmd, env=env_extra, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
