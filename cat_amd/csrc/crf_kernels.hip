@@ -1472,9 +1472,6 @@ __global__ __launch_bounds__(kResThreads) void crf_res_pair_kernel(ResParams pf,
 #ifndef CRF_X_GDEARLY
 #define CRF_X_GDEARLY 1     // crf_grad_den_kernel: the rows of frame t+2 are requested right behind the staging of frame t+1 (0: at the top of frame t+1)
 #endif
-#ifndef CRF_X_ROWMAX
-#define CRF_X_ROWMAX 0      // fac_chain_body: ds_max_f32 of the frame maximum per row end instead of once in the frame's tail (A/B switch)
-#endif
 #ifndef CRF_X_PRIO
 #define CRF_X_PRIO 2        // fac_chain_body: issue priority by progress through the frame's chunks: 0 off, 1 steps at 1/4, 1/2, 3/4 of the
                             // chunks, 2 at 1/2, 3/4, 7/8 (product), 3 at 1/8, 1/4, 1/2 -- profiles/round4_ab_setprio_by_progress.txt
@@ -1783,7 +1780,6 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             }
         };
         constexpr bool EARLY = CRF_X_EARLY != 0 && !K2;
-        constexpr bool ROWMAX = CRF_X_ROWMAX != 0 && IMP && !K2;   // the frame maximum is fed from the row epilogues, not from the frame's tail
         if constexpr (!EARLY) bookkeeping();
         unsigned ends_f = ends;
         int nch_f = nch;
@@ -1856,8 +1852,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                         gu64 *gs = (gu64 *)((char *)slot + 2u * r4);
                         res_publish(gs, 0, tag, Up, same_l2); res_publish(gs, R, tag, Lp, same_l2); res_publish(gs, 2 * R, tag, Ap, same_l2);
                     }
-                    if constexpr (ROWMAX) { const float m_ = row_max16(Up); if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), m_); }
-                    else mymax = __int_as_float(max(__float_as_int(mymax), __float_as_int(Up)));   // (non-negative: bits order like integers; fmaxf canonicalises first)
+                    mymax = __int_as_float(max(__float_as_int(mymax), __float_as_int(Up)));   // (non-negative: bits order like integers; fmaxf canonicalises first)
                 } else {          // k0 = z offsets of the two extra arcs, k1 = label 0 | label 1 << 16
                     const float z0 = *(const float *)(xb + (k0 & 0xffffu)), z1 = *(const float *)(xb + (k0 >> 16));
                     const float e0 = *(const float *)((const char *)EPu + (k1 & 0xffffu)), e1 = *(const float *)((const char *)EPu + (k1 >> 16));
@@ -1882,8 +1877,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                         gu64 *gs = (gu64 *)((char *)slot + 4u * r4);
                         res_publish(gs, 0, tag, zv.x, same_l2); res_publish(gs, 1, tag, zv.y, same_l2);
                     }
-                    if constexpr (ROWMAX) { const float m_ = row_max16(__int_as_float(max(__float_as_int(zv.x), __float_as_int(zv.y)))); if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), m_); }
-                    else mymax = __int_as_float(max(__float_as_int(mymax), max(__float_as_int(zv.x), __float_as_int(zv.y))));
+                    mymax = __int_as_float(max(__float_as_int(mymax), max(__float_as_int(zv.x), __float_as_int(zv.y))));
                 }
             } else {
             const int4 m = *(const int4 *)(RMc + 4u * r4);
@@ -1995,10 +1989,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             }
             mymax = fmaxf(mymax, fm);
         }
-        if constexpr (!ROWMAX) {   // (ROWMAX: every row end has sent its maximum already -- no reduction and no LDS round trip in front of the barrier)
-            mymax = row_max16(mymax);
-            if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), mymax);
-        }
+        mymax = row_max16(mymax);   // (sending the maximum from every row end instead -- no reduction in the tail -- was measured 3 % slower, round 4)
+        if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), mymax);
         sr = sw;
         if (pre) {
             float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;
