@@ -4868,6 +4868,13 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     int rc;
     if ((rc = get_ctx(stream, &cx))) return rc;
     std::lock_guard<std::mutex> call_lock(cx->mu);
+    // A context whose probe found no stream beside the caller's (a device shared with another busy process at that moment can make the
+    // two single-wave probe kernels miss each other) asks again every 256 calls instead of staying on the serial schedule for good.
+    if (!cx->side && cx->flags && !opt_on(kOpt_no_side_stream) && !opt_on(kOpt_trust_side) && (cx->call_id & 255) == 255) {
+        (void)hipStreamSynchronize(stream);
+        cx->side = find_beside(stream, cx->flags, cx->dev, &cx->side_kind, &cx->side_tries);
+        snprintf(cx->side_desc, sizeof(cx->side_desc), "%s (candidate %d, found at call %d)", kSideNames[cx->side_kind], cx->side_tries, cx->call_id + 1);
+    }
     const bool serial = serial_env || !cx->side;              // no side stream: everything in order on the caller's stream
     hipStream_t side = serial ? stream : cx->side;
     // error word, start counter and stage counters live in fine-grained memory (get_ctx); the prep kernel clears them
