@@ -44,6 +44,17 @@ constexpr int kCtcPF = 4;     // frames per emission prefetch batch (ctc_forward
 constexpr int kGradThreads = 256;
 constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
 
+// ---- build-time A/B switches of the frame loops (the defaults are the measured best: DESIGN.md section 2, profiles/round4_ab_*) ----
+#ifndef CRF_X_GDEARLY
+#define CRF_X_GDEARLY 1     // crf_grad_den_kernel: the rows of frame t+2 are requested right behind the staging of frame t+1 (0: at the top of frame t+1)
+#endif
+#ifndef CRF_X_PRIO
+#define CRF_X_PRIO 2        // fac_chain_body: issue priority by progress through the frame's chunks: 0 off, 1 steps at 1/4, 1/2, 3/4 of the
+                            // chunks, 2 at 1/2, 3/4, 7/8 (product), 3 at 1/8, 1/4, 1/2 -- profiles/round4_ab_setprio_by_progress.txt
+#endif
+#ifndef CRF_X_EARLY
+#define CRF_X_EARLY 1       // fac_chain_body: the frame's scale / exponent bookkeeping behind the first batch of gathers (0: in front of it)
+#endif
 struct LossParams {
     GraphDev g;
     const float *logp;
@@ -1347,6 +1358,13 @@ __device__ __forceinline__ void res_chain_body(const ResParams &p, float *lds, c
         char *Sb = (char *)(slot + eoff);
 #pragma unroll
         for (int c0 = 0; c0 < kResNCH; c0 += kResBatch) {
+#if CRF_X_PRIO
+            // issue priority by progress through the frame's chunks, as in fac_chain_body (two waves per SIMD here: the older one used to run ahead)
+            if (c0 == 0) __builtin_amdgcn_s_setprio(3);
+            else if (c0 == 2 * kResBatch) __builtin_amdgcn_s_setprio(2);
+            else if (c0 == 3 * kResBatch) __builtin_amdgcn_s_setprio(1);
+            else if (c0 == 4 * kResBatch) __builtin_amdgcn_s_setprio(0);
+#endif
             if (c0 < nch_f) {
                 // Row epilogues: two dependent LDS reads (label, then e'[label]).  (Tried and measured
                 // slower, both of them: prefetching label and e' for ALL row ends of a batch ahead of the
@@ -1358,7 +1376,7 @@ __device__ __forceinline__ void res_chain_body(const ResParams &p, float *lds, c
 #pragma unroll
                 for (int ci = 0; ci < kResBatch; ++ci) {
                     CRF_RES_CHUNK_ACC(acc, g01, g23, A, c0 + ci, ci);
-                    if (ends_f >> (c0 + ci) & 1u) {
+                    if (__builtin_expect_with_probability((ends_f >> (c0 + ci) & 1u) != 0u, 0, 0.8)) {   // (the common path falls through: fac_chain_body)
                         const float rv = (acc.x + acc.y) * sc;       // q_t[row] (fwd) / b_t[state copy] (bwd)
                         *(float *)(Ob + r4) = rv;
                         const float av = EPu[*(const int *)(RLb + r4)] * rv;  // a_{t+1}[dst] (fwd) / z_{t-1}[pair] (bwd): final, one producer per entry
@@ -1469,16 +1487,6 @@ __global__ __launch_bounds__(kResThreads) void crf_res_pair_kernel(ResParams pf,
 //             extra arc (BP positions / z entries 2*rid, 2*rid + 1).
 // LDS: V0 | V1 (two state vectors of Gp floats) | row metadata int4[R] | EP[2][Vp] | wm | red
 // =============================================================================================
-#ifndef CRF_X_GDEARLY
-#define CRF_X_GDEARLY 1     // crf_grad_den_kernel: the rows of frame t+2 are requested right behind the staging of frame t+1 (0: at the top of frame t+1)
-#endif
-#ifndef CRF_X_PRIO
-#define CRF_X_PRIO 2        // fac_chain_body: issue priority by progress through the frame's chunks: 0 off, 1 steps at 1/4, 1/2, 3/4 of the
-                            // chunks, 2 at 1/2, 3/4, 7/8 (product), 3 at 1/8, 1/4, 1/2 -- profiles/round4_ab_setprio_by_progress.txt
-#endif
-#ifndef CRF_X_EARLY
-#define CRF_X_EARLY 1       // fac_chain_body: the frame's scale / exponent bookkeeping behind the first batch of gathers (0: in front of it)
-#endif
 struct FacParams {
     FacDirDev L;
     int B, T, V, Rout, NT, Rf;
