@@ -1946,10 +1946,13 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             {
                 constexpr int f1 = CRF_X_PRIO == 2 ? 4 : CRF_X_PRIO == 3 ? 1 : 2, f2 = CRF_X_PRIO == 2 ? 6 : CRF_X_PRIO == 3 ? 2 : 4, f3 = CRF_X_PRIO == 2 ? 7 : CRF_X_PRIO == 3 ? 4 : 6;   // eighths of the chunks
                 constexpr int q1 = (f1 * NCHA / 8 + NB - 1) / NB * NB, q2 = (f2 * NCHA / 8 + NB - 1) / NB * NB, q3 = (f3 * NCHA / 8 + NB - 1) / NB * NB;
-                if (c0 == 0) __builtin_amdgcn_s_setprio(3);
-                else if (c0 == q1) __builtin_amdgcn_s_setprio(2);
-                else if (c0 == q2) __builtin_amdgcn_s_setprio(1);
-                else if (c0 == q3) __builtin_amdgcn_s_setprio(0);
+                // (not with two CUs per recursion: a wave that polls for the peer's entries at the lowest priority delays BOTH CUs -- H = 3 072 recursions 4.17 without, 4.24 ms with)
+                if constexpr (!K2) {
+                    if (c0 == 0) __builtin_amdgcn_s_setprio(3);
+                    else if (c0 == q1) __builtin_amdgcn_s_setprio(2);
+                    else if (c0 == q2) __builtin_amdgcn_s_setprio(1);
+                    else if (c0 == q3) __builtin_amdgcn_s_setprio(0);
+                }
             }
 #endif
             // (EARLY: the first batch is gathered by every wave -- the slots of a wave without arcs hold padding, offset 0 and weight 0)
