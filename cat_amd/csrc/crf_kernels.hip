@@ -1121,6 +1121,52 @@ __device__ __forceinline__ float res_fetch_list(gu64 *slot, float *v, const int 
     return mx;
 }
 
+// ... a range AND a list in ONE polling loop (round 4: the two-CU forward frame fetched the peer's U range and then, behind it, its list of
+// L / A entries -- two dependent L2 round trips per frame where one will do): every thread polls up to kPoll granules of the range and one
+// entry of the list together; a list longer than the workgroup takes res_fetch_list for the rest.
+template <int NT>
+__device__ __forceinline__ float res_fetch_both(gu64 *slot, float *v, int lo, int hi, const int *__restrict__ list, int l0, int l1, unsigned tag, int *err, int tid) {
+    float mx = 0.f;
+    const int le = l0 + tid < l1 ? list[l0 + tid] : -1;   // this thread's list entry (first round of the list)
+    bool first = true;
+    for (int base = lo; base < hi || first; base += kPoll * NT) {
+        unsigned pending = 0;
+#pragma unroll
+        for (int q = 0; q < kPoll; ++q)
+            if (base + q * NT + tid < hi) pending |= 1u << q;
+        if (first && le >= 0) pending |= 1u << kPoll;
+        first = false;
+        for (unsigned spins = 0; pending; ++spins) {
+            unsigned long long gv[kPoll + 1];
+#pragma unroll
+            for (int q = 0; q < kPoll; ++q)
+                if (pending >> q & 1) gv[q] = __hip_atomic_load(slot + base + q * NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pending >> kPoll & 1) gv[kPoll] = __hip_atomic_load(slot + le, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 0; q < kPoll; ++q)
+                if ((pending >> q & 1) && (unsigned)(gv[q] >> 32) == tag) {
+                    const float x = __uint_as_float((unsigned)gv[q]);
+                    v[base + q * NT + tid] = x;
+                    mx = fmaxf(mx, x);
+                    pending &= ~(1u << q);
+                }
+            if ((pending >> kPoll & 1) && (unsigned)(gv[kPoll] >> 32) == tag) {
+                const float x = __uint_as_float((unsigned)gv[kPoll]);
+                v[le] = x;
+                mx = fmaxf(mx, x);
+                pending &= ~(1u << kPoll);
+            }
+            if (!pending) break;
+            if (spins > (1u << 24)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (spins > 64) __builtin_amdgcn_s_sleep(8);
+            else if (spins > 2) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (l0 + NT < l1) mx = fmaxf(mx, res_fetch_list<NT>(slot, v, list, l0 + NT, l1, tag, err, tid));
+    return mx;
+}
+
 // Chunk sums in batches of kResBatch chunks: the 4*kResBatch gathers of a batch are one straight-line
 // block (no branch between them), so every wave keeps 24 independent ds_read_b32 in flight -- with
 // only 2 waves per SIMD that, not occupancy, is what hides the LDS latency.  The (uniform) slice-end
@@ -1986,14 +2032,14 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             if (DIR == 0) {
                 // the U entries, and of the L / A entries those this CU's rows gather (a list) -- all of them after the last frame
                 // (logZ; only the CU that computes it)
-                fm = res_fetch<NTH>(slot, Xn, p0, p1, tag, p.err, tid);
                 if (i == lx - 1) {
+                    fm = res_fetch<NTH>(slot, Xn, p0, p1, tag, p.err, tid);
                     if (lead) {
                         fm = fmaxf(fm, res_fetch<NTH>(slot, Xn, R + p0, R + p1, tag, p.err, tid));
                         fm = fmaxf(fm, res_fetch<NTH>(slot, Xn, 2 * R + p0, 2 * R + p1, tag, p.err, tid));
                     }
                 } else {
-                    fm = fmaxf(fm, res_fetch_list<NTH>(slot, Xn, p.xlist, p.xlist_off[k], p.xlist_off[k + 1], tag, p.err, tid));
+                    fm = res_fetch_both<NTH>(slot, Xn, p0, p1, p.xlist, p.xlist_off[k], p.xlist_off[k + 1], tag, p.err, tid);   // (one polling loop for both)
                 }
             } else {
                 fm = res_fetch<NTH>(slot, Xn, 2 * p0, 2 * p1, tag, p.err, tid);
