@@ -184,6 +184,23 @@ __device__ __forceinline__ double wave_max_d(double v) {
                       max(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(hi, 48)));
     return __longlong_as_double((long long)(unsigned)m << 32);
 }
+// ... the same maximum as its high word (an int): what the chains' frame maximum is kept as in LDS (one ds_max_i32 per wave)
+__device__ __forceinline__ int wave_max_hi(double v) {
+    int hi = (int)((unsigned long long)__double_as_longlong(v) >> 32);
+#define CRF_DPP_IMAX(ctrl) hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false))
+    CRF_DPP_IMAX(0x128);
+    CRF_DPP_IMAX(0x124);
+    CRF_DPP_IMAX(0x122);
+    CRF_DPP_IMAX(0x121);
+#undef CRF_DPP_IMAX
+    return max(max(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(hi, 16)), max(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(hi, 48)));
+}
+// rescale exponent from the HIGH WORD of a non-negative double maximum (0: nothing to scale by)
+__device__ __forceinline__ int rescale_exp_hi(int hi) {
+    if (hi <= 0) return 0;
+    const int k = kScaleExpD - (((hi >> 20) & 0x7ff) - 1023);
+    return k < -900 ? -900 : (k > 900 ? 900 : k);
+}
 // fp64 twin of rescale_exp / pow2f for the numerator chains
 __device__ __forceinline__ int rescale_exp_d(double m) {
     if (!(m > 0.0)) return 0;
@@ -738,7 +755,9 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
     const CtcLds c = ctc_carve(lds, Sxp);
-    double *A = c.A, *wm = c.wm;
+    double *A = c.A;
+    int *wmi = (int *)c.wm;                    // [3] frame maxima (high words) in rotation
+    int sr = 1;                                // slot read by the next frame (frame 1 reads slot 1)
     const int *lab = c.lab;
     const int64_t bt0 = (int64_t)b * p.T;
     const bool valid = ctc_setup(p, b, c, L, lx, tid);
@@ -778,8 +797,14 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
             }
         }
         if (tid == 0) p.ECA[bt0] = E;
-        vmax = wave_max_d(vmax);
-        if (lane == 0) wm[kCtcWaves + wave] = vmax;  // wm[t & 1] is read by frame t: slot 1 for t = 1
+        // The frame maximum is ONE LDS word per frame (three in rotation: read / accumulated by ds_max_i32 / cleared), the high word of the
+        // largest value: all the rescale needs is its exponent.  (Round 4; before, eight per-wave doubles that every thread read back and
+        // reduced: 8 LDS reads and 7 fp64 maxima per thread and frame on a latency chain -- and the chains' end decides when the den half
+        // of the grad pass may start.)
+        if (tid < 3) wmi[tid] = 0;
+        __syncthreads();
+        const int hm = wave_max_hi(vmax);
+        if (lane == 0) (void)__hip_atomic_fetch_max(wmi + 1, hm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // slot t % 3 is read by frame t: slot 1 for t = 1
     }
     __syncthreads();
     // Emissions are fetched in BATCHES of kCtcPF frames into two alternating register sets.  A gather from
@@ -831,7 +856,9 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         CRF_TM(tm_on, tm_i + 1);
         if (f == 0) fetch4(std::integral_constant<int, 1 - st>{}, t + kCtcPF);  // after this batch has landed
         CRF_TM(tm_on, tm_i + 2);
-        const int k = rescale_exp_d(frame_max_d(wm + (t & 1) * kCtcWaves));
+        const int k = rescale_exp_hi(wmi[sr]);
+        const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
+        if (tid == 0) wmi[sz] = 0;
         const double sc = pow2d(k);
         E += k;
         double *CArow = p.CA + (bt0 + t) * p.Sc;
@@ -851,8 +878,9 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         }
         CRF_TM(tm_on, tm_i + 3);
         if (tid == 0) p.ECA[bt0 + t] = E;
-        vmax = wave_max_d(vmax);
-        if (lane == 0) wm[((t + 1) & 1) * kCtcWaves + wave] = vmax;
+        const int hm = wave_max_hi(vmax);
+        if (lane == 0) (void)__hip_atomic_fetch_max(wmi + sw, hm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sr = sw;
         CRF_TM(tm_on, tm_i + 4);
         sync_lds();
         CRF_TM(tm_on, tm_i + 5);
@@ -893,7 +921,9 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int V = p.V, lx = p.lx[b], L = p.ly[b], Sx = 2 * L + 1, Sxp = rup64(Sx);
     const CtcLds c = ctc_carve(lds, Sxp);
-    double *Y = c.A, *wm = c.wm;
+    double *Y = c.A;
+    int *wmi = (int *)c.wm;
+    int sr = 1;
     const int *lab = c.lab;
     const int64_t bt0 = (int64_t)b * p.T;
     if (!ctc_setup(p, b, c, L, lx, tid)) return;
@@ -925,8 +955,10 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
             }
         }
         if (tid == 0) p.ECB[bt0 + lx - 1] = F_;
-        vmax = wave_max_d(vmax);
-        if (lane == 0) wm[kCtcWaves + wave] = vmax;  // read by iteration i = 1
+        if (tid < 3) wmi[tid] = 0;                    // (frame maxima: ctc_forward)
+        __syncthreads();
+        const int hm = wave_max_hi(vmax);
+        if (lane == 0) (void)__hip_atomic_fetch_max(wmi + 1, hm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // read by iteration i = 1
     }
     __syncthreads();
     // emissions in batches of kCtcPF frames, as in ctc_forward
@@ -968,7 +1000,9 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
             em[q] = (tid + q * kCtcThreads < Sx) ? exp_scaled_d(x) : 0.0;
         }
         if (f == 0) fetch4(std::integral_constant<int, 1 - st>{}, t - kCtcPF);
-        const int k = rescale_exp_d(frame_max_d(wm + (i & 1) * kCtcWaves));
+        const int k = rescale_exp_hi(wmi[sr]);
+        const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;
+        if (tid == 0) wmi[sz] = 0;
         const double sc = pow2d(k);
         F_ += k;
         double *CBrow = p.CB + (bt0 + t) * p.Sc;
@@ -988,8 +1022,9 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
             }
         }
         if (tid == 0) p.ECB[bt0 + t] = F_;
-        vmax = wave_max_d(vmax);
-        if (lane == 0) wm[((i + 1) & 1) * kCtcWaves + wave] = vmax;
+        const int hm = wave_max_hi(vmax);
+        if (lane == 0) (void)__hip_atomic_fetch_max(wmi + sw, hm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sr = sw;
         sync_lds();
     };
     {
