@@ -46,7 +46,15 @@ constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
 
 // ---- build-time A/B switches of the frame loops (the defaults are the measured best: DESIGN.md section 2, profiles/round4_ab_*) ----
 #ifndef CRF_X_GDEARLY
-#define CRF_X_GDEARLY 1     // crf_grad_den_kernel: the rows of frame t+2 are requested right behind the staging of frame t+1 (0: at the top of frame t+1)
+#define CRF_X_GDEARLY 1     // crf_grad_den_kernel: the rows of frame t+2 are requested right behind the staging of frame t+1 (0: at the top of frame t+1;
+                            // 1: in the one-chunk, one-emission-register instantiation; 2: in every one-chunk instantiation not held to 128 VGPRs)
+#endif
+#ifndef CRF_X_GDMOVE
+#define CRF_X_GDMOVE 1      // ... with the cur <- next register moves spelled out in front of the requests (0: left to the compiler, which waited for the rows
+                            // of t+2 right behind their requests)
+#endif
+#ifndef CRF_X_GDW2
+#define CRF_X_GDW2 1        // crf_grad_den_kernel, rows of 5121 .. 8192 floats: 1 = four row registers per thread at 128 VGPRs (two workgroups per CU)
 #endif
 #ifndef CRF_X_PRIO
 #define CRF_X_PRIO 2        // fac_chain_body: issue priority by progress through the frame's chunks: 0 off, 1 steps at 1/4, 1/2, 3/4 of the
@@ -890,14 +898,29 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         fetch4(I0{}, 1);
         for (int t = 1; t < lx; t += 2 * kCtcPF) {
+            // NESTED, not eight independent `if (t + k < lx)`: behind independent conditions the compiler has to assume that the step which waited for
+            // a batch may not have run, and every later step of the batch waited again -- vmcnt(0), i.e. for the previous frame's row store to be
+            // acknowledged (three frames in eight; round 4, found in the ISA)
             step(I0{}, I0{}, t);
-            if (t + 1 < lx) step(I0{}, I1{}, t + 1);
-            if (t + 2 < lx) step(I0{}, I2{}, t + 2);
-            if (t + 3 < lx) step(I0{}, I3{}, t + 3);
-            if (t + 4 < lx) step(I1{}, I0{}, t + 4);
-            if (t + 5 < lx) step(I1{}, I1{}, t + 5);
-            if (t + 6 < lx) step(I1{}, I2{}, t + 6);
-            if (t + 7 < lx) step(I1{}, I3{}, t + 7);
+            if (t + 1 < lx) {
+                step(I0{}, I1{}, t + 1);
+                if (t + 2 < lx) {
+                    step(I0{}, I2{}, t + 2);
+                    if (t + 3 < lx) {
+                        step(I0{}, I3{}, t + 3);
+                        if (t + 4 < lx) {
+                            step(I1{}, I0{}, t + 4);
+                            if (t + 5 < lx) {
+                                step(I1{}, I1{}, t + 5);
+                                if (t + 6 < lx) {
+                                    step(I1{}, I2{}, t + 6);
+                                    if (t + 7 < lx) step(I1{}, I3{}, t + 7);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
         }
     }
     const double *Af = A + ((lx - 1) & 1) * Sxp;
@@ -1032,14 +1055,27 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         fetch4(I0{}, lx - 2);
         for (int i = 1; i < lx; i += 2 * kCtcPF) {
+            // (nested: see ctc_forward)
             step(I0{}, I0{}, i);
-            if (i + 1 < lx) step(I0{}, I1{}, i + 1);
-            if (i + 2 < lx) step(I0{}, I2{}, i + 2);
-            if (i + 3 < lx) step(I0{}, I3{}, i + 3);
-            if (i + 4 < lx) step(I1{}, I0{}, i + 4);
-            if (i + 5 < lx) step(I1{}, I1{}, i + 5);
-            if (i + 6 < lx) step(I1{}, I2{}, i + 6);
-            if (i + 7 < lx) step(I1{}, I3{}, i + 7);
+            if (i + 1 < lx) {
+                step(I0{}, I1{}, i + 1);
+                if (i + 2 < lx) {
+                    step(I0{}, I2{}, i + 2);
+                    if (i + 3 < lx) {
+                        step(I0{}, I3{}, i + 3);
+                        if (i + 4 < lx) {
+                            step(I1{}, I0{}, i + 4);
+                            if (i + 5 < lx) {
+                                step(I1{}, I1{}, i + 5);
+                                if (i + 6 < lx) {
+                                    step(I1{}, I2{}, i + 6);
+                                    if (i + 7 < lx) step(I1{}, I3{}, i + 7);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -2721,8 +2757,10 @@ constexpr int kGDEpRegs = 4;                                      // V <= 4*256
 // NT threads: 256, or 512 for graphs whose rows do not fit 256 threads' prefetch registers (5 float4 each per row)
 // CH: entries per chunk the index registers hold (kChunk; 8 for graphs with few pairs per label -- V = 500: ~8 -- whose chunk lists the
 // graph compiler cuts at 8: a chunk of 32 slots with 8 pairs spends three quarters of its gathers on padding)
-template <int NCPT, int EPR, int NT = kGDThreads, int CH = kChunk>
-__global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
+// RR: float4 registers per thread and row (rows of up to 4 * RR * NT floats); WPE: waves per SIMD the register budget is held to (4 = 128 VGPRs:
+// two 512-thread workgroups per CU)
+template <int NCPT, int EPR, int NT = kGDThreads, int CH = kChunk, int RR = kGDRowRegs, int WPE = 1>
+__global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
     const int tid = threadIdx.x;
@@ -2823,34 +2861,41 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
     }
     if (tid < 4) nrm[tid] = 0.f;
     // rows are multiples of 64 floats and 256-byte aligned: 16-byte loads, prefetched one frame ahead
-    f32x4 qr[kGDRowRegs], br[kGDRowRegs];
-    float ern[EPR], rwn[EPR];   // next frame's emissions and (accumulate mode) grad row
+    // (one chunk and one emission register per thread only -- the kernel of graphs over <= 256 classes with <= 256 label chunks: V = 72 step 2.89 -> 2.865 ms;
+    // with the larger register sets of the other instantiations the same reordering was 4 % SLOWER at V = 217 / 500: profiles/round4_ab_grad_pass_variants.txt)
+    constexpr bool GDE = CRF_X_GDEARLY != 0 && NCPT == 1 && WPE == 1 && (EPR == 1 || CRF_X_GDEARLY >= 2);
+    constexpr bool GDM = GDE && CRF_X_GDMOVE != 0;
+    f32x4 qr[RR], br[RR];
+    float ern[EPR], rwn[EPR] = {};   // next frame's emissions and (accumulate mode) grad row
 #define CRF_GD_FETCH(t)                                                                                  \
     {                                                                                                    \
         const f32x4 *Qr = (const f32x4 *)(p.Q + (bt0 + (t)) * Rq), *Br = (const f32x4 *)(p.BP + (bt0 + (t)) * Rb); \
-        _Pragma("unroll") for (int i = 0; i < kGDRowRegs; ++i) {                                         \
+        _Pragma("unroll") for (int i = 0; i < RR; ++i) {                                         \
             const int r = tid + i * NT;                                                          \
             qr[i] = 4 * r < Rq ? Qr[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
             br[i] = 4 * r < Rb ? Br[r] : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
         }                                                                                                \
         const float *er_ = p.ep + (bt0 + (t)) * V;                                                       \
         const float *gr_ = p.grad + (bt0 + (t)) * V;                                                     \
-        _Pragma("unroll") for (int q = 0; q < EPR; ++q) {                                          \
-            const int v = tid + q * NT;                                                          \
-            ern[q] = v < V ? er_[v] : 0.f;                                                               \
-            rwn[q] = (p.grad_den_acc && v < V) ? gr_[v] : 0.f;                                           \
+        _Pragma("unroll") for (int q = 0; q < EPR; ++q) {                                                \
+            if constexpr (GDM) {   /* clamped, not predicated (every use is behind v < V): the loads write the loop registers themselves */ \
+                const int v = min(tid + q * NT, V - 1);                                                  \
+                ern[q] = er_[v];                                                                         \
+                if (p.grad_den_acc) rwn[q] = gr_[v];   /* (else: stays 0) */                             \
+            } else {                                                                                     \
+                const int v = tid + q * NT;                                                              \
+                ern[q] = v < V ? er_[v] : 0.f;                                                           \
+                rwn[q] = (p.grad_den_acc && v < V) ? gr_[v] : 0.f;                                       \
+            }                                                                                            \
         }                                                                                                \
     }
 #define CRF_GD_STAGE()                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < kGDRowRegs; ++i) {                                             \
+    _Pragma("unroll") for (int i = 0; i < RR; ++i) {                                             \
         const int r = tid + i * NT;                                                              \
         if (4 * r < Rq) ((f32x4 *)Qs)[r] = qr[i];                                                        \
         if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];                                                        \
     }
     float erc[EPR], rwc[EPR];
-    // (one chunk and one emission register per thread only -- the kernel of graphs over <= 256 classes with <= 256 label chunks: V = 72 step 2.89 -> 2.865 ms;
-    // with the larger register sets of the other instantiations the same reordering was 4 % SLOWER at V = 217 / 500: profiles/round4_ab_grad_pass_variants.txt)
-    constexpr bool GDE = CRF_X_GDEARLY != 0 && NCPT == 1 && EPR == 1;
     if constexpr (GDE) {
         // Round 4: the rows of frame t+2 are requested as soon as frame t+1's have left the registers for the LDS (behind the first barrier of
         // frame t) instead of at the top of frame t+1 -- a normalise-and-store phase and a barrier earlier.  The timing build had shown the
@@ -2884,7 +2929,14 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
                     const float o = __shfl_down(sv, 1 << j, 64);
                     if (segm[i] >> j & 1u) sv += o;
                 }
-                if (!(segm[i] >> 31)) atomicAdd(&gsum[clab[i]], sv);
+                if (!(segm[i] >> 31)) {
+                    if constexpr (WPE > 1) {   // the label re-read from the LDS: as a register it was spilled, and a scratch reload waits for the row prefetch
+                        int lab;
+                        asm volatile("v_lshl_add_u32 %0, %1, 2, %2\n\tds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(lab) : "v"(tid), "s"((unsigned)(uintptr_t)(clab_s + i * NT)) : "memory");   // (the address formed here: as a value it was spilled too)
+                        atomicAdd(&gsum[lab], sv);
+                    } else atomicAdd(&gsum[clab[i]], sv);
+                }
             }
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
@@ -2898,7 +2950,12 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
             if (t + 1 < tl) {
                 CRF_GD_STAGE();                     // (the compiler's vmcnt wait in front of these LDS writes: the rows of frame t+1 -- and frame t-1's row store)
 #pragma unroll
-                for (int q = 0; q < EPR; ++q) { erx[q] = ern[q]; rwx[q] = rwn[q]; }
+                for (int q = 0; q < EPR; ++q) {
+                    // real moves, here: left to the compiler, the copy became "new ern -> its loop register" BEHIND the loads below, with a
+                    // vmcnt(0) in front of it -- the frame waited for the rows of t+2 the moment it had asked for them
+                    if constexpr (GDM) asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(erx[q]), "=&v"(rwx[q]) : "v"(ern[q]), "v"(rwn[q]));
+                    else { erx[q] = ern[q]; rwx[q] = rwn[q]; }
+                }
                 if (t + 2 < tl) CRF_GD_FETCH(t + 2);
             }
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 4);
@@ -2952,7 +3009,14 @@ __global__ __launch_bounds__(NT, 1) void crf_grad_den_kernel(LossParams p) {
                     const float o = __shfl_down(sv, 1 << j, 64);
                     if (segm[i] >> j & 1u) sv += o;
                 }
-                if (!(segm[i] >> 31)) atomicAdd(&gsum[clab[i]], sv);
+                if (!(segm[i] >> 31)) {
+                    if constexpr (WPE > 1) {   // the label re-read from the LDS: as a register it was spilled, and a scratch reload waits for the row prefetch
+                        int lab;
+                        asm volatile("v_lshl_add_u32 %0, %1, 2, %2\n\tds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(lab) : "v"(tid), "s"((unsigned)(uintptr_t)(clab_s + i * NT)) : "memory");   // (the address formed here: as a value it was spilled too)
+                        atomicAdd(&gsum[lab], sv);
+                    } else atomicAdd(&gsum[clab[i]], sv);
+                }
             }
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {  // cleared two frames ahead: its last readers are behind frame t-1's barrier
@@ -3045,7 +3109,10 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
     if (tid < kGCFrames)
         fcs[tid] = (t0 + tid < tl && zc > 0.0) ? ctc_frame_factor(p, b, bt0 + t0 + tid, invc, ezc) : 0.0;
     double an[REGS], bn[REGS];
-    float rown[kGCVRegs];
+    // Loads of FETCH are clamped, not predicated, and nothing is computed from them before CONSUME: with `v < V ? row_[v] : 0.f` (and the fused
+    // term subtracted on the spot) the compiler loaded into temporaries and copied them to the loop registers right behind the requests -- behind
+    // a vmcnt(0), so that every frame waited for the rows it had just asked for (round 4, found in the ISA).
+    float rown[kGCVRegs] = {}, esn[kGCVRegs] = {}, isn = 0.f;
 #define CRF_GC_FETCH(t)                                                                          \
     {                                                                                            \
         const double *Ar = p.CA + (bt0 + (t)) * p.Sc, *Br = p.CB + (bt0 + (t)) * p.Sc;           \
@@ -3055,42 +3122,42 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
         }                                                                                        \
         if (accumulate) {                                                                        \
             const float *row_ = p.grad + (bt0 + (t)) * V;                                        \
-            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) {                               \
-                const int v = tid + q * kGCThreads;                                              \
-                rown[q] = v < V ? row_[v] : 0.f;                                                 \
-            }                                                                                    \
-        } else if (p.fused) {                                                                    \
-            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) rown[q] = 0.f;                  \
+            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) rown[q] = row_[min(tid + q * kGCThreads, V - 1)]; \
         }                                                                                        \
-        if (p.fused) {   /* softmax term of log_softmax's backward, folded into the row the frame starts from */ \
+        if (p.fused) {   /* softmax term of log_softmax's backward, folded (in CONSUME) into the row the frame starts from */ \
             const float *er_ = p.ep + (bt0 + (t)) * V;                                           \
-            const float ks_ = ksm * pow2f(-kEpExp) * p.inv_s[bt0 + (t)];                         \
-            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) {                               \
-                const int v = tid + q * kGCThreads;                                              \
-                if (v < V) rown[q] -= ks_ * er_[v];                                              \
-            }                                                                                    \
+            isn = p.inv_s[bt0 + (t)];                                                            \
+            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) esn[q] = er_[min(tid + q * kGCThreads, V - 1)]; \
         }                                                                                        \
     }
 #define CRF_GC_CONSUME()                                                                         \
     {                                                                                            \
         _Pragma("unroll") for (int i = 0; i < REGS; ++i) prod[i] = (tid + i * kGCThreads < Sx) ? an[i] * bn[i] : 0.0; \
         _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) rowc[q] = rown[q];                  \
+        if (p.fused) {                                                                           \
+            const float ks_ = ksm * pow2f(-kEpExp) * isn;                                        \
+            _Pragma("unroll") for (int q = 0; q < kGCVRegs; ++q) rowc[q] -= ks_ * esn[q];        \
+        }                                                                                        \
     }
     double prod[REGS];
     float rowc[kGCVRegs];
-#pragma unroll
-    for (int q = 0; q < kGCVRegs; ++q) rown[q] = 0.f;
     for (int v = tid; v < 4 * Vp; v += kGCThreads) gc[v] = 0.f;
     if (t0 < tl) {
         CRF_GC_FETCH(t0);
         CRF_GC_CONSUME();
     }
+#pragma unroll
+    for (int i = 0; i < REGS; ++i) asm volatile("" ::"v"(mylab[i]));   // (a use in front of the loop: the labels' loads are waited for HERE, not at their
+                                                                        // first use inside a divergent block of every frame)
     sync_lds();
     // Four label-sum buffers in rotation: frame t adds into buffer t&3 and clears buffer (t+2)&3, whose last
     // readers (the stores of frame t-2) are behind the barrier of frame t-1 -- ONE barrier per frame.
-    for (int t = t0; t < tl; ++t) {
+    // (the last frame peeled off instead of `if (t + 1 < tl)` around FETCH and CONSUME: with the waits for a frame's loads inside a conditional
+    // block the compiler assumed them still in flight at the top of the next frame and waited there -- for the requests of THAT frame too)
+    auto frame = [&](const int t, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
         float *g = gc + (t & 3) * Vp, *gz = gc + ((t + 2) & 3) * Vp;
-        if (t + 1 < tl) CRF_GC_FETCH(t + 1);
+        if constexpr (more) CRF_GC_FETCH(t + 1);
         const double fc = fcs[t - t0];
         if (zc > 0.0) {
             float blank = 0.f;
@@ -3118,14 +3185,16 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
         }
         // take the next frame's loads out of their registers BEFORE this frame's stores are issued (a
         // vmcnt wait behind the stores would also wait for their acknowledgement)
-        if (t + 1 < tl) CRF_GC_CONSUME();
+        if constexpr (more) CRF_GC_CONSUME();
         float *row = p.grad + (bt0 + t) * V;
 #pragma unroll
         for (int q = 0; q < kGCVRegs; ++q) {
             const int v = tid + q * kGCThreads;
             if (v < V) row[v] = out[q];
         }
-    }
+    };
+    for (int t = t0; t + 1 < tl; ++t) frame(t, std::true_type{});
+    if (t0 < tl) frame(tl - 1, std::false_type{});
 #undef CRF_GC_CONSUME
 #undef CRF_GC_FETCH
     if (!accumulate)
@@ -5101,6 +5170,12 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             static LdsMark set6;
             if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<2, 2, 2 * kGDThreads>, l, set6, "grad den"))) return r2;
             hipLaunchKernelGGL((crf_grad_den_kernel<2, 2, 2 * kGDThreads>), gg, dim3(2 * kGDThreads), l, st, p);
+        } else if (gd_wide && CRF_X_GDW2 && w.Rq <= 32 * kGDThreads && w.Rb <= 32 * kGDThreads) {
+            // rows of 5121 .. 8192 floats: 512 threads with four row registers each, held to 128 VGPRs so that a CU takes TWO workgroups (the
+            // five-register form below compiles to 148 VGPRs: one workgroup, eight waves, per CU -- the estimated S = 6836 graph ran on that)
+            static LdsMark set8;
+            if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<1, 2, 2 * kGDThreads, kChunk, 4, 4>, l, set8, "grad den"))) return r2;
+            hipLaunchKernelGGL((crf_grad_den_kernel<1, 2, 2 * kGDThreads, kChunk, 4, 4>), gg, dim3(2 * kGDThreads), l, st, p);
         } else if (gd_wide) {   // rows of more than 5120 floats: 512 threads per workgroup (one chunk per thread up to 512 chunks)
             if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<1, 2, 2 * kGDThreads>, l, set5, "grad den"))) return r2;
             hipLaunchKernelGGL((crf_grad_den_kernel<1, 2, 2 * kGDThreads>), gg, dim3(2 * kGDThreads), l, st, p);
