@@ -239,6 +239,23 @@ __device__ __forceinline__ void sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// LDS reads whose ISSUE point is fixed in the source (the compiler sinks an ordinary read to its first use, behind whatever is computed in
+// between).  The value may be used only behind lds_landed() of the same variable -- the compiler does not know these are LDS operations and
+// inserts no wait of its own; its waits for its own LDS operations stay correct (lgkmcnt counts in order: at worst they wait for these too).
+__device__ __forceinline__ double lds_issue_f64(const double *q) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)q));
+    return v;
+}
+__device__ __forceinline__ int lds_issue_i32(const int *q) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)q));
+    return v;
+}
+__device__ __forceinline__ void lds_landed(double &a, double &b, double &c, int &w) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(w));
+}
+
 // In-kernel phase timing for diagnosis (build with CRF_BUILD_DEFS=-DCRF_TIMING; tools/timing_probe.py):
 // one chosen workgroup stamps s_memtime (shader cycles) at phase boundaries into g_tm, read back with
 // crf_timing_read().  Compiled out of the product build.
@@ -855,6 +872,22 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         [[maybe_unused]] const bool tm_on = b == 3 && t >= 100 && t < 228 && wave == 0;
         [[maybe_unused]] const int tm_i = 14336 + (t - 100) * 8;
         CRF_TM(tm_on, tm_i + 0);
+        // The frame's LDS reads -- its maximum and the three neighbours of every state -- are issued TOGETHER, unconditionally (clamped index,
+        // coefficient 0 where the transition does not exist: fma(0, x, a) = a exactly) and, with one or two states per thread, in FRONT of the
+        // emissions' exp, which needs registers only.  As `if (s >= 1) ...; if (skip) ...` each neighbour sat in its own divergent block behind
+        // its own lgkmcnt(0), and the maximum's read was cut off from them by thread 0's clearing store: four LDS round trips in a row on the
+        // frame's dependency chain, all behind the exp (round 4, found in the ISA).  (NR > 2: that costs registers the kernel does not have.)
+        constexpr bool RT = NR <= 2;
+        int wv = 0;
+        double a0[NR], a1[NR], a2[NR];
+        if constexpr (RT) {
+            wv = lds_issue_i32(wmi + sr);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int s0 = min(tid + i * kCtcThreads, Sxp - 1);
+                a0[i] = lds_issue_f64(Ac + s0); a1[i] = lds_issue_f64(Ac + max(s0 - 1, 0)); a2[i] = lds_issue_f64(Ac + max(s0 - 2, 0));
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             float x = lr[st][f][i] - mr[st][f];
@@ -864,9 +897,16 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         CRF_TM(tm_on, tm_i + 1);
         if (f == 0) fetch4(std::integral_constant<int, 1 - st>{}, t + kCtcPF);  // after this batch has landed
         CRF_TM(tm_on, tm_i + 2);
-        const int k = rescale_exp_hi(wmi[sr]);
+        auto nbr = [&](int i) __attribute__((always_inline)) {
+            const int s0 = min(tid + i * kCtcThreads, Sxp - 1);
+            a0[i] = Ac[s0]; a1[i] = Ac[max(s0 - 1, 0)]; a2[i] = Ac[max(s0 - 2, 0)];
+        };
+        if constexpr (RT) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) lds_landed(a0[i], a1[i], a2[i], wv);
+        } else wv = wmi[sr];
+        const int k = rescale_exp_hi(wv);
         const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
-        if (tid == 0) wmi[sz] = 0;
         const double sc = pow2d(k);
         E += k;
         double *CArow = p.CA + (bt0 + t) * p.Sc;
@@ -874,18 +914,18 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int s = tid + i * kCtcThreads;
+            if constexpr (!RT) nbr(i);
+            double a = fma((s >= 1 && s < Sx) ? rho : 0.0, a1[i], a0[i]);
+            a = fma(skip[i] ? rho2 : 0.0, a2[i], a);
+            const double v = sc * em[i] * a;
             if (s < Sx) {
-                double a = Ac[s];
-                if (s >= 1) a = fma(rho, Ac[s - 1], a);
-                if (skip[i]) a = fma(rho2, Ac[s - 2], a);
-                const double v = sc * em[i] * a;
                 An[s] = v;
                 CArow[s] = v;
-                vmax = fmax(vmax, v);
             }
+            vmax = fmax(vmax, s < Sx ? v : 0.0);
         }
         CRF_TM(tm_on, tm_i + 3);
-        if (tid == 0) p.ECA[bt0 + t] = E;
+        if (tid == 0) { wmi[sz] = 0; p.ECA[bt0 + t] = E; }
         const int hm = wave_max_hi(vmax);
         if (lane == 0) (void)__hip_atomic_fetch_max(wmi + sw, hm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         sr = sw;
@@ -1016,6 +1056,17 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         const double *Yc = Y + ((i - 1) & 1) * Sxp;
         double *Yn = Y + (i & 1) * Sxp;
         double em[NR];
+        constexpr bool RT = NR <= 2;   // (the frame's LDS reads together, unconditional, in front of the exp: see ctc_forward)
+        int wv = 0;
+        double a0[NR], a1[NR], a2[NR];
+        if constexpr (RT) {
+            wv = lds_issue_i32(wmi + sr);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int s0 = min(tid + q * kCtcThreads, Sxp - 1);
+                a0[q] = lds_issue_f64(Yc + s0); a1[q] = lds_issue_f64(Yc + min(s0 + 1, Sxp - 1)); a2[q] = lds_issue_f64(Yc + min(s0 + 2, Sxp - 1));
+            }
+        }
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             float x = lr[st][f][q] - mr[st][f];
@@ -1023,9 +1074,16 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
             em[q] = (tid + q * kCtcThreads < Sx) ? exp_scaled_d(x) : 0.0;
         }
         if (f == 0) fetch4(std::integral_constant<int, 1 - st>{}, t - kCtcPF);
-        const int k = rescale_exp_hi(wmi[sr]);
+        auto nbr = [&](int q) __attribute__((always_inline)) {
+            const int s0 = min(tid + q * kCtcThreads, Sxp - 1);
+            a0[q] = Yc[s0]; a1[q] = Yc[min(s0 + 1, Sxp - 1)]; a2[q] = Yc[min(s0 + 2, Sxp - 1)];
+        };
+        if constexpr (RT) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) lds_landed(a0[q], a1[q], a2[q], wv);
+        } else wv = wmi[sr];
+        const int k = rescale_exp_hi(wv);
         const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;
-        if (tid == 0) wmi[sz] = 0;
         const double sc = pow2d(k);
         F_ += k;
         double *CBrow = p.CB + (bt0 + t) * p.Sc;
@@ -1033,18 +1091,18 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int s = tid + q * kCtcThreads;
+            if constexpr (!RT) nbr(q);
+            double a = fma(s + 1 < Sx ? rho : 0.0, a1[q], a0[q]);
+            a = fma(skip[q] ? rho2 : 0.0, a2[q], a);
+            const double bx = sc * a;
+            const double y = em[q] * bx;
             if (s < Sx) {
-                double a = Yc[s];
-                if (s + 1 < Sx) a = fma(rho, Yc[s + 1], a);
-                if (skip[q]) a = fma(rho2, Yc[s + 2], a);
-                const double bx = sc * a;
-                const double y = em[q] * bx;
                 CBrow[s] = bx;
                 Yn[s] = y;
-                vmax = fmax(vmax, y);
             }
+            vmax = fmax(vmax, s < Sx ? y : 0.0);
         }
-        if (tid == 0) p.ECB[bt0 + t] = F_;
+        if (tid == 0) { wmi[sz] = 0; p.ECB[bt0 + t] = F_; }
         const int hm = wave_max_hi(vmax);
         if (lane == 0) (void)__hip_atomic_fetch_max(wmi + sw, hm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         sr = sw;
