@@ -1935,13 +1935,17 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             for (int q = 0; q < EPR; ++q) { const int v = tid + q * NTH; if (v < V) epn[q] = er[v]; }
         }
         const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
-        const int4 m4 = *(const int4 *)(wm + sr * 4);          // (non-negative floats: their bits order like integers)
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        const i32x4_t m4 = *(const i32x4_t *)(wm + sr * 4);    // (non-negative floats: their bits order like integers)
         // The frame's scale and exponent are worked out BEHIND the first batch of gathers (EARLY: the batch loop calls `bookkeeping`
         // once its first gathers are requested -- they need nothing but the vector; the scale enters in the row epilogues only):
         // with the scale first, every wave of the workgroup sat out one LDS round trip right after the frame barrier, the LDS idle.
         float sc = 1.f;
         float *Orow = nullptr;
         auto bookkeeping = [&]() __attribute__((always_inline)) {
+            // (the maxima's use ends up in FRONT of the first gathers all the same -- the scheduler gives their four registers to the gathers' addresses -- so
+            // the frame still starts with one LDS round trip.  Reading them by inline asm BEHIND the gathers instead: metric step 2.833 vs 2.848 ms, but the
+            // S = 513 graph 2.012 vs 1.978 -- dropped, profiles/round4_ab_waits_found_in_the_isa.txt)
             const int ksc = rescale_exp_bits_uniform((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
             sc = pow2f(ksc);
             if (DIR == 1) last_sc = sc;
