@@ -338,6 +338,7 @@ void set_error(const std::string &msg);
     X(stage_fill,       "C  staged schedule for den grids of up to this percent of the CUs (default 75)")                     \
     X(stages,           "C  number of grad stages")                                                                          \
     X(piece,            "C  iterations per grad stage")                                                                      \
+    X(first_shift,      "C  first grad stage this many 16-frame blocks later (shortens the LAST stage by as much)")           \
     X(gd_full_grid,     "C  stage launches of the grad pass as full grids")                                                  \
     X(ctc_after,        "C  0 / 1: numerator chains beside / after the denominator recursions")                              \
     X(serial_chains,    "C  everything on the caller's stream")                                                              \

@@ -5197,6 +5197,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
             const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
             first = std::max(half, ((int)T - body + kGDFrames - 1) / kGDFrames * kGDFrames);
+            const int fs = opt(kOpt_first_shift, 0);
+            if (fs > 0) first = std::min((int)T - kGDFrames, first + fs * kGDFrames);
         }
         nstage = 1;
         bound[1] = first;
