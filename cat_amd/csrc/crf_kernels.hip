@@ -47,7 +47,7 @@ constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
 // ---- build-time A/B switches of the frame loops (the defaults are the measured best: DESIGN.md section 2, profiles/round4_ab_*) ----
 #ifndef CRF_X_GDEARLY
 #define CRF_X_GDEARLY 1     // crf_grad_den_kernel: the rows of frame t+2 are requested right behind the staging of frame t+1 (0: at the top of frame t+1;
-                            // 1: in the one-chunk, one-emission-register instantiation; 2: in every one-chunk instantiation not held to 128 VGPRs)
+                            // 1: in the one-chunk, one-emission-register instantiation; 2: in every one-chunk instantiation not held to 128 VGPRs; 3: two-chunk ones too)
 #endif
 #ifndef CRF_X_GDMOVE
 #define CRF_X_GDMOVE 1      // ... with the cur <- next register moves spelled out in front of the requests (0: left to the compiler, which waited for the rows
@@ -2925,7 +2925,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
     // rows are multiples of 64 floats and 256-byte aligned: 16-byte loads, prefetched one frame ahead
     // (one chunk and one emission register per thread only -- the kernel of graphs over <= 256 classes with <= 256 label chunks: V = 72 step 2.89 -> 2.865 ms;
     // with the larger register sets of the other instantiations the same reordering was 4 % SLOWER at V = 217 / 500: profiles/round4_ab_grad_pass_variants.txt)
-    constexpr bool GDE = CRF_X_GDEARLY != 0 && NCPT == 1 && WPE == 1 && (EPR == 1 || CRF_X_GDEARLY >= 2);
+    constexpr bool GDE = CRF_X_GDEARLY != 0 && WPE == 1 && ((NCPT == 1 && (EPR == 1 || CRF_X_GDEARLY >= 2)) || CRF_X_GDEARLY >= 3);
     constexpr bool GDM = GDE && CRF_X_GDMOVE != 0;
     f32x4 qr[RR], br[RR];
     float ern[EPR], rwn[EPR] = {};   // next frame's emissions and (accumulate mode) grad row
