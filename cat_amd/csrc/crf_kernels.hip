@@ -2924,7 +2924,8 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
     if (tid < 4) nrm[tid] = 0.f;
     // rows are multiples of 64 floats and 256-byte aligned: 16-byte loads, prefetched one frame ahead
     // (one chunk and one emission register per thread only -- the kernel of graphs over <= 256 classes with <= 256 label chunks: V = 72 step 2.89 -> 2.865 ms;
-    // with the larger register sets of the other instantiations the same reordering was 4 % SLOWER at V = 217 / 500: profiles/round4_ab_grad_pass_variants.txt)
+    // in the other instantiations the same reordering was 4 % slower at V = 217 / 500 while the copy-behind-the-loads wait described below was still in it, and
+    // makes no difference without it (levels 2 / 3 of the switch): profiles/round4_ab_grad_pass_variants.txt, round4_ab_waits_found_in_the_isa.txt)
     constexpr bool GDE = CRF_X_GDEARLY != 0 && WPE == 1 && ((NCPT == 1 && (EPR == 1 || CRF_X_GDEARLY >= 2)) || CRF_X_GDEARLY >= 3);
     constexpr bool GDM = GDE && CRF_X_GDMOVE != 0;
     f32x4 qr[RR], br[RR];
