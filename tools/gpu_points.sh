@@ -31,7 +31,7 @@ run V500 --V 500
 run mid3072 --histories 3072 --steps 5
 run mid4096 --histories 4096 --steps 5
 run large --histories 8192 --fanout 32 --steps 3 --warmup 1
-# (config #5's graph takes ~150 s to compile: SKIP_C5=1 leaves the point out of a short run)
+# (the config #5 point is the long one -- a 4.3 M-arc graph to generate, compile and run at 148 ms per step: SKIP_C5=1 leaves it out of a short run)
 [ -z "$SKIP_C5" ] && run c5 --B 8 --T 3000 --V 5000 --histories 32768 --fanout 64 --steps 2 --warmup 1
 # estimated n-gram den_lm graphs (cat_amd.den_lm.prep_den_lm on a synthetic corpus): in-degree profile of a real LM
 for a in "4000 250" "12000 800" "40000 2000"; do timeout 600 python tools/bench_fst.py $a 2>/dev/null | tail -3; done | tee $OUT/pt_${TAG}_estimated.txt
