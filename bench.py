@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--ddp-head", action="store_true", help="time the DDP stand-in model also at N = 1")
     ap.add_argument("--ddp-layers", type=int, default=12, help="stand-in acoustic model: residual MLP blocks (8.4 M parameters each)")
     ap.add_argument("--ddp-steps", type=int, default=5)
+    ap.add_argument("--allow-serial", action="store_true",
+                    help="print a headline line even if the loss ran its serial schedule (no stream beside the caller's: ~1.6x slower); "
+                         "without it such a run prints a `not_measured` record and exits 3")
     ap.add_argument("--share-device", action="store_true",
                     help="harness check on a 1-GPU box: N ranks on cuda:0 over gloo; every world_size > 1 leg runs, `value` is null (not a measurement)")
     return ap.parse_args()
@@ -196,6 +199,19 @@ def main():
     # a timing of a call whose gradient is NaN is not a measurement (round 3 found T = 3000 points of rounds 1 - 2 that were)
     assert np.isfinite(loss_val) and bool(torch.isfinite(x.grad).all().item()), "non-finite loss or gradient at this bench point"
     side_stream, call_streams = ctc_crf._C.last_side_stream(), ctc_crf._C.last_call_streams()
+    fallback_den, fallback_num = ctc_crf._C.last_fallback_counts(torch.cuda.current_stream(dev).cuda_stream)
+    # A run on the SERIAL schedule (the library found no stream that runs beside the caller's) is a 1.6 x slower configuration that a
+    # correctly set-up process does not have: it must not become a headline number silently (round 3 measured one without noticing).
+    serial_run = call_streams < 2 and not share
+    if serial_run and not args.allow_serial:
+        if rank == 0:
+            print(json.dumps({"metric": "utterances/sec CTC-CRF fwd+bwd", "value": None, "unit": "utterances/s", "n_gpus": world,
+                              "not_measured": f"the loss ran its serial schedule (call_streams={call_streams}, side stream: {side_stream}); "
+                                              "pass --allow-serial to measure it anyway",
+                              "serial_ms_per_step": round(dt / args.steps * 1e3, 4)}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(3)
     workspace_bytes = int(ctc_crf._C._lib.crf_workspace_bytes(ctc_crf._C.graph_for(dev), B, T, V, int(max(ly))))
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
@@ -375,7 +391,9 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world} (batch sharded, no data-path collective)",
                        "world_size": world, "devices": devices},
             "loss": round(loss_val, 6), "grad_finite": True,
-            "schedule": {"call_streams": call_streams, "side_stream": side_stream, "rccl_initialised": bool(use_dist and not share)},
+            "schedule": {"call_streams": call_streams, "side_stream": side_stream, "rccl_initialised": bool(use_dist and not share),
+                         "serial": bool(serial_run)},
+            "fallback_utterances": {"denominator": fallback_den, "numerator": fallback_num},
             "workspace_bytes": workspace_bytes,
             "event_blocks": event_blocks,
             "roofline": roofline,

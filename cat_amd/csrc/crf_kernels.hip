@@ -43,6 +43,7 @@ constexpr int kCtcRegs = 8;   // ctc states per thread                  -> 2L+1 
 constexpr int kCtcPF = 4;     // frames per emission prefetch batch (ctc_forward)
 constexpr int kGradThreads = 256;
 constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
+constexpr int kFlagFallback = 40;   // words [40], [41] behind the error word: utterances of the last call redone by the denominator / numerator fallback (crf_finalize_kernel)
 
 // ---- build-time A/B switches of the frame loops (the defaults are the measured best: DESIGN.md section 2, profiles/round4_ab_*) ----
 #ifndef CRF_X_GDEARLY
@@ -63,6 +64,19 @@ constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
 #ifndef CRF_X_EARLY
 #define CRF_X_EARLY 1       // fac_chain_body: the frame's scale / exponent bookkeeping behind the first batch of gathers (0: in front of it)
 #endif
+#ifndef CRF_X_LAG
+#define CRF_X_LAG 1         // fac_chain_body (one CU per recursion): the scale of frame t+1 is worked out in the TAIL of frame t from the maximum
+                            // deposited in frame t-1 -- known before barrier t, so no frame starts with an LDS round trip for its scale (0: the scale of
+                            // frame t from the maximum of its own source vector, read behind the barrier) -- profiles/round5_ab_lagged_scale.txt
+#endif
+// Lagged scale: the vector of frame t+1 is produced with a scale chosen before its size is known.  With u_t = (exponent of max X_t) + k_t
+// the exponent of the SCALED source of frame t, the rule k_{t+1} = kLagTarget - u_t gives u_{t+1} = kLagTarget + kEpExp + g_t, where 2^g_t is
+// what frame t's emissions and weights did to the maximum (g_t in [-8, 1] for ordinary network outputs): the scaled maximum of a frame depends
+// on the growth of ONE earlier frame, nothing accumulates.  Any integer k is exact (a power of two; the exponent word E carries the sum), so
+// only the range is at stake: a frame that shrinks the vector by more than 2^(kLagTarget + kEpExp - kLagLow) -- 62 nats below the row maximum in one
+// frame, against 131 with the unlagged rule -- marks the utterance for the log-shifted fallback (crf_robust_den_kernel), as total underflow does.
+constexpr int kLagTarget = -40;   // u_{t+1} = 24 + g_t: where the unlagged rule puts every frame's maximum (2^kScaleExp), give or take the frame's growth
+constexpr int kLagLow = -66;      // u_t below this: the rows of the frame (q ~ 2^u) could underflow in the grad pass's q * b products
 struct LossParams {
     GraphDev g;
     const float *logp;
@@ -1901,6 +1915,15 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     };
     const bool pre_w = wave * kWave < V;                     // this wave holds emissions
     float last_sc = 1.f;                                     // scale of the last frame (rowless states, after the loop)
+    // lagged scale (CRF_X_LAG): exponent of the NEXT frame's scale, worked out in the tail of the frame before; the first frame of a
+    // launch takes the unlagged rule on the vector it starts from (any integer is exact).  lag_lo: the smallest scaled maximum seen (below kLagLow: fallback).
+    constexpr bool LAG = CRF_X_LAG != 0 && !K2;
+    [[maybe_unused]] int ksc_nx = 0, lag_lo = 0x7fffffff;
+    if constexpr (LAG) {
+        typedef int i32x4_t __attribute__((ext_vector_type(4)));
+        const i32x4_t m4 = *(const i32x4_t *)(wm + sr * 4);
+        ksc_nx = rescale_exp_bits_uniform((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));
+    }
     constexpr int EPR = NTH >= 2 * kResThreads ? 1 : kEpRegsR;   // (V <= 2 * 512 everywhere: use_factored)
     float epn[EPR] = {};                                    // next emission row, in flight across the frame (waves that hold emissions only)
     // this utterance's emissions, rows and exponents (the frame loop adds 32-bit offsets: one s_mul instead of a 64-bit product per address)
@@ -1936,7 +1959,8 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         }
         const int sw = sr == 2 ? 0 : sr + 1, sz = sw == 2 ? 0 : sw + 1;   // accumulated during this frame / cleared in it
         typedef int i32x4_t __attribute__((ext_vector_type(4)));
-        const i32x4_t m4 = *(const i32x4_t *)(wm + sr * 4);    // (non-negative floats: their bits order like integers)
+        [[maybe_unused]] i32x4_t m4{};
+        if constexpr (!LAG) m4 = *(const i32x4_t *)(wm + sr * 4);    // (non-negative floats: their bits order like integers)
         // The frame's scale and exponent are worked out BEHIND the first batch of gathers (EARLY: the batch loop calls `bookkeeping`
         // once its first gathers are requested -- they need nothing but the vector; the scale enters in the row epilogues only):
         // with the scale first, every wave of the workgroup sat out one LDS round trip right after the frame barrier, the LDS idle.
@@ -1946,7 +1970,9 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             // (the maxima's use ends up in FRONT of the first gathers all the same -- the scheduler gives their four registers to the gathers' addresses -- so
             // the frame still starts with one LDS round trip.  Reading them by inline asm BEHIND the gathers instead: metric step 2.833 vs 2.848 ms, but the
             // S = 513 graph 2.012 vs 1.978 -- dropped, profiles/round4_ab_waits_found_in_the_isa.txt)
-            const int ksc = rescale_exp_bits_uniform((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
+            int ksc;
+            if constexpr (LAG) ksc = ksc_nx;   // (worked out in the tail of the frame before)
+            else ksc = rescale_exp_bits_uniform((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
             sc = pow2f(ksc);
             if (DIR == 1) last_sc = sc;
             if (DIR == 0) {
@@ -2124,7 +2150,9 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             // STATIC priorities for the younger waves: slower.)
             {
                 constexpr int f1 = CRF_X_PRIO == 2 ? 4 : CRF_X_PRIO == 3 ? 1 : 2, f2 = CRF_X_PRIO == 2 ? 6 : CRF_X_PRIO == 3 ? 2 : 4, f3 = CRF_X_PRIO == 2 ? 7 : CRF_X_PRIO == 3 ? 4 : 6;   // eighths of the chunks
-                constexpr int q1 = (f1 * NCHA / 8 + NB - 1) / NB * NB, q2 = (f2 * NCHA / 8 + NB - 1) / NB * NB, q3 = (f3 * NCHA / 8 + NB - 1) / NB * NB;
+                constexpr int qlast = (NCHA - 1) / NB * NB;   // start of the last batch: a threshold rounded up beyond it would never be reached (768 x 20 in batches of 4: 7/8 -> 20)
+                constexpr int q1 = (f1 * NCHA / 8 + NB - 1) / NB * NB, q2 = (f2 * NCHA / 8 + NB - 1) / NB * NB,
+                              q3 = (f3 * NCHA / 8 + NB - 1) / NB * NB < qlast ? (f3 * NCHA / 8 + NB - 1) / NB * NB : qlast;
                 // (not with two CUs per recursion: a wave that polls for the peer's entries at the lowest priority delays BOTH CUs -- H = 3 072 recursions 4.17 without, 4.24 ms with)
                 if constexpr (!K2) {
                     if (c0 == 0) __builtin_amdgcn_s_setprio(3);
@@ -2179,6 +2207,11 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             }
             mymax = fmaxf(mymax, fm);
         }
+        // lagged scale: the maximum of THIS frame's source vector (deposited during the frame before, complete since the last barrier) gives
+        // the scale of the NEXT frame -- requested here, where the gathers' registers are free, ahead of the wave maximum's DPP chain; the
+        // scalar arithmetic runs while the deposit below is on its way
+        [[maybe_unused]] i32x4_t m4n{};
+        if constexpr (LAG) m4n = *(const i32x4_t *)(wm + sr * 4);
         mymax = row_max16(mymax);   // (sending the maximum from every row end instead -- no reduction in the tail -- was measured 3 % slower, round 4)
         if (rowlead) lds_fmax(wm + sw * 4 + (lane >> 4), mymax);
         sr = sw;
@@ -2186,6 +2219,15 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             float *EPw = EP + (DIR == 0 ? 1 - par : par) * Vp;
 #pragma unroll
             for (int q = 0; q < EPR; ++q) { const int v = tid + q * NTH; if (v < V) EPw[v] = epn[q]; }
+        }
+        if constexpr (LAG) {   // (behind the emission staging: ONE wait for the LDS in the tail, the one the barrier needs anyway)
+            const unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane(max(max(m4n.x, m4n.y), max(m4n.z, m4n.w)));
+            int u = (int)(bits >> 23) - 127 + ksc_nx;            // exponent of the scaled maximum of this frame's source (ksc_nx: still this frame's scale)
+            int kn = kLagTarget - u;
+            // (all on the scalar unit; lag_lo: the smallest u of the recursion -- an all-zero vector lands far below kLagLow too, it is flagged at the end anyway)
+            asm("s_min_i32 %0, %0, %1" : "+s"(lag_lo) : "s"(u) : "scc");
+            asm("s_max_i32 %0, %0, %1\n\ts_min_i32 %0, %0, %2" : "+s"(kn) : "s"(-100), "s"(100) : "scc");
+            ksc_nx = kn;
         }
         CRF_TM(tm_on, tm_i + 3);
 #ifdef CRF_TIMING
@@ -2214,6 +2256,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         const float *Xc = X + (i1 & 1) * Gp;
         for (int s = tid; s < G; s += NTH) state[s] = Xc[s];
         if (tid == 0) state[Gp] = __int_as_float(E);
+        if (tid == 0 && LAG && lag_lo < kLagLow) p.redo[DIR * p.B + b] = 1;  // (the flag does not travel with the parked state)
         return;
     }
     if (flagged)
@@ -2225,7 +2268,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         for (int s = tid; s < G; s += NTH) part += Xf[s] * p.x_end[s];
         const float zs = res_block_sum<NW>(part, (float *)red, tid);
         const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
-        if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); if (!(zs > 0.f && zs < INFINITY)) p.redo[b] = 1; }
+        if (tid == 0) { p.den_zs[b] = zs; p.den_ez[b] = E; p.cost_alpha[b] = to_log(zs, E, mxs); if (!(zs > 0.f && zs < INFINITY) || (LAG && lag_lo < kLagLow)) p.redo[b] = 1; }
     } else {
         if (lx > 0) {
             __syncthreads();  // drains vmcnt: this workgroup's own stores to the spare row are visible to it
@@ -2255,7 +2298,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             }
         }
         const double mxs = res_mx_total<NW>(p, b, lx, red, tid);
-        if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E; p.cb_mxs[b] = mxs; if (!(zb > 0.f && zb < INFINITY)) p.redo[p.B + b] = 1; }
+        if (tid == 0) { p.cb_part[(size_t)b * kResMaxK] = zb; p.cb_F[b] = E; p.cb_mxs[b] = mxs; if (!(zb > 0.f && zb < INFINITY) || (LAG && lag_lo < kLagLow)) p.redo[p.B + b] = 1; }
     }
 }
 
@@ -4327,10 +4370,16 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_ctc_fix_kernel(LossPa
 // loss = sum_b(c_den*logZ_b - c_ctc*logp_b); copies the per-utterance costs out (one workgroup)
 __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
     __shared__ double red[4];
+    __shared__ int nfall[2];
     const int tid = threadIdx.x;
     double part = 0.0;
+    if (tid < 2) nfall[tid] = 0;
+    __syncthreads();
     for (int b = tid; b < p.B; b += 256) {
         double c = 0.0;
+        // utterances that were redone by a fallback (denominator: log-shifted recursions; numerator: log-domain chains) -- crf_last_fallback_counts
+        if (p.c_den != 0.f && (p.redo[b] | p.redo[p.B + b])) atomicAdd(&nfall[0], 1);
+        if (p.c_ctc != 0.f && p.redo_ctc[b]) atomicAdd(&nfall[1], 1);
         if (p.c_den != 0.f) {
             if (p.res && !(p.redo[b] | p.redo[p.B + b])) {  // backward partition sum = sum of the K per-CU partials (redone utterances: written by the robust kernel)
                 float zb = 0.f;
@@ -4353,6 +4402,7 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
     if (tid == 0) p.loss[0] = (p.res && *p.err) ? __builtin_nanf("") : (float)(red[0] + red[1] + red[2] + red[3]);
+    if (tid < 2) p.err[kFlagFallback + tid] = nfall[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4494,6 +4544,7 @@ struct DevCtx {
     hipEvent_t fork{}, join{}, ev[kMaxStages]{}, evb[kMaxStages]{};
     int *flags = nullptr;     // fine-grained (uncached, cross-XCD coherent) words: [0] error word, [1] start counter, [16..32) stage counters
     bool warned = false;
+    int reprobes = 0;         // probes for a side stream after the first one found none (loss_impl: at calls 256, 1 024, 4 096)
     int side_kind = 0, side_tries = 0;   // find_beside: what kind of stream the side stream is, how many candidates were probed
     char side_desc[96] = "none";
 };
@@ -4566,6 +4617,10 @@ static hipStream_t find_beside(hipStream_t owner, int *flags, int dev, int *kind
     int tries = 0;
     for (const auto &ph : plan) {
         if (only > 0 && ph.kind != only) continue;
+        // hipExtStreamCreateWithCUMask has no flags argument: the stream it makes is a BLOCKING one, i.e. it synchronises implicitly with the
+        // legacy null stream -- beside the null stream (torch's default) the two probe kernels can never overlap, the candidate would only
+        // cost its time-out.  (Beside any other owner it is a last resort with that caveat: null-stream work of the process orders with it.)
+        if (ph.kind == kSideMask && owner == nullptr && only != kSideMask) continue;
         for (int i = 0; i < ph.count && !found; ++i) {
             hipStream_t cand = make_candidate(ph.kind, dev);
             if (!cand) break;
@@ -4686,6 +4741,7 @@ struct Prof {
 static thread_local Prof g_prof;
 static thread_local int g_call_streams = 1;          // crf_last_call_streams
 static thread_local const char *g_side_desc = "none";   // crf_last_side_stream
+static thread_local const int *g_last_err_word = nullptr;   // error word (+ kFlagFallback: fallback counts) of this thread's last call -- crf_last_fallback_counts
 static thread_local const char *g_den_kernel = "";   // template instantiation of the denominator recursions' kernel in the last call (crf_last_den_kernel)
 static void prof_mark(int slot, bool stop, hipStream_t st) {
     if (!g_prof.on) return;
@@ -5094,10 +5150,18 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     std::lock_guard<std::mutex> call_lock(cx->mu);
     // A context whose probe found no stream beside the caller's (a device shared with another busy process at that moment can make the
     // two single-wave probe kernels miss each other) asks again every 256 calls instead of staying on the serial schedule for good.
-    if (!cx->side && cx->flags && !opt_on(kOpt_no_side_stream) && !opt_on(kOpt_trust_side) && (cx->call_id & 255) == 255) {
-        (void)hipStreamSynchronize(stream);
-        cx->side = find_beside(stream, cx->flags, cx->dev, &cx->side_kind, &cx->side_tries);
-        snprintf(cx->side_desc, sizeof(cx->side_desc), "%s (candidate %d, found at call %d)", kSideNames[cx->side_kind], cx->side_tries, cx->call_id + 1);
+    // (at most three more probes, at calls 256, 1 024 and 4 096: a process that cannot have a second queue at all -- GPU_MAX_HW_QUEUES=1 --
+    // must not pay a dozen candidates' time-outs every 256 steps for the rest of the run; never while the caller's stream is being captured)
+    if (!cx->side && cx->flags && !opt_on(kOpt_no_side_stream) && !opt_on(kOpt_trust_side) && cx->reprobes < 3 &&
+        cx->call_id + 1 == (256 << (2 * cx->reprobes))) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        ++cx->reprobes;
+        if (cap == hipStreamCaptureStatusNone) {
+            (void)hipStreamSynchronize(stream);
+            cx->side = find_beside(stream, cx->flags, cx->dev, &cx->side_kind, &cx->side_tries);
+            snprintf(cx->side_desc, sizeof(cx->side_desc), "%s (candidate %d, found at call %d)", kSideNames[cx->side_kind], cx->side_tries, cx->call_id + 1);
+        }
     }
     const bool serial = serial_env || !cx->side;              // no side stream: everything in order on the caller's stream
     hipStream_t side = serial ? stream : cx->side;
@@ -5108,6 +5172,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     g_call_streams = 1;
     g_side_desc = cx->side_desc;
     if (have_flags) { p.err = cx->flags; p.clear = cx->flags; p.nclear = 64; }
+    g_last_err_word = p.err;
     for (bool &u : g_prof.used) u = false;
     prof_mark(7, false, stream);
     prof_mark(0, false, stream);
@@ -5618,6 +5683,16 @@ int crf_timing_read(unsigned long long *out, int n) {
     (void)out; (void)n;
     return 0;  // not a timing build
 #endif
+}
+
+int crf_last_fallback_counts(int32_t *out2, void *stream) {
+    if (!out2) { set_error("crf_last_fallback_counts: null pointer"); return CRF_ERR_ARG; }
+    out2[0] = out2[1] = -1;
+    if (!g_last_err_word) { set_error("crf_last_fallback_counts: no call in this thread yet"); return CRF_ERR_ARG; }
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpy(out2, g_last_err_word + kFlagFallback, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error(std::string("crf_last_fallback_counts: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+    return CRF_OK;
 }
 
 const char *crf_last_den_kernel(void) { return g_den_kernel; }

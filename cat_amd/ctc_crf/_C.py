@@ -8,6 +8,7 @@ import ctypes
 import os
 import sys
 import threading
+import warnings
 from typing import Dict, Optional
 
 import torch
@@ -61,12 +62,14 @@ _lib.crf_last_error.restype = ctypes.c_char_p
 _lib.crf_last_den_kernel.restype = ctypes.c_char_p
 _lib.crf_last_call_streams.restype = ctypes.c_int
 _lib.crf_last_side_stream.restype = ctypes.c_char_p
+_lib.crf_last_fallback_counts.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]
+_lib.crf_last_fallback_counts.restype = ctypes.c_int
 _lib.crf_version.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
     "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_debug_res_emulate", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
-    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_call_streams", "crf_last_side_stream", "crf_last_error", "crf_version",
+    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_call_streams", "crf_last_side_stream", "crf_last_fallback_counts", "crf_last_error", "crf_version",
 )
 
 PROFILE_SLOTS = ("prep", "den_fwd_chain", "den_bwd_chain", "ctc_fwd_chain", "ctc_bwd_chain", "grad",
@@ -97,6 +100,31 @@ def last_call_streams() -> int:
 def last_side_stream() -> str:
     """Kind of the side stream of the last call's context and how many candidates were probed (include/ctc_crf_hip.h)."""
     return _lib.crf_last_side_stream().decode()
+
+
+def last_fallback_counts(stream: int = 0):
+    """(denominator, numerator): utterances of this thread's last call that a fallback redid.  Synchronises `stream` -- diagnostics only."""
+    buf = (ctypes.c_int32 * 2)()
+    _check(_lib.crf_last_fallback_counts(buf, _vp(stream)))
+    return int(buf[0]), int(buf[1])
+
+
+_SERIAL_WARNED = False
+
+
+def _warn_if_serial() -> None:
+    """The library found no stream that runs beside the caller's: every kernel of the loss runs one after the other on the caller's
+    stream -- same results, about 1.6 x the step time at the benchmark shape.  The C library says so on stderr (once per context); a
+    training script sees it here, once per process, where Python's warning filters and loggers can pick it up."""
+    global _SERIAL_WARNED
+    if _SERIAL_WARNED:
+        return
+    desc = _lib.crf_last_side_stream().decode()
+    if desc.startswith("none"):
+        _SERIAL_WARNED = True
+        warnings.warn(f"ctc_crf: no HIP stream of this process runs beside the caller's stream (side stream: {desc}); the CTC-CRF loss runs its "
+                      "kernels one after the other -- correct, but about 1.6x slower than the two-stream schedule. Usual cause: every hardware "
+                      "queue of the process is shared with the caller's stream (GPU_MAX_HW_QUEUES too small).", RuntimeWarning, stacklevel=3)
 
 
 def version() -> str:
@@ -420,6 +448,8 @@ def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch
                                        N, T, V, max_l, c_den, c_ctc, _ptr(grad), _ptr(loss), _ptr(c_alpha),
                                        _ptr(c_beta), _ptr(c_ctc_t), _ptr(invalid), _ptr(ws), ws_bytes, _vp(stream))
     _check(rc)
+    if c_den != 0.0 and c_ctc != 0.0:
+        _warn_if_serial()
     del meta
     extras = dict(costs_alpha=c_alpha, costs_beta=c_beta, costs_ctc=c_ctc_t, invalid=invalid) if want_costs else {}
     return loss, grad, extras

@@ -179,6 +179,12 @@ int crf_last_call_streams(void);
  * beside the caller's and how many candidates had been probed by then (crf_kernels.hip find_beside).  The reference runs everything
  * on the caller's stream (binding.cpp:75,102) and has nothing to report. */
 const char *crf_last_side_stream(void);
+/* How many utterances of this thread's last call were redone by a fallback: out2[0] = denominator (crf_robust_den_kernel: the scaled fp32
+ * recursions lost the utterance's mass, or -- lagged scale -- a frame shrank the vector by more than 2^90), out2[1] = numerator
+ * (crf_robust_ctc_kernel: frames outside the fp64 range of the rescaled chains).  Synchronises `stream` (the stream of that call) and
+ * copies two words: a diagnostic for benchmarks and tests, not for the training loop.  The reference has no fallback: its log-domain
+ * kernels (den_calculate.cu:29-35) pay exp + log1p on every arc instead. */
+int crf_last_fallback_counts(int32_t *out2, void *stream);
 int crf_profile_read(float *ms_out, int n);
 
 /* Diagnostics, timing builds only (CRF_BUILD_DEFS=-DCRF_TIMING python -m cat_amd.build --force): copies

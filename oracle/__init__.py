@@ -115,7 +115,9 @@ def ctc_crf(g: Dict, logits: np.ndarray, labels: np.ndarray, lx: np.ndarray, ly:
     """_CTC_CRF.forward restatement -> dict(loss, grad [B,T,V], costs_den[B], costs_ctc[B])."""
     lib = _load()
     if threads is not None:
-        os.environ["OMP_NUM_THREADS"] = str(threads)
+        # (the environment variable is read once, when libgomp is loaded -- i.e. before this line: set the ICV through the runtime's
+        # own entry point, which liboracle.so's dependency on libgomp makes visible through its handle)
+        lib.omp_set_num_threads(ctypes.c_int(int(threads)))
     logits = np.ascontiguousarray(logits, dtype=np.float32)
     B, T, V = logits.shape
     labels = np.ascontiguousarray(labels, dtype=np.int32)
