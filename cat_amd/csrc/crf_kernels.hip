@@ -64,8 +64,16 @@ constexpr int kFlagFallback = 40;   // words [40], [41] behind the error word: u
 #ifndef CRF_X_EARLY
 #define CRF_X_EARLY 1       // fac_chain_body: the frame's scale / exponent bookkeeping behind the first batch of gathers (0: in front of it)
 #endif
+#ifndef CRF_X_GFIRST
+#define CRF_X_GFIRST 0      // fac_chain_body (one CU per recursion): a frame BEGINS with its first batch of gathers -- everything else a frame starts with
+                            // (stage check, emission prefetch, scale, exponent bookkeeping, row pointers: ~35 scalar instructions, ~4 cycles of a
+                            // wave's issue each) follows behind a scheduling barrier, while the gathers are on their way -- profiles/round5_ab_*.txt
+#endif
+#ifndef CRF_X_KCLATE
+#define CRF_X_KCLATE 0      // fac_chain_body, table geometries: the first slice's row constants are requested behind the first batch of gathers (0: at the frame top)
+#endif
 #ifndef CRF_X_LAG
-#define CRF_X_LAG 1         // fac_chain_body (one CU per recursion): the scale of frame t+1 is worked out in the TAIL of frame t from the maximum
+#define CRF_X_LAG 0         // fac_chain_body (one CU per recursion): the scale of frame t+1 is worked out in the TAIL of frame t from the maximum
                             // deposited in frame t-1 -- known before barrier t, so no frame starts with an LDS round trip for its scale (0: the scale of
                             // frame t from the maximum of its own source vector, read behind the barrier) -- profiles/round5_ab_lagged_scale.txt
 #endif
@@ -73,10 +81,13 @@ constexpr int kFlagFallback = 40;   // words [40], [41] behind the error word: u
 // the exponent of the SCALED source of frame t, the rule k_{t+1} = kLagTarget - u_t gives u_{t+1} = kLagTarget + kEpExp + g_t, where 2^g_t is
 // what frame t's emissions and weights did to the maximum (g_t in [-8, 1] for ordinary network outputs): the scaled maximum of a frame depends
 // on the growth of ONE earlier frame, nothing accumulates.  Any integer k is exact (a power of two; the exponent word E carries the sum), so
-// only the range is at stake: a frame that shrinks the vector by more than 2^(kLagTarget + kEpExp - kLagLow) -- 62 nats below the row maximum in one
-// frame, against 131 with the unlagged rule -- marks the utterance for the log-shifted fallback (crf_robust_den_kernel), as total underflow does.
-constexpr int kLagTarget = -40;   // u_{t+1} = 24 + g_t: where the unlagged rule puts every frame's maximum (2^kScaleExp), give or take the frame's growth
-constexpr int kLagLow = -66;      // u_t below this: the rows of the frame (q ~ 2^u) could underflow in the grad pass's q * b products
+// only the range is at stake -- and not in the recursions first but in the GRAD pass, which multiplies a row of q ~ 2^u_t with a row of
+// b ~ 2^u'_t and e' 2^-kEpExp ~ 2^g: with the unlagged rule both rows sit at 2^kScaleExp whatever the frame did, here they carry the frame's
+// growth (found by tests/test_gpu_parity.py::test_lagged_scale_window: NaN gradients at 45 nats with the first thresholds).  Hence: a frame
+// whose scaled maximum falls below 2^kLagLow -- it shrank the vector by more than 2^40, 28 nats below the row maximum in ONE frame, against
+// 131 nats with the unlagged rule -- marks the utterance for the log-shifted fallback (crf_robust_den_kernel), as total underflow does.
+constexpr int kLagTarget = -28;   // u_{t+1} = 36 + g_t (the next vector's maximum: 2^(100 + g_t + g_{t+1}) < 2^127)
+constexpr int kLagLow = -4;       // u_t below this: q * b * e' could leave the fp32 range in the grad pass
 struct LossParams {
     GraphDev g;
     const float *logp;
@@ -1918,12 +1929,16 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     // lagged scale (CRF_X_LAG): exponent of the NEXT frame's scale, worked out in the tail of the frame before; the first frame of a
     // launch takes the unlagged rule on the vector it starts from (any integer is exact).  lag_lo: the smallest scaled maximum seen (below kLagLow: fallback).
     constexpr bool LAG = CRF_X_LAG != 0 && !K2;
-    [[maybe_unused]] int ksc_nx = 0, lag_lo = 0x7fffffff;
+    // The maximum read in the tail of frame t travels to frame t+1 in a VECTOR register (lag_mx, the same bits in every lane) and is turned
+    // into the scale there, BEHIND the frame's first gathers: lag_k is the exponent of the scale of the frame before.  First frame of a
+    // launch: lag_mx = the maximum of the vector it starts from and lag_k = kLagTarget - kScaleExp give exactly the unlagged rule.
+    [[maybe_unused]] int lag_k = kLagTarget - kScaleExp, lag_lo = 0x7fffffff, lag_mx = 0;
     if constexpr (LAG) {
         typedef int i32x4_t __attribute__((ext_vector_type(4)));
         const i32x4_t m4 = *(const i32x4_t *)(wm + sr * 4);
-        ksc_nx = rescale_exp_bits_uniform((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));
+        lag_mx = max(max(m4.x, m4.y), max(m4.z, m4.w));
     }
+    constexpr bool GFIRST = CRF_X_GFIRST != 0 && CRF_X_EARLY != 0 && !K2;
     constexpr int EPR = NTH >= 2 * kResThreads ? 1 : kEpRegsR;   // (V <= 2 * 512 everywhere: use_factored)
     float epn[EPR] = {};                                    // next emission row, in flight across the frame (waves that hold emissions only)
     // this utterance's emissions, rows and exponents (the frame loop adds 32-bit offsets: one s_mul instead of a 64-bit product per address)
@@ -1931,8 +1946,6 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
     float *Out_b = p.Out + bt0 * p.Rout;
     int *Eo_b = p.Eout + bt0;
     auto frame = [&](const int par, int i) __attribute__((always_inline)) {
-        const int t = DIR == 0 ? i : lx - 1 - i;
-        if (FLAG && i == next_bound) publish_stage();
         [[maybe_unused]] const bool tm_on = b == 3 && i >= 100 && i < 228 && wave == 0;
         [[maybe_unused]] const int tm_i = (DIR * 4) * 1024 + (i - 100) * 8;
         CRF_TM(tm_on, tm_i + 0);
@@ -1940,6 +1953,21 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         if (b == 3 && i >= 150 && i < 158 && wave == 0) CRF_TM(true, 12288 + 1024 + (DIR * 4) * 8 + (i - 150));  // frame start
 #endif
         const char *xb = (const char *)lds + par * XB;
+        // GFIRST: the frame's first batch of gathers needs the source vector and nothing else -- it is requested before anything else is
+        // worked out (every wave: idle waves hold padding arcs, offset 0 and weight 0).  A wave issues one instruction per ~4 cycles whatever
+        // it is (tools/ubench_issue.py), and the ~35 scalar instructions a frame used to begin with kept the LDS idle for ~200 cycles right
+        // behind every barrier (timing build, round 5: "frame top" 240 cycles with nothing to wait for).
+        constexpr int NB0 = NB < NCHA ? NB : NCHA;
+        [[maybe_unused]] f32x2 g01_0[NB0], g23_0[NB0];
+        if constexpr (GFIRST) {
+#if CRF_X_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
+            CRF_RES_GATHER_N(g01_0, g23_0, A, xb, 0, NB0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int t = DIR == 0 ? i : lx - 1 - i;
+        if (FLAG && i == next_bound) publish_stage();
         char *xnb = (char *)lds + (1 - par) * XB;
         const float *EPu = EP + (DIR == 0 ? par : 1 - par) * Vp;     // e'_t (fwd) / e'_{t-1} (bwd)
         const int tpre = DIR == 0 ? t + 1 : t - 2;
@@ -1971,8 +1999,17 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             // the frame still starts with one LDS round trip.  Reading them by inline asm BEHIND the gathers instead: metric step 2.833 vs 2.848 ms, but the
             // S = 513 graph 2.012 vs 1.978 -- dropped, profiles/round4_ab_waits_found_in_the_isa.txt)
             int ksc;
-            if constexpr (LAG) ksc = ksc_nx;   // (worked out in the tail of the frame before)
-            else ksc = rescale_exp_bits_uniform((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
+            if constexpr (LAG) {
+                // lag_mx: maximum of the source vector of the frame BEFORE (read in that frame's tail), lag_k: that frame's scale
+                const unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane(lag_mx);
+                int u = (int)(bits >> 23) - 127 + lag_k;             // exponent of the scaled maximum of that frame's source
+                ksc = kLagTarget - u;
+                // (all on the scalar unit; lag_lo: the smallest u of the recursion -- an all-zero vector lands far below kLagLow too, it is flagged at the end anyway)
+                const int uu = i == i0 ? 0x7fffffff : u;           // (the first frame's u is the start-up convention above, not a measurement)
+                asm("s_min_i32 %0, %0, %1" : "+s"(lag_lo) : "s"(uu) : "scc");
+                asm("s_max_i32 %0, %0, %1\n\ts_min_i32 %0, %0, %2" : "+s"(ksc) : "s"(-100), "s"(100) : "scc");
+                lag_k = ksc;
+            } else ksc = rescale_exp_bits_uniform((unsigned)__builtin_amdgcn_readfirstlane(max(max(m4.x, m4.y), max(m4.z, m4.w))));   // (uniform)
             sc = pow2f(ksc);
             if (DIR == 1) last_sc = sc;
             if (DIR == 0) {
@@ -2001,12 +2038,16 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
         float mymax = 0.f;
         CRF_TM(tm_on, tm_i + 1);
         unsigned r4 = (unsigned)(row0 + lane) * 4u;   // 4 * row id
+        constexpr bool EARLY_ = CRF_X_EARLY != 0;
         [[maybe_unused]] gu64 *slot = nullptr;        // K2: the granules of the vector this frame produces
         [[maybe_unused]] const unsigned tag = (unsigned)(i + 1);
         if constexpr (K2) slot = xchd + (size_t)(1 - par) * G;
         typedef std::conditional_t<DIR == 0, uint2, uint4> rct_t;
         [[maybe_unused]] rct_t kc{};                  // RL: constants of the slice that ends next
-        if constexpr (RL) kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * r4);
+        // (KCLATE: the first slice's constants are requested BEHIND the first batch of gathers -- sixteen waves' 8- / 16-byte-per-lane reads
+        // in front of them keep the LDS busy for 64 / 128 cycles right behind the barrier before the first gather is served)
+        constexpr bool KCLATE = CRF_X_KCLATE != 0 && RL && EARLY_ && !K2;
+        if constexpr (RL && !KCLATE) kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * r4);
         // the end of a slice (row): everything between the row's sum and its entries of the next vector
         auto row_end = [&](const unsigned ks) __attribute__((always_inline)) {   // ks: slice number (uniform)
             // rows longer than a lane's registers lie on 2^lg adjacent lanes (res_layout.cpp place_rows): a butterfly
@@ -2155,7 +2196,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                               q3 = (f3 * NCHA / 8 + NB - 1) / NB * NB < qlast ? (f3 * NCHA / 8 + NB - 1) / NB * NB : qlast;
                 // (not with two CUs per recursion: a wave that polls for the peer's entries at the lowest priority delays BOTH CUs -- H = 3 072 recursions 4.17 without, 4.24 ms with)
                 if constexpr (!K2) {
-                    if (c0 == 0) __builtin_amdgcn_s_setprio(3);
+                    if (c0 == 0) { if constexpr (!GFIRST) __builtin_amdgcn_s_setprio(3); }
                     else if (c0 == q1) __builtin_amdgcn_s_setprio(2);
                     else if (c0 == q2) __builtin_amdgcn_s_setprio(1);
                     else if (c0 == q3) __builtin_amdgcn_s_setprio(0);
@@ -2165,7 +2206,18 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
             // (EARLY: the first batch is gathered by every wave -- the slots of a wave without arcs hold padding, offset 0 and weight 0)
             if ((EARLY && c0 == 0) || c0 < nch_f) {
                 f32x2 g01[NB], g23[NB];
-                CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb);
+                if (GFIRST && c0 == 0) {
+#pragma unroll
+                    for (int ci = 0; ci < NB0; ++ci) { g01[ci] = g01_0[ci]; g23[ci] = g23_0[ci]; }
+                } else {
+                    CRF_RES_GATHER_N(g01, g23, A, xb, c0, nb);
+                }
+                if constexpr (KCLATE) {
+                    if (c0 == 0) {
+                        asm volatile("" ::: "memory");   // (keeps the read behind the gathers in the instruction stream)
+                        kc = *(const rct_t *)(RMc + (DIR == 0 ? 2u : 4u) * r4);
+                    }
+                }
                 if constexpr (EARLY) { if (c0 == 0) bookkeeping(); }
 #pragma unroll
                 for (int ci = 0; ci < nb; ++ci) {
@@ -2220,15 +2272,7 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
 #pragma unroll
             for (int q = 0; q < EPR; ++q) { const int v = tid + q * NTH; if (v < V) EPw[v] = epn[q]; }
         }
-        if constexpr (LAG) {   // (behind the emission staging: ONE wait for the LDS in the tail, the one the barrier needs anyway)
-            const unsigned bits = (unsigned)__builtin_amdgcn_readfirstlane(max(max(m4n.x, m4n.y), max(m4n.z, m4n.w)));
-            int u = (int)(bits >> 23) - 127 + ksc_nx;            // exponent of the scaled maximum of this frame's source (ksc_nx: still this frame's scale)
-            int kn = kLagTarget - u;
-            // (all on the scalar unit; lag_lo: the smallest u of the recursion -- an all-zero vector lands far below kLagLow too, it is flagged at the end anyway)
-            asm("s_min_i32 %0, %0, %1" : "+s"(lag_lo) : "s"(u) : "scc");
-            asm("s_max_i32 %0, %0, %1\n\ts_min_i32 %0, %0, %2" : "+s"(kn) : "s"(-100), "s"(100) : "scc");
-            ksc_nx = kn;
-        }
+        if constexpr (LAG) lag_mx = max(max(m4n.x, m4n.y), max(m4n.z, m4n.w));   // (behind the emission staging: ONE wait for the LDS in the tail, the one the barrier needs anyway)
         CRF_TM(tm_on, tm_i + 3);
 #ifdef CRF_TIMING
         if (b == 3 && i >= 150 && i < 158) CRF_TM(true, 15360 + (DIR * 16 + wave) * 8 + (i - 150));   // this wave's arrival at the frame barrier
@@ -5693,6 +5737,15 @@ int crf_last_fallback_counts(int32_t *out2, void *stream) {
     if (e == hipSuccess) e = hipMemcpy(out2, g_last_err_word + kFlagFallback, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { set_error(std::string("crf_last_fallback_counts: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
     return CRF_OK;
+}
+
+const char *crf_build_switches(void) {
+    return "LAG=" CRF_STR(CRF_X_LAG) " KCLATE=" CRF_STR(CRF_X_KCLATE) " PRIO=" CRF_STR(CRF_X_PRIO) " EARLY=" CRF_STR(CRF_X_EARLY)
+           " GFIRST=" CRF_STR(CRF_X_GFIRST) " GDEARLY=" CRF_STR(CRF_X_GDEARLY) " GDMOVE=" CRF_STR(CRF_X_GDMOVE) " GDW2=" CRF_STR(CRF_X_GDW2)
+#ifdef CRF_TIMING
+           " TIMING=1"
+#endif
+        ;
 }
 
 const char *crf_last_den_kernel(void) { return g_den_kernel; }

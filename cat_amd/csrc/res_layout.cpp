@@ -56,6 +56,13 @@ inline int chunks_of(size_t deg) { return std::max(1, (int)((deg + kResW - 1) / 
 // Step 1: decide where every row lives (CU, wave, slice, lane) from the row LENGTHS only.
 struct SliceAt { int k, w, c0, len, rid0; std::vector<int> rows; int ord; int lg = 0; };   // ord: number of the slice within its wave;
                                                       // lg > 0: every row of the slice is cut into 2^lg pieces on 2^lg adjacent lanes
+// Waves [0, g_emis_waves) of a factored workgroup also stage the next frame's emission row (crf_kernels.hip fac_chain_body, `pre_w`): the
+// request at the frame top, and in the tail a wait for it that -- vmcnt counts in order -- includes the acknowledgement of the wave's own
+// write-through row stores, ~400 cycles in which that wave alone stands in front of the frame barrier (timing build, round 5: wave 0 arrived
+// 270 cycles behind every other wave of the forward recursion, 6 % of the frame).  The placement charges those waves kEmisCost chunks and
+// hands them the LIGHTEST slice list of their SIMD.  Set by build_factored around its place_rows calls (0: all waves alike).
+static thread_local int g_emis_waves = 0;
+
 bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm, int piece, bool spread = false) {
     o->arcs.assign((size_t)K * gm.words * gm.threads, 0u);
     o->wave_info.assign((size_t)K * gm.waves, uint4{0u, 0u, 0u, 0u});
@@ -129,7 +136,9 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
         std::vector<std::vector<int>> lists(gm.waves);
         std::vector<int> cost(gm.waves, 0);
         if (packed) {
-            auto wcost = [&](int w) { return load[w] + kEpiCost * cnt[w]; };
+            const int kEmisCost = opt(kOpt_res_emis, 8);   // (metric graph: 0 / 3 / 5 / 8 / 12 -> recursions 2.576 / 2.585 / 2.561 / 2.550 / 2.577 ms; V = 217: 2.690 -> 2.625: profiles/round5_ab_emission_waves.txt)
+            const int nem = (gm.maxsl && K == 1) ? std::min(g_emis_waves, gm.waves / 2) : 0;
+            auto wcost = [&](int w) { return load[w] + kEpiCost * cnt[w] + (w < nem ? kEmisCost : 0); };
             // objective: (max cost, sum of squares) lexicographically, folded into one number
             const bool by_simd = gm.maxsl && gm.waves % 4 == 0 && !opt_on(kOpt_res_no_simd_order);
             auto objective = [&]() {
@@ -181,12 +190,15 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
                 for (int g = 0; g < 4; ++g) {
                     std::vector<int> ws;
                     for (int w = g; w < gm.waves; w += 4) ws.push_back(w);
+                    // (round 5: the waves that stage emissions -- ids below nem -- come LAST in that order and so get the lightest lists: with
+                    // issue priorities by progress the age of a wave matters less than the ~400 cycles its tail waits for the row stores)
+                    if (nem > 0 && kEmisCost > 0) std::stable_partition(ws.begin(), ws.end(), [&](int w) { return w >= nem; });
                     std::vector<int> order = ws;
-                    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+                    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] - (a < nem ? kEmisCost : 0) > cost[b] - (b < nem ? kEmisCost : 0); });
                     std::vector<std::vector<int>> nl;
                     std::vector<int> nload, ncnt, ncost;
                     for (int w : order) { nl.push_back(lists[w]); nload.push_back(load[w]); ncnt.push_back(cnt[w]); ncost.push_back(cost[w]); }
-                    for (size_t i = 0; i < ws.size(); ++i) { lists[ws[i]] = nl[i]; load[ws[i]] = nload[i]; cnt[ws[i]] = ncnt[i]; cost[ws[i]] = ncost[i]; }
+                    for (size_t i = 0; i < ws.size(); ++i) { lists[ws[i]] = nl[i]; load[ws[i]] = nload[i]; cnt[ws[i]] = ncnt[i]; cost[ws[i]] = wcost(ws[i]); }
                 }
             }
             if (opt_on(kOpt_verbose)) {
@@ -1141,6 +1153,8 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (short_only)   // graphs with rows longer than a lane's registers (every den_lm estimated from text) run 2-3 % faster with the
         for (auto &r : fsub)   // row constants in the LDS table (level 1; measured): leave them to it
             if (chunks_of(r.size()) > gm->nch) { if (long_bail) *long_bail = true; *retry_next = true; return CRF_OK; }
+    struct EmisGuard { ~EmisGuard() { g_emis_waves = 0; } } emis_guard;   // (reset on every way out of this function)
+    g_emis_waves = (max_lab + kWave) / kWave;                            // waves that hold emissions at V = max label + 1, i.e. ceil(V / 64): place_rows_piece
     DirOut fo;
     std::vector<SliceAt> fslices;
     if (!place_rows(fsub, deal_rows(fsub, K), K, &fo, &fslices, *gm)) {

@@ -65,11 +65,12 @@ _lib.crf_last_side_stream.restype = ctypes.c_char_p
 _lib.crf_last_fallback_counts.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_void_p]
 _lib.crf_last_fallback_counts.restype = ctypes.c_int
 _lib.crf_version.restype = ctypes.c_char_p
+_lib.crf_build_switches.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
     "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_debug_res_emulate", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
-    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_call_streams", "crf_last_side_stream", "crf_last_fallback_counts", "crf_last_error", "crf_version",
+    "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_call_streams", "crf_last_side_stream", "crf_last_fallback_counts", "crf_build_switches", "crf_last_error", "crf_version",
 )
 
 PROFILE_SLOTS = ("prep", "den_fwd_chain", "den_bwd_chain", "ctc_fwd_chain", "ctc_bwd_chain", "grad",
@@ -129,6 +130,11 @@ def _warn_if_serial() -> None:
 
 def version() -> str:
     return _lib.crf_version().decode()
+
+
+def build_switches() -> Dict[str, int]:
+    """The CRF_X_* build-time switches of the loaded library (include/ctc_crf_hip.h crf_build_switches)."""
+    return {k: int(v) for k, v in (kv.split("=") for kv in _lib.crf_build_switches().decode().split())}
 
 
 def _check(rc: int) -> None:

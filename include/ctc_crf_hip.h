@@ -185,6 +185,9 @@ const char *crf_last_side_stream(void);
  * copies two words: a diagnostic for benchmarks and tests, not for the training loop.  The reference has no fallback: its log-domain
  * kernels (den_calculate.cu:29-35) pay exp + log1p on every arc instead. */
 int crf_last_fallback_counts(int32_t *out2, void *stream);
+/* The build-time A/B switches of the frame loops this library was compiled with, e.g. "LAG=1 KCLATE=0 PRIO=2 EARLY=1 ..." (crf_kernels.hip,
+ * CRF_X_*: the defaults are the measured best; tools build variants with CRF_BUILD_DEFS=-DCRF_X_...=n and tests ask which one they run). */
+const char *crf_build_switches(void);
 int crf_profile_read(float *ms_out, int n);
 
 /* Diagnostics, timing builds only (CRF_BUILD_DEFS=-DCRF_TIMING python -m cat_amd.build --force): copies

@@ -60,3 +60,27 @@ def test_serial_schedule_is_still_correct():
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["call_streams"] == 1 and rec["den_kernel"].startswith("crf_fac_pair_kernel<false"), rec
     assert rec["grad_finite"] and rec["grad_err_vs_oracle"] <= 1e-4, rec
+    # ... and it is LOUD: once through Python's warnings (a trainer's logger sees it), not only on the C library's stderr
+    assert r.stderr.count("RuntimeWarning: ctc_crf: no HIP stream of this process runs beside the caller's stream") == 1, r.stderr[-3000:]
+
+
+def test_bench_refuses_a_headline_on_the_serial_schedule():
+    """A silent 1.6 x regression must not become a BENCH value (round 3 recorded one): without --allow-serial a run on the serial
+    schedule prints a `not_measured` record and exits 3; with it the line says `"serial": true`."""
+    env = dict(os.environ, CRF_DEBUG="no_side_stream=1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--B", "8", "--T", "320", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["value"] is None and "serial schedule" in rec["not_measured"], rec
+    r = subprocess.run(cmd + ["--allow-serial"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["value"] > 0 and rec["schedule"]["serial"] is True and rec["schedule"]["call_streams"] == 1, rec
+    # the ordinary run of the same shape: two streams, a headline, no fallback utterance on random inputs
+    env.pop("CRF_DEBUG")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["value"] > 0 and rec["schedule"]["serial"] is False and rec["schedule"]["call_streams"] >= 2, rec
+    assert rec["fallback_utterances"] == {"denominator": 0, "numerator": 0}, rec
