@@ -314,6 +314,7 @@ void set_error(const std::string &msg);
     X(res_epi,          "G  layout cost model: slice end in chunks (default 4)")                                             \
     X(res_piece,        "G  multi-lane rows: piece size in percent of a lane's chunks (default: the cost model's choice)")   \
     X(res_no_simd_order,"G  layout: no SIMD-aware placement of the waves' slice lists")                                      \
+    X(res_simd0,        "G  factored layouts: handicap of SIMD 0 in the placement's cost model, in chunks (default 0)")                  \
     X(res_emis,         "G  factored layouts: what the emission staging costs a wave that holds emissions, in chunks (default 8; 0: waves treated alike)") \
     X(res_no_spread,    "G  small graphs: rows that fit a lane are not cut into pieces to give every wave a share")          \
     X(res_owner_first,  "G  multi-lane rows: the first lane of a group owns the outputs (no rotation)")                      \

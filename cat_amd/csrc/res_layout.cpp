@@ -136,6 +136,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
         std::vector<std::vector<int>> lists(gm.waves);
         std::vector<int> cost(gm.waves, 0);
         if (packed) {
+            const int kSimd0 = (gm.maxsl && K == 1) ? opt(kOpt_res_simd0, 0) : 0;
             const int kEmisCost = opt(kOpt_res_emis, 8);   // (metric graph: 0 / 3 / 5 / 8 / 12 -> recursions 2.576 / 2.585 / 2.561 / 2.550 / 2.577 ms; V = 217: 2.690 -> 2.625: profiles/round5_ab_emission_waves.txt)
             const int nem = (gm.maxsl && K == 1) ? std::min(g_emis_waves, gm.waves / 2) : 0;
             auto wcost = [&](int w) { return load[w] + kEpiCost * cnt[w] + (w < nem ? kEmisCost : 0); };
@@ -144,7 +145,7 @@ bool place_rows_piece(const Rows &rows, const std::vector<int> &row_cu, int K, D
             auto objective = [&]() {
                 int64_t mx = 0, sq = 0;
                 if (by_simd) {   // waves w, w + 4, w + 8 share a SIMD and take turns on it: what the frame waits for is the busiest SIMD
-                    int64_t g[4] = {0, 0, 0, 0};
+                    int64_t g[4] = {kSimd0, 0, 0, 0};
                     for (int w = 0; w < gm.waves; ++w) { const int64_t c = wcost(w); g[w & 3] += c; sq += c * c; }
                     for (int i = 0; i < 4; ++i) mx = std::max(mx, g[i]);
                     return mx * 1000000 + sq;
