@@ -116,7 +116,9 @@ struct FacDev {
     const int4 *frow_meta;     // [Rf] {U byte offset | main label << 16, L offset | A offset << 16, tail weight bits, tail label}
                                //      plain rows: U = A = sink, tail weight 0
     int NT;                    // unused (0)
-    int threads;               // workgroup size the tables were built for: 768 (21 chunks per thread) or 512 (30)
+    int threads;               // workgroup size the tables were built for: 1024 (15 chunks per thread), 768 (21) or 512 (30)
+    int imp;                   // the entries of a row lie where its row id says (every geometry but the 512-thread FALLBACK; the 512-thread
+                               // layout of the two-utterance kernel, HostGraph::facp, is implicit too)
     int K;                     // CUs per recursion: 1, or 2 (graphs of 120 k - 240 k arcs: each CU holds half of the rows and the whole
                                // state vector, the products cross through L2 every frame like the generic layout's; rcl geometry only)
     const int *xlist;          // K = 2, forward: the L / A entries (and plain states) CU k fetches from its peer every frame,
@@ -287,6 +289,12 @@ struct HostGraph {
     std::vector<StreamDev *> streams;   // one per (AL, tasks wanted) used so far
     FacBatchH fb;                       // factored rows of the utterance-minor kernels (T o LM graphs), see StreamDev
     FacHostCopy fh;                     // host copy of dev.fac's tables
+    // A SECOND factored layout for the two-utterance kernel (crf_fac_pair2_kernel on 512 threads x 30 chunks, 256 VGPRs per wave): built next
+    // to a 1024-thread main layout, taken by calls whose batch is larger than the one-utterance kernel's staged schedule holds
+    // (crf_kernels.hip use_facp).  It has its own rows, entries and grad-pass lists, so a call works with one of the two throughout.
+    FacDev facp{};
+    FacHostCopy fhp;
+    int ncu = 256;                      // compute units of the graph's device (0 / host-only: 256)
     ResHostCopy rh;                     // host copy of dev.res's tables
     std::vector<int> h_src, h_dst, h_lab;   // the graph's arcs as compiled (graphs of up to 2^20 arcs: the emulations' plain reference)
     std::vector<float> h_w, h_start, h_end; // exp(weight), exp(start), exp(end)
@@ -324,6 +332,7 @@ void set_error(const std::string &msg);
     X(regauge_minhash,  "G  re-gauging: find the two states of a history by min-hashing (what graphs of millions of arcs take)") \
     X(verbose,          "G  print layout statistics to stderr")                                                             \
     X(emu_drop_list,    "-  crf_debug_fac_emulate: drop the two-CU fetch list (negative control of the emulation)")          \
+    X(emu_facp,         "-  crf_debug_fac_emulate: the two-utterance kernel's layout (HostGraph::facp) instead of the main one")  \
     X(emu_verbose,      "-  crf_debug_fac_emulate: per-frame masses to stderr")                                              \
     X(bat_no_fac,       "GC utterance-minor kernels: plain arc streams instead of the factored ones")                        \
     X(bat_task,         "C  utterance-minor kernels: steps per task")                                                        \
@@ -349,6 +358,7 @@ void set_error(const std::string &msg);
     X(side_kind,        "X  side stream candidates of one kind only: 1 plain, 2 high priority, 3 low priority, 4 CU-masked")  \
     X(aux_stream,       "C  numerator fallback chains on the third stream: 1 always, 0 never (default: when a recent call needed them)")  \
     X(no_aux_stream,    "X  no third stream for this context (numerator fallback chains in front of the grad stages)")      \
+    X(no_facp,          "G  no second (512-thread) factored layout for the two-utterance kernel")                            \
     X(fac_pair2,        "C  factored recursions with TWO utterances per workgroup: 1 = for any batch, 0 = never (default: batches above CUs / 2)")
 
 enum Opt : int {
@@ -379,7 +389,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
                    const std::vector<float> &start_lin, const std::vector<float> &end_lin);
 // Arc streams for UL (8, 16, 32 or 64) utterances per group cut into about `want` tasks per direction, built and uploaded
 // on first use (thread-safe; a graph keeps every variant it has been asked for).
-int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out3);
+int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out3, int which = 0);   // which = 1: the two-utterance kernel's layout (HostGraph::facp)
 int debug_emulate_resident(const HostGraph *h, int T, unsigned seed, double *out3);
 int ensure_stream_tables(HostGraph *h, int UL, int want, const StreamDev **out);
 bool stream_fac(const HostGraph *h, int UL);   // factored streams for groups of UL utterances?

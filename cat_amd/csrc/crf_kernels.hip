@@ -2366,10 +2366,13 @@ __device__ __forceinline__ void lds_st2(unsigned a, f32x2 v) { *(__attribute__((
 __device__ __forceinline__ unsigned addr2_lo(unsigned w, unsigned base) { unsigned r; asm("v_mad_u32_u16 %0, %1, 2, %2" : "=v"(r) : "v"(w), "s"(base)); return r; }
 __device__ __forceinline__ unsigned addr2_hi(unsigned w, unsigned base) { unsigned r; asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(r) : "v"(w), "s"(base)); return r; }
 
-template <int DIR, bool FLAG, int NCH, int NB, bool ML, bool RL>
+template <int DIR, bool FLAG, int NTH, int NCH, int NB, bool ML, bool RL>
 __device__ __forceinline__ void fac_chain_body2(const FacParams &p, float *lds, const int pair) {
-    constexpr int NTH = kFac3Threads, NW = NTH / kWave;
+    // NTH: 768 (the one-utterance kernel's 768-thread layouts as they are; 168 registers per wave -- this kernel spills there) or
+    // 512 x 30 chunks (round 5: a layout of its own, HostGraph::facp; two waves per SIMD with 256 registers each)
+    constexpr int NW = NTH / kWave;
     constexpr bool RC = !RL;
+    static_assert(NTH == kFac3Threads || (NTH == kResThreads && RL), "two utterances per workgroup: 768 threads, or 512 threads with the row table");
     constexpr int NCHA = RC ? kFac3ArcCh : NCH;
     constexpr int RCW = NCHA * 6;
     static_assert(!RC || NCH == kFac3NCH, "row constants in registers: 20 chunks of arcs + the constants' slot");
@@ -2745,12 +2748,12 @@ __global__ __launch_bounds__(NTH) void crf_fac_pair_kernel(FacParams pf, FacPara
     else fac_chain_body<1, FLAG, NTH, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - B);
 }
 // ... with TWO UTTERANCES per workgroup: 2 * ceil(B / 2) workgroups, forward recursions first
-template <bool FLAG, int NCH, int NBF, int NBB, bool ML, bool RL>
-__global__ __launch_bounds__(kFac3Threads) void crf_fac_pair2_kernel(FacParams pf, FacParams pb) {
+template <bool FLAG, int NTH, int NCH, int NBF, int NBB, bool ML, bool RL>
+__global__ __launch_bounds__(NTH) void crf_fac_pair2_kernel(FacParams pf, FacParams pb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int np = pf.npair;
-    if ((int)blockIdx.x < np) fac_chain_body2<0, FLAG, NCH, NBF, ML, RL>(pf, lds, (int)blockIdx.x);
-    else fac_chain_body2<1, FLAG, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - np);
+    if ((int)blockIdx.x < np) fac_chain_body2<0, FLAG, NTH, NCH, NBF, ML, RL>(pf, lds, (int)blockIdx.x);
+    else fac_chain_body2<1, FLAG, NTH, NCH, NBB, ML, RL>(pb, lds, (int)blockIdx.x - np);
 }
 // ... with TWO CUs per recursion: 2 * nbu * 2 workgroups for the utterances [b0, b0 + nbu), forward recursions first; the
 // two CUs of a recursion 8 block ids apart (block x is observed on XCD x % 8: one L2 for the hand-off; a matter of speed only)
@@ -4457,6 +4460,7 @@ struct WsLayout {
     int64_t xch_bytes;
     int64_t Rq, Rb;
     bool res, gv, fac;
+    int p2mode;                  // two utterances per workgroup: 0 no, 1 on the main factored layout, 2 on HostGraph::facp (pair2_mode)
     bool bat; int UL; int64_t Bp, off_ept, off_Af, off_Zb, off_bsm;   // utterance-minor layout (large graphs)
     bool gv_robust;              // the robust fallback kernels keep their vectors in global memory too
     int64_t off_gvec, off_state, state_stride, gvec_stride, off_dump, dump_stride;
@@ -4482,6 +4486,8 @@ static bool use_factored(const HostGraph *h, int64_t V) {
     return h && h->dev.fac.ok && V <= (int64_t)kEpRegsR * kResThreads &&
            std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1)) <= (size_t)160 * 1024;
 }
+
+static int pair2_mode(const HostGraph *h, int64_t B, int64_t V);
 
 // LDS of the robust fallback kernels (the larger of the two directions)
 static size_t robust_lds_bytes(const HostGraph *h, int V, bool gv) {
@@ -4510,8 +4516,10 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     { const int v = opt(kOpt_bat_ul, 0); if (v == 8 || v == 16 || v == 32 || v == 64) w.UL = v; }
     w.Bp = (B + w.UL - 1) / w.UL * w.UL;
     // (rows are at least Pr wide: the robust fallback stores them in pair order, whatever layout the fast kernels use)
-    w.Rq = h ? std::max<int64_t>(w.fac ? h->dev.fac.Rq : w.res ? h->dev.res.f.R : h->dev.Pr, h->dev.Pr) : 0;
-    w.Rb = h ? std::max<int64_t>(w.fac ? h->dev.fac.Rbp : w.res ? h->dev.res.b.R : h->dev.Pr, h->dev.Pr) : 0;
+    w.p2mode = w.fac ? pair2_mode(h, B, V) : 0;
+    const FacDev *FX = w.fac ? (w.p2mode == 2 ? &h->facp : &h->dev.fac) : nullptr;   // the factored layout this call works with
+    w.Rq = h ? std::max<int64_t>(w.fac ? FX->Rq : w.res ? h->dev.res.f.R : h->dev.Pr, h->dev.Pr) : 0;
+    w.Rb = h ? std::max<int64_t>(w.fac ? FX->Rbp : w.res ? h->dev.res.b.R : h->dev.Pr, h->dev.Pr) : 0;
     w.off_ep = o; o = al(o + B * T * V * 4);
     w.off_mx = o; o = al(o + B * T * 4);
     w.off_moff = o; o = al(o + B * T * 4);   // fused log_softmax only (crf_loss_fwd_bwd_logits)
@@ -4529,7 +4537,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_cbad = o; o = al(o + B * T * 4);   // frames of the numerator marked for the log-domain fallback
     // tagged granules [2 slots] of both directions, then one XCD-id word per CU of every recursion
     w.xch_bytes = (w.res && !w.fac && h->dev.res.K > 1) ? al((B * 2 * ((int64_t)h->dev.res.f.G + h->dev.res.b.G) + 2 * B * kResMaxK) * 8)
-                : (w.fac && h->dev.fac.K > 1) ? al((B * 2 * ((int64_t)h->dev.fac.f.G + h->dev.fac.b.G) + 2 * B * kResMaxK) * 8) : 0;
+                : (w.fac && FX->K > 1) ? al((B * 2 * ((int64_t)FX->f.G + FX->b.G) + 2 * B * kResMaxK) * 8) : 0;
     w.off_xch = o; o = al(o + w.xch_bytes + 256 + 8 * B);   // granules | error word, start counter | per-utterance progress of the two den recursions
     w.off_row0 = o; o = al(o + (w.res ? B * w.Rb * 4 : 0));
     w.off_ept = o; o = al(o + (w.bat ? T * V * w.Bp * 4 : 0));
@@ -4541,7 +4549,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.gvec_stride = h ? 3 * (int64_t)rup64(h->dev.S) + 5 * (int64_t)h->dev.Pr : 0;
     w.off_gvec = o; o = al(o + ((w.gv || w.gv_robust) ? B * w.gvec_stride * 4 : 0));
     // factored recursions launched in segments park their state vector + exponent here: [2 dir][B][stride]
-    w.state_stride = w.fac ? rup64(std::max(h->dev.fac.f.G, h->dev.fac.b.G)) + 64 : 0;
+    w.state_stride = w.fac ? rup64(std::max(FX->f.G, FX->b.G)) + 64 : 0;
     w.off_state = o; o = al(o + 2 * B * w.state_stride * 4);
     // two utterances per workgroup: one dump row per (direction, pair) for the row stores of an utterance that has ended
     w.dump_stride = w.fac ? al(std::max(w.Rq, w.Rb)) : 0;
@@ -4870,30 +4878,44 @@ static size_t fac_lds_bytes(const HostGraph *h, int V, int dir) {
            ((size_t)2 * rup64(V + 1) + 2 * nw + 2 * nw + 16) * sizeof(float);
 }
 // ... of the two-utterance kernels (fac_chain_body2): float2 state vectors and emission rows, the same row table
-static size_t fac2u_lds_bytes(const HostGraph *h, int V, int dir) {
-    const FacDev &F = h->dev.fac;
+static size_t fac2u_lds_bytes(const FacDev &F, int V, int dir) {
     const FacDirDev &L = dir == 0 ? F.f : F.b;
     const size_t table = F.rcl ? (size_t)(L.R + 64) * (dir == 0 ? 8 : 16) : (dir == 1 ? (size_t)L.R * 8 : (size_t)0);
-    return (size_t)2 * rup64(L.G) * 8 + table + (size_t)2 * rup64(V + 1) * 8 + 24 * 4 + (kFac3Threads / kWave) * 8 + 64;
+    return (size_t)2 * rup64(L.G) * 8 + table + (size_t)2 * rup64(V + 1) * 8 + 24 * 4 + (F.threads / kWave) * 8 + 64;
 }
-// Two utterances per workgroup?  For batches whose one-utterance grid (2 B workgroups) is larger than the device: switch
-// fac_pair2 = 1 forces it for any batch, 0 forbids it.  768-thread geometries on one CU per recursion only, and both vectors must fit the LDS twice over.
-static bool use_fac_pair2(const HostGraph *h, int64_t B, int64_t V, int ncu) {
+// Two utterances per workgroup?  -> 0: no; 1: on the main layout (its 768-thread geometries, as they are); 2: on the second layout
+// (HostGraph::facp, 512 threads x 30 chunks: built beside a main layout of another geometry).  Switch fac_pair2 = 1 forces it for any
+// batch, 0 forbids it.  One CU per recursion only, and both float2 vectors must fit the LDS.
+//   main layout, 768 threads (round 3): the pair kernel's frame is 3.65 us against 1.98 us for one utterance -- 126 of a thread's 168
+//   registers hold arcs, 26 - 39 dwords spill -- so it wins only where the one-utterance grid no longer fits the device at once
+//   (2 B > CUs): B = 256: 10.1 against 10.5 ms per step; B = 128: 5.9 against 5.3; B = 96: 5.7 against 4.4.
+//   second layout (round 5; 512 threads x 30 chunks, no spills inside the frame loop): the frame for two utterances is 3.25 us -- still
+//   1.9 x the one-utterance frame: with eight waves the kernel is bound by what ONE wave can issue (30 chunks x 12 instructions + two
+//   epilogues per slice, ~4.3 cycles each), not by the LDS whose gathers it halves.  Measured (metric graph, ms per step, this kernel /
+//   the one-utterance kernel; profiles/round5_ab_two_utterances_512.txt): B = 64 5.08 / 2.81, B = 96 5.18 / 3.95, B = 128 5.39 / 4.92,
+//   B = 192 7.83 / 8.77, B = 256 9.2 - 9.4 / 9.46 -- it pays where the one-utterance grid needs two rounds of the device: 2 B > CUs.
+static int pair2_mode(const HostGraph *h, int64_t B, int64_t V) {
     const FacDev &F = h->dev.fac;
     const int sw = opt(kOpt_fac_pair2, -1);
-    if (sw == 0 || !F.ok || F.K != 1 || F.threads != kFac3Threads) return false;
-    if (std::max(fac2u_lds_bytes(h, (int)V, 0), fac2u_lds_bytes(h, (int)V, 1)) > (size_t)160 * 1024) return false;
-    // Measured (B per GPU, metric graph, one box): the pair kernel's frame is 3.65 us against 1.98 us for one utterance -- its row
-    // epilogues and bookkeeping double while 126 of a thread's 168 registers hold arcs, and the compiler keeps only 4 - 8 of a batch's
-    // gathers in flight -- so it wins only where the one-utterance grid no longer fits the device at once (2 B > CUs):
-    // B = 256: 10.1 against 10.5 ms per step; B = 128: 5.9 against 5.3; B = 96: 5.7 against 4.4.
-    return sw == 1 || 2 * B > ncu;
+    if (sw == 0 || !F.ok || F.K != 1) return 0;
+    const int ncu = h->ncu > 0 ? h->ncu : 256;
+    if (h->facp.ok && std::max(fac2u_lds_bytes(h->facp, (int)V, 0), fac2u_lds_bytes(h->facp, (int)V, 1)) <= (size_t)160 * 1024 &&
+        V <= (int64_t)kEpRegsR * kResThreads) {
+        if (sw == 1 || 2 * B > ncu) return 2;
+        return 0;
+    }
+    if (F.threads != kFac3Threads) return 0;
+    if (std::max(fac2u_lds_bytes(F, (int)V, 0), fac2u_lds_bytes(F, (int)V, 1)) > (size_t)160 * 1024) return 0;
+    return (sw == 1 || 2 * B > ncu) ? 1 : 0;
 }
 #ifndef CRF_FAC4_NB
 #define CRF_FAC4_NB 2       // chunks gathered per batch by the 1024-thread kernels (3: one weight pair spills INSIDE the frame loop, behind a vmcnt(0))
 #endif
 #ifndef CRF_FAC4_NB_ML
 #define CRF_FAC4_NB_ML 2    // ... with multi-lane rows: the butterfly's registers make batches of 3 spill (V = 217: recursions 3.32 -> 3.02 ms)
+#endif
+#ifndef CRF_FAC5_NB2
+#define CRF_FAC5_NB2 4      // ... by the two-utterance kernel on 512 threads x 30 chunks (256 registers per wave: 16 ds_read_b64 = 32 registers in flight)
 #endif
 #ifndef CRF_FAC3_NB2
 #define CRF_FAC3_NB2 2      // chunks gathered per batch by the two-utterance kernels (8 ds_read_b64 = 16 registers in flight)
@@ -5023,24 +5045,38 @@ static int launch_fac_pair2(const LossParams &lp, size_t lds, hipStream_t st, in
 #define CRF_LAUNCH_RL2(NCH_, ML_, NAME_, MARK_)                                                                                 \
     {                                                                                                                           \
         static LdsMark MARK_;                                                                                                   \
-        auto *k = crf_fac_pair2_kernel<FLAG, NCH_, CRF_FAC3_NB2, CRF_FAC3_NB2, ML_, true>;                                      \
-        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true," NAME_ ",true>" : "crf_fac_pair2_kernel<false," NAME_ ",true>";       \
+        auto *k = crf_fac_pair2_kernel<FLAG, kFac3Threads, NCH_, CRF_FAC3_NB2, CRF_FAC3_NB2, ML_, true>;                        \
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,768," NAME_ ",true>" : "crf_fac_pair2_kernel<false,768," NAME_ ",true>"; \
         if ((rc = ensure_lds((const void *)k, lds, MARK_, "fac pair2"))) return rc;                                             \
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);                                                       \
     }
+#define CRF_LAUNCH_P512(ML_, NAME_, MARK_)                                                                                      \
+    {                                                                                                                           \
+        static LdsMark MARK_;                                                                                                   \
+        auto *k = crf_fac_pair2_kernel<FLAG, kResThreads, kResNCH, CRF_FAC5_NB2, CRF_FAC5_NB2, ML_, true>;                      \
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,512,30," NAME_ ",true>" : "crf_fac_pair2_kernel<false,512,30," NAME_ ",true>"; \
+        if ((rc = ensure_lds((const void *)k, lds, MARK_, "fac pair2"))) return rc;                                             \
+        hipLaunchKernelGGL(k, grid, dim3(kResThreads), lds, st, pf, pb);                                                        \
+    }
+    if (F.threads == kResThreads) {   // the second layout (HostGraph::facp): 512 threads x 30 chunks, row table, implicit entries
+        if (!F.imp || !F.rcl) { set_error("two-utterance kernel on 512 threads: not the second layout"); return CRF_ERR_ARG; }
+        if (!ml) CRF_LAUNCH_P512(false, CRF_STR(CRF_FAC5_NB2) "," CRF_STR(CRF_FAC5_NB2) ",false", mp512n)
+        else CRF_LAUNCH_P512(true, CRF_STR(CRF_FAC5_NB2) "," CRF_STR(CRF_FAC5_NB2) ",true", mp512m)
+    } else
     if (F.rcl == 1 && !ml) CRF_LAUNCH_RL2(kFac3ArcCh, false, "20," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false", mp20n)
     else if (F.rcl == 1) CRF_LAUNCH_RL2(kFac3ArcCh, true, "20," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true", mp20m)
     else if (F.rcl == 2 && !ml) CRF_LAUNCH_RL2(kFac3LNCH, false, "21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false", mp21n)
     else if (F.rcl == 2) CRF_LAUNCH_RL2(kFac3LNCH, true, "21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true", mp21m)
 #undef CRF_LAUNCH_RL2
+#undef CRF_LAUNCH_P512
     else if (ml) {
-        auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, true, false>;
-        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,false>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,false>";
+        auto *k = crf_fac_pair2_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, true, false>;
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,768,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,false>" : "crf_fac_pair2_kernel<false,768,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",true,false>";
         if ((rc = ensure_lds((const void *)k, lds, m2m, "fac pair2"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     } else {
-        auto *k = crf_fac_pair2_kernel<FLAG, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, false, false>;
-        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,false>" : "crf_fac_pair2_kernel<false,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,false>";
+        auto *k = crf_fac_pair2_kernel<FLAG, kFac3Threads, kFac3NCH, CRF_FAC3_NB2, CRF_FAC3_NB2, false, false>;
+        g_den_kernel = FLAG ? "crf_fac_pair2_kernel<true,768,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,false>" : "crf_fac_pair2_kernel<false,768,21," CRF_STR(CRF_FAC3_NB2) "," CRF_STR(CRF_FAC3_NB2) ",false,false>";
         if ((rc = ensure_lds((const void *)k, lds, m2, "fac pair2"))) return rc;
         hipLaunchKernelGGL(k, grid, dim3(kFac3Threads), lds, st, pf, pb);
     }
@@ -5121,9 +5157,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     size_t lds_chain = 0;
     if (den && !res && !bat) lds_chain = std::max(chain_lds_bytes(h, (int)V, Sc, 0, gv), chain_lds_bytes(h, (int)V, Sc, 1, gv));
     if (res && !fac) lds_chain = std::max(res_lds_bytes(h, (int)V, 0, h->res_rows_cu_f), res_lds_bytes(h, (int)V, 1, h->res_rows_cu_b));
-    if (fac) lds_chain = std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1));
+    if (fac) lds_chain = w.p2mode ? std::max(fac2u_lds_bytes(w.p2mode == 2 ? h->facp : h->dev.fac, (int)V, 0), fac2u_lds_bytes(w.p2mode == 2 ? h->facp : h->dev.fac, (int)V, 1))
+                                  : std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1));
     if (ctc) lds_chain = std::max(lds_chain, chain_lds_bytes(h, (int)V, Sc, 2));
-    const int gnc_all = den ? std::max(std::max(h->dev.NC, h->dev.res.NC), h->dev.fac.ok ? h->dev.fac.NC : 0) : 0;
+    const int gnc_all = den ? std::max(std::max(h->dev.NC, h->dev.res.NC), std::max(h->dev.fac.ok ? h->dev.fac.NC : 0, h->facp.ok ? h->facp.NC : 0)) : 0;
     // the generic grad kernel stages the two rows of a frame in LDS when they fit, else gathers them from L2
     const bool grad_stage = !den || bat || ((size_t)rup64((int)w.Rq) + rup64((int)w.Rb) + rup64(gnc_all) + 2 * (size_t)rup64((int)V)) * 4 <= 150 * 1024;
     const size_t lds_grad = ((den && !bat && grad_stage ? (size_t)rup64((int)w.Rq) + rup64((int)w.Rb) : 0) + rup64(bat ? 0 : gnc_all) + 2 * (size_t)rup64((int)V)) * sizeof(float);
@@ -5134,6 +5171,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
 
     LossParams p{};
     if (den) p.g = h->dev;
+    // the factored layout this call works with: the main one, or -- two utterances per workgroup on 512 threads -- the second one
+    // (ws_layout has sized the rows for it); everything below reads it through p.g.fac / FX
+    const FacDev *FX = (den && w.fac) ? (w.p2mode == 2 ? &h->facp : &h->dev.fac) : nullptr;
+    if (FX) p.g.fac = *FX;
     p.logp = logp; p.labels = labels; p.lab_off = lab_off; p.lx = lx; p.ly = ly;
     p.B = (int)B; p.T = (int)T; p.V = (int)V; p.Sc = Sc;
     p.c_den = c_den; p.c_ctc = c_ctc;
@@ -5144,7 +5185,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.Q = (float *)(base + w.off_Q); p.BP = (float *)(base + w.off_BP);
     p.Rq = (int)w.Rq; p.Rb = (int)w.Rb; p.res = fac ? 2 : res ? 1 : 0; p.grad_stage = grad_stage ? 1 : 0;
     if (fac) {
-        const FacDev &F = h->dev.fac;
+        const FacDev &F = *FX;
         p.gq = F.gq; p.gb = F.gb; p.gchunk = F.chunk_off; p.glab = F.lab_chunk_off; p.gNC = F.NC;
     } else if (den) {
         p.gq = res ? h->dev.res.gq : h->dev.perm; p.gb = res ? h->dev.res.gb : h->dev.perm;
@@ -5254,8 +5295,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, cx->dev);
     // The denominator half of the grad pass has a streaming kernel (index pairs in registers, rows
     // prefetched); it needs 16-bit row indices, rows of <= kGDRowRegs*256 floats and <= 2 chunks per thread.
-    const int gnc = den ? (fac ? h->dev.fac.NC : res ? h->dev.res.NC : h->dev.NC) : 0;
-    const int gcap = fac ? h->dev.fac.chunk_cap : kChunk;       // entries per chunk of the grad pass's pair lists
+    const int gnc = den ? (fac ? FX->NC : res ? h->dev.res.NC : h->dev.NC) : 0;
+    const int gcap = fac ? FX->chunk_cap : kChunk;       // entries per chunk of the grad pass's pair lists
     const bool gd_wide = den && (w.Rq > 4 * kGDRowRegs * kGDThreads || w.Rb > 4 * kGDRowRegs * kGDThreads);   // 512-thread grad workgroups
     const bool fast_den = den && w.Rq <= 8 * kGDRowRegs * kGDThreads && w.Rb <= 8 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
                           gnc <= 4 * kGDThreads && V <= kGDEpRegs * kGDThreads && !opt_on(kOpt_no_fast_grad);
@@ -5279,9 +5320,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const int stages_env = opt(kOpt_stages, 0);
     const int pieces = stages_env > 0 ? stages_env : (segmode ? 4 : 12);   // measured: 4 / 8 / 12 pieces -> call 4.06 / 3.98 / 3.93 ms (flags)
     // two utterances per workgroup (use_fac_pair2): the den grid is 2 * ceil(B / 2) workgroups instead of 2 B
-    const bool pair2 = fac && !segmode && use_fac_pair2(h, B, V, ncu_dev);   // (no segment relaunches in that kernel)
+    const bool pair2 = fac && w.p2mode != 0;   // (pair2_mode, decided with the workspace layout: the rows are sized for the layout it names)
     const int64_t den_wgs = pair2 ? 2 * ((B + 1) / 2) : 2 * B;
-    const bool staged = fac && h->dev.fac.K == 1 && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && den_wgs * 100 <= (int64_t)ncu_dev * opt(kOpt_stage_fill, 75);   // (B = 80: 4.16 -> 3.56 ms, B = 96: 4.37 -> 4.26, B = 112 at 90 %: 5.33 -> 5.57)
+    // (the two-utterance kernel has no segment relaunches: where stream-level waits are refused it runs unstaged)
+    const bool staged = fac && FX->K == 1 && ctc && fast_den && fast_ctc && !serial && !no_overlap && have_flags && !(pair2 && segmode) && den_wgs * 100 <= (int64_t)ncu_dev * opt(kOpt_stage_fill, 75);   // (B = 80: 4.16 -> 3.56 ms, B = 96: 4.37 -> 4.26, B = 112 at 90 %: 5.33 -> 5.57)
     // Stage bounds.  Nothing can be released before the two recursions have met, so the first stage ends at half of
     // the frames or later; after that a piece of `piece` iterations releases 2 * piece / 16 frame blocks per
     // utterance.  The grad pass has half of the chip and is bandwidth-bound there (~2 TB/s against the 2.2 TB/s the
@@ -5318,7 +5360,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     p.gd_nb = nstage + 1;
     for (int k = 0; k <= nstage && k < 16; ++k) p.gd_bound[k] = bound[k];
     float *fstate = (float *)(base + w.off_state), *bstate = fstate + B * w.state_stride;
-    const size_t lds_fac = !fac ? 0 : pair2 ? std::max(fac2u_lds_bytes(h, (int)V, 0), fac2u_lds_bytes(h, (int)V, 1))
+    const size_t lds_fac = !fac ? 0 : pair2 ? std::max(fac2u_lds_bytes(*FX, (int)V, 0), fac2u_lds_bytes(*FX, (int)V, 1))
                                               : std::max(fac_lds_bytes(h, (int)V, 0), fac_lds_bytes(h, (int)V, 1));
     const size_t lds_ctc = chain_lds_bytes(h, (int)V, Sc, 2);
 
@@ -5419,8 +5461,8 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     auto launch_den = [&](hipStream_t st) -> int {
         prof_mark(1, false, st); prof_mark(2, false, st);
         int r2 = CRF_OK;
-        const CoresGuard cores((fac && h->dev.fac.K > 1) || (res && !fac && h->dev.res.K > 1), cx->dev, st);
-        if (fac && h->dev.fac.K > 1) {
+        const CoresGuard cores((fac && FX->K > 1) || (res && !fac && h->dev.res.K > 1), cx->dev, st);
+        if (fac && FX->K > 1) {
             const int grp = std::max(1, ncu_dev / 4);
             for (int b0 = 0; b0 < (int)B && !r2; b0 += grp) r2 = launch_fac2_pair(p, lds_fac, st, b0, std::min(grp, (int)B - b0));
         } else if (fac && pair2) {
@@ -5611,7 +5653,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         const int ctc_after_env = opt(kOpt_ctc_after, -1);
         // (factored, one CU per recursion: the den grid leaves ncu - den_wgs CUs free -- B = 96: 64 of them -- and the numerator
         // chains, four workgroups to a CU, run there beside it, behind the start gate so that the den workgroups get their CUs first)
-        const bool fac1 = fac && h->dev.fac.K == 1;
+        const bool fac1 = fac && FX->K == 1;
         const bool after = ctc_after_env >= 0 ? ctc_after_env != 0 : fac1 ? den_wgs >= ncu_dev : (res && h->dev.res.K > 1);
         if (!after && fac1 && have_flags) {
             if ((rc = fork_side())) return rc;

@@ -1055,6 +1055,7 @@ int compile_graph(int64_t S, int64_t A, const int32_t *src, const int32_t *dst, 
     }
     auto *h = new HostGraph();
     h->device = device; h->S = S; h->A = A; h->P = P; h->regauged = regauged ? 1 : 0;
+    if (device >= 0) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) h->ncu = n; else (void)hipGetLastError(); }
     h->fwd_padded_arcs = fe.padded_arcs; h->bwd_padded_arcs = be.padded_arcs;
     h->fwd_conflicts = fe.conflict_cycles; h->bwd_conflicts = be.conflict_cycles;
     for (auto &r : frows) h->max_in_deg = std::max(h->max_in_deg, (int)r.size());
@@ -1175,7 +1176,7 @@ int crf_graph_dims(const crf_graph *g, int64_t *S, int64_t *A, int64_t *P, int64
 int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
     if (!g || !g->h || !out) { crf::set_error("null argument"); return CRF_ERR_ARG; }
     const crf::HostGraph *h = g->h;
-    const int64_t v[26] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
+    const int64_t v[27] = {h->S, h->A, h->P, h->dev.Pr, h->dev.Sr, h->fwd_padded_arcs, h->bwd_padded_arcs,
                            h->fwd_conflicts, h->bwd_conflicts, (int64_t)h->max_in_deg * 100000 + h->max_out_deg,
                            h->res_stats.K, h->res_stats.slots_f, h->res_stats.slots_b, h->res_stats.conflicts_f,
                            h->res_stats.conflicts_b, (int64_t)h->dev.res.f.R * 100000 + h->dev.res.b.R,
@@ -1183,8 +1184,9 @@ int crf_graph_stats(const crf_graph *g, int64_t *out, int n) {
                            h->fac_stats.slots_f, h->fac_stats.slots_b, h->fac_stats.fused,
                            h->fac_stats.Gf * 100000 + h->fac_stats.Gb,
                            h->fac_stats.ok ? (h->dev.fac.threads == crf::kFac4Threads ? (h->dev.fac.K > 1 ? 5 : 4) : h->dev.fac.threads != crf::kFac3Threads ? 2 : h->dev.fac.K > 1 ? 3 : h->dev.fac.rcl ? 1 : 0) : -1,
-                           h->fac_stats.ok ? (h->dev.fac.threads == crf::kFac4Threads ? crf::kFac4NCH : h->dev.fac.threads != crf::kFac3Threads ? crf::kResNCH : h->dev.fac.rcl == 2 ? crf::kFac3LNCH : crf::kFac3ArcCh) : 0};
-    for (int i = 0; i < n && i < 26; ++i) out[i] = v[i];
+                           h->fac_stats.ok ? (h->dev.fac.threads == crf::kFac4Threads ? crf::kFac4NCH : h->dev.fac.threads != crf::kFac3Threads ? crf::kResNCH : h->dev.fac.rcl == 2 ? crf::kFac3LNCH : crf::kFac3ArcCh) : 0,
+                           h->facp.ok};
+    for (int i = 0; i < n && i < 27; ++i) out[i] = v[i];
     return CRF_OK;
 }
 
@@ -1192,7 +1194,7 @@ int crf_debug_decode_check(int nslot, int ncombo) { return crf::debug_check_deco
 
 int crf_debug_fac_emulate(const crf_graph *g, int T, unsigned seed, double *out3) {
     if (!g || !g->h || !out3 || T < 1) { crf::set_error("bad argument"); return CRF_ERR_ARG; }
-    return crf::debug_emulate_factored(g->h, T, seed, out3);
+    return crf::debug_emulate_factored(g->h, T, seed, out3, crf::opt_on(crf::kOpt_emu_facp) ? 1 : 0);
 }
 
 int crf_debug_res_emulate(const crf_graph *g, int T, unsigned seed, double *out3) {

@@ -39,6 +39,10 @@ constexpr Geom kGeomFac3L21{kFac3Threads, kFac3Threads / kWave, kFac3LNCH, kFac3
 // 1024 threads (four waves per SIMD at <= 128 VGPRs), 15 chunks of arcs per thread, row constants in the LDS table: as many arc
 // slots as 768 x 20, and as many registers per wave left beside the arcs (128 - 90 against 168 - 126)
 constexpr Geom kGeomFac4L{kFac4Threads, kFac4Threads / kWave, kFac4NCH, kFac4NCH * 6, 10, 1};
+// 512 threads x 30 chunks with the row constants in the LDS table and implicit entries: the TWO-UTTERANCE kernel's layout (level 6,
+// HostGraph::facp).  Two waves per SIMD own 256 registers each: 180 hold arcs, and what a second set of accumulators, 8-byte gather
+// results and two epilogues need fits beside them -- the 768-thread version of that kernel (168 registers) spilled 26 - 39 dwords.
+constexpr Geom kGeomFac512L{kResThreads, kResWaves, kResNCH, kResWords, 10, 1};
 
 struct DirOut {
     std::vector<unsigned> arcs;   // [K][kResWords][kResThreads]
@@ -303,7 +307,19 @@ static bool place_rows_sized(const Rows &rows, const std::vector<int> &row_cu, i
     return true;
 }
 bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut *o, std::vector<SliceAt> *slices, const Geom &gm = kGeomRes) {
-    if (!place_rows_sized(rows, row_cu, K, o, slices, gm)) return false;
+    if (!place_rows_sized(rows, row_cu, K, o, slices, gm)) {
+        // Eight waves of 30 chunks (the two-utterance kernel's geometry) pack worse than sixteen of 15: a row of 16 - 30 chunks fits a lane
+        // and makes a slice as long as a whole wave.  Cut such rows too (pieces of half a lane and less), as the 1024-thread geometry has to.
+        if (!(gm.multilane && gm.maxsl && gm.nch >= 2 * kFac4NCH && opt(kOpt_res_piece, 0) <= 0)) return false;
+        bool have = false;
+        for (int piece : {gm.nch / 2, gm.nch * 2 / 5, gm.nch / 3, gm.nch / 4}) {
+            DirOut cand;
+            std::vector<SliceAt> cs;
+            if (!place_rows_piece(rows, row_cu, K, &cand, &cs, gm, piece, true)) continue;
+            if (!have || cand.simd_cost < o->simd_cost) { *o = std::move(cand); *slices = std::move(cs); have = true; }
+        }
+        return have;
+    }
     // SMALL graphs (fewer slices than waves: most waves of the workgroup would have no rows at all while a few walk 10 - 15
     // chunks one batch after the other -- S = 513: 5 slices on 16 waves, 1.15 us per frame of which the arcs need a quarter):
     // cut the rows into 2 or 4 pieces on adjacent lanes although they would fit one, so that every wave has a short list.
@@ -1006,7 +1022,8 @@ static std::vector<int> deal_rows(const Rows &rows, int K) {
 static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int> &pair_dst, const std::vector<int> &pair_lab,
                                const Rows &in_arcs_of_pair, const Rows &out_arcs_of_state, const std::vector<float> &start_lin,
                                const std::vector<float> &end_lin, int level, bool *retry_next, int dup_mask, int *new_mask, bool short_only = false, bool *long_bail = nullptr, int K = 1) {
-    FacDev &F = h->dev.fac;
+    const bool second = level == 6;                          // the two-utterance kernel's layout: HostGraph::facp / fhp
+    FacDev &F = second ? h->facp : h->dev.fac;
     F = FacDev{};
     if (opt_on(kOpt_no_factored) || opt_on(kOpt_no_resident)) return CRF_OK;
     const bool verbose = opt_on(kOpt_verbose);
@@ -1094,9 +1111,9 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     // Geometry: 768 threads (3 waves per SIMD at <= 168 VGPRs; 20 chunks of arcs and the constants of up to 3 rows per
     // thread) when both directions fit it, else 512 threads x 30 chunks (2 waves per SIMD); CRF_FAC_THREADS=512 forces
     // the latter.
-    const bool lvl_table = level == 1 || level == 3 || level == 4;   // row constants in the LDS table: 20 chunks of arcs per thread (1) or 21 (3)
-    const Geom *gm = level == 0 ? &kGeomFac3 : level == 1 ? &kGeomFac3L : level == 3 ? &kGeomFac3L21 : level == 4 ? &kGeomFac4L : &kGeomFac512;
-    const bool allow3 = level != 2;               // a larger geometry is left to try
+    const bool lvl_table = level == 1 || level == 3 || level == 4 || level == 6;   // row constants in the LDS table: 20 chunks of arcs per thread (1) or 21 (3)
+    const Geom *gm = level == 0 ? &kGeomFac3 : level == 1 ? &kGeomFac3L : level == 3 ? &kGeomFac3L21 : level == 4 ? &kGeomFac4L : level == 6 ? &kGeomFac512L : &kGeomFac512;
+    const bool allow3 = level != 2 && level != 6; // a larger geometry is left to try
     const bool rcregs = level == 0;               // row constants in registers
     const bool implicit = gm->maxsl > 0;   // entries numbered by row id, row constants in registers (below)
     // entries (512-thread layout): [U of every pair][sink][L of every pair][A of every pair][plain states]
@@ -1436,7 +1453,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     arrange_grad_pairs(&gq, &gb, gchunk, &gcb, &gca);
     if (verbose) fprintf(stderr, "[fac_layout] grad pass: LDS cycles per frame for the pair gathers %lld as listed, %lld arranged (%d chunks)\n", (long long)gcb, (long long)gca, (int)gchunk.size() - 1);
 
-    h->fac_stats = FacBuildStats{0, nmatched, nsolo, (int64_t)tail_rows.size(), fo.slots, bo.slots, nfused, Gf, Gb};   // (ok: set with F.ok below)
+    if (!second) h->fac_stats = FacBuildStats{0, nmatched, nsolo, (int64_t)tail_rows.size(), fo.slots, bo.slots, nfused, Gf, Gb};   // (ok: set with F.ok below)
     if (verbose)
         fprintf(stderr, "[fac_layout] matched pairs %lld, solo slots %lld, tail rows %zu (NT=%d), fwd rows %d slots %lld (extra LDS cycles %lld), bwd rows %d (fused %lld) slots %lld (extra %lld), Gf=%d Gb=%d\n",
                 (long long)nmatched, (long long)nsolo, tail_rows.size(), NT, Rf, (long long)fo.slots, (long long)fo.conflicts, Rb, (long long)nfused, (long long)bo.slots, (long long)bo.conflicts, Gf, Gb);
@@ -1445,8 +1462,9 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         // kernel families, crf_kernels.hip use_factored).  Too much with the second copy of the gathered entries: build that
         // direction again without it.  (level 1: the forward table has 8 bytes per row, and both have 64 rows of slack.)
         const int V0 = std::max(max_lab + 1, 256);
-        const size_t tail = ((size_t)2 * ((V0 + 1 + 63) / 64 * 64) + 4 * (size_t)gm->waves + 16) * 4 + 256;
-        auto need = [&](int G, int R, int rb) { return (size_t)2 * ((G + 63) / 64 * 64) * 4 + (size_t)(R + (lvl_table ? 64 : 0)) * rb + tail; };
+        const size_t esz = second ? 8 : 4;        // (the two-utterance kernel keeps float2 state vectors and emission rows: fac2u_lds_bytes)
+        const size_t tail = ((size_t)2 * ((V0 + 1 + 63) / 64 * 64) + 4 * (size_t)gm->waves + 16) * esz + 256;
+        auto need = [&](int G, int R, int rb) { return (size_t)2 * ((G + 63) / 64 * 64) * esz + (size_t)(R + (lvl_table ? 64 : 0)) * rb + tail; };
         auto cu_rows = [&](const DirOut &o) { int m = 0; for (int k = 0; k < K; ++k) m = std::max(m, o.cu_row_off[(size_t)k + 1] - o.cu_row_off[(size_t)k]); return m; };   // (two CUs: a CU's table holds its own rows)
         const bool f_ok = need(Gf, K > 1 ? cu_rows(fo) : Rf, lvl_table ? 8 : 16) <= (size_t)160 * 1024, b_ok = need(Gb, K > 1 ? cu_rows(bo) : Rb, 16) <= (size_t)160 * 1024;
         if (!f_ok || !b_ok) {
@@ -1462,7 +1480,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     for (auto &wi : fo.wave_info) if (wi.w) F.multilane = 1;
     for (auto &wi : bo.wave_info) if (wi.w) F.multilane = 1;
     F.f.R = Rf; F.f.G = Gf; F.b.R = Rb; F.b.G = Gb; F.f.dup = fdup * 4; F.b.dup = bdup * 4;
-    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.chunk_cap = cap; F.threads = gm->threads; F.rcl = level == 1 ? 1 : level == 3 ? 2 : level == 4 ? 1 : 0; F.K = K;
+    F.NT = NT; F.Rq = Rq; F.Rbp = 2 * Rb; F.NC = (int)gchunk.size() - 1; F.chunk_cap = cap; F.threads = gm->threads; F.imp = implicit ? 1 : 0; F.rcl = level == 1 ? 1 : level == 3 ? 2 : (level == 4 || level == 6) ? 1 : 0; F.K = K;
     for (int k = 0; k < 3; ++k) F.xlist_off[k] = xlist_off[k];
     for (int k = 0; k <= 2; ++k) { F.f.cu_row[k] = fo.cu_row_off[(size_t)std::min(k, K)]; F.b.cu_row[k] = bo.cu_row_off[(size_t)std::min(k, K)]; }
     int rc;
@@ -1474,8 +1492,8 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         (rc = up(h, gchunk, &F.chunk_off)) || (rc = up(h, glab, &F.lab_chunk_off)) || (rc = up(h, xlist, &F.xlist)))
         return rc;
     F.ok = 1;
-    h->fac_stats.ok = 1;
-    FacHostCopy &C = h->fh;
+    if (!second) h->fac_stats.ok = 1;
+    FacHostCopy &C = second ? h->fhp : h->fh;
     C.farcs = fo.arcs; C.barcs = bo.arcs; C.fwi = fo.wave_info; C.bwi = bo.wave_info; C.frow_meta = frow_meta; C.brow_meta = brow_meta;
     C.x_start = x_start; C.x_end = x_end; C.z_end = z_end; C.brow_start = brow_start; C.brow_end = brow_end; C.bx_w = bx_w;
     C.start_lin = start_lin; C.end_lin = end_lin; C.z_lab = z_lab; C.bx_idx = bx_idx; C.xlist = xlist; C.words = gm->words;
@@ -1529,6 +1547,19 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
         }
         if (rc != CRF_OK || !retry) break;
     }
+    // The two-utterance kernel's own layout (512 threads x 30 chunks, table, implicit entries) beside a main layout on one CU per
+    // recursion that is not a 768-thread one (those the two-utterance kernel takes as they are).  Does not fit / no structure: facp.ok = 0.
+    h->facp = FacDev{};
+    if (rc == CRF_OK && h->dev.fac.ok && h->dev.fac.K == 1 && h->dev.fac.threads != kFac3Threads && !opt_on(kOpt_no_facp) && thr != 512) {
+        bool retry = false;
+        int mask = 3, nm = 3;
+        for (;;) {
+            rc = build_factored_impl(h, S, P, pair_dst, pair_lab, in_arcs_of_pair, out_arcs_of_state, start_lin, end_lin, 6, &retry, mask, &nm, false, nullptr, 1);
+            if (rc != CRF_OK || retry || nm == mask) break;
+            mask = nm;
+        }
+        if (opt_on(kOpt_verbose)) fprintf(stderr, "[fac_layout] second layout (two utterances per workgroup, 512 x 30): %s\n", h->facp.ok ? "built" : "not available");
+    }
     return rc;
 }
 
@@ -1540,14 +1571,14 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
 // NaN, so a gather of an entry that never crosses poisons the result).  fp64, no rescaling, random emissions, T frames.
 // out3 = {plain forward sum over the graph's own tables, factored forward, factored backward}; they must agree.
 static double plain_forward(const HostGraph *h, const std::vector<std::vector<double>> &e);
-int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out3) {
-    const FacDev &F = h->dev.fac;
-    const FacHostCopy &C = h->fh;
+int debug_emulate_factored(const HostGraph *h, int T, unsigned seed, double *out3, int which) {
+    const FacDev &F = which ? h->facp : h->dev.fac;
+    const FacHostCopy &C = which ? h->fhp : h->fh;
     out3[0] = out3[1] = out3[2] = 0.0;
     if (!F.ok || C.words == 0) { set_error("no factored layout"); return CRF_ERR_UNSUPPORTED; }
     auto fail = [&](const std::string &why) { set_error("factored layout emulation: " + why); return CRF_ERR_ARG; };
     const int S = (int)h->S, V = h->dev.max_label + 1, NTH = F.threads, NW = NTH / kWave, K = F.K, words = C.words;
-    const bool implicit = NTH != kResThreads, rcregs = implicit && !F.rcl;
+    const bool implicit = F.imp != 0, rcregs = implicit && !F.rcl;
     uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
     auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return 0.5 + (double)(rng % 1000003) / 1000003.0; };
     std::vector<std::vector<double>> e((size_t)T, std::vector<double>((size_t)V + 1, 0.0));   // e[t][V] = 0: "no label"

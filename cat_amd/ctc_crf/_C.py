@@ -199,11 +199,11 @@ def graph_dims(handle: int):
 
 
 def graph_stats(handle: int):
-    buf = (_i64 * 26)()
-    _check(_lib.crf_graph_stats(_vp(handle), buf, 26))
+    buf = (_i64 * 27)()
+    _check(_lib.crf_graph_stats(_vp(handle), buf, 27))
     k = ("S", "A", "P", "Pr", "Sr", "fwd_ell_arcs", "bwd_ell_arcs", "fwd_bank_conflicts", "bwd_bank_conflicts", "deg",
          "res_K", "res_fwd_slots", "res_bwd_slots", "res_fwd_bank_conflicts", "res_bwd_bank_conflicts", "res_rows",
-         "fac", "fac_matched_pairs", "regauged", "fac_tail_rows", "fac_fwd_slots", "fac_bwd_slots", "fac_fused_rows", "fac_G", "fac_geom", "fac_chunks")
+         "fac", "fac_matched_pairs", "regauged", "fac_tail_rows", "fac_fwd_slots", "fac_bwd_slots", "fac_fused_rows", "fac_G", "fac_geom", "fac_chunks", "facp")
     d = dict(zip(k, [int(x) for x in buf]))
     d["max_in_deg"], d["max_out_deg"] = d["deg"] // 100000, d.pop("deg") % 100000
     d["res_fwd_rows"], d["res_bwd_rows"] = d["res_rows"] // 100000, d.pop("res_rows") % 100000

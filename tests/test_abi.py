@@ -297,6 +297,62 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
         assert g >= 0 and agree(r), (env, g, r)
 
 
+def test_second_layout_for_two_utterances_emulated_on_the_host(tmp_path, golden_dir):
+    """Round 5: beside a 1024-thread main layout the graph compiler builds a SECOND factored layout -- 512 threads x 30 chunks, row
+    constants in the LDS table, implicit entries (HostGraph::facp) -- for the two-utterance kernel (crf_fac_pair2_kernel<.., 512, 30, ..>:
+    256 registers per wave instead of the 168 its 768-thread version spills at).  It has its own rows, entries and grad-pass lists;
+    the same emulation (switch emu_facp) walks it: forward / backward sums = the plain recursion, pair lists = the path mass.  Graphs
+    whose main layout is a 768-thread one or lies on two CUs get none (the two-utterance kernel takes 768-thread layouts as they are)."""
+    import math
+    import ctc_crf
+    from cat_amd import den_lm
+    core = ctc_crf._C
+
+    def emu(path, T=4, **env):
+        with crf_env(**env):
+            h = core.compile_graph_host_only(path)
+            st = core.graph_stats(h)
+            r = None
+            if st["facp"]:
+                with crf_env(CRF_EMU_FACP=1):
+                    r = core.debug_fac_emulate(h, T, 11)
+            core._lib.crf_graph_destroy(ctypes.c_void_p(h))
+            return st, r
+
+    def agree(r):
+        return all(math.isfinite(x) and x > 0 for x in r) and abs(r[1] - r[0]) <= 1e-9 * r[0] and abs(r[2] - r[0]) <= 1e-6 * r[0]
+
+    small = os.path.join(str(tmp_path), "small.fst")
+    synth_den_lm(24, 96, 8, seed=13, path=small)
+    bench = os.path.join(str(tmp_path), "bench.fst")
+    synth_den_lm(72, 2048, 24, seed=0, path=bench)
+    v217 = os.path.join(str(tmp_path), "v217.fst")
+    synth_den_lm(217, 2048, 24, seed=0, path=v217)
+    rng = np.random.default_rng(5)
+    V = 40
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(1200):
+        L, sq, a, b = int(rng.integers(8, 30)), [], 0, 0
+        for _ in range(L):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
+        seqs.append(sq)
+    est = os.path.join(str(tmp_path), "est.fst")
+    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150)                   # multi-lane rows
+    for path in (small, os.path.join(golden_dir, "den_lm_fixture.fst"), bench, v217, est):
+        st, r = emu(path, T=3 if path in (bench, v217) else 4)
+        assert st["fac_geom"] == 4 and st["facp"] == 1 and agree(r), (path, st["fac_geom"], st["facp"], r)
+        st, r = emu(path, T=3, CRF_FAC_NO_DUP=1)
+        assert st["facp"] == 1 and agree(r), (path, r)
+    for env in ({"CRF_FAC_THREADS": 768}, {"CRF_FAC_K2": 1}, {"CRF_NO_FACP": 1}, {"CRF_FAC_THREADS": 512}):
+        st, r = emu(small, **env)
+        assert st["facp"] == 0 and r is None, env
+    mid = os.path.join(str(tmp_path), "mid.fst")
+    synth_den_lm(72, 3072, 24, seed=0, path=mid)                  # two CUs per recursion: no second layout
+    st, r = emu(mid)
+    assert st["fac_geom"] == 3 and st["facp"] == 0
+
+
 def test_generic_resident_layout_emulated_on_the_host(tmp_path, golden_dir):
     """crf_debug_res_emulate: the generic register-resident layout (any graph that fits K <= 4 compute units: pair rows forward,
     state copies backward, long rows split into sub-rows with virtual copies of their entry, one produced entry per row) walked
