@@ -356,6 +356,7 @@ void set_error(const std::string &msg);
     X(no_side_stream,   "X  no side stream for this context")                                                                \
     X(trust_side,       "X  take a side stream without probing that it runs beside the caller's (profiler counter passes)")  \
     X(side_kind,        "X  side stream candidates of one kind only: 1 plain, 2 high priority, 3 low priority, 4 CU-masked")  \
+    X(grad_par3,        "C  staged schedule: 1 = the den half of the grad pass on the third stream beside the numerator half (atomic adds into zeroed rows; measured slower, default 0)") \
     X(aux_stream,       "C  numerator fallback chains on the third stream: 1 always, 0 never (default: when a recent call needed them)")  \
     X(no_aux_stream,    "X  no third stream for this context (numerator fallback chains in front of the grad stages)")      \
     X(no_facp,          "G  no second (512-thread) factored layout for the two-utterance kernel")                            \

@@ -43,6 +43,14 @@ constexpr int kCtcRegs = 8;   // ctc states per thread                  -> 2L+1 
 constexpr int kCtcPF = 4;     // frames per emission prefetch batch (ctc_forward)
 constexpr int kGradThreads = 256;
 constexpr int kGradFrames = 4;  // frames per crf_grad_kernel workgroup
+// The streaming grad kernels normalise every frame by its own sum, so the power of two they take out of e' * sum(q * b) is free -- and must
+// leave the product in range at BOTH ends: the label sums sit at ~2^40 (two rows rescaled to 2^20; up to 2^55 for a label with thousands of
+// pairs), e' = exp(logp - rowmax) * 2^64 reaches down to 2^-125.  Rounds 1 - 4 took out 2^-64 ("undo the emissions' factor"): a frame whose
+// ALLOWED labels all lie 100 - 131 nats below the row maximum -- the recursions carry it, nothing is flagged -- then had e' * 2^-64 * 2^40
+// below the smallest normal float and came out with zero or garbage posteriors, silently (found in round 5 by
+// tests/test_gpu_parity.py::test_single_frame_shrink_window[110]: gradient 90 % off, loss right).  2^-4: the product stays normal wherever
+// e' itself is, and 2^64 * 2^55 * 2^-4 < 2^127 at the other end.
+constexpr int kGradDescale = 4;
 constexpr int kFlagFallback = 40;   // words [40], [41] behind the error word: utterances of the last call redone by the denominator / numerator fallback (crf_finalize_kernel)
 
 // ---- build-time A/B switches of the frame loops (the defaults are the measured best: DESIGN.md section 2, profiles/round4_ab_*) ----
@@ -114,8 +122,11 @@ struct LossParams {
     int gd_stage, gd_nb;          // crf_grad_den_kernel: process only the 16-frame blocks completed by den segment `gd_stage` (0 = all)
     int gd_nf;                    // > 0: the launch holds only 2 * gd_nf candidate blocks per utterance (see the kernel)
     int gd_bound[16];             //   segment k (1-based) runs the recursion iterations [gd_bound[k-1], gd_bound[k])
-    int grad_den_acc;             // crf_grad_den_kernel: add to the row (the numerator half has written it) instead of writing
+    int grad_den_acc;             // crf_grad_den_kernel: 1 = add to the row (the numerator half has written it) instead of writing; 2 = atomic add into a
+                                  // row the prep kernel has zeroed (the numerator half adds its part from ANOTHER stream at the same time)
+    int zero_grad;                // crf_prep_kernel: zero the gradient rows (the two halves of the grad pass then ADD, in any order)
     int grad_phase;               // crf_grad_kernel: 0 = den and ctc in one pass, 1 = den part only (writes), 2 = ctc part only (subtracts)
+                                  // (crf_grad_ctc_kernel: 0 writes, 2 subtracts from the row, 3 = atomic add into a zeroed row)
     int b0;                       // first utterance of this launch (resident kernels with K > 1 run in groups)
     unsigned long long *xch;      // [2][B][2][G] tagged granules for the K-way exchange of the state vector
     float *cb_part;               // [B][kResMaxK] partial backward partition sums
@@ -340,6 +351,10 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     const int64_t f = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
     if (f >= (int64_t)p.B * p.T) return;
     const int b = (int)(f / p.T), t = (int)(f % p.T);
+    if (p.zero_grad) {                            // (every frame, the ones past the utterance's length too)
+        float *gr = p.grad + f * p.V;
+        for (int v = sub; v < p.V; v += G) gr[v] = 0.f;
+    }
     if (t >= p.lx[b]) return;                     // (whole groups of G lanes leave together)
     auto gmax = [](float v) {
 #pragma unroll
@@ -3034,11 +3049,11 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             if constexpr (GDM) {   /* clamped, not predicated (every use is behind v < V): the loads write the loop registers themselves */ \
                 const int v = min(tid + q * NT, V - 1);                                                  \
                 ern[q] = er_[v];                                                                         \
-                if (p.grad_den_acc) rwn[q] = gr_[v];   /* (else: stays 0) */                             \
+                if (p.grad_den_acc == 1) rwn[q] = gr_[v];   /* (else: stays 0) */                        \
             } else {                                                                                     \
                 const int v = tid + q * NT;                                                              \
                 ern[q] = v < V ? er_[v] : 0.f;                                                           \
-                rwn[q] = (p.grad_den_acc && v < V) ? gr_[v] : 0.f;                                       \
+                rwn[q] = (p.grad_den_acc == 1 && v < V) ? gr_[v] : 0.f;                                  \
             }                                                                                            \
         }                                                                                                \
     }
@@ -3116,7 +3131,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
                 const int v = tid + q * NT;
-                u[q] = v < V ? (erc[q] * pow2f(-kEpExp)) * gsum[v] : 0.f;
+                u[q] = v < V ? (erc[q] * pow2f(-kGradDescale)) * gsum[v] : 0.f;
                 part += u[q];
             }
             part = wave_sum(part);
@@ -3130,7 +3145,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
                 const int v = tid + q * NT;
-                if (v < V) row[v] = rwc[q] + u[q] * inv;   // rwc = 0 unless accumulating onto the numerator half
+                if (v < V) { if (p.grad_den_acc == 2) unsafeAtomicAdd(row + v, u[q] * inv); else row[v] = rwc[q] + u[q] * inv; }   // rwc = 0 unless accumulating onto the numerator half
                 erc[q] = erx[q]; rwc[q] = rwx[q];
             }
         }
@@ -3192,7 +3207,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
                 const int v = tid + q * NT;
-                u[q] = v < V ? (erc[q] * pow2f(-kEpExp)) * gsum[v] : 0.f;
+                u[q] = v < V ? (erc[q] * pow2f(-kGradDescale)) * gsum[v] : 0.f;
                 part += u[q];
                 erc[q] = ern[q];
             }
@@ -3210,7 +3225,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
                 const int v = tid + q * NT;
-                if (v < V) row[v] = rw[q] + u[q] * inv;   // rw = 0 unless accumulating onto the numerator half
+                if (v < V) { if (p.grad_den_acc == 2) unsafeAtomicAdd(row + v, u[q] * inv); else row[v] = rw[q] + u[q] * inv; }   // rw = 0 unless accumulating onto the numerator half
             }
         }
     }
@@ -3244,6 +3259,7 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
     const int b = blockIdx.y, V = p.V, Vp = rup64(V);
     const int lx = p.lx[b];
     const bool accumulate = p.grad_phase == 2;
+    const bool atomic = p.grad_phase == 3;    // the row starts at zero (prep) and the den half adds its part from another stream: add, never read
     float *gc = lds;                          // [4][Vp] in rotation
     double *fcs = (double *)(gc + 4 * Vp);    // [kGCFrames]
     const int64_t bt0 = (int64_t)b * p.T;
@@ -3343,14 +3359,17 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
 #pragma unroll
         for (int q = 0; q < kGCVRegs; ++q) {
             const int v = tid + q * kGCThreads;
-            if (v < V) row[v] = out[q];
+            if (v < V) {   // (atomic: global_atomic_add_f32 -- the gradient is ordinary device memory; most labels of a frame carry no numerator mass)
+                if (atomic) { if (out[q] != 0.f) unsafeAtomicAdd(row + v, out[q]); }
+                else row[v] = out[q];
+            }
         }
     };
     for (int t = t0; t + 1 < tl; ++t) frame(t, std::true_type{});
     if (t0 < tl) frame(tl - 1, std::false_type{});
 #undef CRF_GC_CONSUME
 #undef CRF_GC_FETCH
-    if (!accumulate)
+    if (!accumulate && !atomic)
         for (int t = max(t0, tl); t < t1; ++t) {
             float *row = p.grad + (bt0 + t) * V;
             for (int v = tid; v < V; v += kGCThreads) row[v] = 0.f;
@@ -3908,7 +3927,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_grad_kernel(BatchParams
             for (int q = p0 + aj; q < p1; q += AL) acc = fmaf(Qt[(size_t)q * UL + ul], Bt[(size_t)q * UL + ul], acc);
             acc = arc_lane_sum<UL>(acc);                          // (every arc lane of the utterance holds the sum)
         }
-        const float uv = active ? (et[(size_t)v * UL + ul] * pow2f(-kEpExp)) * acc : 0.f;
+        const float uv = active ? (et[(size_t)v * UL + ul] * pow2f(-kGradDescale)) * acc : 0.f;
         part += uv;
         if (aj == 0 && real) row[v] = uv;                          // un-normalised; 0 past the utterance's length
     }
@@ -5258,17 +5277,6 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     g_side_desc = cx->side_desc;
     if (have_flags) { p.err = cx->flags; p.clear = cx->flags; p.nclear = 64; }
     g_last_err_word = p.err;
-    for (bool &u : g_prof.used) u = false;
-    prof_mark(7, false, stream);
-    prof_mark(0, false, stream);
-    if (V <= 256) hipLaunchKernelGGL(crf_prep_kernel<16>, dim3((unsigned)((frames + 15) / 16)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(crf_prep_kernel<64>, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
-    prof_mark(0, true, stream);
-    LAUNCH_CHECK("crf_prep_kernel");
-    if (res && (w.xch_bytes > 0 || !have_flags)) {  // exchange granules (tags) and the error word start at zero in every call
-        if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256 + 8 * (size_t)B, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
-    }
-
     static LdsMark lds_mark_grad;
     if ((rc = ensure_lds((const void *)crf_grad_kernel, lds_grad, lds_mark_grad, "grad"))) return rc;
     bool forked = false, side_used = false;
@@ -5485,6 +5493,30 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         return r2;
     };
 
+    // Three streams (round 5, switch grad_par3; OFF): the numerator half of the grad pass (side stream) and the staged den half (third stream)
+    // run BESIDE each other and both ADD into gradient rows the prep kernel has zeroed (0 + x + y: two addends per element, the same bits
+    // in either order).  The idea: on one stream the stages queue behind the numerator chains and their grad half, and graphs whose
+    // recursions are shorter than that (S = 513: recursions 1.25 ms, step 1.92) wait for them.  Measured SLOWER everywhere
+    // (profiles/round5_ab_three_streams.txt: metric 2.79 -> 2.85 ms, S = 513 1.92 -> 2.01, V = 217 3.39 -> 3.51, estimated S = 3 006 2.44 -> 2.78):
+    // the stage workgroups then share the free CUs with the numerator chains -- a serial fp64 latency chain whose frames get longer -- and
+    // what the stages gain by starting early the chains lose.  Not when a recent call needed the numerator's log-domain fallback (the
+    // third stream then carries its chains), nor in segment mode.
+    const int aux_env0 = opt(kOpt_aux_stream, -1);
+    const int seen0 = cx->seen ? *(volatile int *)cx->seen : 0;
+    const bool ctc_wants_aux = aux_env0 >= 0 ? aux_env0 != 0 : (seen0 > 0 && p.call_id - seen0 <= 16);
+    const bool par3 = staged && !segmode && cx->aux != nullptr && !(robust_env != 0 && ctc_wants_aux) && opt(kOpt_grad_par3, 0) != 0;
+    p.zero_grad = par3 ? 1 : 0;
+    for (bool &u : g_prof.used) u = false;
+    prof_mark(7, false, stream);
+    prof_mark(0, false, stream);
+    if (V <= 256) hipLaunchKernelGGL(crf_prep_kernel<16>, dim3((unsigned)((frames + 15) / 16)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(crf_prep_kernel<64>, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, stream, p);
+    prof_mark(0, true, stream);
+    LAUNCH_CHECK("crf_prep_kernel");
+    if (res && (w.xch_bytes > 0 || !have_flags)) {  // exchange granules (tags) and the error word start at zero in every call
+        if ((e = hipMemsetAsync(p.xch, 0, (size_t)w.xch_bytes + 256 + 8 * (size_t)B, stream)) != hipSuccess) { set_error("hipMemsetAsync(xch)"); return CRF_ERR_HIP; }
+    }
+
     if (bat) {
         // Utterance-minor denominator (large graphs): one launch per frame on the caller's stream, forward step of
         // frame j and backward step of frame T - j together; the numerator pair runs beside them on the side stream.
@@ -5598,7 +5630,33 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         hipLaunchKernelGGL(crf_gate_kernel, dim3(1), dim3(1), 0, side, started, (int)den_wgs);
         if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
         prof_mark(5, false, side);
-        if ((rc = launch_grad_ctc(0, side))) return rc;
+        if ((rc = launch_grad_ctc(par3 ? 3 : 0, side))) return rc;
+        if (par3) {
+            // the den half of the grad pass on the THIRD stream, stage by stage behind the same stream-level waits, adding with atomics;
+            // the side stream goes on with the numerator (fallback chains, if any) and takes the third stream back in behind it
+            if ((e = hipStreamWaitEvent(cx->aux, cx->fork, 0)) != hipSuccess) { set_error(std::string("hipStreamWaitEvent(aux fork): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+            p.grad_den_acc = 2;
+            for (int k = 0; k < nstage; ++k) {
+                if ((e = hipStreamWaitValue32(cx->aux, cx->flags + 16 + k + 1, (uint32_t)(2 * B), hipStreamWaitValueGte, 0xffffffffu)) != hipSuccess) {
+                    // not available here: from the next call on, segments (and no third stream).  This call: wait for the recursions to END
+                    (void)hipGetLastError();
+                    use_segments = true;
+                    if ((e = hipEventRecord(cx->ev[0], stream)) != hipSuccess || (e = hipStreamWaitEvent(cx->aux, cx->ev[0], 0)) != hipSuccess) {
+                        set_error(std::string("hipStreamWaitEvent: ") + hipGetErrorString(e)); return CRF_ERR_HIP;
+                    }
+                }
+                if ((rc = launch_grad_den(cx->aux, k + 1))) return rc;
+            }
+            if ((e = hipEventRecord(cx->ev_b, cx->aux)) != hipSuccess) { set_error(std::string("hipEventRecord(aux): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+            g_call_streams = 3;
+            ctc_pass1 = robust_env != 0;
+            if (ctc_pass1 && (rc = launch_robust_ctc_chains(side, 1))) return rc;
+            if ((e = hipStreamWaitEvent(side, cx->ev_b, 0)) != hipSuccess) { set_error(std::string("hipStreamWaitEvent(aux): ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+            // (the marked frames' posteriors are subtracted behind BOTH halves: a plain read-modify-write of rows nobody adds to any more)
+            if (ctc_pass1 && (rc = launch_robust_ctc_fix(side, 1))) return rc;
+            prof_mark(5, true, side);
+            if ((rc = join_side())) return rc;
+        } else {
         // Numerator fallback, pass 1.  The chains of the marked utterances can take as long as the scaled ones did (T = 3 000, L = 500,
         // every utterance marked: 3 ms): on the third stream they run beside the grad stages instead of in front of them, and the
         // marked frames' posteriors are subtracted behind the last stage (the stages ADD gamma_den: the order does not matter).
@@ -5646,6 +5704,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         if (ctc_pass1 && (rc = launch_robust_ctc_fix(side, 1))) return rc;
         prof_mark(5, true, side);
         if ((rc = join_side())) return rc;   // the last grad launch is behind every stage of the recursions
+        }
     } else if (den && ctc && !serial) {
         // Denominator pair on the caller's stream, numerator pair beside it on the side stream -- unless the den
         // workgroups own every CU (register-resident layouts with 2B (x K) >= CUs): then the numerator recursions run

@@ -553,15 +553,18 @@ def test_robust_fallback_forced(crf, tmp_path, mode):
     assert post_err(gd.cpu().numpy(), np.asarray(den[0])) <= TOL
 
 
-@pytest.mark.parametrize("nats", [10.0, 25.0, 45.0, 80.0, 110.0])
-def test_single_frame_shrink_window(crf, tmp_path, nats):
+@pytest.mark.parametrize("nats,mode", [(10.0, "factored"), (25.0, "factored"), (45.0, "factored"), (80.0, "factored"), (120.0, "factored")] + [(110.0, m) for m in MODES])
+def test_single_frame_shrink_window(crf, tmp_path, nats, mode):
     """A label the den_lm forbids `nats` above everything else, in every frame of utterance 0 and in a stretch of utterance 1: every
     frame shrinks the recursions' vectors by e^-nats.  Up to ~131 nats the scaled-fp32 recursions carry that themselves -- each frame is
     rescaled from the maximum of its OWN source vector, so the rows the grad pass multiplies always sit at 2^20 -- and no utterance
     may take the fallback (`crf_last_fallback_counts`).  A build with the lagged scale (CRF_X_LAG=1: the scale of frame t+1 chosen before
     the size of its vector is known; measured and not adopted) lets the rows carry the frame's growth and hands such utterances
     to the log-shifted fallback from 28 nats on -- its first thresholds gave NaN gradients at 45 nats here.  Either way the result is
-    the fp64 oracle's (the reference's log-domain arithmetic, den_calculate.cu:29-35, has no such window)."""
+    the fp64 oracle's (the reference's log-domain arithmetic, den_calculate.cu:29-35, has no such window).
+    110 nats, every kernel family: what this test FOUND in round 5 -- the streaming grad kernels took 2^-64 out of e' * sum(q * b) before
+    normalising the frame, and between ~100 and 131 nats that product left the fp32 range although recursions, loss and flags were fine:
+    the gradient of rounds 1 - 4 was 90 % off there, silently (kGradDescale, crf_kernels.hip)."""
     g, p = small_synth(tmp_path, 9, 24, 5, 7)             # tokens 1..8; label 9 exists only in the network output
     B, T, V = 3, 40, 10
     rng = np.random.default_rng(22)
@@ -573,15 +576,15 @@ def test_single_frame_shrink_window(crf, tmp_path, nats):
     _, labels, lx, ly = make_batch(g, B, T, 9, seed=3, ragged=True)
     lx[:] = [40, 36, 31]
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
-    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode="factored")
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=0.1, mode=mode)
     nden, nnum = crf._C.last_fallback_counts(torch.cuda.current_stream().cuda_stream)
     assert np.isfinite(loss) and np.isfinite(grad).all()
     assert abs(loss - ref["loss"]) <= TOL * abs(ref["loss"])
     for b in range(B):
         assert rel_err(grad[b], ref["grad"][b]) <= TOL
     assert nnum == 0
-    if not crf._C.build_switches().get("LAG"):
-        assert nden == 0, (nats, nden)
+    if not crf._C.build_switches().get("LAG") or not mode.startswith("factored") or "k2" in mode or "pair2" in mode:
+        assert nden == 0 or nats >= 120.0, (nats, nden)     # (120 nats +- the inputs' spread: some frames beyond what e' can hold -- the fallback may take them)
     else:
         assert nden == (2 if nats >= 45.0 else 0) or nats == 25.0, (nats, nden)   # (25 nats: at the lagged rule's threshold)
 
