@@ -72,6 +72,9 @@ constexpr int kFlagFallback = 40;   // words [40], [41] behind the error word: u
 #ifndef CRF_X_EARLY
 #define CRF_X_EARLY 1       // fac_chain_body: the frame's scale / exponent bookkeeping behind the first batch of gathers (0: in front of it)
 #endif
+#ifndef CRF_X_GCHK
+#define CRF_X_GCHK 1        // crf_grad_den_kernel: the emission-weighted lost-term bound per frame (0: only "the frame's mass is a normal float"; A/B of what the check costs)
+#endif
 #ifndef CRF_X_GFIRST
 #define CRF_X_GFIRST 0      // fac_chain_body (one CU per recursion): a frame BEGINS with its first batch of gathers -- everything else a frame starts with
                             // (stage check, emission prefetch, scale, exponent bookkeeping, row pointers: ~35 scalar instructions, ~4 cycles of a
@@ -3114,7 +3117,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
                 const int v = tid + q * NT;
                 if (v < V) gzero[v] = 0.f;
             }
-            if (tid == 0) { nrm[(t + 2) & 3] = 0.f; nrm[4 + ((t + 2) & 3)] = 0.f; nrm[8 + ((t + 2) & 3)] = 0.f; }
+            if (tid == 0) { nrm[(t + 2) & 3] = 0.f; nrm[8 + ((t + 2) & 3)] = 0.f; }
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 2);
             sync_lds();                             // every gather of frame t is done: the row buffers are free
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 3);
@@ -3130,21 +3133,18 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
                 if (t + 2 < tl) CRF_GD_FETCH(t + 2);
             }
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 4);
-            float u[EPR], part = 0.f, part2 = 0.f, emx = 0.f;
+            float u[EPR], part = 0.f, emx = 0.f;
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
                 const int v = tid + q * NT;
                 u[q] = v < V ? (erc[q] * pow2f(-kGradDescale)) * gsum[v] : 0.f;
                 part += u[q];
-                part2 += v < V ? gsum[v] : 0.f;
-                emx = fmaxf(emx, v <= g.max_label && v < V ? erc[q] : 0.f);
+                if (CRF_X_GCHK) emx = fmaxf(emx, v <= g.max_label && v < V ? erc[q] : 0.f);
             }
             part = wave_sum(part);
-            part2 = wave_sum(part2);
-            emx = wave_max(emx);
+            if (CRF_X_GCHK) emx = wave_max(emx);
             if ((tid & 63) == 0 && part != 0.f) atomicAdd(&nrm[t & 3], part);
-            if ((tid & 63) == 0 && part2 != 0.f) atomicAdd(&nrm[4 + (t & 3)], part2);
-            if ((tid & 63) == 0 && emx > 0.f) atomicMax((int *)&nrm[8 + (t & 3)], __float_as_int(emx));   // (non-negative floats order like their bits)
+            if (CRF_X_GCHK && (tid & 63) == 0 && emx > 0.f) atomicMax((int *)&nrm[8 + (t & 3)], __float_as_int(emx));   // (non-negative floats order like their bits)
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
             sync_lds();                             // rows of frame t+1 visible, normaliser complete
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 6);
@@ -3152,13 +3152,12 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             const float inv = nv > 0.f ? p.c_den / nv : 0.f;
             // The utterance goes to the log-domain fallback when a frame's mass is not a NORMAL positive float -- zero, denormal (c / nv = inf,
             // inf * 0 = NaN), inf, NaN -- or when products the rows can no longer hold could have mattered: a pair whose q (or b) lies below
-            // 2^-126 is lost from rows scaled to 2^20, i.e. terms below 2^-105; (a) the OVERLAP sum(q * b) below 2^-78 means the frame's own
-            // terms are of that size (forward and backward mass ~100 nats apart); (b) a lost term weighs at most e'max * 2^-4 * 2^-105 with
-            // e'max the largest emission of a label the graph has: a frame mass below 2^13 times that (1e-4) could be missing most of
-            // itself -- e.g. two alignments, one through the frame's best label and one 70 nats below it whose rows are the healthy ones
-            // (tests/test_gpu_fuzz.py, round 5: posteriors 0 / 1 instead of 0.94 / 0.06 in single frames, costs exact).
-            if (tid == 0 && p.redo &&
-                !(nv >= 0x1p-120f && nv < INFINITY && nrm[4 + (t & 3)] >= 0x1p-78f && nv >= nrm[8 + (t & 3)] * 0x1p-96f)) p.redo[b] = 1;
+            // 2^-126 is lost from rows scaled to 2^20, i.e. terms below 2^-105, at most 2^-92 of them together; a lost term weighs at most
+            // e'max * 2^-4 * 2^-105 with e'max the largest emission of a label the graph has.  A frame mass below e'max * 2^-82 could be missing
+            // more than 1e-4 of itself -- forward and backward mass ~100 nats apart, or two alignments, one through the frame's best label
+            // and one 70 nats below it whose rows are the healthy ones (tests/test_gpu_fuzz.py, round 5: posteriors 0 / 1 instead of
+            // 0.94 / 0.06 in single frames, costs exact).
+            if (tid == 0 && p.redo && !(nv >= 0x1p-120f && nv < INFINITY && nv >= nrm[8 + (t & 3)] * 0x1p-82f)) p.redo[b] = 1;
             float *row = p.grad + (bt0 + t) * V;
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
@@ -3209,7 +3208,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
                 const int v = tid + q * NT;
                 if (v < V) gzero[v] = 0.f;
             }
-            if (tid == 0) { nrm[(t + 2) & 3] = 0.f; nrm[4 + ((t + 2) & 3)] = 0.f; nrm[8 + ((t + 2) & 3)] = 0.f; }
+            if (tid == 0) { nrm[(t + 2) & 3] = 0.f; nrm[8 + ((t + 2) & 3)] = 0.f; }
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 2);
             sync_lds();                             // every gather of frame t is done: the row buffers are free
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 3);
@@ -3221,25 +3220,22 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             // gamma[t][v] = u_v / sum_v u_v with u_v = e'_t[v] * (label sum): the posteriors of a frame sum to 1, so
             // the frame normalises itself -- no logZ, no per-frame exponents, hence no dependence on the END of the
             // recursions (the pass runs beside them).  e' is taken without its 2^kEpExp (range: label sums reach 2^50).
-            float u[EPR], part = 0.f, part2 = 0.f, emx = 0.f;
+            float u[EPR], part = 0.f, emx = 0.f;
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
                 const int v = tid + q * NT;
                 u[q] = v < V ? (erc[q] * pow2f(-kGradDescale)) * gsum[v] : 0.f;
                 part += u[q];
-                part2 += v < V ? gsum[v] : 0.f;
-                emx = fmaxf(emx, v <= g.max_label && v < V ? erc[q] : 0.f);
+                if (CRF_X_GCHK) emx = fmaxf(emx, v <= g.max_label && v < V ? erc[q] : 0.f);
                 erc[q] = ern[q];
             }
             float rw[EPR];
 #pragma unroll
             for (int q = 0; q < EPR; ++q) { rw[q] = rwc[q]; rwc[q] = rwn[q]; }
             part = wave_sum(part);
-            part2 = wave_sum(part2);
-            emx = wave_max(emx);
+            if (CRF_X_GCHK) emx = wave_max(emx);
             if ((tid & 63) == 0 && part != 0.f) atomicAdd(&nrm[t & 3], part);
-            if ((tid & 63) == 0 && part2 != 0.f) atomicAdd(&nrm[4 + (t & 3)], part2);
-            if ((tid & 63) == 0 && emx > 0.f) atomicMax((int *)&nrm[8 + (t & 3)], __float_as_int(emx));
+            if (CRF_X_GCHK && (tid & 63) == 0 && emx > 0.f) atomicMax((int *)&nrm[8 + (t & 3)], __float_as_int(emx));
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 5);
             sync_lds();                             // rows of frame t+1 visible, normaliser complete
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 6);
@@ -3247,13 +3243,12 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             const float inv = nv > 0.f ? p.c_den / nv : 0.f;
             // The utterance goes to the log-domain fallback when a frame's mass is not a NORMAL positive float -- zero, denormal (c / nv = inf,
             // inf * 0 = NaN), inf, NaN -- or when products the rows can no longer hold could have mattered: a pair whose q (or b) lies below
-            // 2^-126 is lost from rows scaled to 2^20, i.e. terms below 2^-105; (a) the OVERLAP sum(q * b) below 2^-78 means the frame's own
-            // terms are of that size (forward and backward mass ~100 nats apart); (b) a lost term weighs at most e'max * 2^-4 * 2^-105 with
-            // e'max the largest emission of a label the graph has: a frame mass below 2^13 times that (1e-4) could be missing most of
-            // itself -- e.g. two alignments, one through the frame's best label and one 70 nats below it whose rows are the healthy ones
-            // (tests/test_gpu_fuzz.py, round 5: posteriors 0 / 1 instead of 0.94 / 0.06 in single frames, costs exact).
-            if (tid == 0 && p.redo &&
-                !(nv >= 0x1p-120f && nv < INFINITY && nrm[4 + (t & 3)] >= 0x1p-78f && nv >= nrm[8 + (t & 3)] * 0x1p-96f)) p.redo[b] = 1;
+            // 2^-126 is lost from rows scaled to 2^20, i.e. terms below 2^-105, at most 2^-92 of them together; a lost term weighs at most
+            // e'max * 2^-4 * 2^-105 with e'max the largest emission of a label the graph has.  A frame mass below e'max * 2^-82 could be missing
+            // more than 1e-4 of itself -- forward and backward mass ~100 nats apart, or two alignments, one through the frame's best label
+            // and one 70 nats below it whose rows are the healthy ones (tests/test_gpu_fuzz.py, round 5: posteriors 0 / 1 instead of
+            // 0.94 / 0.06 in single frames, costs exact).
+            if (tid == 0 && p.redo && !(nv >= 0x1p-120f && nv < INFINITY && nv >= nrm[8 + (t & 3)] * 0x1p-82f)) p.redo[b] = 1;
             float *row = p.grad + (bt0 + t) * V;
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
@@ -5975,7 +5970,7 @@ int crf_last_fallback_counts(int32_t *out2, void *stream) {
 
 const char *crf_build_switches(void) {
     return "LAG=" CRF_STR(CRF_X_LAG) " KCLATE=" CRF_STR(CRF_X_KCLATE) " PRIO=" CRF_STR(CRF_X_PRIO) " EARLY=" CRF_STR(CRF_X_EARLY)
-           " GFIRST=" CRF_STR(CRF_X_GFIRST) " GDEARLY=" CRF_STR(CRF_X_GDEARLY) " GDMOVE=" CRF_STR(CRF_X_GDMOVE) " GDW2=" CRF_STR(CRF_X_GDW2)
+           " GFIRST=" CRF_STR(CRF_X_GFIRST) " GCHK=" CRF_STR(CRF_X_GCHK) " GDEARLY=" CRF_STR(CRF_X_GDEARLY) " GDMOVE=" CRF_STR(CRF_X_GDMOVE) " GDW2=" CRF_STR(CRF_X_GDW2)
 #ifdef CRF_TIMING
            " TIMING=1"
 #endif
