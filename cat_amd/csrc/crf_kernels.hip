@@ -72,6 +72,10 @@ constexpr int kFlagFallback = 40;   // words [40], [41] behind the error word: u
 #ifndef CRF_X_EARLY
 #define CRF_X_EARLY 1       // fac_chain_body: the frame's scale / exponent bookkeeping behind the first batch of gathers (0: in front of it)
 #endif
+#ifndef CRF_X_CTCSUM
+#define CRF_X_CTCSUM 0      // crf_grad_ctc_kernel: mark a frame whose posteriors do not sum to one (built with the round-5 fixes; +16 % on that kernel, and what it
+                            // caught is decided in front of the grad pass by crf_ctc_check_kernel and the frame factor's range check: the fuzz is green without it)
+#endif
 #ifndef CRF_X_GCHK
 #define CRF_X_GCHK 1        // crf_grad_den_kernel: the emission-weighted lost-term bound per frame (0: only "the frame's mass is a normal float"; A/B of what the check costs)
 #endif
@@ -2932,7 +2936,21 @@ constexpr int kGDEpRegs = 4;                                      // V <= 4*256
 // graph compiler cuts at 8: a chunk of 32 slots with 8 pairs spends three quarters of its gathers on padding)
 // RR: float4 registers per thread and row (rows of up to 4 * RR * NT floats); WPE: waves per SIMD the register budget is held to (4 = 128 VGPRs:
 // two 512-thread workgroups per CU)
+// The mass checks of frame `tt` of the grad den pass (see the comment at the normaliser): on the SCALAR unit, on the floats' bits (non-negative
+// floats order like integers; times 2^-82 = 82 off the exponent field), collected in one uniform word
+#define CRF_GD_CHECK(tt)                                                                                                     \
+    do {                                                                                                                     \
+        const unsigned nvb = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(nrm[(tt) & 3]));                         \
+        const unsigned emb = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(nrm[8 + ((tt) & 3)]));                   \
+        const unsigned thr = emb > (82u << 23) ? emb - (82u << 23) : 0u;                                                     \
+        frame_bad |= (unsigned)(!(nvb >= 0x03800000u && nvb < 0x7f800000u && nvb >= thr));                                   \
+    } while (0)
 template <int NCPT, int EPR, int NT = kGDThreads, int CH = kChunk, int RR = kGDRowRegs, int WPE = 1>
+// (The instantiation of the metric graph, <1, 1>, compiles to 152 registers, and 152 it has to stay: registers are granted in eights, three workgroups
+// of 4 x 152 leave a SIMD 56, two leave it 208 = the two waves of 104 that a numerator-chain workgroup puts on every SIMD.  At 153 (-> 160) a chain
+// workgroup fits beside ONE grad workgroup only, the grad launch's queue never lets a CU fall that low, and the chains of batches whose grad pass
+// runs unstaged beside them (B >= 128, two CUs per recursion) ran AFTER it: B = 128 4.8 -> 5.6 ms per step, found by bisecting round 5's own
+// commits (profiles/round5_ab_one_register.txt).  The compiler ignores amdgpu_num_vgpr here; tests/test_isa_checks.py holds the number.)
 __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
@@ -3040,6 +3058,10 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
     constexpr bool GDE = CRF_X_GDEARLY != 0 && WPE == 1 && ((NCPT == 1 && (EPR == 1 || CRF_X_GDEARLY >= 2)) || CRF_X_GDEARLY >= 3);
     constexpr bool GDM = GDE && CRF_X_GDMOVE != 0;
     f32x4 qr[RR], br[RR];
+    unsigned frame_bad = 0;          // (uniform: a frame of this block failed the mass checks below)
+    // where a frame's checks are made: behind its normaliser, or -- the metric graph's instantiation, which has no register to spare there (see the
+    // kernel's head) -- at the top of the next frame (the others grew by 20 registers or spilled when theirs were moved: measured on the compiler's report)
+    constexpr bool kCheckTop = NCPT == 1 && EPR == 1;
     float ern[EPR], rwn[EPR] = {};   // next frame's emissions and (accumulate mode) grad row
 #define CRF_GD_FETCH(t)                                                                                  \
     {                                                                                                    \
@@ -3088,6 +3110,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
         for (int t = t0; t < tl; ++t) {
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
             float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
+            if (kCheckTop && t > t0) CRF_GD_CHECK(t - 1);   // (frame t-1's, here, where few registers live)
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 1);
 #pragma unroll
             for (int i = 0; i < NCPT; ++i) {
@@ -3156,8 +3179,8 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             // e'max * 2^-4 * 2^-105 with e'max the largest emission of a label the graph has.  A frame mass below e'max * 2^-82 could be missing
             // more than 1e-4 of itself -- forward and backward mass ~100 nats apart, or two alignments, one through the frame's best label
             // and one 70 nats below it whose rows are the healthy ones (tests/test_gpu_fuzz.py, round 5: posteriors 0 / 1 instead of
-            // 0.94 / 0.06 in single frames, costs exact).
-            if (tid == 0 && p.redo && !(nv >= 0x1p-120f && nv < INFINITY && nv >= nrm[8 + (t & 3)] * 0x1p-82f)) p.redo[b] = 1;
+            // 0.94 / 0.06 in single frames, costs exact).  CRF_GD_CHECK; the flag is stored once, behind the loop.
+            if (!kCheckTop) CRF_GD_CHECK(t);
             float *row = p.grad + (bt0 + t) * V;
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
@@ -3178,6 +3201,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
         for (int t = t0; t < tl; ++t) {
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
             float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
+            if (kCheckTop && t > t0) CRF_GD_CHECK(t - 1);   // (frame t-1's, here, where few registers live)
             if (t + 1 < tl) CRF_GD_FETCH(t + 1);   // lands while frame t is reduced
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 1);
 #pragma unroll
@@ -3247,8 +3271,8 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             // e'max * 2^-4 * 2^-105 with e'max the largest emission of a label the graph has.  A frame mass below e'max * 2^-82 could be missing
             // more than 1e-4 of itself -- forward and backward mass ~100 nats apart, or two alignments, one through the frame's best label
             // and one 70 nats below it whose rows are the healthy ones (tests/test_gpu_fuzz.py, round 5: posteriors 0 / 1 instead of
-            // 0.94 / 0.06 in single frames, costs exact).
-            if (tid == 0 && p.redo && !(nv >= 0x1p-120f && nv < INFINITY && nv >= nrm[8 + (t & 3)] * 0x1p-82f)) p.redo[b] = 1;
+            // 0.94 / 0.06 in single frames, costs exact).  CRF_GD_CHECK; the flag is stored once, behind the loop.
+            if (!kCheckTop) CRF_GD_CHECK(t);
             float *row = p.grad + (bt0 + t) * V;
 #pragma unroll
             for (int q = 0; q < EPR; ++q) {
@@ -3259,6 +3283,9 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
     }
 #undef CRF_GD_STAGE
 #undef CRF_GD_FETCH
+    if (kCheckTop && tl > t0) CRF_GD_CHECK(tl - 1);   // (the last frame's: its normaliser was complete at the last barrier)
+    if (frame_bad && tid == 0 && p.redo) p.redo[b] = 1;
+#undef CRF_GD_CHECK
     if (!p.grad_den_acc)
         for (int t = max(t0, tl); t < t1; ++t) {  // frames past the utterance's length: zero rows
             float *row = p.grad + (bt0 + t) * V;
@@ -3364,24 +3391,24 @@ __global__ __launch_bounds__(kGCThreads) void crf_grad_ctc_kernel(LossParams p) 
             for (int i = 0; i < REGS; ++i)
                 if (tid + i * kGCThreads < Sx) {
                     const float pr = (float)(prod[i] * fc);  // a posterior, in [0,1]
-                    if (tid & 1) { atomicAdd(&g[mylab[i]], pr); tot += pr; }
+                    if (tid & 1) { atomicAdd(&g[mylab[i]], pr); if (CRF_X_CTCSUM) tot += pr; }
                     else blank += pr;
                 }
             blank = wave_sum(blank);
-            tot = wave_sum(tot);
-            if (lane == 0) { atomicAdd(&g[0], blank); atomicAdd(&gt[t & 3], tot + blank); }
+            if (CRF_X_CTCSUM) tot = wave_sum(tot);
+            if (lane == 0) { atomicAdd(&g[0], blank); if (CRF_X_CTCSUM) atomicAdd(&gt[t & 3], tot + blank); }
         }
 #pragma unroll
         for (int q = 0; q < kGCVRegs; ++q) {
             const int v = tid + q * kGCThreads;
             if (v < V) gz[v] = 0.f;
         }
-        if (tid == 0) gt[(t + 2) & 3] = 0.f;
+        if (CRF_X_CTCSUM && tid == 0) gt[(t + 2) & 3] = 0.f;
         sync_lds();
         // The posteriors of a frame sum to ONE.  A frame whose scaled products do not -- the chains' rescaled fp64 rows lost the states that
         // carry it, or Z itself is off -- is left out here and MARKED like the frames beyond the factor's range: the log-domain chains redo
         // it (round 5: tests/test_gpu_fuzz.py found frames summing to 617, to inf and to 0 behind a finite, correct-looking cost).
-        const bool fbad = zc > 0.0 && fc != 0.0 && !(fabsf(gt[t & 3] - 1.f) <= 1e-3f);
+        const bool fbad = CRF_X_CTCSUM != 0 && zc > 0.0 && fc != 0.0 && !(fabsf(gt[t & 3] - 1.f) <= 1e-3f);
         if (fbad && tid == 0) { p.ctc_bad[bt0 + t] = 1; atomicMax(&p.redo_ctc[b], 1); }
         float out[kGCVRegs];
 #pragma unroll
@@ -5590,7 +5617,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         return CRF_OK;
     };
     // the denominator recursions of the whole batch on `st` (every layout; both directions per launch)
-    auto launch_den = [&](hipStream_t st) -> int {
+    auto launch_den = [&](hipStream_t st, bool with_check = true) -> int {
         prof_mark(1, false, st); prof_mark(2, false, st);
         int r2 = CRF_OK;
         const CoresGuard cores((fac && FX->K > 1) || (res && !fac && h->dev.res.K > 1), cx->dev, st);
@@ -5610,13 +5637,13 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             for (int b0 = 0; b0 < (int)B && !r2; b0 += grp) r2 = launch_res_pair(p, l, b0, std::min(grp, (int)B - b0), st);
         } else if (gv) {
             r2 = launch_den_pair<true>(p, std::max(chain_lds_bytes(h, (int)V, Sc, 0, true), chain_lds_bytes(h, (int)V, Sc, 1, true)), st);
-            return r2 ? r2 : launch_den_check(st);
+            return (r2 || !with_check) ? r2 : launch_den_check(st);
         } else {
             r2 = launch_den_pair<false>(p, std::max(chain_lds_bytes(h, (int)V, Sc, 0), chain_lds_bytes(h, (int)V, Sc, 1)), st);
-            return r2 ? r2 : launch_den_check(st);
+            return (r2 || !with_check) ? r2 : launch_den_check(st);
         }
         prof_mark(1, true, st); prof_mark(2, true, st);
-        return r2 ? r2 : launch_den_check(st);
+        return (r2 || !with_check) ? r2 : launch_den_check(st);
     };
 
     // Three streams (round 5, switch grad_par3; OFF): the numerator half of the grad pass (side stream) and the staged den half (third stream)
@@ -5874,8 +5901,12 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             }
             prof_mark(5, true, stream);
         } else {
-            if ((rc = launch_den(stream))) return rc;
+            // (the consistency check BEHIND the fork: the numerator chains -- a latency chain that wants its workgroups resident at once -- are
+            // released by the end of the recursions and get the CUs first; with the check in front of the fork the grad launch below, which
+            // follows it on this stream without an event in between, filled the device first: B = 128 ctc chains 1.5 -> 2.4 ms)
+            if ((rc = launch_den(stream, false))) return rc;
             if ((rc = fork_side())) return rc;            // numerator pair starts when the den recursions have drained
+            if ((rc = launch_den_check(stream))) return rc;
             if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
             prof_mark(5, false, stream);
             if (fast_den) {
@@ -5970,7 +6001,7 @@ int crf_last_fallback_counts(int32_t *out2, void *stream) {
 
 const char *crf_build_switches(void) {
     return "LAG=" CRF_STR(CRF_X_LAG) " KCLATE=" CRF_STR(CRF_X_KCLATE) " PRIO=" CRF_STR(CRF_X_PRIO) " EARLY=" CRF_STR(CRF_X_EARLY)
-           " GFIRST=" CRF_STR(CRF_X_GFIRST) " GCHK=" CRF_STR(CRF_X_GCHK) " GDEARLY=" CRF_STR(CRF_X_GDEARLY) " GDMOVE=" CRF_STR(CRF_X_GDMOVE) " GDW2=" CRF_STR(CRF_X_GDW2)
+           " GFIRST=" CRF_STR(CRF_X_GFIRST) " GCHK=" CRF_STR(CRF_X_GCHK) " CTCSUM=" CRF_STR(CRF_X_CTCSUM) " GDEARLY=" CRF_STR(CRF_X_GDEARLY) " GDMOVE=" CRF_STR(CRF_X_GDMOVE) " GDW2=" CRF_STR(CRF_X_GDW2)
 #ifdef CRF_TIMING
            " TIMING=1"
 #endif

@@ -82,3 +82,41 @@ def test_inline_lds_reads_of_this_build():
     n, bad = mod.check(open(_assembly(mod)).read().split("\n"))
     assert n >= 100, n          # (the numerator chains of four label-length classes, forward and backward: 176 on ROCm 7.2)
     assert not bad, "\n".join(bad[:10])
+
+
+def _kernel_meta(path):
+    """{mangled kernel name: {vgpr_count, vgpr_spill_count, ...}} from the amdhsa.kernels metadata of the assembly."""
+    import re
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"\s+\.name:\s+(\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.match(r"\s+\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+@pytest.mark.timeout(900)
+def test_register_budgets_the_schedule_relies_on():
+    """Occupancy is part of the schedule, and ONE register changes it (VGPRs are granted in eights, 512 per SIMD lane):
+    - the metric graph's grad den kernel (256 threads: one wave per SIMD and workgroup) at <= 152: two of its workgroups leave a SIMD
+      208 registers = the two waves of 104 a numerator-chain workgroup puts there.  At 153 the chains of B >= 128 ran BEHIND the grad pass:
+      4.8 -> 5.6 ms per step, found by bisecting (profiles/round5_ab_one_register.txt);
+    - the numerator chains of short label sequences at <= 104;
+    - the 1024-thread recursions at <= 128 (4 waves per SIMD), the 768-thread ones at <= 168 (3), the 512 x 30 two-utterance geometry at <= 256,
+      none of them spilling inside the frame loop (the few spilled prologue constants are counted and capped)."""
+    mod = _tool()
+    meta = _kernel_meta(_assembly(mod))
+    gd = meta["_ZN3crf19crf_grad_den_kernelILi1ELi1ELi256ELi32ELi5ELi1EEEvNS_10LossParamsE"]
+    assert gd["vgpr_count"] <= 152 and gd["vgpr_spill_count"] == 0, gd
+    ch = meta["_ZN3crf19crf_ctc_pair_kernelILi1EEEvNS_10LossParamsE"]          # (label sequences of the metric shape: one register set per thread)
+    assert ch["vgpr_count"] <= 104 and ch["vgpr_spill_count"] == 0, ch
+    pairs = {k: v for k, v in meta.items() if "crf_fac_pair_kernelILb" in k}
+    assert len(pairs) >= 12
+    for k, v in pairs.items():
+        cap = 128 if "ELi1024ELi15E" in k else 168 if "ELi768E" in k else 256
+        assert v["vgpr_count"] <= cap and v["vgpr_spill_count"] <= 8, (k, v)     # (a handful of spills outside the frame loop: the prologue's constants)
