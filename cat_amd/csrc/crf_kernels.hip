@@ -76,6 +76,9 @@ constexpr int kFlagFallback = 40;   // words [40], [41] behind the error word: u
 #define CRF_X_CTCSUM 0      // crf_grad_ctc_kernel: mark a frame whose posteriors do not sum to one (built with the round-5 fixes; +16 % on that kernel, and what it
                             // caught is decided in front of the grad pass by crf_ctc_check_kernel and the frame factor's range check: the fuzz is green without it)
 #endif
+#ifndef CRF_X_CTCWPE
+#define CRF_X_CTCWPE 5
+#endif
 #ifndef CRF_X_GCHK
 #define CRF_X_GCHK 1        // crf_grad_den_kernel: the emission-weighted lost-term bound per frame (0: only "the frame's mass is a normal float"; A/B of what the check costs)
 #endif
@@ -129,6 +132,12 @@ struct LossParams {
     int gd_stage, gd_nb;          // crf_grad_den_kernel: process only the 16-frame blocks completed by den segment `gd_stage` (0 = all)
     int gd_nf;                    // > 0: the launch holds only 2 * gd_nf candidate blocks per utterance (see the kernel)
     int gd_bound[16];             //   segment k (1-based) runs the recursion iterations [gd_bound[k-1], gd_bound[k])
+    int gd_persist;               // crf_grad_den_kernel: 1 = ONE launch for the stages gd_stage .. gd_nb-1 -- 1-D grid, stage-major, the candidates of stage k
+    int gd_poff[17];              //   from block gd_poff[k] on -- whose workgroups wait for their stage's counter themselves:
+    const int *gd_cnt;            //   the den kernels' stage counters (FacParams::stage_cnt; fine-grained memory) ...
+    int gd_target;                //   ... and the value that releases a stage (2 B: every recursion has published it)
+    int gd_fpb[16];               //   frames per workgroup in stage k: kGDFrames, or a divisor of it -- the short last stages, where a workgroup's 16 frames one after the
+                                  //   other (4 - 5 us each) would BE the tail: a block is still of the stage its 16 frames make it, and split among 16 / fpb workgroups there
     int grad_den_acc;             // crf_grad_den_kernel: 1 = add to the row (the numerator half has written it) instead of writing; 2 = atomic add into a
                                   // row the prep kernel has zeroed (the numerator half adds its part from ANOTHER stream at the same time)
     int zero_grad;                // crf_prep_kernel: zero the gradient rows (the two halves of the grad pass then ADD, in any order)
@@ -851,6 +860,12 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
         mylab[i] = s < Sx ? lab[s] : 0;
         skip[i] = s < Sx && s >= 2 && mylab[i] != 0 && mylab[i] != lab[s - 2];
     }
+    // the label as an UNSIGNED byte offset: the emission loads are then `global_load v, v_off, s[row]` -- a uniform row base and one VGPR; with
+    // a signed index the compiler kept a 64-bit pointer per lane (logp + label) and added the row to it with a v_lshl_add_u64 per load: the
+    // kernel's 97th register, one more than lets a chain workgroup sit beside two grad workgroups of up to 160 (round 5, crf_grad_den_kernel's head)
+    unsigned labo[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) labo[i] = (unsigned)mylab[i] * 4u;
     int E = kScaleExpD;
     const double rho = ctc_rho(p, b, Sx, lx, c.red, tid), rho2 = rho * rho;
     // The frame maximum used for the (exact, power-of-two) rescale is taken from the values as they are
@@ -889,18 +904,18 @@ __device__ __forceinline__ void ctc_forward(const LossParams &p, int b, float *l
     // memory latency.  Batching leaves ONE such wait per kCtcPF frames, for loads issued kCtcPF frames ago.
     // The row maximum is read through a per-lane (VGPR) address: as a scalar load it would be counted by
     // lgkmcnt and the per-frame LDS barrier would wait for it.
-    int vz;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
     float lr[2][kCtcPF][NR], mr[2][kCtcPF];
     auto fetch1 = [&](auto SET, auto F, int t) __attribute__((always_inline)) {
         constexpr int st = decltype(SET)::value, f = decltype(F)::value;
         if (t < lx) {
             const int64_t row0 = (bt0 + t) * V;
-            mr[st][f] = p.mx[bt0 + t + vz];
+            unsigned vz;   // (a fresh zero per load: hoisted out of the loop, `p.mx + vz` was a 64-bit pointer per lane -- and the register the kernel spilled)
+            asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+            mr[st][f] = *(const float *)((const char *)(p.mx + bt0 + t) + vz);
             if (p.in_dtype == 0) {   // (one uniform branch around the batch: the fp32 loads stay as they were)
                 const float *row = p.logp + row0;
 #pragma unroll
-                for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? row[mylab[i]] : 0.f;
+                for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? *(const float *)((const char *)row + labo[i]) : 0.f;
             } else {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) lr[st][f][i] = (tid + i * kCtcThreads < Sx) ? ld_x(p, row0 + mylab[i]) : 0.f;
@@ -1048,6 +1063,9 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
         mylab[i] = s < Sx ? lab[s] : 0;
         skip[i] = (s + 2 < Sx) && lab[s + 2] != 0 && lab[s + 2] != mylab[i];
     }
+    unsigned labo[NR];   // (see ctc_forward)
+#pragma unroll
+    for (int i = 0; i < NR; ++i) labo[i] = (unsigned)mylab[i] * 4u;
     int F_ = kScaleExpD;
     const double rho = ctc_rho(p, b, Sx, lx, c.red, tid), rho2 = rho * rho;
     {   // t = lx-1
@@ -1075,18 +1093,18 @@ __device__ __forceinline__ void ctc_backward(const LossParams &p, int b, float *
     }
     __syncthreads();
     // emissions in batches of kCtcPF frames, as in ctc_forward
-    int vz;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
     float lr[2][kCtcPF][NR], mr[2][kCtcPF];
     auto fetch1 = [&](auto SET, auto F, int t) __attribute__((always_inline)) {
         constexpr int st = decltype(SET)::value, f = decltype(F)::value;
         if (t >= 0) {
             const int64_t row0 = (bt0 + t) * V;
-            mr[st][f] = p.mx[bt0 + t + vz];
+            unsigned vz;   // (a fresh zero per load: hoisted out of the loop, `p.mx + vz` was a 64-bit pointer per lane -- and the register the kernel spilled)
+            asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+            mr[st][f] = *(const float *)((const char *)(p.mx + bt0 + t) + vz);
             if (p.in_dtype == 0) {
                 const float *row = p.logp + row0;
 #pragma unroll
-                for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? row[mylab[q]] : 0.f;
+                for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? *(const float *)((const char *)row + labo[q]) : 0.f;
             } else {
 #pragma unroll
                 for (int q = 0; q < NR; ++q) lr[st][f][q] = (tid + q * kCtcThreads < Sx) ? ld_x(p, row0 + mylab[q]) : 0.f;
@@ -2820,7 +2838,7 @@ __global__ __launch_bounds__(kChainThreads) void crf_den_pair_kernel(LossParams 
 }
 // NR: ctc states per thread, chosen by the host from the batch's longest label sequence.
 template <int NR>
-__global__ __launch_bounds__(kCtcThreads) void crf_ctc_pair_kernel(LossParams p) {
+__global__ __launch_bounds__(kCtcThreads, NR == 1 ? CRF_X_CTCWPE : 1) void crf_ctc_pair_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if ((int)blockIdx.x < p.B) ctc_forward<NR>(p, (int)blockIdx.x, lds);
     else ctc_backward<NR>(p, (int)blockIdx.x - p.B, lds);
@@ -2946,20 +2964,49 @@ constexpr int kGDEpRegs = 4;                                      // V <= 4*256
         frame_bad |= (unsigned)(!(nvb >= 0x03800000u && nvb < 0x7f800000u && nvb >= thr));                                   \
     } while (0)
 template <int NCPT, int EPR, int NT = kGDThreads, int CH = kChunk, int RR = kGDRowRegs, int WPE = 1>
-// (The instantiation of the metric graph, <1, 1>, compiles to 152 registers, and 152 it has to stay: registers are granted in eights, three workgroups
-// of 4 x 152 leave a SIMD 56, two leave it 208 = the two waves of 104 that a numerator-chain workgroup puts on every SIMD.  At 153 (-> 160) a chain
-// workgroup fits beside ONE grad workgroup only, the grad launch's queue never lets a CU fall that low, and the chains of batches whose grad pass
-// runs unstaged beside them (B >= 128, two CUs per recursion) ran AFTER it: B = 128 4.8 -> 5.6 ms per step, found by bisecting round 5's own
-// commits (profiles/round5_ab_one_register.txt).  The compiler ignores amdgpu_num_vgpr here; tests/test_isa_checks.py holds the number.)
+// (Registers, a property of the SCHEDULE: they are granted in eights, a SIMD has 512 per lane.  The instantiation of the metric graph, <1, 1>, runs
+// three workgroups to a CU (one wave each per SIMD) and, for batches whose grad pass is not staged (B >= 128, two CUs per recursion), BESIDE the
+// numerator chains, whose workgroup puts two waves on every SIMD: 2 x 160 + 2 x 96 = 512.  Round 5 found it the hard way: this kernel went from 152
+// to 153 registers (-> 160) while the chains were at 97 (-> 104): a chain workgroup then fitted beside ONE grad workgroup only, the grad launch's
+// queue never lets a CU fall that low, and the chains ran AFTER the grad pass: B = 128 4.8 -> 5.6 ms per step, found by bisecting the round's own
+// commits (profiles/round5_ab_one_register.txt).  Now: chains <= 96 (crf_ctc_pair_kernel<1>, held by its launch bounds), this kernel <= 160;
+// tests/test_isa_checks.py holds both numbers on the compiler's own metadata.  amdgpu_num_vgpr is ignored by this compiler.)
 __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
+    int b = blockIdx.y;
     int blk = blockIdx.x;
+    int stg = p.gd_stage, nfc = p.gd_nf, fpb = kGDFrames, sub = 0;
+    if (p.gd_persist) {
+        // ONE launch for all remaining stages (round 5).  Per-stage launches behind stream-level waits cost the pass ~5 us per wait even when the
+        // counter had long passed, and every launch ends on a partly empty device (1 024 workgroups on 384 slots: 2.67 rounds) before the next may
+        // begin: 232 us per 128-iteration stage against the 219 us the recursions take to release one -- the pass fell 14 us further behind
+        // with every stage and reached the recursions' end 75 us late with the whole last stage still to do (profiles/round5_ab_grad_one_launch.txt).
+        // Here the grid is 1-D and stage-major (the dispatcher hands out workgroups in that order), a workgroup finds its stage, leaves at once if
+        // its block is not of that stage, sets up, and only then waits (one lane, s_sleep between polls) for the counter the den kernels bump: the
+        // last stage's workgroups sit ready when the recursions end.  No deadlock: the launch is enqueued behind stage 1's stream-level wait, i.e.
+        // when every den workgroup has run half of its frames -- all of them hold their CUs and need nothing from this kernel.
+        stg = p.gd_stage;
+        while (stg + 1 < p.gd_nb && blk >= p.gd_poff[stg + 1]) ++stg;
+        nfc = (p.gd_bound[stg] - p.gd_bound[stg - 1] + kGDFrames - 1) / kGDFrames + 3;
+        fpb = p.gd_fpb[stg];
+        // candidate-major, the utterances side by side: workgroup i runs on XCD i % 8, and utterance-major with 2 * nfc = 16 candidates
+        // (pieces of 80 iterations) put every utterance's candidate j on the same XCD -- the five with work on five XCDs, three XCDs idle:
+        // 2.73 -> 2.92 ms per step (profiles/round5_ab_grad_one_launch.txt)
+        const int nsub = kGDFrames / fpb;
+        const int r = blk - p.gd_poff[stg];
+        const int r2 = r / p.B;
+        b = r - r2 * p.B;
+        blk = r2 / nsub;
+        sub = r2 - blk * nsub;
+        // (uniform, but integer division runs on the vector unit: back into scalar registers)
+        b = __builtin_amdgcn_readfirstlane(b); blk = __builtin_amdgcn_readfirstlane(blk); sub = __builtin_amdgcn_readfirstlane(sub);
+        stg = __builtin_amdgcn_readfirstlane(stg); nfc = __builtin_amdgcn_readfirstlane(nfc); fpb = __builtin_amdgcn_readfirstlane(fpb);
+    }
     const int V = p.V;
     const int lx = p.lx[b], Rq = p.Rq, Rb = p.Rb, NC = p.gNC;
-    if (p.gd_nf > 0) {
+    if (nfc > 0) {
         // Compact launch of stage k > 1: the blocks a stage completes are two short runs -- those whose last frame
         // the FORWARD recursion reached in this stage, from block bound[k-1]/16 on, and those whose first frame the
         // BACKWARD recursion reached, from block (lx-1-bound[k])/16 on -- so the launch holds gd_nf candidates of
@@ -2967,7 +3014,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
         // others held a workgroup slot and 37 KB of LDS for the ~2 us it takes to find that out).  The runs are
         // taken one block wider than needed on both sides; the exact test below decides, and a block of both runs
         // is taken by the forward one.
-        const int k = p.gd_stage, nf = p.gd_nf;
+        const int k = stg, nf = nfc;
         const int flo = p.gd_bound[k - 1] / kGDFrames - 1;
         const int blo = (lx - 1 - p.gd_bound[k]) / kGDFrames - 1;
         if (blk < nf) blk = flo + blk;
@@ -2982,7 +3029,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
     float *nrm = gd + 4 * Vp;                                               // [4] per-frame normalisers; gd: [4][Vp] label sums, both in rotation
     int *clab_s = (int *)(nrm + kGDFrames);                                 // [NC] label of each chunk (prologue only)
     const int64_t bt0 = (int64_t)b * p.T;
-    const int t0 = blk * kGDFrames, t1 = min(t0 + kGDFrames, p.T), tl = min(t1, lx);
+    int t0 = blk * kGDFrames, t1 = min(t0 + kGDFrames, p.T), tl = min(t1, lx);
     if (p.gd_stage > 0) {
         // Staged mode: the den recursions run in segments (iteration bounds gd_bound[]), and after segment k an event
         // releases the launch with gd_stage = k.  A block belongs to the FIRST stage at which both its Q rows
@@ -2994,8 +3041,15 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             if (p.gd_bound[k] < lx - 1 - t0) sb = k + 1;
         }
         const int mine = t0 < tl ? max(sf, sb) : 1;                // blocks past the utterance: first stage
-        if (mine != p.gd_stage) return;
+        if (mine != stg) return;
+        if (fpb < kGDFrames) {                                     // this workgroup's share of the block
+            t0 += sub * fpb;
+            t1 = min(t0 + fpb, t1);
+            tl = min(t1, lx);
+            if (t0 >= tl) return;                                  // (stages > 1 add to rows the numerator half has written: nothing to zero)
+        }
     }
+    t0 = __builtin_amdgcn_readfirstlane(t0); t1 = __builtin_amdgcn_readfirstlane(t1); tl = __builtin_amdgcn_readfirstlane(tl);
 
     unsigned idx[NCPT][CH];
     constexpr int HS = CH < 16 ? CH : 16;
@@ -3091,6 +3145,20 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
         if (4 * r < Rq) ((f32x4 *)Qs)[r] = qr[i];                                                        \
         if (4 * r < Rb) ((f32x4 *)Bs)[r] = br[i];                                                        \
     }
+    if (p.gd_persist) {
+        // set up; now the stage's rows.  The counter is bumped behind a drain of every wave's row stores and a barrier (publish_stage), the
+        // words are uncached in L2; an agent-scope acquire before the first row load (rows of the call before may sit in this XCD's L2).
+        if (tid == 0) {
+            const int *c = p.gd_cnt + stg;
+            for (unsigned spins = 0; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < p.gd_target; ++spins) {
+                if (spins > (1u << 21)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // (~7 s)
+                if ((spins & 63u) == 63u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                __builtin_amdgcn_s_sleep(127);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     float erc[EPR], rwc[EPR];
     if constexpr (GDE) {
         // Round 4: the rows of frame t+2 are requested as soon as frame t+1's have left the registers for the LDS (behind the first barrier of
@@ -3106,7 +3174,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             if (t0 + 1 < tl) CRF_GD_FETCH(t0 + 1);
         }
         sync_lds();
-        [[maybe_unused]] const bool tm_on = blk == 46 && blockIdx.y == 3 && tid < 64;   // (T = 1500: a block of the first stage, the middle of utterance 3)
+        [[maybe_unused]] const bool tm_on = blk == 46 && b == 3 && tid < 64;   // (T = 1500: a block of the first stage, the middle of utterance 3)
         for (int t = t0; t < tl; ++t) {
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
             float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
@@ -3197,7 +3265,7 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
             for (int q = 0; q < EPR; ++q) { erc[q] = ern[q]; rwc[q] = rwn[q]; }
         }
         sync_lds();
-        [[maybe_unused]] const bool tm_on = blk == 46 && blockIdx.y == 3 && tid < 64;   // (T = 1500: a block of the first stage, the middle of utterance 3)
+        [[maybe_unused]] const bool tm_on = blk == 46 && b == 3 && tid < 64;   // (T = 1500: a block of the first stage, the middle of utterance 3)
         for (int t = t0; t < tl; ++t) {
             CRF_TM(tm_on, 8192 + (t - t0) * 8 + 0);
             float *gsum = gd + (t & 3) * Vp, *gzero = gd + ((t + 2) & 3) * Vp;
@@ -5484,7 +5552,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     // 3.41 / 3.53 ms; pieces that shrink towards the end (256,192,128,96,64 ...) were no better than equal ones.
     // CRF_PIECE / CRF_STAGES override (segment mode: 4 pieces, each relaunch costs ~40 us).
     int bound[kMaxStages + 1] = {0};
-    int nstage = 1;
+    int nstage = 1, gd_piece = 0;
     bound[1] = (int)T;
     if (staged && T >= 256) {
         const int half = (int)((T / 2 + kGDFrames - 1) / kGDFrames * kGDFrames);
@@ -5494,8 +5562,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             piece = ((int)T - half + nshort - 1) / nshort;
             piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
         } else {
-            piece = 128;
-            while ((kMaxStages - 2) * piece < (int)T - half && piece < (int)T) piece += 128;   // the stage counters cover T - half
+            // (round 5, one grad launch for all stages: a stage costs the grad pass nothing any more and the recursions one drain + barrier;
+            // pieces of 48 .. 96 iterations all give 2.71 ms where 128 gives 2.75 and round 4's per-stage launches 2.82: profiles/round5_ab_grad_one_launch.txt)
+            piece = opt_on(kOpt_gd_stage_launches) ? 128 : 80;
+            while ((kMaxStages - 4) * piece < (int)T - half && piece < (int)T) piece += opt_on(kOpt_gd_stage_launches) ? 128 : 16;   // the stage counters cover T - half
             const int piece_env = opt(kOpt_piece, 0);
             if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
             const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
@@ -5504,9 +5574,25 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             if (fs > 0) first = std::min((int)T - kGDFrames, first + fs * kGDFrames);
         }
         nstage = 1;
+        gd_piece = piece;
         bound[1] = first;
         while (bound[nstage] < T && nstage < kMaxStages - 1) { bound[nstage + 1] = std::min((int)T, bound[nstage] + piece); ++nstage; }
         bound[nstage] = (int)T;
+        // taper: the last stage is what is left to do when the recursions have ended; with one grad launch for all stages (its workgroups
+        // wait themselves) a stage costs the grad pass nothing and the recursions one drain + barrier, so the last pieces are halved down
+        // to `taper` iterations: ..., piece, piece / 2, piece / 4, ..., taper
+        const int taper = stages_env > 0 || segmode || opt_on(kOpt_gd_stage_launches) ? 0 : (opt(kOpt_taper, 32) + kGDFrames - 1) / kGDFrames * kGDFrames;
+        if (taper > 0 && taper < piece && nstage >= 3) {
+            int desc[kMaxStages + 8], n = 0, pos = (int)T;             // stage ends from the last one backwards
+            desc[n++] = pos;
+            for (int q = taper; q < piece && n < 8; q *= 2) { pos -= q; desc[n++] = pos; }
+            while (pos - piece > first + kGDFrames && n < kMaxStages + 6) { pos -= piece; desc[n++] = pos; }
+            if (pos > first && n + 1 <= kMaxStages - 1) {               // (the piece behind `first` takes what is left: 16 .. piece + 16 iterations)
+                nstage = n + 1;
+                bound[1] = first;
+                for (int k = 0; k < n; ++k) bound[2 + k] = desc[n - 1 - k];
+            }
+        }
     }
     p.gd_nb = nstage + 1;
     for (int k = 0; k <= nstage && k < 16; ++k) p.gd_bound[k] = bound[k];
@@ -5516,13 +5602,28 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const size_t lds_ctc = chain_lds_bytes(h, (int)V, Sc, 2);
 
     const dim3 ggrid((unsigned)((T + kGradFrames - 1) / kGradFrames), (unsigned)B);
-    auto launch_grad_den = [&](hipStream_t st, int stage) -> int {
+    auto launch_grad_den = [&](hipStream_t st, int stage, bool persist = false) -> int {
         p.gd_stage = stage;
         const size_t l = ((size_t)rup64((int)w.Rq + 1) + rup64((int)w.Rb + 1) + 4 * rup64((int)V) + kGDFrames + rup64(gnc)) * sizeof(float);
         dim3 gg((unsigned)((T + kGDFrames - 1) / kGDFrames), (unsigned)B);
         p.gd_nf = 0;
+        p.gd_persist = 0;
         const bool full_grid = opt_on(kOpt_gd_full_grid);
-        if (stage > 1 && !full_grid) {   // (stage 1 is the middle of every utterance: all blocks are candidates)
+        if (persist) {   // the stages `stage` .. nstage in one launch (see the kernel): 2 * nf candidates per utterance and stage, stage-major
+            p.gd_persist = 1;
+            p.gd_cnt = cx->flags + 16;
+            p.gd_target = (int)(2 * B);
+            int64_t tot = 0;
+            const int sub_env = opt(kOpt_gd_sub, 16);              // frames per workgroup in a last stage shorter than `piece` (16: whole blocks)
+            const int fsub = sub_env == 8 ? 8 : sub_env == 4 ? 4 : sub_env == 2 ? 2 : kGDFrames;
+            for (int k = stage; k < p.gd_nb; ++k) {
+                p.gd_poff[k] = (int)tot;
+                p.gd_fpb[k] = (k == p.gd_nb - 1 && p.gd_bound[k] - p.gd_bound[k - 1] < gd_piece) ? fsub : kGDFrames;   // (the LAST stage only)
+                tot += 2 * (int64_t)((p.gd_bound[k] - p.gd_bound[k - 1] + kGDFrames - 1) / kGDFrames + 3) * (kGDFrames / p.gd_fpb[k]) * B;
+            }
+            p.gd_poff[p.gd_nb] = (int)tot;
+            gg = dim3((unsigned)tot, 1);
+        } else if (stage > 1 && !full_grid) {   // (stage 1 is the middle of every utterance: all blocks are candidates)
             p.gd_nf = (p.gd_bound[stage] - p.gd_bound[stage - 1] + kGDFrames - 1) / kGDFrames + 3;
             if (2 * p.gd_nf < (int)gg.x) gg.x = (unsigned)(2 * p.gd_nf); else p.gd_nf = 0;
         }
@@ -5837,7 +5938,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             }
         }
         p.grad_den_acc = 1;
+        // (one launch for the stages 2 ..: behind stage 1's wait -- every recursion has run half of its frames, every den workgroup is resident)
+        const bool gd_one = !segmode && nstage >= 3 && !opt_on(kOpt_gd_stage_launches);
         for (int k = 0; k < nstage; ++k) {
+            if (gd_one && k == 1) { if ((rc = launch_grad_den(side, 2, true))) return rc; break; }
             if (!segmode) {
                 if ((e = hipStreamWaitValue32(side, cx->flags + 16 + k + 1, (uint32_t)(2 * B), hipStreamWaitValueGte, 0xffffffffu)) != hipSuccess) {
                     // not available here: from the next call on, segments.  This call: wait for the recursions to END

@@ -103,18 +103,18 @@ def _kernel_meta(path):
 @pytest.mark.timeout(900)
 def test_register_budgets_the_schedule_relies_on():
     """Occupancy is part of the schedule, and ONE register changes it (VGPRs are granted in eights, 512 per SIMD lane):
-    - the metric graph's grad den kernel (256 threads: one wave per SIMD and workgroup) at <= 152: two of its workgroups leave a SIMD
-      208 registers = the two waves of 104 a numerator-chain workgroup puts there.  At 153 the chains of B >= 128 ran BEHIND the grad pass:
-      4.8 -> 5.6 ms per step, found by bisecting (profiles/round5_ab_one_register.txt);
-    - the numerator chains of short label sequences at <= 104;
+    - the metric graph's grad den kernel (256 threads: one wave per SIMD and workgroup) at <= 160 and the numerator chains of short label
+      sequences (512 threads: two waves per SIMD) at <= 96: two grad workgroups and a chain workgroup share a CU, 2 x 160 + 2 x 96 = 512.
+      At 153 (-> 160) and 97 (-> 104) the chains of B >= 128 ran BEHIND the grad pass: 4.8 -> 5.6 ms per step, found by bisecting
+      (profiles/round5_ab_one_register.txt);
     - the 1024-thread recursions at <= 128 (4 waves per SIMD), the 768-thread ones at <= 168 (3), the 512 x 30 two-utterance geometry at <= 256,
       none of them spilling inside the frame loop (the few spilled prologue constants are counted and capped)."""
     mod = _tool()
     meta = _kernel_meta(_assembly(mod))
     gd = meta["_ZN3crf19crf_grad_den_kernelILi1ELi1ELi256ELi32ELi5ELi1EEEvNS_10LossParamsE"]
-    assert gd["vgpr_count"] <= 152 and gd["vgpr_spill_count"] == 0, gd
+    assert gd["vgpr_count"] <= 160 and gd["vgpr_spill_count"] == 0, gd
     ch = meta["_ZN3crf19crf_ctc_pair_kernelILi1EEEvNS_10LossParamsE"]          # (label sequences of the metric shape: one register set per thread)
-    assert ch["vgpr_count"] <= 104 and ch["vgpr_spill_count"] == 0, ch
+    assert ch["vgpr_count"] <= 96 and ch["vgpr_spill_count"] == 0, ch
     pairs = {k: v for k, v in meta.items() if "crf_fac_pair_kernelILb" in k}
     assert len(pairs) >= 12
     for k, v in pairs.items():
