@@ -132,6 +132,7 @@ struct LossParams {
     int gd_stage, gd_nb;          // crf_grad_den_kernel: process only the 16-frame blocks completed by den segment `gd_stage` (0 = all)
     int gd_nf;                    // > 0: the launch holds only 2 * gd_nf candidate blocks per utterance (see the kernel)
     int gd_bound[16];             //   segment k (1-based) runs the recursion iterations [gd_bound[k-1], gd_bound[k])
+    int fin_fold;                 // crf_robust_grad_kernel: workgroup (0, 0) also does what crf_finalize_kernel does (which is then not launched)
     int gd_persist;               // crf_grad_den_kernel: 1 = ONE launch for the stages gd_stage .. gd_nb-1 -- 1-D grid, stage-major, the candidates of stage k
     int gd_poff[17];              //   from block gd_poff[k] on -- whose workgroups wait for their stage's counter themselves:
     const int *gd_cnt;            //   the den kernels' stage counters (FacParams::stage_cnt; fine-grained memory) ...
@@ -384,15 +385,41 @@ __global__ __launch_bounds__(256) void crf_prep_kernel(LossParams p) {
     };
     const int64_t r0 = f * p.V;
     float m = -INFINITY;
-    for (int v = sub; v < p.V; v += G) m = fmaxf(m, ld_x(p, r0 + v));
-    m = gmax(m);
-    if (m == -INFINITY) m = 0.f;
     float *er = p.ep + f * p.V;
     float ssum = 0.f;
-    for (int v = sub; v < p.V; v += G) {
-        const float d = ld_x(p, r0 + v) - m;
-        er[v] = exp_scaled(d, kEpExp);
-        if (p.fused) ssum += __expf(d);
+    constexpr int NX = 16;                        // row entries a lane keeps (V <= 16 G: every vocabulary the factored kernels take)
+    if (p.V <= NX * G) {
+        // one pass over the row: its entries stay in registers between the maximum and the exp (round 5; the second pass re-read them through
+        // the cache, a second memory round trip on the only kernel in front of the recursions: 23.7 -> see profiles/round5_ab_grad_one_launch.txt)
+        float x[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            if (k * G >= p.V) break;              // (uniform)
+            const int v = sub + k * G;
+            x[k] = v < p.V ? ld_x(p, r0 + v) : -INFINITY;
+            m = fmaxf(m, x[k]);
+        }
+        m = gmax(m);
+        if (m == -INFINITY) m = 0.f;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            if (k * G >= p.V) break;
+            const int v = sub + k * G;
+            if (v < p.V) {
+                const float d = x[k] - m;
+                er[v] = exp_scaled(d, kEpExp);
+                if (p.fused) ssum += __expf(d);
+            }
+        }
+    } else {
+        for (int v = sub; v < p.V; v += G) m = fmaxf(m, ld_x(p, r0 + v));
+        m = gmax(m);
+        if (m == -INFINITY) m = 0.f;
+        for (int v = sub; v < p.V; v += G) {
+            const float d = ld_x(p, r0 + v) - m;
+            er[v] = exp_scaled(d, kEpExp);
+            if (p.fused) ssum += __expf(d);
+        }
     }
     if (p.fused) {
         ssum = gsum(ssum);
@@ -4311,7 +4338,8 @@ __global__ __launch_bounds__(kChainThreads) void crf_robust_den_kernel(LossParam
 // grad rows of the redone utterances: gamma_den[t][v] = softmax_v( d_t[v] + ln sum_{p: lab_p = v} Q_t[p] * BP_t[p] ) in fp64,
 // combined with the numerator half exactly as crf_grad_kernel does.  grid (frames-in-parallel, B); rows gathered from L2.
 // LDS: csum[NC] | gl (double)[Vp] | gc[Vp] | red (double)[4]
-__global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParams p) {
+__device__ __forceinline__ void finalize_body(const LossParams &p);
+__device__ __forceinline__ void robust_grad_body(const LossParams &p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const GraphDev &g = p.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -4607,8 +4635,8 @@ __global__ __launch_bounds__(kGradThreads) void crf_robust_ctc_fix_kernel(LossPa
     }
 }
 
-// loss = sum_b(c_den*logZ_b - c_ctc*logp_b); copies the per-utterance costs out (one workgroup)
-__global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
+// loss = sum_b(c_den*logZ_b - c_ctc*logp_b); copies the per-utterance costs out (one workgroup of 256 threads)
+__device__ __forceinline__ void finalize_body(const LossParams &p) {
     __shared__ double red[4];
     __shared__ int nfall[2];
     const int tid = threadIdx.x;
@@ -4643,6 +4671,15 @@ __global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) {
     __syncthreads();
     if (tid == 0) p.loss[0] = (p.res && *p.err) ? __builtin_nanf("") : (float)(red[0] + red[1] + red[2] + red[3]);
     if (tid < 2) p.err[kFlagFallback + tid] = nfall[tid];
+}
+__global__ __launch_bounds__(256) void crf_finalize_kernel(LossParams p) { finalize_body(p); }
+// The last launch of a call with a denominator: the grad rows of the redone utterances (none, as a rule: every workgroup leaves at once) and, in
+// workgroup (0, 0), the call's sums -- they need nothing of what the other workgroups write, and as a launch of their own they were one more
+// dispatch (~5 us + the gap in front of it) behind the end of the grad pass (round 5; p.fin_fold, crf_loss_fwd_bwd)
+static_assert(kGradThreads == 256, "finalize_body is written for 256 threads");
+__global__ __launch_bounds__(kGradThreads) void crf_robust_grad_kernel(LossParams p) {
+    robust_grad_body(p);
+    if (p.fin_fold && blockIdx.x == 0 && blockIdx.y == 0) { __syncthreads(); finalize_body(p); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -6041,6 +6078,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         }
         prof_mark(5, true, stream);
     }
+    bool fin_folded = false;
     if (den && robust_env != 0) {
         // Fallback for utterances whose scaled-fp32 recursion lost all its mass: redone in a per-frame log-shifted form
         // (crf_robust_den_kernel).  Workgroups of unflagged utterances leave at once -- two near-empty launches per call.
@@ -6057,13 +6095,17 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         LAUNCH_CHECK("crf_robust_den_kernel");
         const size_t lg = (size_t)rup64(h->dev.NC) * 4 + (size_t)rup64((int)V) * 12 + 64;
         if ((rc = ensure_lds((const void *)crf_robust_grad_kernel, lg, mg, "robust grad"))) return rc;
+        // (the call's sums in this launch unless the numerator's second fallback pass, which rewrites costs, is still to come)
+        fin_folded = !(ctc && robust_env != 0 && !ctc_pass1) && !opt_on(kOpt_no_fin_fold) && !g_prof.on;
+        p.fin_fold = fin_folded ? 1 : 0;
         hipLaunchKernelGGL(crf_robust_grad_kernel, dim3(16, (unsigned)B), dim3(kGradThreads), lg, stream, p);
+        p.fin_fold = 0;
         LAUNCH_CHECK("crf_robust_grad_kernel");
     }
     // (the staged schedule's pass 1 ran behind the only kernel that marks frames: nothing is left for a second pass there)
     if (ctc && robust_env != 0 && !ctc_pass1 && (rc = launch_robust_ctc(stream, 2))) return rc;
     prof_mark(6, false, stream);
-    hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
+    if (!fin_folded) hipLaunchKernelGGL(crf_finalize_kernel, dim3(1), dim3(256), 0, stream, p);
     prof_mark(6, true, stream);
     prof_mark(7, true, stream);
     g_prof.have = g_prof.on;

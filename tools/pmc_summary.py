@@ -47,10 +47,11 @@ def main():
         shutil.copy(ks[0], os.path.join(PROF, f"{ROUND}_{tag}_kernel_stats.csv"))
     traffic, sq = {}, {}
     fe, wr, s = counters(tag, "fetch"), counters(tag, "write"), counters(tag, "sq")
-    def nsteps(acc, what):   # calls of the loss in that profiling pass = launches of the finalize kernel
-        for k, cs in acc.items():
-            if "crf_finalize_kernel" in k and what in cs:
-                return max(1, len(cs[what]))
+    def nsteps(acc, what):   # calls of the loss in that profiling pass = launches of the finalize kernel (round 5: folded into the robust grad launch)
+        for name in ("crf_finalize_kernel", "crf_robust_grad_kernel"):
+            for k, cs in acc.items():
+                if name in k and what in cs:
+                    return max(1, len(cs[what]))
         return 1
     for k in sorted(set(fe) | set(wr)):
         if "crf" not in k:

@@ -5,7 +5,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
 ks.sort()
-fin = [i for i, k in enumerate(ks) if "crf_finalize" in k[2]]
+# the last kernel of a call: crf_finalize_kernel, or -- since round 5 folded into it -- the robust grad launch
+fin = [i for i, k in enumerate(ks) if "crf_finalize" in k[2]] or [i for i, k in enumerate(ks) if "crf_robust_grad" in k[2]]
 if len(fin) < 2: sys.exit("need at least two calls in the trace")
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -2          # a call in the middle of the run
 a, b = fin[which - 1] + 1, fin[which]
