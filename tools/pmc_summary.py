@@ -48,7 +48,7 @@ def main():
     traffic, sq = {}, {}
     fe, wr, s = counters(tag, "fetch"), counters(tag, "write"), counters(tag, "sq")
     def nsteps(acc, what):   # calls of the loss in that profiling pass = launches of the finalize kernel (round 5: folded into the robust grad launch)
-        for name in ("crf_finalize_kernel", "crf_robust_grad_kernel"):
+        for name in ("crf_robust_grad_kernel", "crf_finalize_kernel"):   # (one robust grad launch per call with a denominator; finalize only where it is not folded in)
             for k, cs in acc.items():
                 if name in k and what in cs:
                     return max(1, len(cs[what]))
