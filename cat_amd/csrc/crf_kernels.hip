@@ -5369,6 +5369,71 @@ int crf_den_kernels(const crf_graph *g, int64_t B, int64_t T, int64_t V) {
     return w.bat ? 3 : w.fac ? 2 : w.res ? 1 : 0;
 }
 
+// Stage bounds of the staged grad pass (crf_loss_fwd_bwd; crf_debug_stage_plan shows them to the tests): bound[0] = 0 < bound[1] < ... < bound[nstage] = T,
+// stage k = the recursions' iterations [bound[k-1], bound[k]).  Returns nstage; *gd_piece = the length of the equal pieces.
+static int plan_grad_stages(int64_t T, bool segmode, int stages_env, int pieces, int *bound, int *gd_piece_out) {
+    int nstage = 1, gd_piece = 0;
+    bound[0] = 0;
+    bound[1] = (int)T;
+    if (T >= 256) {
+        const int half = (int)((T / 2 + kGDFrames - 1) / kGDFrames * kGDFrames);
+        int piece, first = half;
+        if (stages_env > 0 || segmode) {
+            const int nshort = std::max(1, std::min(std::min(pieces, kMaxStages - 2), (int)(T - half) / 32));
+            piece = ((int)T - half + nshort - 1) / nshort;
+            piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
+        } else {
+            // (round 5, one grad launch for all stages: a stage costs the grad pass nothing any more and the recursions one drain + barrier;
+            // pieces of 48 .. 96 iterations all give 2.71 ms where 128 gives 2.75 and round 4's per-stage launches 2.82: profiles/round5_ab_grad_one_launch.txt)
+            piece = opt_on(kOpt_gd_stage_launches) ? 128 : 80;
+            while ((kMaxStages - 4) * piece < (int)T - half && piece < (int)T) piece += opt_on(kOpt_gd_stage_launches) ? 128 : 16;   // the stage counters cover T - half
+            const int piece_env = opt(kOpt_piece, 0);
+            if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
+            const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
+            first = std::max(half, ((int)T - body + kGDFrames - 1) / kGDFrames * kGDFrames);
+            const int fs = opt(kOpt_first_shift, 0);
+            if (fs > 0) first = std::min((int)T - kGDFrames, first + fs * kGDFrames);
+        }
+        nstage = 1;
+        gd_piece = piece;
+        bound[1] = first;
+        while (bound[nstage] < T && nstage < kMaxStages - 1) { bound[nstage + 1] = std::min((int)T, bound[nstage] + piece); ++nstage; }
+        bound[nstage] = (int)T;
+        // taper: the last stage is what is left to do when the recursions have ended; with one grad launch for all stages (its workgroups
+        // wait themselves) a stage costs the grad pass nothing and the recursions one drain + barrier, so the last pieces are halved down
+        // to `taper` iterations: ..., piece, piece / 2, piece / 4, ..., taper
+        const int taper = stages_env > 0 || segmode || opt_on(kOpt_gd_stage_launches) ? 0 : (opt(kOpt_taper, 32) + kGDFrames - 1) / kGDFrames * kGDFrames;
+        if (taper > 0 && taper < piece && nstage >= 3) {
+            int desc[kMaxStages + 8], n = 0, pos = (int)T;             // stage ends from the last one backwards
+            desc[n++] = pos;
+            for (int q = taper; q < piece && n < 8; q *= 2) { pos -= q; desc[n++] = pos; }
+            while (pos - piece > first + kGDFrames && n < kMaxStages + 6) { pos -= piece; desc[n++] = pos; }
+            if (pos > first && n + 1 <= kMaxStages - 1) {               // (the piece behind `first` takes what is left: 16 .. piece + 16 iterations)
+                nstage = n + 1;
+                bound[1] = first;
+                for (int k = 0; k < n; ++k) bound[2 + k] = desc[n - 1 - k];
+            }
+        }
+    }
+    *gd_piece_out = gd_piece;
+    return nstage;
+}
+
+// The one-launch grad pass's grid (crf_grad_den_kernel, gd_persist): first block of the candidates of the stages `stage` .. nstage, frames per
+// workgroup in each; returns the number of workgroups
+static int64_t plan_grad_grid(const int *bound, int nstage, int stage, int64_t B, int gd_piece, int *poff, int *fpb) {
+    int64_t tot = 0;
+    const int sub_env = opt(kOpt_gd_sub, 16);              // frames per workgroup in a last stage shorter than `piece` (16: whole blocks)
+    const int fsub = sub_env == 8 ? 8 : sub_env == 4 ? 4 : sub_env == 2 ? 2 : kGDFrames;
+    for (int k = stage; k <= nstage; ++k) {
+        poff[k] = (int)tot;
+        fpb[k] = (k == nstage && bound[k] - bound[k - 1] < gd_piece) ? fsub : kGDFrames;   // (the LAST stage only)
+        tot += 2 * (int64_t)((bound[k] - bound[k - 1] + kGDFrames - 1) / kGDFrames + 3) * (kGDFrames / fpb[k]) * B;
+    }
+    poff[nstage + 1] = (int)tot;
+    return tot;
+}
+
 static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dtype, const int32_t *labels, const int32_t *lab_off,
                      const int32_t *lx, const int32_t *ly, int64_t B, int64_t T, int64_t V,
                      int64_t max_label_len, float c_den, float c_ctc, float *grad, float *loss,
@@ -5591,46 +5656,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     int bound[kMaxStages + 1] = {0};
     int nstage = 1, gd_piece = 0;
     bound[1] = (int)T;
-    if (staged && T >= 256) {
-        const int half = (int)((T / 2 + kGDFrames - 1) / kGDFrames * kGDFrames);
-        int piece, first = half;
-        if (stages_env > 0 || segmode) {
-            const int nshort = std::max(1, std::min(std::min(pieces, kMaxStages - 2), (int)(T - half) / 32));
-            piece = ((int)T - half + nshort - 1) / nshort;
-            piece = (piece + kGDFrames - 1) / kGDFrames * kGDFrames;
-        } else {
-            // (round 5, one grad launch for all stages: a stage costs the grad pass nothing any more and the recursions one drain + barrier;
-            // pieces of 48 .. 96 iterations all give 2.71 ms where 128 gives 2.75 and round 4's per-stage launches 2.82: profiles/round5_ab_grad_one_launch.txt)
-            piece = opt_on(kOpt_gd_stage_launches) ? 128 : 80;
-            while ((kMaxStages - 4) * piece < (int)T - half && piece < (int)T) piece += opt_on(kOpt_gd_stage_launches) ? 128 : 16;   // the stage counters cover T - half
-            const int piece_env = opt(kOpt_piece, 0);
-            if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
-            const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
-            first = std::max(half, ((int)T - body + kGDFrames - 1) / kGDFrames * kGDFrames);
-            const int fs = opt(kOpt_first_shift, 0);
-            if (fs > 0) first = std::min((int)T - kGDFrames, first + fs * kGDFrames);
-        }
-        nstage = 1;
-        gd_piece = piece;
-        bound[1] = first;
-        while (bound[nstage] < T && nstage < kMaxStages - 1) { bound[nstage + 1] = std::min((int)T, bound[nstage] + piece); ++nstage; }
-        bound[nstage] = (int)T;
-        // taper: the last stage is what is left to do when the recursions have ended; with one grad launch for all stages (its workgroups
-        // wait themselves) a stage costs the grad pass nothing and the recursions one drain + barrier, so the last pieces are halved down
-        // to `taper` iterations: ..., piece, piece / 2, piece / 4, ..., taper
-        const int taper = stages_env > 0 || segmode || opt_on(kOpt_gd_stage_launches) ? 0 : (opt(kOpt_taper, 32) + kGDFrames - 1) / kGDFrames * kGDFrames;
-        if (taper > 0 && taper < piece && nstage >= 3) {
-            int desc[kMaxStages + 8], n = 0, pos = (int)T;             // stage ends from the last one backwards
-            desc[n++] = pos;
-            for (int q = taper; q < piece && n < 8; q *= 2) { pos -= q; desc[n++] = pos; }
-            while (pos - piece > first + kGDFrames && n < kMaxStages + 6) { pos -= piece; desc[n++] = pos; }
-            if (pos > first && n + 1 <= kMaxStages - 1) {               // (the piece behind `first` takes what is left: 16 .. piece + 16 iterations)
-                nstage = n + 1;
-                bound[1] = first;
-                for (int k = 0; k < n; ++k) bound[2 + k] = desc[n - 1 - k];
-            }
-        }
-    }
+    if (staged && T >= 256) nstage = plan_grad_stages(T, segmode, stages_env, pieces, bound, &gd_piece);
     p.gd_nb = nstage + 1;
     for (int k = 0; k <= nstage && k < 16; ++k) p.gd_bound[k] = bound[k];
     float *fstate = (float *)(base + w.off_state), *bstate = fstate + B * w.state_stride;
@@ -5650,15 +5676,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             p.gd_persist = 1;
             p.gd_cnt = cx->flags + 16;
             p.gd_target = (int)(2 * B);
-            int64_t tot = 0;
-            const int sub_env = opt(kOpt_gd_sub, 16);              // frames per workgroup in a last stage shorter than `piece` (16: whole blocks)
-            const int fsub = sub_env == 8 ? 8 : sub_env == 4 ? 4 : sub_env == 2 ? 2 : kGDFrames;
-            for (int k = stage; k < p.gd_nb; ++k) {
-                p.gd_poff[k] = (int)tot;
-                p.gd_fpb[k] = (k == p.gd_nb - 1 && p.gd_bound[k] - p.gd_bound[k - 1] < gd_piece) ? fsub : kGDFrames;   // (the LAST stage only)
-                tot += 2 * (int64_t)((p.gd_bound[k] - p.gd_bound[k - 1] + kGDFrames - 1) / kGDFrames + 3) * (kGDFrames / p.gd_fpb[k]) * B;
-            }
-            p.gd_poff[p.gd_nb] = (int)tot;
+            const int64_t tot = plan_grad_grid(p.gd_bound, p.gd_nb - 1, stage, B, gd_piece, p.gd_poff, p.gd_fpb);
             gg = dim3((unsigned)tot, 1);
         } else if (stage > 1 && !full_grid) {   // (stage 1 is the middle of every utterance: all blocks are candidates)
             p.gd_nf = (p.gd_bound[stage] - p.gd_bound[stage - 1] + kGDFrames - 1) / kGDFrames + 3;
@@ -6111,6 +6129,24 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     g_prof.have = g_prof.on;
     LAUNCH_CHECK("crf_finalize_kernel");
 #undef LAUNCH_CHECK
+    return CRF_OK;
+}
+
+int crf_debug_stage_plan(int64_t T, int64_t B, int32_t *out, int n_out) {
+    if (!out || n_out < 4 + 4 * (kMaxStages + 2) || T < 1 || B < 1) { set_error("crf_debug_stage_plan: out needs 4 + 4 * 18 ints"); return CRF_ERR_ARG; }
+    int bound[kMaxStages + 2] = {0}, poff[kMaxStages + 2] = {0}, fpb[kMaxStages + 2] = {0}, gd_piece = 0;
+    const bool segmode = opt_on(kOpt_segments);
+    const int stages_env = opt(kOpt_stages, 0);
+    const int nstage = plan_grad_stages(T, segmode, stages_env, stages_env > 0 ? stages_env : (segmode ? 4 : 12), bound, &gd_piece);
+    const bool one = !segmode && nstage >= 3 && !opt_on(kOpt_gd_stage_launches);
+    const int64_t tot = one ? plan_grad_grid(bound, nstage, 2, B, gd_piece, poff, fpb) : 0;
+    out[0] = nstage; out[1] = gd_piece; out[2] = one ? 1 : 0; out[3] = (int32_t)tot;
+    for (int k = 0; k < kMaxStages + 2; ++k) {
+        out[4 + k] = bound[k];
+        out[4 + (kMaxStages + 2) + k] = poff[k];
+        out[4 + 2 * (kMaxStages + 2) + k] = fpb[k];
+        out[4 + 3 * (kMaxStages + 2) + k] = k >= 1 && k <= nstage ? (bound[k] - bound[k - 1] + kGDFrames - 1) / kGDFrames + 3 : 0;   // candidates per run (nfc)
+    }
     return CRF_OK;
 }
 

@@ -69,7 +69,7 @@ _lib.crf_build_switches.restype = ctypes.c_char_p
 
 EXPORTED_SYMBOLS = (
     "crf_graph_create", "crf_graph_create_from_arcs", "crf_graph_destroy", "crf_graph_dims", "crf_graph_stats",
-    "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_debug_res_emulate", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
+    "crf_workspace_bytes", "crf_den_kernels", "crf_debug_stream_check", "crf_debug_decode_check", "crf_debug_facbatch_check", "crf_debug_fac_emulate", "crf_debug_res_emulate", "crf_debug_stage_plan", "crf_loss_fwd_bwd", "crf_loss_fwd_bwd_logits", "crf_profile_enable", "crf_profile_read", "crf_timing_read", "crf_stage_i32",
     "crf_debug_set", "crf_debug_unset", "crf_debug_list", "crf_last_den_kernel", "crf_last_call_streams", "crf_last_side_stream", "crf_last_fallback_counts", "crf_build_switches", "crf_last_error", "crf_version",
 )
 
@@ -244,6 +244,19 @@ def debug_fac_emulate(handle: int, T: int = 6, seed: int = 1):
     _lib.crf_debug_fac_emulate.restype = ctypes.c_int
     _check(_lib.crf_debug_fac_emulate(_vp(handle), T, seed, out))
     return float(out[0]), float(out[1]), float(out[2])
+
+
+def debug_stage_plan(T: int, B: int):
+    """The stage plan of the staged grad pass (include/ctc_crf_hip.h: crf_debug_stage_plan; no GPU) under the current debug switches."""
+    n = 18
+    out = (ctypes.c_int32 * (4 + 4 * n))()
+    _lib.crf_debug_stage_plan.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
+    _lib.crf_debug_stage_plan.restype = ctypes.c_int
+    _check(_lib.crf_debug_stage_plan(T, B, out, len(out)))
+    ns = int(out[0])
+    arr = lambda j: [int(out[4 + j * n + k]) for k in range(n)]
+    return {"nstage": ns, "piece": int(out[1]), "one_launch": bool(out[2]), "workgroups": int(out[3]),
+            "bound": arr(0)[:ns + 1], "poff": arr(1)[:ns + 2], "fpb": arr(2)[:ns + 1], "nf": arr(3)[:ns + 1]}
 
 
 def debug_res_emulate(handle: int, T: int = 6, seed: int = 1):

@@ -107,6 +107,12 @@ int crf_debug_facbatch_check(const crf_graph *g, int64_t *out4);
  * rowless states, and with two compute units per recursion exactly what crosses between them (a gather of anything else yields
  * NaN).  out3 = {sum over end states by the graph's own row tables, factored forward, factored backward}: all three agree. */
 int crf_debug_fac_emulate(const crf_graph *g, int T, unsigned seed, double *out3);
+/* Test aid (no GPU): the stage plan of the staged grad pass for utterances of up to T frames and a batch of B, as crf_loss_fwd_bwd makes it
+ * under the current debug switches (piece, taper, stages, segments, gd_stage_launches, gd_sub).  out (n_out >= 76 ints): [0] number of stages,
+ * [1] length of the equal pieces, [2] 1 when the stages 2.. are ONE launch, [3] workgroups of that launch, then four arrays of 18 ints indexed by
+ * the stage: its end (bound[0] = 0 ... bound[nstage] = T, in iterations of the recursions), its first workgroup in the one launch, frames per
+ * workgroup, candidate blocks per run.  tests/test_stage_plan.py walks the grid the way crf_grad_den_kernel does: every frame block once. */
+int crf_debug_stage_plan(int64_t T, int64_t B, int32_t *out, int n_out);
 /* The same for the GENERIC register-resident layout over K compute units (any graph that fits: rows = pairs forward, state
  * copies backward, one produced entry per row, every product exchanged): out3 = {sum by the recursion over the graph's arcs,
  * layout forward, layout backward}; the grad pass's pair lists are checked frame by frame as well. */
