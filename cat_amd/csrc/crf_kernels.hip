@@ -6027,7 +6027,11 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // (factored, one CU per recursion: the den grid leaves ncu - den_wgs CUs free -- B = 96: 64 of them -- and the numerator
         // chains, four workgroups to a CU, run there beside it, behind the start gate so that the den workgroups get their CUs first)
         const bool fac1 = fac && FX->K == 1;
-        const bool after = ctc_after_env >= 0 ? ctc_after_env != 0 : fac1 ? den_wgs >= ncu_dev : (res && h->dev.res.K > 1);
+        // (round 5: not only when the den grid owns EVERY CU.  Between the staged schedule's limit -- three quarters of the CUs -- and a full device the
+        // chains ran beside the recursions on the few CUs they leave, 2 B chain workgroups on 256 - 2 B CUs, and took longer than the recursions: B = 100 /
+        // 104 / 112 / 120 4.40 / 4.54 / 4.82 / 5.16 ms per step; behind them, beside the den half of the grad pass: 4.28 / 4.38 / 4.48 / 4.61,
+        // profiles/round5_ab_grad_one_launch.txt)
+        const bool after = ctc_after_env >= 0 ? ctc_after_env != 0 : fac1 ? den_wgs * 100 > (int64_t)ncu_dev * opt(kOpt_stage_fill, 75) : (res && h->dev.res.K > 1);
         if (!after && fac1 && have_flags) {
             if ((rc = fork_side())) return rc;
             if ((rc = launch_den(stream))) return rc;
