@@ -23,6 +23,16 @@ typedef std::vector<std::vector<std::pair<int, float>>> Rows;
 
 // geometry of one resident workgroup: threads, waves, chunks per thread (registers), words per thread
 struct Geom { int threads, waves, nch, words, maxsl, multilane; };   // maxsl: slices per wave (0 = any number); multilane: long rows on adjacent lanes
+// Cost model of the row spreading for SMALL graphs ("SMALL graphs" below): a frame costs max(kSpreadSimdWeight x the busiest SIMD's chunk sum,
+// kSpreadWaveWeight x the heaviest wave's chunks) -- ~49 cycles per chunk of a saturated SIMD's sum against ~70 per chunk of a wave alone on its SIMD (a batch of
+// gathers is an LDS round trip; tools/ubench_issue.py, profiles/round4_ubench_issue.txt).  Calibrated on S = 513 (5 slices on 16 waves: 1.26 -> 0.92 us per frame,
+// round 4) and checked there and on a second small graph against the unspread layout by tests/test_gpu_parity.py::test_small_graphs_spread_rows.
+constexpr int kSpreadSimdWeight = 5, kSpreadWaveWeight = 7;
+// Geometry choice, 1024 x 15 against 768 x 20 / 21 (threads x chunks): graphs with more than kLongRowArcs forward arcs in rows longer than a lane's registers, those
+// being more than 1 / kLongRowShareDen of all, keep the 768-thread geometries.  Two data points (den_lm estimated from text, profiles/round4_r4y_point_estimated.txt):
+// S = 3 006, 14.9 k of 20.5 k arcs in such rows, is faster on 1024 threads (recursions 2.28 -> 2.13 ms), S = 6 836, 27.3 k of 49.0 k, slower (3.41 -> 3.51): the
+// threshold sits between them; `fac_threads=768/1024` overrides.
+constexpr size_t kLongRowArcs = 20000, kLongRowShareDen = 5;
 constexpr Geom kGeomRes{kResThreads, kResWaves, kResNCH, kResWords, 0, 0};
 constexpr Geom kGeomFac512{kResThreads, kResWaves, kResNCH, kResWords, 0, 1};   // factored layout, 512 threads (row constants in LDS)
 constexpr Geom kGeomFac3{kFac3Threads, kFac3Threads / kWave, kFac3ArcCh, kFac3NCH * 6, kFac3MaxSl, 1};
@@ -320,6 +330,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
         }
         return have;
     }
+    // (kSpreadSimdWeight / kSpreadWaveWeight, at the head of this file: the two cycle counts of the comparison below, in units of 10 cycles per chunk)
     // SMALL graphs (fewer slices than waves: most waves of the workgroup would have no rows at all while a few walk 10 - 15
     // chunks one batch after the other -- S = 513: 5 slices on 16 waves, 1.15 us per frame of which the arcs need a quarter):
     // cut the rows into 2 or 4 pieces on adjacent lanes although they would fit one, so that every wave has a short list.
@@ -327,7 +338,7 @@ bool place_rows(const Rows &rows, const std::vector<int> &row_cu, int K, DirOut 
     // round trip: ~70 cycles per chunk for a wave alone on its SIMD against ~49 per chunk of a saturated SIMD's sum,
     // tools/ubench_issue.py): compare max(5 x busiest SIMD, 7 x heaviest wave).
     if (gm.multilane && K == 1 && opt(kOpt_res_piece, 0) <= 0 && !opt_on(kOpt_res_no_spread) && (int)slices->size() < gm.waves) {
-        auto frame_est = [](const DirOut &d) { return std::max<int64_t>((int64_t)d.simd_cost * 5, (int64_t)d.est_cost * 7); };
+        auto frame_est = [](const DirOut &d) { return std::max<int64_t>((int64_t)d.simd_cost * kSpreadSimdWeight, (int64_t)d.est_cost * kSpreadWaveWeight); };
         int maxlen = 1;
         for (auto &r : rows) maxlen = std::max(maxlen, std::min(gm.nch, chunks_of(r.size())));
         for (int div : {2, 4}) {
@@ -1166,7 +1177,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
         // (round 4, with issue priorities by progress: S = 3 006 -- 14.9 k of 20.5 k forward arcs in such rows -- is now FASTER on 1024
         // threads, recursions 2.28 -> 2.13 ms; S = 6 836 -- 27.3 k of 49.0 k -- still slower, 3.41 -> 3.51: the share alone does not
         // decide, the number of multi-lane slices a wave has to finish per frame does)
-        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * 5 > all_arcs && long_arcs > 20000) { *retry_next = true; return CRF_OK; }
+        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * kLongRowShareDen > all_arcs && long_arcs > kLongRowArcs) { *retry_next = true; return CRF_OK; }
     }
     if (short_only)   // graphs with rows longer than a lane's registers (every den_lm estimated from text) run 2-3 % faster with the
         for (auto &r : fsub)   // row constants in the LDS table (level 1; measured): leave them to it
@@ -1357,7 +1368,7 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
     if (level == 4) {   // (the same test as on the forward rows above: a graph whose BACKWARD rows are mostly multi-lane keeps 768 threads too)
         size_t long_arcs = 0, all_arcs = 0;
         for (auto &r : bsub) { all_arcs += r.size(); if (chunks_of(r.size()) > gm->nch) long_arcs += r.size(); }
-        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * 5 > all_arcs && long_arcs > 20000) { *retry_next = true; return CRF_OK; }
+        if (opt(kOpt_fac_threads, 0) != 1024 && long_arcs * kLongRowShareDen > all_arcs && long_arcs > kLongRowArcs) { *retry_next = true; return CRF_OK; }
     }
     if (short_only)
         for (auto &r : bsub)

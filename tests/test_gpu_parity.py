@@ -1046,3 +1046,34 @@ def test_functional_and_errors(crf, golden_dir, tmp_path):
     with pytest.raises(AssertionError):  # dtype asserts of CTC_CRF_LOSS.forward (__init__.py:116-124)
         crf.CTC_CRF_LOSS()(lp.double(), torch.tensor([1], dtype=torch.int32), torch.tensor([5], dtype=torch.int32),
                            torch.tensor([1], dtype=torch.int32))
+
+
+@pytest.mark.parametrize("H,fanout", [(256, 16), (96, 12)])
+def test_small_graphs_spread_rows(crf, tmp_path, H, fanout):
+    """Small den_lm (fewer slices of rows than the workgroup has waves) get their rows cut into pieces on adjacent lanes so that every wave has a
+    short list (res_layout.cpp "SMALL graphs", a cost model calibrated on S = 513: round-4 advisor).  Both layouts -- the spread one the planner
+    picks and the unspread one behind `res_no_spread` -- against the oracle, on the calibration graph and on a second one."""
+    from cat_amd.den_lm import synth_den_lm
+    V = 72
+    p = os.path.join(str(tmp_path), "small.fst")
+    g = synth_den_lm(V, H, fanout, 0, path=p)
+    logits, labels, lx, ly = make_batch(g, 5, 150, V, seed=H, ragged=True)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=0.1)
+    stats = {}
+    for name, opts in (("spread", {}), ("unspread", {"res_no_spread": 1})):
+        with crf._C.debug_opts(**opts):
+            ctx = crf.CRFContext(p, 0)
+            st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+            assert st["fac"] == 1 and st["fac_geom"] == 4, st          # the 1024-thread geometry takes both
+            stats[name] = (st["fac_fwd_slots"], st["fac_bwd_slots"], st["fac_chunks"], st["fac_Gf"], st["fac_Gb"])
+            x = torch.tensor(logits, device="cuda:0", requires_grad=True)
+            loss = crf.CTC_CRF_LOSS(lamb=0.1)(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32), torch.tensor(ly, dtype=torch.int32))
+            loss.backward()
+            grad = x.grad.cpu().numpy()
+            del ctx
+        assert abs(loss.item() - ref["loss"]) <= TOL * abs(ref["loss"]), name
+        for b in range(5):
+            assert rel_err(grad[b], ref["grad"][b]) <= TOL, (name, b)
+    print(stats)
+    if H == 256:
+        assert stats["spread"] != stats["unspread"], stats            # (the calibration graph IS spread by default)
