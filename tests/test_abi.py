@@ -455,6 +455,6 @@ def test_debug_switches_are_set_by_name_not_from_the_environment(tmp_path):
     finally:
         core.debug_set("no_factored", None)
     assert fac() == 1
-    src = open(os.path.join(ROOT, "cat_amd", "csrc", "crf_kernels.hip")).read() + open(os.path.join(ROOT, "cat_amd", "csrc", "fst_graph.cpp")).read() + \
-        open(os.path.join(ROOT, "cat_amd", "csrc", "res_layout.cpp")).read()
+    csrc = os.path.join(ROOT, "cat_amd", "csrc")
+    src = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h", ".cpp")))
     assert "getenv" not in src

@@ -1,6 +1,6 @@
 """CPU tests of what can be read off the compiled gfx950 code without a GPU (hipcc cross-compiles here).
 
-`tools/isa_check_lds_issue.py`: the inline-asm LDS reads of the numerator chains (crf_kernels.hip lds_issue_* / lds_landed) are
+`tools/isa_check_lds_issue.py`: the inline-asm LDS reads of the numerator chains (crf_device.h lds_issue_* / lds_landed) are
 asynchronous loads the compiler knows nothing about; the check proves on the ISA of THIS build that nothing touches their destination
 registers between the read and its wait (round-4 advisor: checked by eye for one compiler version only).  The assembly (~90 s of hipcc)
 is cached under the system temp directory, keyed by a hash of the sources and the compiler version."""
@@ -27,8 +27,10 @@ def _tool():
 
 def _assembly(mod):
     h = hashlib.sha256()
-    for f in ("cat_amd/csrc/crf_kernels.hip", "cat_amd/csrc/crf_internal.h", "include/ctc_crf_hip.h"):
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+    csrc = os.path.join(ROOT, "cat_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + ["../../include/ctc_crf_hip.h"]:
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
     h.update(subprocess.run([HIPCC, "--version"], capture_output=True).stdout)
     path = os.path.join(tempfile.gettempdir(), f"crf_isa_{h.hexdigest()[:16]}.s")
     if not os.path.exists(path):

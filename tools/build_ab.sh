@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_ab.sh name:"-Ddefs" ... -- A/B builds of the library into cat_amd/lib_ab/lib<name>.so, in parallel (hipcc cross-compiles
-# without a GPU; ~100 s each).  `prod` as a name rebuilds the product library cat_amd/lib/libctc_crf_hip.so.
+# without a GPU; ~45 s each, the kernel families compile in parallel).  `prod` as a name rebuilds the product library cat_amd/lib/libctc_crf_hip.so.
 #   tools/build_ab.sh prod lag0:"-DCRF_X_LAG=0" tm:"-DCRF_TIMING"
 mkdir -p cat_amd/lib_ab
 for v in "$@"; do

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/isa_check_lds_issue.py -- build-time check of the inline-asm LDS reads (crf_kernels.hip: lds_issue_f64 / lds_issue_i32 / lds_landed).
+"""tools/isa_check_lds_issue.py -- build-time check of the inline-asm LDS reads (k_*.hip: lds_issue_f64 / lds_issue_i32 / lds_landed).
 
 Those helpers issue `ds_read` from inline assembly so that the ISSUE point holds, and wait for it in a second asm (`s_waitcnt lgkmcnt(0)`).
 The compiler does not know that the destination registers are written asynchronously: nothing in the language stops it from copying,
@@ -28,10 +28,9 @@ REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
 
 def assemble(path):
-    src = os.path.join(ROOT, "cat_amd", "csrc", "crf_kernels.hip")
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cat_amd", "csrc"), *os.environ.get("CRF_BUILD_DEFS", "").split(), src, "-o", path]
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, ROOT)
+    from cat_amd.build import assemble as asm   # every kernel family (cat_amd/csrc/k_*.hip), assembled in parallel, one file
+    asm(path)
 
 
 def regs(text):

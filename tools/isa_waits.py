@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/isa_waits.py -- where does a kernel WAIT?  Compiles cat_amd/csrc/crf_kernels.hip to gfx950 assembly (device only, a minute, no GPU
+"""tools/isa_waits.py -- where does a kernel WAIT?  Compiles cat_amd/csrc/k_*.hip to gfx950 assembly (device only, a minute, no GPU
 needed) and prints, for every loop of the kernels whose mangled name contains KEY, the sequence of memory instructions, barriers and
 s_waitcnt vmcnt(...) in layout order -- runs of the same instruction folded.  What to look for (round 4, DESIGN.md section 2 "Waits the
 compiler put where the source meant none"): a `s_waitcnt vmcnt(0)` right BEHIND a group of prefetch loads (vmcnt counts in order: the frame
@@ -23,10 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def assemble(path):
-    src = os.path.join(ROOT, "cat_amd", "csrc", "crf_kernels.hip")
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cat_amd", "csrc"), *os.environ.get("CRF_BUILD_DEFS", "").split(), src, "-o", path]
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    sys.path.insert(0, ROOT)
+    from cat_amd.build import assemble as asm   # every kernel family (cat_amd/csrc/k_*.hip), assembled in parallel, one file
+    asm(path)
 
 
 def functions(lines, key):
