@@ -125,7 +125,7 @@ static WsLayout ws_layout(const HostGraph *h, int64_t B, int64_t T, int64_t V, i
     w.off_ept = o; o = al(o + (w.bat ? T * V * w.Bp * 4 : 0));
     w.off_Af = o; o = al(o + (w.bat ? 2 * ((int64_t)h->dev.S + (h->fb.ok ? h->fb.NU : 0)) * w.Bp * 4 : 0));   // (+ the U entries of factored streams)
     w.off_Zb = o; o = al(o + (w.bat ? 2 * (int64_t)h->dev.P * w.Bp * 4 : 0));
-    w.off_bsm = o; o = al(o + (w.bat ? 12 * w.Bp * 4 : 0));        // mxf[3], mxb[3], Ef, Fb, zs, zb
+    w.off_bsm = o; o = al(o + (w.bat ? (12 * w.Bp + 640) * 4 : 0));   // mxf[3], mxb[3], Ef, Fb, zs, zb | grid barrier words [512], time-out word (persistent launch)
     w.gv = h && !w.res && !w.bat && std::max((size_t)3 * rup64(h->dev.S), (size_t)4 * h->dev.Pr) * 4 + 2 * (size_t)rup64((int)V) * 4 + 1024 > 160 * 1024;
     w.gv_robust = h && robust_lds_bytes(h, (int)V, false) > 160 * 1024;
     // (floats per utterance: the streaming kernels' fp32 vectors, or the log-domain fallback's fp64 ones -- forward A[2][Sp] + Ql[Pr], backward Z[2][Pr] + BPst[2][Pr])
@@ -1139,6 +1139,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         unsigned *bsm = (unsigned *)(base + w.off_bsm);
         bp.mxf = bsm; bp.mxb = bsm + 3 * w.Bp; bp.Ef = (int *)(bsm + 6 * w.Bp); bp.Fb = (int *)(bsm + 7 * w.Bp);
         bp.zs = (float *)(bsm + 8 * w.Bp); bp.zb = (float *)(bsm + 9 * w.Bp);
+        bp.bar = bsm + 12 * w.Bp; bp.err = (int *)(bsm + 12 * w.Bp + 512);
         bp.den_zs = p.den_zs; bp.cost_alpha = p.cost_alpha; bp.cost_beta = p.cost_beta; bp.den_ez = p.den_ez; bp.redo = p.redo;
         bp.grad = grad; bp.c_den = c_den;
         if (ctc) {
@@ -1151,20 +1152,28 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         // the tasks wanted per direction follow from the occupancy the runtime reports, shared by the combos
         const int64_t ncombo = 2 * (int64_t)ngrp;
         const bool bfac = stream_fac(g->h, w.UL);                  // factored streams (T o LM graphs, groups of >= 32 utterances)
+        // ALL frames in one persistent launch (round 6) when its grid is co-resident by the runtime's own count -- switch bat_persist: 0 =
+        // one launch per frame (rounds 2 - 5; also the fallback), 1 = persistent (default)
+        const bool want_persist = opt(kOpt_bat_persist, 1) != 0;
+        auto bat_fn = [&](bool persist) -> const void * {
+#define CRF_BAT_FN(K) (w.UL == 64 ? (bfac ? (const void *)K<64, 4, true> : (const void *)K<64, 4, false>)    \
+                     : w.UL == 32 ? (bfac ? (const void *)K<32, 4, true> : (const void *)K<32, 4, false>)    \
+                     : w.UL == 16 ? (bfac ? (const void *)K<16, 4, true> : (const void *)K<16, 4, false>)    \
+                                  : (bfac ? (const void *)K<8, 4, true> : (const void *)K<8, 4, false>))
+            return persist ? CRF_BAT_FN(crf_batch_persist_kernel) : CRF_BAT_FN(crf_batch_frame_kernel);
+#undef CRF_BAT_FN
+        };
         int wg_cu = 0;
-        {
-            const void *fn = w.UL == 64 ? (bfac ? (const void *)crf_batch_frame_kernel<64, 4, true> : (const void *)crf_batch_frame_kernel<64, 4>)
-                           : w.UL == 32 ? (bfac ? (const void *)crf_batch_frame_kernel<32, 4, true> : (const void *)crf_batch_frame_kernel<32, 4>)
-                           : w.UL == 16 ? (bfac ? (const void *)crf_batch_frame_kernel<16, 4, true> : (const void *)crf_batch_frame_kernel<16, 4>)
-                           : (bfac ? (const void *)crf_batch_frame_kernel<8, 4, true> : (const void *)crf_batch_frame_kernel<8, 4>);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, fn, kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = 2; }
-        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_cu, bat_fn(want_persist), kBatThreads, 0) != hipSuccess || wg_cu < 1) { (void)hipGetLastError(); wg_cu = want_persist ? 0 : 2; }
+        bool persist = want_persist && wg_cu >= 1;
+        if (want_persist && !persist) wg_cu = 2;
         // ... times 70 %: a launch is bound by the L2s and the fabric, not by the CUs, and fewer, longer tasks pay the task set-up
         // (three dependent trips to a cold L2) less often.  Measured, S = 16 385 / B = 64 (repeatable to 0.3 %): 100 / 85 / 70 /
         // 60 / 55 / 45 / 35 % -> 30.7 / 29.5 / 28.8 / 30.6 / 31.8 / 28.5 / 31.3 ms per step (the dips: workgroups per XCD just
         // above a multiple of its 32 CUs); config #5 at B = 8: 100 / 70 / 50 % -> 145.3 / 143.6 / 152.6 ms.  CRF_BAT_FILL overrides.
         const int fill_env = opt(kOpt_bat_fill, 0);
         const int64_t fill = fill_env > 0 && fill_env <= 100 ? fill_env : 70;
+        const int64_t slots = (int64_t)ncu_dev * wg_cu;            // workgroups the device holds at once
         const int want = (int)std::max<int64_t>(16, (int64_t)ncu_dev * wg_cu * kBatWaves * 15 / 16 * fill / 100 / ncombo);
         const StreamDev *sdv = nullptr;
         if ((rc = ensure_stream_tables(g->h, w.UL, want, &sdv))) return rc;
@@ -1177,6 +1186,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         const int64_t wg_combo = (tasks_max + kBatWaves - 1) / kBatWaves + ((sdv->f.nrest > 64 || sdv->b.nrest > 64) ? (std::max(sdv->f.nrest, sdv->b.nrest) + 4 * kBatWaves - 1) / (4 * kBatWaves) : 0);
         const unsigned nslot = (unsigned)(ncombo < 8 ? (wg_combo + (8 / ncombo) - 1) / (8 / ncombo) : wg_combo * ((ncombo + 7) / 8));
         const unsigned G = 8 * nslot;
+        if (persist && (int64_t)G > slots) persist = false;        // (the grid barrier needs every workgroup resident)
         prof_mark(1, false, stream); prof_mark(2, false, stream);
 #define CRF_BAT_UL(KERNEL, GRID, ...)                                                                        \
         switch (w.UL) {                                                                                       \
@@ -1188,25 +1198,25 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         CRF_BAT_UL(crf_batch_transpose_kernel, dim3((unsigned)((V + 63) / 64), (unsigned)T, ngrp), bp);
         hipLaunchKernelGGL(crf_batch_init_kernel, dim3((unsigned)(((int64_t)bp.SX * w.Bp + kBatThreads - 1) / kBatThreads)), dim3(kBatThreads), 0, stream, bp);
         LAUNCH_CHECK("crf_batch_init_kernel");
-        g_den_kernel = w.UL == 64 ? (bfac ? "crf_batch_frame_kernel<64,4,true>" : "crf_batch_frame_kernel<64,4,false>")
-                     : w.UL == 32 ? (bfac ? "crf_batch_frame_kernel<32,4,true>" : "crf_batch_frame_kernel<32,4,false>")
-                     : w.UL == 16 ? (bfac ? "crf_batch_frame_kernel<16,4,true>" : "crf_batch_frame_kernel<16,4,false>")
-                     : (bfac ? "crf_batch_frame_kernel<8,4,true>" : "crf_batch_frame_kernel<8,4,false>");
-        for (int j = 0; j <= (int)T; ++j) {
-            bp.j = j;
-            switch (w.UL) {   // (4: batches of gathers in flight per wave; 2 measured 6 % slower, 8 needs more registers than a wave has)
-                case 64: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<64, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
-                         else hipLaunchKernelGGL((crf_batch_frame_kernel<64, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
-                         break;
-                case 32: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
-                         else hipLaunchKernelGGL((crf_batch_frame_kernel<32, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
-                         break;
-                case 16: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
-                         else hipLaunchKernelGGL((crf_batch_frame_kernel<16, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
-                         break;
-                default: if (bfac) hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4, true>), dim3(G), dim3(kBatThreads), 0, stream, bp);
-                         else hipLaunchKernelGGL((crf_batch_frame_kernel<8, 4>), dim3(G), dim3(kBatThreads), 0, stream, bp);
-                         break;
+        static const char *const kBatNames[2][4][2] = {
+            {{"crf_batch_frame_kernel<8,4,false>", "crf_batch_frame_kernel<8,4,true>"}, {"crf_batch_frame_kernel<16,4,false>", "crf_batch_frame_kernel<16,4,true>"},
+             {"crf_batch_frame_kernel<32,4,false>", "crf_batch_frame_kernel<32,4,true>"}, {"crf_batch_frame_kernel<64,4,false>", "crf_batch_frame_kernel<64,4,true>"}},
+            {{"crf_batch_persist_kernel<8,4,false>", "crf_batch_persist_kernel<8,4,true>"}, {"crf_batch_persist_kernel<16,4,false>", "crf_batch_persist_kernel<16,4,true>"},
+             {"crf_batch_persist_kernel<32,4,false>", "crf_batch_persist_kernel<32,4,true>"}, {"crf_batch_persist_kernel<64,4,false>", "crf_batch_persist_kernel<64,4,true>"}}};
+        g_den_kernel = kBatNames[persist ? 1 : 0][w.UL == 64 ? 3 : w.UL == 32 ? 2 : w.UL == 16 ? 1 : 0][bfac ? 1 : 0];
+        {
+            void *args[] = {(void *)&bp};
+            const void *fn = bat_fn(persist);
+            if (persist) {
+                // (co-resident grids of two callers must not interleave: each could become partially resident and wait for the rest)
+                CoresGuard guard(true, cx->dev, stream);
+                bp.j = 0;
+                if ((e = hipLaunchKernel(fn, dim3(G), dim3(kBatThreads), args, 0, stream)) != hipSuccess) { set_error(std::string("crf_batch_persist_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+            } else {
+                for (int j = 0; j <= (int)T; ++j) {   // (4: batches of gathers in flight per wave; 2 measured 6 % slower, 8 needs more registers than a wave has)
+                    bp.j = j;
+                    if ((e = hipLaunchKernel(fn, dim3(G), dim3(kBatThreads), args, 0, stream)) != hipSuccess) { set_error(std::string("crf_batch_frame_kernel: ") + hipGetErrorString(e)); return CRF_ERR_HIP; }
+                }
             }
         }
         LAUNCH_CHECK("crf_batch_frame_kernel");

@@ -338,6 +338,7 @@ void set_error(const std::string &msg);
     X(bat_task,         "C  utterance-minor kernels: steps per task")                                                        \
     X(bat_ul,           "C  utterance-minor kernels: utterances per group (8, 16, 32, 64)")                                  \
     X(bat_fill,         "C  utterance-minor kernels: percent of the device's workgroup slots a launch takes (default 70)")   \
+    X(bat_persist,      "C  utterance-minor kernels: 1 = all frames in ONE persistent launch with a grid barrier per frame (default when the grid is co-resident), 0 = one launch per frame") \
     X(force_batch,      "C  utterance-minor kernels for every graph")                                                        \
     X(no_batch,         "C  streaming kernels instead of the utterance-minor ones")                                          \
     X(robust,           "C  0: never run the robust fallbacks, 1: every utterance takes them (denominator and numerator)")  \

@@ -148,6 +148,8 @@ struct BatchParams {
     float *grad;                   // [B][T][V]
     float c_den;
     int j;                         // launch number: forward frame j, backward frame T - j
+    unsigned *bar;                 // crf_batch_persist_kernel: [512] words of the grid barrier, zeroed by crf_batch_init_kernel
+    int *err;                      // ... its time-out word (crf_batch_cost_kernel turns the costs into NaN)
 };
 constexpr int kBatThreads = 256, kBatWaves = kBatThreads / kWave;
 constexpr int kStreamBatch = 4, kStreamChunk = 128;   // steps per batch; batches * AL per 4 KB chunk (batches in flight: template parameter D)
@@ -164,6 +166,7 @@ constexpr int stream_lds() { return FAC ? 2 * kStreamRecB + 2 * 64 * 16 * 4 + st
 template <int UL> __global__ void crf_batch_transpose_kernel(BatchParams p);
 __global__ void crf_batch_init_kernel(BatchParams p);
 template <int UL, int D, bool FAC = false> __global__ void crf_batch_frame_kernel(BatchParams p);
+template <int UL, int D, bool FAC = false> __global__ void crf_batch_persist_kernel(BatchParams p);
 template <int UL> __global__ void crf_batch_zsum_kernel(BatchParams p);
 __global__ void crf_batch_cost_kernel(BatchParams p);
 template <int UL> __global__ void crf_batch_grad_kernel(BatchParams p);

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_init_kernel(BatchParams
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
         __syncthreads();
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * pow2f(kScaleExp);
+        for (int i = threadIdx.x; i < 640; i += kBatThreads) p.bar[i] = 0u;   // grid barrier words and time-out word of the persistent launch
         for (int u = threadIdx.x; u < p.Bp; u += kBatThreads) {
             p.mxf[u] = __float_as_uint(m); p.mxf[p.Bp + u] = 0u; p.mxf[2 * p.Bp + u] = 0u;
             p.mxb[u] = 0u; p.mxb[p.Bp + u] = 0u; p.mxb[2 * p.Bp + u] = 0u;
@@ -78,12 +79,61 @@ __device__ __forceinline__ float arc_lane_max(float v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// PERSISTENT form (round 6; crf_batch_persist_kernel below): all frames in ONE launch, the kernel boundary replaced by a grid barrier.
+// Only the state vectors (and the per-utterance maxima) cross compute units inside the launch; they do so by PER-ACCESS agent-scope
+// operations -- sc1 (write-through) stores and sc1 loads, which bypass the reading CU's L1 and are served by its XCD's L2 or the fabric
+// (MI355X_MICROARCH.md "inter-workgroup visibility") -- so no wave ever executes a bulk buffer_wbl2 / buffer_inv (round 3's
+// persistent experiment fenced in every wave: 80 us per frame; profiles/round6_grid_barrier.txt: this protocol 0 stale values in
+// 3 x 1 500 frames x 150 MB of checked gathers, the empty barrier 2.2 us).  Arc records, row descriptors and emissions are written
+// before the launch and stay plainly cached; Q / BP rows are read by a later kernel.  PERS = false compiles to the plain accesses of
+// the per-frame launches.
+// ---------------------------------------------------------------------------------------------
+#define CRF_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#ifndef CRF_X_BATLD
+#define CRF_X_BATLD 0       // TIMING EXPERIMENTS ONLY (wrong results): the persistent kernel's 16-byte gathers as 1 = plain global loads, 2 = buffer loads without sc1
+#endif
+template <bool PERS>
+struct VecRef {                                                    // a state vector of one utterance group: base + byte size
+    const char *base;
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ VecRef(const float *p, size_t bytes) : base((const char *)p) {
+        if constexpr (PERS) rs = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x27000);
+    }
+    __device__ __forceinline__ f32x4 ld4(unsigned off) const {      // 16 bytes at byte offset off
+        if constexpr (PERS && CRF_X_BATLD != 1) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, CRF_X_BATLD == 2 ? 0 : 16));
+        else return *(const f32x4 *)(base + off);
+    }
+    __device__ __forceinline__ float ld1(size_t idx) const {
+        if constexpr (PERS) return __builtin_bit_cast(float, __hip_atomic_load((const unsigned *)base + idx, CRF_RLX_AGENT));
+        else return ((const float *)base)[idx];
+    }
+    __device__ __forceinline__ void st4(size_t idx, const f32x4 &v) const {   // 16 bytes at FLOAT index idx
+        if constexpr (PERS) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (unsigned)idx * 4u, 0, 16);
+        else *(f32x4 *)(base + idx * 4) = v;
+    }
+    __device__ __forceinline__ void st1(size_t idx, float v) const {
+        if constexpr (PERS) __hip_atomic_store((unsigned *)base + idx, __float_as_uint(v), CRF_RLX_AGENT);
+        else ((float *)base)[idx] = v;
+    }
+};
+template <bool PERS>
+__device__ __forceinline__ unsigned ld_word(const unsigned *p) {
+    if constexpr (PERS) return __hip_atomic_load(p, CRF_RLX_AGENT);
+    else return *p;
+}
+template <bool PERS>
+__device__ __forceinline__ void st_word(unsigned *p, unsigned v) {
+    if constexpr (PERS) __hip_atomic_store(p, v, CRF_RLX_AGENT);
+    else *p = v;
+}
+
 // sum over the arcs [a0, a1) of w * X[idx][u].  The wave fetches 64 arcs at a time (one coalesced 512-byte load), the arc
 // lanes of an utterance then walk them through lane broadcasts: the gathers of a chunk are independent loads, all in flight
 // together -- with the arc fetched inside the loop every gather waited for its own arc first (two dependent trips to L2 per
 // arc: 77 us per frame on the S = 16 k graph).
-template <int UL>
-__device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int a0, int a1, const float *__restrict__ X, int ul, int lane, int aj) {
+template <int UL, bool PERS>
+__device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int a0, int a1, const VecRef<PERS> &X, int ul, int lane, int aj) {
     constexpr int AL = 64 / UL;
     float acc0 = 0.f, acc1 = 0.f;
     for (int c = a0; c < a1; c += 64) {
@@ -102,8 +152,8 @@ __device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int 
                 const int l1 = min((i + 1) * AL + aj, 63);
                 s1 = __shfl(arc.x, l1); w1 = i + 1 < steps ? __shfl(arc.y, l1) : 0;
             }
-            acc0 = fmaf(X[(size_t)s0 * UL + ul], __int_as_float(w0), acc0);
-            acc1 = fmaf(X[(size_t)s1 * UL + ul], __int_as_float(w1), acc1);
+            acc0 = fmaf(X.ld1((size_t)s0 * UL + ul), __int_as_float(w0), acc0);
+            acc1 = fmaf(X.ld1((size_t)s1 * UL + ul), __int_as_float(w1), acc1);
         }
     }
     return arc_lane_sum<UL>(acc0 + acc1);
@@ -120,9 +170,12 @@ __device__ __forceinline__ float bat_row_sum(const int2 *__restrict__ arcs, int 
 // the gathers -- D batches of kStreamBatch in flight, consumed in order behind partial vmcnt waits -- and a row's stores;
 // a wait for something just requested happens nowhere.  epi(acc, m, e) is called at every bundle end with the row's
 // descriptor {state, pair, label} and the four utterances' emissions et[label].
-template <int UL, int D, int NM, int NR, typename Epi>
-__device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk, const float *__restrict__ X, const float *__restrict__ et,
-                                           int uq, int aj, int lane, char *ldsw, int tmi, Epi &&epi) {
+template <int UL, int D, int NM, int NR, bool PERS, typename Epi>
+__device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk, const VecRef<PERS> &X, const float *__restrict__ et,
+                                           int uq, int aj, int lane, char *ldsw, int tmi, const bool fill, Epi &&epi) {
+    // fill (uniform): the task's records and row descriptors are fetched into the wave's slice of LDS as described above.  false: they ARE
+    // there -- the persistent kernel's later frames of a wave with ONE task of at most two chunks of records, which then fetches nothing
+    // but state-vector entries and emissions
     constexpr int LG = UL / 4, AL = 64 / LG, CB = kStreamChunk / AL;
     static_assert(kStreamBatch == 4 && CB % D == 0 && CB >= D, "a chunk holds a whole number of pipeline rounds");
     static_assert((NM == 1 && NR == 1) || (NM == 3 && (NR == 3 || NR == 4)), "plain or factored rows");
@@ -132,7 +185,7 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk
     const int bund0 = __builtin_amdgcn_readfirstlane(tk.z), nbund = __builtin_amdgcn_readfirstlane(tk.w);
     CRF_TM(tmi >= 0, tmi + 2);
     const int4 *gsrc = (const int4 *)sd.recs + (size_t)b0 * AL * 2 + lane;   // a chunk = 256 int4: four per lane (the stream is padded)
-    {   // chunk 0 -> LDS half 0 (the only wait for something just requested: once per task)
+    if (fill) {   // chunk 0 -> LDS half 0 (the only wait for something just requested: once per task)
         const int4 s0 = gsrc[0], s1 = gsrc[64], s2 = gsrc[128], s3 = gsrc[192];
         const int4 *mp = sd.meta + (size_t)bund0 * AL * NM;
         constexpr int MAXB = stream_max_bundles(UL, NM == 3);
@@ -147,16 +200,17 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk
             if ((NMW * 64 == MAXB * AL * NM) || q * 64 + lane < MAXB * AL * NM) mlds[q * 64 + lane] = mm[q];   // (the slice ends there)
     }
     CRF_TM(tmi >= 0, tmi + 3);
-    int4 st0 = gsrc[256], st1 = gsrc[320], st2 = gsrc[384], st3 = gsrc[448];   // chunk 1 (padding if there is none)
+    int4 st0 = int4{0, 0, 0, 0}, st1 = st0, st2 = st0, st3 = st0;
+    if (fill) { st0 = gsrc[256]; st1 = gsrc[320]; st2 = gsrc[384]; st3 = gsrc[448]; }   // chunk 1 (padding if there is none)
     gsrc += 512;
     const f32x4 *et4 = (const f32x4 *)et + uq;                     // et[label * UL + 4 uq ..]
-    const f32x4 *X4 = (const f32x4 *)X + uq;                       // X[entry * UL + 4 uq ..]
     // value k of the row (bundle bd, lane group aj): emissions of its label(s), entries its epilogue reads
     auto ringsrc = [&](const int bd, const int k) __attribute__((always_inline)) -> f32x4 {
         const int4 *m = mlds + ((size_t)bd * AL + aj) * NM;
         if (k == 0) return et4[(size_t)m[0].z * LG];
         if (k == 1) return et4[(size_t)m[NM > 1 ? 1 : 0].z * LG];
-        return X4[(size_t)(k == 2 ? m[NM > 1 ? 2 : 0].x : m[NM > 1 ? 2 : 0].z) * LG];
+        // X[entry * UL + 4 uq ..]; a padding row's entry may be -1 (it used to read in front of the vector; the value is never used)
+        return X.ld4((unsigned)max(k == 2 ? m[NM > 1 ? 2 : 0].x : m[NM > 1 ? 2 : 0].z, 0) * (unsigned)(UL * 4) + (unsigned)uq * 16u);
     };
     // values of bundles 0 and 1 -> ring (written once the first gathers are out), bundle 2 -> eA
     f32x4 ei0[NR], ei1[NR], eA[NR];
@@ -174,10 +228,10 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk
         // (a record's index is entry * UL with the flag in bit 31: the shift to bytes drops the flag -- one VALU per gather --
         // and the address is a 32-bit offset to a uniform base)
         fl[j] = (unsigned)__builtin_amdgcn_readfirstlane(r0.x) >> 31;
-        x[j][0] = *(const f32x4 *)((const char *)X + (((unsigned)r0.x << 2) + uq16));
-        x[j][1] = *(const f32x4 *)((const char *)X + (((unsigned)r0.z << 2) + uq16));
-        x[j][2] = *(const f32x4 *)((const char *)X + (((unsigned)r1.x << 2) + uq16));
-        x[j][3] = *(const f32x4 *)((const char *)X + (((unsigned)r1.z << 2) + uq16));
+        x[j][0] = X.ld4(((unsigned)r0.x << 2) + uq16);
+        x[j][1] = X.ld4(((unsigned)r0.z << 2) + uq16);
+        x[j][2] = X.ld4(((unsigned)r1.x << 2) + uq16);
+        x[j][3] = X.ld4(((unsigned)r1.z << 2) + uq16);
         w[j][0] = __int_as_float(r0.y); w[j][1] = __int_as_float(r0.w); w[j][2] = __int_as_float(r1.y); w[j][3] = __int_as_float(r1.w);
     };
     auto consume = [&](const int j) __attribute__((always_inline)) {
@@ -199,7 +253,7 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk
         }
     };
     auto stage = [&](const int c) __attribute__((always_inline)) {   // entering chunk c: chunk c + 1 -> the other half, ask for chunk c + 2
-        if ((c + 1) * CB < nb) {
+        if (fill && (c + 1) * CB < nb) {
             char *h = ldsw + ((c + 1) & 1) * kStreamRecB;
             *(int4 *)(h + lane * 16) = st0; *(int4 *)(h + (64 + lane) * 16) = st1;
             *(int4 *)(h + (128 + lane) * 16) = st2; *(int4 *)(h + (192 + lane) * 16) = st3;
@@ -233,96 +287,109 @@ __device__ __forceinline__ void bat_stream(const StreamDirDev &sd, const int4 tk
     CRF_TM(tmi >= 0, tmi + 5);
 }
 
-// One frame of both recursions.  1-D grid of 8 * nslot workgroups; block b sits on XCD b % 8 (observed; a matter of speed
-// only) and works for ONE combo = (utterance group, direction):
-//   #combos <  8: XCD x serves combo x % #combos together with the other XCDs of that residue, the combo's workgroups
-//                 ("chunks") dealt round-robin among them;
-//   #combos >= 8: XCD x serves the combos x, x + 8, ..., its slots dealt round-robin among them.
-// The waves of a combo take the tasks of its arc stream (rows with one entering pair: all of a T o LM graph) and then the
-// remaining rows one at a time (bat_row_sum: one utterance per lane, 64 / UL arcs of the row side by side).
-template <int UL, int D, bool FAC>
-__global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParams p) {
-    constexpr int ALR = 64 / UL;                                   // rest rows: arc lanes per utterance
-    constexpr int LG = UL / 4;                                     // stream: lanes per row (64 / LG rows side by side)
-    constexpr int NM = FAC ? 3 : 1;                                // descriptor words per stream row
-    __shared__ unsigned umax[UL];                                  // maximum of the vector this workgroup wrote, per utterance (float bits)
-    __shared__ __attribute__((aligned(16))) char stage[kBatWaves][stream_lds<UL, FAC>()];   // bat_stream: records, value ring, descriptors of a wave's task
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // (timing build: launch 700, four workgroups of the first XCD x their four waves, 16 stamps each from g_tm[14000])
-    const int tmi = (p.j == 700 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) % 24 == 0 && (blockIdx.x >> 3) < 96) ? 14000 + (((blockIdx.x >> 3) / 24) * 4 + wave) * 16 : -1;
-    CRF_TM(tmi >= 0, tmi + 0);
-    char *ldsw = stage[wave];
-    const int ul = lane % UL, aj = lane / UL;                      // rest rows and the per-utterance scalars: utterance ul of the group
-    const int uq = lane % LG, sj = lane / LG;                      // stream: utterances 4 uq .. 4 uq + 3, row sj of the bundle
-    const int T = p.T, P = p.P;
-    int combo, chunk, nchunk;
-    bat_decode((int)blockIdx.x, (int)gridDim.x, 2 * p.ngrp, &combo, &chunk, &nchunk);   // (crf_internal.h)
-    const int dir = combo & 1, grp = combo >> 1;
-    const int u = grp * UL + ul;
-    const int lx = u < p.B ? p.lx[u] : 0;
-    const int u4 = grp * UL + 4 * uq;                              // first of the lane's four utterances (stream)
-    int lx4[4];
+// What a workgroup (and each of its lanes) is in EVERY frame: its combo, its utterances and their lengths, its first task -- worked
+// out once per launch (the persistent kernel keeps it in registers over all frames).
+template <int UL>
+struct BatWg {
+    int dir, grp, chunk, nchunk, w0, NW;
+    int ul, aj, uq, sj;                                            // rest rows: utterance ul, arc lane aj; stream: utterances 4 uq .. 4 uq + 3, row sj of a bundle
+    int u, lx, u4, lx4[4];
+    bool lead;                                                     // one writer per utterance for the scalars
+    int4 tk0;                                                      // the wave's first task descriptor
+};
+template <int UL>
+__device__ __forceinline__ BatWg<UL> bat_setup(const BatchParams &p, int lane, int wave) {
+    constexpr int LG = UL / 4;
+    BatWg<UL> c;
+    int combo;
+    bat_decode((int)blockIdx.x, (int)gridDim.x, 2 * p.ngrp, &combo, &c.chunk, &c.nchunk);   // (crf_internal.h)
+    c.dir = combo & 1; c.grp = combo >> 1;
+    c.ul = lane % UL; c.aj = lane / UL; c.uq = lane % LG; c.sj = lane / LG;
+    c.u = c.grp * UL + c.ul;
+    c.lx = c.u < p.B ? p.lx[c.u] : 0;
+    c.u4 = c.grp * UL + 4 * c.uq;                                  // first of the lane's four utterances (stream)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) lx4[c] = u4 + c < p.B ? p.lx[u4 + c] : 0;
-    const int w0 = chunk * kBatWaves + wave, NW = nchunk * kBatWaves;   // this wave among the waves of its combo
+    for (int k = 0; k < 4; ++k) c.lx4[k] = c.u4 + k < p.B ? p.lx[c.u4 + k] : 0;
+    c.w0 = c.chunk * kBatWaves + wave; c.NW = c.nchunk * kBatWaves;   // this wave among the waves of its combo
     // the wave's first task descriptor: asked for before anything else (it heads the chain descriptor -> records and row
     // descriptors -> emissions -> first gathers, three dependent trips to a cold L2 at the start of every launch)
-    const StreamDirDev &sdd = dir == 0 ? p.st.f : p.st.b;
-    int4 tk0 = int4{0, 0, 0, 0};
-    if (w0 < sdd.ntasks) tk0 = sdd.tasks[w0];
-    const bool lead = chunk == 0 && wave == 0 && aj == 0;          // one writer per utterance for the scalars
+    const StreamDirDev &sdd = c.dir == 0 ? p.st.f : p.st.b;
+    c.tk0 = int4{0, 0, 0, 0};
+    if (c.w0 < sdd.ntasks) c.tk0 = sdd.tasks[c.w0];
+    c.lead = c.chunk == 0 && wave == 0 && c.aj == 0;
+    return c;
+}
+
+// One frame of both recursions: launch number j = forward frame j, backward frame T - j.  The waves of a combo take the tasks of its
+// arc stream (rows with one entering pair: all of a T o LM graph) and then the remaining rows one at a time (bat_row_sum: one utterance
+// per lane, 64 / UL arcs of the row side by side).  PERS: the state vectors and the per-utterance maxima by agent-scope accesses (above).
+template <int UL, int D, bool FAC, bool PERS>
+__device__ __forceinline__ void bat_frame(const BatchParams &p, const BatWg<UL> &c, const int j, unsigned *umax, char *ldsw, const int tmi, bool &filled) {
+    constexpr int ALR = 64 / UL;                                   // rest rows: arc lanes per utterance
+    constexpr int NM = FAC ? 3 : 1;                                // descriptor words per stream row
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ul = c.ul, aj = c.aj, uq = c.uq, sj = c.sj, dir = c.dir, grp = c.grp, u = c.u, lx = c.lx, u4 = c.u4, w0 = c.w0, NW = c.NW;
+    const int T = p.T, P = p.P;
     const BatchDev &g = p.g;
     const size_t gS = (size_t)grp * p.SX * UL, gP = (size_t)grp * P * UL, gV = (size_t)grp * p.V * UL;
     const size_t Sall = (size_t)p.SX * p.Bp, Pall = (size_t)P * p.Bp, Vall = (size_t)p.V * p.Bp;
+    // persistent launch: a wave with ONE task whose records fit the two halves of its LDS slice (kStreamChunk batches per lane group) fills the
+    // slice in its first frame only -- records and row descriptors are the same in every frame
+    constexpr int kResidentBatches = 2 * (kStreamChunk / (64 / (UL / 4)));
+    const StreamDirDev &sdd = dir == 0 ? p.st.f : p.st.b;
+    const bool one_task = w0 < sdd.ntasks && w0 + NW >= sdd.ntasks && __builtin_amdgcn_readfirstlane(c.tk0.y) <= kResidentBatches;
+    const bool fill = !(PERS && one_task && filled);               // (filled: an earlier frame of this launch has run the wave's task)
     if (tid < UL) umax[tid] = 0u;
     __syncthreads();
-    CRF_TM(tmi >= 0 && lx4[0] + lx4[1] + lx4[2] + lx4[3] + lx >= 0, tmi + 1);   // (the scalar loads have landed)
+    CRF_TM(tmi >= 0 && c.lx4[0] + c.lx4[1] + c.lx4[2] + c.lx4[3] + lx >= 0, tmi + 1);   // (the scalar loads have landed)
     float mymax = 0.f;                                             // rest rows: utterance ul
     f32x4 mymax4 = {0.f, 0.f, 0.f, 0.f};                           // stream: the lane's four utterances
     if (dir == 0) {
-        const int t = p.j;
+        const int t = j;
         if (t >= T) return;
         const bool active = t < lx;
-        const int k = rescale_exp(__uint_as_float(p.mxf[(t % 3) * p.Bp + u]));
+        const int k = rescale_exp(__uint_as_float(ld_word<PERS>(p.mxf + (t % 3) * p.Bp + u)));
         const float sc = pow2f(k);
         f32x4 sc4;
         bool act4[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { sc4[c] = pow2f(rescale_exp(__uint_as_float(p.mxf[(t % 3) * p.Bp + u4 + c]))); act4[c] = t < lx4[c]; }
+        for (int q = 0; q < 4; ++q) { sc4[q] = pow2f(rescale_exp(__uint_as_float(ld_word<PERS>(p.mxf + (t % 3) * p.Bp + u4 + q)))); act4[q] = t < c.lx4[q]; }
         const bool all4 = act4[0] && act4[1] && act4[2] && act4[3];
-        const float *Ac = p.Af + (size_t)(t & 1) * Sall + gS;
-        float *An = p.Af + (size_t)((t + 1) & 1) * Sall + gS;
+        const VecRef<PERS> Ac(p.Af + (size_t)(t & 1) * Sall + gS, (size_t)p.SX * UL * 4);
+        const VecRef<PERS> An(p.Af + (size_t)((t + 1) & 1) * Sall + gS, (size_t)p.SX * UL * 4);
         const float *et = p.ept + (size_t)t * Vall + gV;
         float *Qt = p.Q + (size_t)t * Pall + gP;
+        filled = true;
         for (int task = w0; task < p.st.f.ntasks; task += NW)
-            bat_stream<UL, D, NM, FAC ? 3 : 1>(p.st.f, task == w0 ? tk0 : p.st.f.tasks[task], Ac, et, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
+            bat_stream<UL, D, NM, FAC ? 3 : 1, PERS>(p.st.f, task == w0 ? c.tk0 : p.st.f.tasks[task], Ac, et, uq, sj, lane, ldsw, tmi, fill, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
                 if (m[0].x < 0) return;                            // padding row of the last bundle
                 // an utterance that has ended keeps a_lx where it is: nobody writes that buffer for it again
                 // (crf_batch_zsum_kernel reads it there)
                 const f32x4 q = acc * sc4, an = e[0] * q;
-                float *qp = Qt + (size_t)m[0].y * UL + 4 * uq, *ap = An + (size_t)m[0].x * UL + 4 * uq;
-                if (all4) { *(f32x4 *)qp = q; *(f32x4 *)ap = an; }
+                float *qp = Qt + (size_t)m[0].y * UL + 4 * uq;
+                const size_t ai = (size_t)m[0].x * UL + 4 * uq;
+                if (all4) { *(f32x4 *)qp = q; An.st4(ai, an); }
                 else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) if (act4[c]) { qp[c] = q[c]; ap[c] = an[c]; }
+                    for (int q_ = 0; q_ < 4; ++q_) if (act4[q_]) { qp[q_] = q[q_]; An.st1(ai + q_, an[q_]); }
                 }
                 f32x4 top = an;                                    // the largest entry this row writes
                 if constexpr (FAC) {
                     if (m[1].x >= 0) {                             // the couple's tail row, folded in: q = w * U_t, and U_{t+1} = both states' a
                         const float tw = __int_as_float(m[2].y);
                         const f32x4 qt = e[2] * (f32x4){tw, tw, tw, tw} * sc4, at = e[1] * qt, un = an + at;
-                        float *qp1 = Qt + (size_t)m[1].y * UL + 4 * uq, *ap1 = An + (size_t)m[1].x * UL + 4 * uq, *up = An + (size_t)m[2].x * UL + 4 * uq;
-                        if (all4) { *(f32x4 *)qp1 = qt; *(f32x4 *)ap1 = at; *(f32x4 *)up = un; }
+                        float *qp1 = Qt + (size_t)m[1].y * UL + 4 * uq;
+                        const size_t ai1 = (size_t)m[1].x * UL + 4 * uq, ui = (size_t)m[2].x * UL + 4 * uq;
+                        if (all4) { *(f32x4 *)qp1 = qt; An.st4(ai1, at); An.st4(ui, un); }
                         else {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) if (act4[c]) { qp1[c] = qt[c]; ap1[c] = at[c]; up[c] = un[c]; }
+                            for (int q_ = 0; q_ < 4; ++q_) if (act4[q_]) { qp1[q_] = qt[q_]; An.st1(ai1 + q_, at[q_]); An.st1(ui + q_, un[q_]); }
                         }
                         top = un;
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (act4[c]) mymax4[c] = fmaxf(mymax4[c], top[c]);
+                for (int q_ = 0; q_ < 4; ++q_) if (act4[q_]) mymax4[q_] = fmaxf(mymax4[q_], top[q_]);
             });
         for (int i = w0; i < p.st.f.nrest; i += NW) {
             const int r = __builtin_amdgcn_readfirstlane(p.st.f.rest[i]);
@@ -333,47 +400,48 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
             float acc = 0.f;
             if (ds.w & 0x40000000) {                               // one pair enters the state
                 const float e = et[(size_t)(ds.w & 0xffff) * UL + ul];   // (requested before the arcs)
-                const float q = bat_row_sum<UL>(g.farcs, ds.x, ds.y, Ac, ul, lane, aj) * sc;
+                const float q = bat_row_sum<UL, PERS>(g.farcs, ds.x, ds.y, Ac, ul, lane, aj) * sc;
                 if (aj == 0 && active) Qt[(size_t)ds.z * UL + ul] = q;
                 acc = e * q;
             } else {
                 for (int kk = ds.z; kk < ds.w; ++kk) {
                     int4 pl = g.stp[kk];
                     pl.z = __builtin_amdgcn_readfirstlane(pl.z); pl.w = __builtin_amdgcn_readfirstlane(pl.w);
-                    const float q = bat_row_sum<UL>(g.farcs, pl.z, pl.w, Ac, ul, lane, aj) * sc;
+                    const float q = bat_row_sum<UL, PERS>(g.farcs, pl.z, pl.w, Ac, ul, lane, aj) * sc;
                     if (aj == 0 && active) Qt[(size_t)pl.x * UL + ul] = q;
                     acc = fmaf(et[(size_t)pl.y * UL + ul], q, acc);
                 }
             }
-            if (aj == 0 && active) An[(size_t)d * UL + ul] = acc;
+            if (aj == 0 && active) An.st1((size_t)d * UL + ul, acc);
             if (active) mymax = fmaxf(mymax, acc);
         }
-        if (lead) {
-            if (active) p.Ef[u] += k + kEpExp;                    // exponent of a_{t+1}
-            p.mxf[((t + 2) % 3) * p.Bp + u] = 0u;                  // the slot the launch after next adds to
+        if (c.lead) {
+            if (active) st_word<PERS>((unsigned *)p.Ef + u, ld_word<PERS>((const unsigned *)p.Ef + u) + (unsigned)(k + kEpExp));   // exponent of a_{t+1}
+            st_word<PERS>(p.mxf + ((t + 2) % 3) * p.Bp + u, 0u);   // the slot the launch after next adds to
         }
     } else {
-        const int t = T - p.j;                                     // t = T (nothing active yet) ... 0
+        const int t = T - j;                                       // t = T (nothing active yet) ... 0
         const bool active = t < lx;                                // b_t of this utterance is computed
         const bool starts = t - 1 == lx - 1 && lx > 0;             // frame t-1 is its last frame: z_{lx-1} is set up
-        const int k = rescale_exp(__uint_as_float(p.mxb[(p.j % 3) * p.Bp + u]));
+        const int k = rescale_exp(__uint_as_float(ld_word<PERS>(p.mxb + (j % 3) * p.Bp + u)));
         const float sc = pow2f(k);
         f32x4 sc4;
         bool act4[4], st4[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            sc4[c] = pow2f(rescale_exp(__uint_as_float(p.mxb[(p.j % 3) * p.Bp + u4 + c])));
-            act4[c] = t < lx4[c]; st4[c] = t == lx4[c] && lx4[c] > 0;
+        for (int q = 0; q < 4; ++q) {
+            sc4[q] = pow2f(rescale_exp(__uint_as_float(ld_word<PERS>(p.mxb + (j % 3) * p.Bp + u4 + q))));
+            act4[q] = t < c.lx4[q]; st4[q] = t == c.lx4[q] && c.lx4[q] > 0;
         }
         const bool all4 = act4[0] && act4[1] && act4[2] && act4[3];
-        const float *Zc = p.Zb + (size_t)(p.j & 1) * Pall + gP;
-        float *Zn = p.Zb + (size_t)((p.j + 1) & 1) * Pall + gP;
+        const VecRef<PERS> Zc(p.Zb + (size_t)(j & 1) * Pall + gP, (size_t)P * UL * 4);
+        const VecRef<PERS> Zn(p.Zb + (size_t)((j + 1) & 1) * Pall + gP, (size_t)P * UL * 4);
         const float *ep1 = p.ept + (size_t)(t >= 1 ? t - 1 : 0) * Vall + gV;   // (t = 0: read, not used)
         float *BPt = t >= 1 ? p.BP + (size_t)(t - 1) * Pall + gP : nullptr;
         const bool any_active = __ballot(active) != 0ull;
-        if (any_active || __ballot(starts) != 0ull)
+        if (any_active || __ballot(starts) != 0ull) {
+            filled = true;
             for (int task = w0; task < p.st.b.ntasks; task += NW)
-                bat_stream<UL, D, NM, FAC ? 4 : 1>(p.st.b, task == w0 ? tk0 : p.st.b.tasks[task], Zc, ep1, uq, sj, lane, ldsw, tmi, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
+                bat_stream<UL, D, NM, FAC ? 4 : 1, PERS>(p.st.b, task == w0 ? c.tk0 : p.st.b.tasks[task], Zc, ep1, uq, sj, lane, ldsw, tmi, fill, [&](const f32x4 &acc, const int4 *m, const f32x4 *e) __attribute__((always_inline)) {
                     if (m[0].x < 0) return;
                     // one output (plain rows), or the two states of a couple: the common out-arcs' sum + each state's extra arc
                     auto output = [&](const f32x4 &bv, const int st_, const int pr_, const f32x4 &em) __attribute__((always_inline)) {
@@ -381,34 +449,36 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
                             const float st = p.start_lin[st_];
                             if (st != 0.f) {
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) if (act4[c]) atomicAdd(&p.zb[u4 + c], st * bv[c]);
+                                for (int q_ = 0; q_ < 4; ++q_) if (act4[q_]) atomicAdd(&p.zb[u4 + q_], st * bv[q_]);
                             }
                             return;
                         }
-                        float *bp = BPt + (size_t)pr_ * UL + 4 * uq, *zp = Zn + (size_t)pr_ * UL + 4 * uq;
+                        float *bp = BPt + (size_t)pr_ * UL + 4 * uq;
+                        const size_t zi = (size_t)pr_ * UL + 4 * uq;
                         if (all4) {
                             const f32x4 z = em * bv;
-                            *(f32x4 *)bp = bv; *(f32x4 *)zp = z;
+                            *(f32x4 *)bp = bv; Zn.st4(zi, z);
                             mymax4 = __builtin_elementwise_max(mymax4, z);
                         } else {
                             const float eend = p.end_lin[st_] * pow2f(kScaleExp);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                if (act4[c] || st4[c]) {
-                                    const float out = act4[c] ? bv[c] : eend, z = em[c] * out;
-                                    bp[c] = out; zp[c] = z;
-                                    mymax4[c] = fmaxf(mymax4[c], z);
+                            for (int q_ = 0; q_ < 4; ++q_)
+                                if (act4[q_] || st4[q_]) {
+                                    const float out = act4[q_] ? bv[q_] : eend, z = em[q_] * out;
+                                    bp[q_] = out; Zn.st1(zi + q_, z);
+                                    mymax4[q_] = fmaxf(mymax4[q_], z);
                                 }
                         }
                     };
                     if constexpr (FAC) {
-                        const float w0 = __int_as_float(m[2].y), w1 = __int_as_float(m[2].w);
-                        output(__builtin_elementwise_fma(e[2], (f32x4){w0, w0, w0, w0}, acc) * sc4, m[0].x, m[0].y, e[0]);
-                        if (m[1].x >= 0) output(__builtin_elementwise_fma(e[3], (f32x4){w1, w1, w1, w1}, acc) * sc4, m[1].x, m[1].y, e[1]);
+                        const float w0_ = __int_as_float(m[2].y), w1_ = __int_as_float(m[2].w);
+                        output(__builtin_elementwise_fma(e[2], (f32x4){w0_, w0_, w0_, w0_}, acc) * sc4, m[0].x, m[0].y, e[0]);
+                        if (m[1].x >= 0) output(__builtin_elementwise_fma(e[3], (f32x4){w1_, w1_, w1_, w1_}, acc) * sc4, m[1].x, m[1].y, e[1]);
                     } else {
                         output(acc * sc4, m[0].x, m[0].y, e[0]);
                     }
                 });
+        }
         for (int i = w0; i < p.st.b.nrest; i += NW) {
             const int r = __builtin_amdgcn_readfirstlane(p.st.b.rest[i]);
             const int s = __builtin_amdgcn_readfirstlane(g.brow_s[r]);
@@ -418,7 +488,7 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
             const bool one = (ds.w & 0x40000000) != 0;
             float e1 = 0.f;
             if (one && t >= 1) e1 = ep1[(size_t)(ds.w & 0xffff) * UL + ul];      // (requested before the arcs)
-            const float bv = any_active ? bat_row_sum<UL>(g.barcs, ds.x, ds.y, Zc, ul, lane, aj) * sc : 0.f;
+            const float bv = any_active ? bat_row_sum<UL, PERS>(g.barcs, ds.x, ds.y, Zc, ul, lane, aj) * sc : 0.f;
             if (t == 0) {
                 const float st = p.start_lin[s];
                 if (st != 0.f && active && aj == 0) atomicAdd(&p.zb[u], st * bv);
@@ -426,38 +496,163 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParam
                 const float out = active ? bv : p.end_lin[s] * pow2f(kScaleExp);
                 if (one) {
                     const float z = e1 * out;
-                    if (aj == 0) { BPt[(size_t)ds.z * UL + ul] = out; Zn[(size_t)ds.z * UL + ul] = z; }
+                    if (aj == 0) { BPt[(size_t)ds.z * UL + ul] = out; Zn.st1((size_t)ds.z * UL + ul, z); }
                     mymax = fmaxf(mymax, z);
                 } else {
                     for (int kk = ds.z + aj; kk < ds.w; kk += ALR) {
                         const int4 pl = g.stp[kk];
                         BPt[(size_t)pl.x * UL + ul] = out;
                         const float z = ep1[(size_t)pl.y * UL + ul] * out;
-                        Zn[(size_t)pl.x * UL + ul] = z;
+                        Zn.st1((size_t)pl.x * UL + ul, z);
                         mymax = fmaxf(mymax, z);
                     }
                 }
             }
         }
-        if (lead) {
-            if (starts) p.Fb[u] = kScaleExp;
-            else if (active) p.Fb[u] += k + kEpExp;
-            p.mxb[((p.j + 2) % 3) * p.Bp + u] = 0u;
+        if (c.lead) {
+            if (starts) st_word<PERS>((unsigned *)p.Fb + u, (unsigned)kScaleExp);
+            else if (active) st_word<PERS>((unsigned *)p.Fb + u, ld_word<PERS>((const unsigned *)p.Fb + u) + (unsigned)(k + kEpExp));
+            st_word<PERS>(p.mxb + ((j + 2) % 3) * p.Bp + u, 0u);
+        }
+    }
+    // persistent launch: the emission lines the NEXT frame starts with (its first three bundles' labels) are asked for now, so that they
+    // sit in the L2 when that frame requests them behind the grid barrier (a new frame reads a new slab of e': a miss to the fabric
+    // otherwise, on the frame's critical path); the values are not used -- they are waited for at the end of this function, where
+    // every wave drains its stores anyway
+    f32x4 warm[NM == 1 ? 3 : 6];
+    bool warmed = false;
+    if constexpr (PERS) {
+        const int jn = j + 1;
+        const int tn = dir == 0 ? jn : T - jn - 1;                 // the frame whose emissions iteration jn reads
+        if (one_task && filled && tn >= 0 && tn < T) {
+            const int nbund = __builtin_amdgcn_readfirstlane(c.tk0.w);
+            constexpr int LGs = UL / 4, ALs = 64 / LGs;
+            const int4 *mlds = (const int4 *)(ldsw + 2 * kStreamRecB + 2 * 64 * 16 * (NM == 1 ? 1 : 4));
+            const f32x4 *et4 = (const f32x4 *)(p.ept + (size_t)tn * Vall + gV) + uq;
+#pragma unroll
+            for (int bd = 0; bd < 3; ++bd) {
+                const int4 *m = mlds + ((size_t)(bd < nbund ? bd : 0) * ALs + sj) * NM;
+                warm[(NM == 1 ? 1 : 2) * bd] = et4[(size_t)m[0].z * LGs];
+                if constexpr (NM > 1) warm[2 * bd + 1] = et4[(size_t)m[1].z * LGs];
+            }
+            warmed = true;
         }
     }
     // maximum of the vector this launch wrote, per utterance: lanes -> LDS (the values are non-negative: their bits order
     // like unsigned integers) -> one atomic per utterance and workgroup
     if (mymax > 0.f) atomicMax(&umax[ul], __float_as_uint(mymax));
 #pragma unroll
-    for (int c = 0; c < 4; ++c) if (mymax4[c] > 0.f) atomicMax(&umax[4 * uq + c], __float_as_uint(mymax4[c]));
+    for (int q_ = 0; q_ < 4; ++q_) if (mymax4[q_] > 0.f) atomicMax(&umax[4 * uq + q_], __float_as_uint(mymax4[q_]));
     __syncthreads();
     if (tid < UL) {
         const unsigned m = umax[tid];
-        unsigned *slot = (dir == 0 ? p.mxf : p.mxb) + ((p.j + 1) % 3) * p.Bp + grp * UL + tid;
+        unsigned *slot = (dir == 0 ? p.mxf : p.mxb) + ((j + 1) % 3) * p.Bp + grp * UL + tid;
         if (m != 0u) atomicMax(slot, m);
+    }
+    if constexpr (PERS) {
+        if (warmed) {
+#pragma unroll
+            for (int q_ = 0; q_ < (NM == 1 ? 3 : 6); ++q_) asm volatile("" : : "v"(warm[q_]));
+        }
     }
     CRF_TM(tmi >= 0, tmi + 6);
 }
+
+// One frame per launch: the kernel boundary is the grid barrier and what makes the vectors visible across XCDs.  1-D grid of 8 * nslot
+// workgroups; block b sits on XCD b % 8 (observed; a matter of speed only) and works for ONE combo = (utterance group, direction):
+//   #combos <  8: XCD x serves combo x % #combos together with the other XCDs of that residue, the combo's workgroups
+//                 ("chunks") dealt round-robin among them;
+//   #combos >= 8: XCD x serves the combos x, x + 8, ..., its slots dealt round-robin among them.
+template <int UL, int D, bool FAC>
+__global__ __launch_bounds__(kBatThreads) void crf_batch_frame_kernel(BatchParams p) {
+    __shared__ unsigned umax[UL];                                  // maximum of the vector this workgroup wrote, per utterance (float bits)
+    __shared__ __attribute__((aligned(16))) char stage[kBatWaves][stream_lds<UL, FAC>()];   // bat_stream: records, value ring, descriptors of a wave's task
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (timing build: launch 700, four workgroups of the first XCD x their four waves, 16 stamps each from g_tm[14000])
+    const int tmi = (p.j == 700 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) % 24 == 0 && (blockIdx.x >> 3) < 96) ? 14000 + (((blockIdx.x >> 3) / 24) * 4 + wave) * 16 : -1;
+    CRF_TM(tmi >= 0, tmi + 0);
+    const BatWg<UL> c = bat_setup<UL>(p, lane, wave);
+    bool filled = false;
+    bat_frame<UL, D, FAC, false>(p, c, p.j, umax, stage[wave], tmi, filled);
+}
+
+// ALL frames in one launch (round 6): the same frame body, the launch boundary replaced by a grid barrier -- an XCD-hierarchical counter
+// barrier (tools/grid_barrier_probe.hip: 2.2 us per frame empty at 256 workgroups, 3.6 us with a 1 MB sc1 exchange; one flat counter
+// 3.8 / 5.9): every wave drains its own stores (they are write-through: performed when acknowledged), the workgroup's lane 0 arrives at
+// its XCD's counter, the XCD's last arriver goes on to the top counter and, once all XCDs are there, publishes the XCD's generation word,
+// which the others poll (relaxed sc1 loads, s_sleep).  Workgroups per XCD come from a census at the start of the launch (HW_REG_XCC_ID;
+// any placement is correct, b % 8 is only the expected one).  What the per-frame launch paid 12 of its 16.8 us for -- cold instruction
+// caches, an invalidated L2, three dependent trips to the fabric before the first gather (profiles/round2_r2w_timing_probe_batch.txt) --
+// is paid once: the task descriptor stays in registers, arc records and row descriptors stay in the XCD's L2.
+// The grid must be co-resident (the host checks it against the occupancy the runtime reports and falls back to one launch per frame
+// otherwise); every spin is bounded, a time-out sets p.err (the costs of the call then come out as NaN) instead of hanging.
+// bar: [0] census barrier | [16 + 16 x] arrivals of XCD x | [160 + 16 x] generation of XCD x | [300] top | [304 + x] workgroups on XCD x
+__device__ __forceinline__ bool bat_poll_ge(unsigned *w, unsigned target, int *err) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(w, CRF_RLX_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > (1u << 22)) { __hip_atomic_store(err, 1, CRF_RLX_AGENT); return false; }   // ~seconds: a workgroup of the grid is not resident
+    }
+}
+template <int UL, int D, bool FAC>
+__global__ __launch_bounds__(kBatThreads, 2) void crf_batch_persist_kernel(BatchParams p) {   // (2: two workgroups per CU = two waves per SIMD -- VGPRs + AGPRs <= 256)
+    __shared__ unsigned umax[UL];
+    __shared__ unsigned bar_s[2];                                  // workgroups on this XCD, XCDs in use
+    __shared__ __attribute__((aligned(16))) char stage[kBatWaves][stream_lds<UL, FAC>()];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const BatWg<UL> c = bat_setup<UL>(p, lane, wave);
+    unsigned *bar = p.bar;
+    if (tid == 0) {                                                // census, then one flat barrier so that every count is final
+        __hip_atomic_fetch_add(bar + 304 + xcc, 1u, CRF_RLX_AGENT);
+        __hip_atomic_fetch_add(bar + 0, 1u, CRF_RLX_AGENT);
+        bat_poll_ge(bar + 0, gridDim.x, p.err);
+        unsigned n = 0;
+        for (int x = 0; x < 8; ++x) n += __hip_atomic_load(bar + 304 + x, CRF_RLX_AGENT) != 0u;
+        bar_s[0] = __hip_atomic_load(bar + 304 + xcc, CRF_RLX_AGENT); bar_s[1] = n;
+    }
+    __syncthreads();
+    const unsigned nx = bar_s[0], nxcd = bar_s[1];
+    bool filled = false;                                           // the wave's slice of LDS holds its task's records and row descriptors
+    for (int j = 0; j <= p.T; ++j) {
+        const int tmi = (j == 700 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) % 24 == 0 && (blockIdx.x >> 3) < 96) ? 14000 + (((blockIdx.x >> 3) / 24) * 4 + wave) * 16 : -1;
+        CRF_TM(tmi >= 0, tmi + 0);
+#ifdef CRF_TIMING
+        if (j == 700 && tid == 0 && blockIdx.x < 1000) g_tm[5000 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // frame start (100 MHz, device-wide)
+#endif
+        bat_frame<UL, D, FAC, true>(p, c, j, umax, stage[wave], tmi, filled);
+        if (j == p.T) break;                                       // nothing in this launch reads what the last frame wrote
+        // ---- the frame boundary ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave: its vector stores and maxima are performed
+        CRF_TM(tmi >= 0, tmi + 7);
+        __syncthreads();
+        CRF_TM(tmi >= 0, tmi + 10);
+#ifdef CRF_TIMING
+        if (j == 700 && tid == 0 && blockIdx.x < 1000) g_tm[2000 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // every workgroup's arrival at the grid barrier
+#endif
+        if (tid == 0) {
+            const unsigned f1 = (unsigned)(j + 1);
+            const unsigned old = __hip_atomic_fetch_add(bar + 16 + 16 * xcc, 1u, CRF_RLX_AGENT);
+            if (old + 1u == nx * f1) {                             // the XCD's last arriver
+                __hip_atomic_fetch_add(bar + 300, 1u, CRF_RLX_AGENT);
+                bat_poll_ge(bar + 300, nxcd * f1, p.err);
+                __hip_atomic_store(bar + 160 + 16 * xcc, f1, CRF_RLX_AGENT);
+            } else {
+                bat_poll_ge(bar + 160 + 16 * xcc, f1, p.err);
+            }
+        }
+        __syncthreads();
+#ifdef CRF_TIMING
+        if (j == 700 && tid == 0 && blockIdx.x < 1000) { g_tm[3000 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); g_tm[4000 + blockIdx.x] = xcc; }
+#endif
+        CRF_TM(tmi >= 0, tmi + 11);
+    }
+}
+
 
 // zs[u] = sum_s a_{lx}[s][u] * end[s].  grid (ceil(S / (4 * 64)), 1, Bp / UL): a wave sums 64 states
 template <int UL>
@@ -493,8 +688,9 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_cost_kernel(BatchParams
             zs = zb = z0 * pow2f(kScaleExp); ef = fb = kScaleExp;
         }
         p.den_zs[b] = zs; p.den_ez[b] = ef;
-        p.cost_alpha[b] = to_log(zs, ef, mxs);
-        p.cost_beta[b] = to_log(zb, fb, mxs);
+        const bool timed_out = *p.err != 0;                        // the persistent launch's grid barrier gave up: no result
+        p.cost_alpha[b] = timed_out ? __builtin_nanf("") : to_log(zs, ef, mxs);
+        p.cost_beta[b] = timed_out ? __builtin_nanf("") : to_log(zb, fb, mxs);
         if (!(zs > 0.f && zs < INFINITY)) p.redo[b] = 1;
         if (!(zb > 0.f && zb < INFINITY)) p.redo[p.B + b] = 1;
     }
@@ -543,6 +739,8 @@ __global__ __launch_bounds__(kBatThreads) void crf_batch_grad_kernel(BatchParams
     template __global__ void crf_batch_transpose_kernel<UL>(BatchParams);             \
     template __global__ void crf_batch_frame_kernel<UL, 4, false>(BatchParams);       \
     template __global__ void crf_batch_frame_kernel<UL, 4, true>(BatchParams);        \
+    template __global__ void crf_batch_persist_kernel<UL, 4, false>(BatchParams);     \
+    template __global__ void crf_batch_persist_kernel<UL, 4, true>(BatchParams);      \
     template __global__ void crf_batch_zsum_kernel<UL>(BatchParams);                  \
     template __global__ void crf_batch_grad_kernel<UL>(BatchParams);
 CRF_INST_BAT(64)

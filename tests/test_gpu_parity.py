@@ -27,7 +27,7 @@ def crf():
     return ctc_crf
 
 
-MODES = ["factored", "factored_768", "factored_rcl", "factored_k2", "factored_k2_1024", "factored_pair2", "factored_pair2_512", "resident", "streaming", "batch"]
+MODES = ["factored", "factored_768", "factored_rcl", "factored_k2", "factored_k2_1024", "factored_pair2", "factored_pair2_512", "resident", "streaming", "batch", "batch_frames"]
 
 
 _env = crf_env   # (debug switches of the library, tests/util.py)
@@ -41,7 +41,7 @@ class _mode(crf_env):
     def __init__(self, mode):
         self.mode = mode
         kw = dict(
-            CRF_NO_RESIDENT=mode in ("streaming", "batch"),
+            CRF_NO_RESIDENT=mode in ("streaming", "batch", "batch_frames"),
             CRF_NO_FACTORED=not mode.startswith("factored"),
             # "factored_rcl": the factored kernels' 768-thread variant with the row constants in an LDS table (what graphs with more
             # than three slices of rows per wave take by themselves), forced for every graph with the T o LM structure
@@ -59,10 +59,13 @@ class _mode(crf_env):
             # "factored": the planner's own order (1024 threads x 15 chunks first since round 3); "factored_768": the 768-thread
             # geometries first (row constants in registers where the rows allow), which is also what the two-utterance kernels need
             CRF_FAC_THREADS=768 if mode in ("factored_768", "factored_pair2") else 1024 if mode == "factored_k2_1024" else 0)
-        # "batch": the utterance-minor kernels (one launch per frame), what graphs that fit no register-resident layout
-        # take by default; "streaming": the persistent one-workgroup-per-utterance fallback (no_batch is read per call)
-        if mode in ("streaming", "batch"):
+        # "batch": the utterance-minor kernels, what graphs that fit no register-resident layout take by default -- since round 6 all
+        # frames in ONE persistent launch with a grid barrier per frame; "batch_frames": the same frame body as one launch per frame
+        # (rounds 2 - 5; the fallback when the grid is not co-resident); "streaming": the persistent one-workgroup-per-utterance
+        # fallback (no_batch is read per call)
+        if mode in ("streaming", "batch", "batch_frames"):
             kw["CRF_NO_BATCH"] = mode == "streaming"
+            kw["CRF_BAT_PERSIST"] = mode != "batch_frames"
         super().__init__(**kw)
 
 
@@ -70,7 +73,7 @@ def run_hip(crf, den_lm, logits, labels, lx, ly, lamb=0.1, size_average=True, mo
     with _mode(mode):   # (CRF_NO_RESIDENT / CRF_NO_FACTORED are read when the graph is created, CRF_NO_BATCH per call)
         ctx = crf.CRFContext(den_lm, 0)
         st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
-        if mode in ("streaming", "batch"):
+        if mode in ("streaming", "batch", "batch_frames"):
             assert st["res_K"] == 0 and st["fac"] == 0
         if mode == "resident":
             assert st["fac"] == 0

@@ -131,6 +131,41 @@ __global__ __launch_bounds__(256) void persistent_kernel(Params p) {
     }
 }
 
+// ---- which LOAD instruction?  (round 6, after the first persistent kernel: its sc1 gathers as raw BUFFER loads ran 40 % slower than the
+// per-frame kernel's plain global loads.)  The frame's gathers alone, one launch per frame so that every flavour is correct, 16 loads in
+// flight per lane: LD 0 plain global_load_dwordx4, 1 buffer_load_dwordx4 (aux 0), 2 buffer_load_dwordx4 sc1, 3 global_load_dwordx4 sc1
+// (inline asm, waited for by hand), 4 global_load_dwordx4 nt
+template <int LD>
+__global__ __launch_bounds__(256) void gather_kernel(Params p) {
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = 8 / p.C, combo = (b & 7) % p.C, idx = (b >> 3) * per + (b & 7) / p.C;
+    const u32x4 *src = p.vec + (size_t)combo * p.n4;
+    const unsigned nseg = (unsigned)p.n4 / 8u;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, p.n4 * 16, 0x27000);
+    unsigned acc = 0;
+    for (int r = 0; r < p.R; r += 16) {
+        u32x4 v[16];
+        unsigned at[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const unsigned seg = (hash32((unsigned)(((idx * 4 + wave) * 4096 + r + k) * 8 + (lane >> 3)) ^ (unsigned)(p.f0 * 0x9e3779b9u)) & 0xffffffu) * nseg >> 24;
+            at[k] = seg * 8u + (unsigned)(lane & 7);
+            if (LD == 0) v[k] = src[at[k]];
+            else if (LD == 1) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, at[k] * 16u, 0, 0);
+            else if (LD == 2) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, at[k] * 16u, 0, 16);
+            else if (LD == 3) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v[k]) : "v"(at[k] * 16u), "s"(src) : "memory");
+            else v[k] = __builtin_nontemporal_load(src + at[k]);
+        }
+        if (LD == 3) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+            asm volatile("" : "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : : "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += (v[k].y != at[k]);
+    }
+    if (acc) atomicAdd(p.err, acc);
+}
+
 // the same frame as its own launch (the kernel boundary is the barrier): plain stores and loads
 __global__ __launch_bounds__(256) void frame_kernel(Params p) {
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -223,6 +258,37 @@ int main(int argc, char **argv) {
             }
             printf("one launch per frame                 : %8.3f us per frame   wrong values %u\n", best * 1000.f / T, herr);
             fflush(stdout);
+        }
+        if (&c == &cfgs[1] || &c == &cfgs[2]) {   // load flavours
+            Params p{ctr, vec, err, 1, c.G, c.C, n4, c.R / 16 * 16, c.W, 3, 0, 0};
+            const char *names[] = {"global_load plain", "buffer_load aux 0", "buffer_load sc1", "global_load sc1 (asm)", "global_load nt"};
+            for (int ld = 0; ld < 5; ++ld) {
+                float best = 1e30f;
+                unsigned herr = 0;
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipMemcpy(vec, h.data(), h.size() * 16, hipMemcpyHostToDevice));
+                    CK(hipMemsetAsync(err, 0, 64, st));
+                    CK(hipEventRecord(e0, st));
+                    for (int f = 0; f < 300; ++f) {
+                        p.f0 = f;
+                        switch (ld) {
+                            case 0: hipLaunchKernelGGL(gather_kernel<0>, dim3(c.G), dim3(256), 0, st, p); break;
+                            case 1: hipLaunchKernelGGL(gather_kernel<1>, dim3(c.G), dim3(256), 0, st, p); break;
+                            case 2: hipLaunchKernelGGL(gather_kernel<2>, dim3(c.G), dim3(256), 0, st, p); break;
+                            case 3: hipLaunchKernelGGL(gather_kernel<3>, dim3(c.G), dim3(256), 0, st, p); break;
+                            default: hipLaunchKernelGGL(gather_kernel<4>, dim3(c.G), dim3(256), 0, st, p); break;
+                        }
+                    }
+                    CK(hipEventRecord(e1, st));
+                    CK(hipStreamSynchronize(st));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
+                    unsigned e2; CK(hipMemcpy(&e2, err, 4, hipMemcpyDeviceToHost));
+                    herr += e2;
+                }
+                printf("gathers only, one launch per frame, %-24s: %8.3f us per frame   wrong values %u\n", names[ld], best * 1000.f / 300, herr);
+                fflush(stdout);
+            }
         }
         CK(hipFree(vec));
     }
