@@ -249,9 +249,10 @@ def main():
     den_path = ctc_crf._C.den_kernels(ctc_crf._C.graph_for(dev), B, T, V)   # what a call of this shape takes (asked of the library)
     batch_path = den_path == "batch"
     kname = {"factored": "crf_fac2_pair_kernel" if gstats.get("fac_geom") == 3 else "crf_fac_pair_kernel", "resident": "crf_res_pair_kernel",
-             "batch": "crf_batch_frame_kernel", "streaming": "crf_den_pair_kernel"}[den_path]
+             "batch": "crf_batch_persist_kernel", "streaming": "crf_den_pair_kernel"}[den_path]
     den_symbol = ctc_crf._C.last_den_kernel()    # e.g. crf_fac_pair_kernel<true,768,21,4,4,false,false,0> (this thread's last call)
-    launches = (T + 1) if batch_path else 1     # utterance-minor kernels: one launch per frame (forward frame j + backward frame T-j)
+    # utterance-minor kernels: one persistent launch (round 6), or one launch per frame (forward frame j + backward frame T-j) when the grid is not co-resident
+    launches = (T + 1) if batch_path and "persist" not in (den_symbol or "") else 1
     # HBM traffic from the PMC counters: measured by tools/gpu_prof.sh (separate rocprofv3 --pmc passes) and committed
     # keyed by workload; any other workload prints null instead of a number that does not belong to it
     traffic, traffic_path = None, None

@@ -1142,10 +1142,6 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         bp.bar = bsm + 12 * w.Bp; bp.err = (int *)(bsm + 12 * w.Bp + 512);
         bp.den_zs = p.den_zs; bp.cost_alpha = p.cost_alpha; bp.cost_beta = p.cost_beta; bp.den_ez = p.den_ez; bp.redo = p.redo;
         bp.grad = grad; bp.c_den = c_den;
-        if (ctc) {
-            if ((rc = fork_side())) return rc;
-            if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
-        }
         const unsigned ngrp = (unsigned)(w.Bp / w.UL);
         bp.ngrp = (int)ngrp;
         // one task per wave, ONE round of workgroups (a second round with a fraction of the device doubled the launch):
@@ -1187,6 +1183,17 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         const unsigned nslot = (unsigned)(ncombo < 8 ? (wg_combo + (8 / ncombo) - 1) / (8 / ncombo) : wg_combo * ((ncombo + 7) / 8));
         const unsigned G = 8 * nslot;
         if (persist && (int64_t)G > slots) persist = false;        // (the grid barrier needs every workgroup resident)
+        // The numerator chains run BESIDE the per-frame launches (side stream) but BEHIND the persistent launch, beside the grad pass: a
+        // co-resident grid sized for the device's slots must not share them -- with the chains' 2 B workgroups on the CUs, G = 416 of 512
+        // slots no longer fitted at once (S = 12 289, B = 64: a CU that holds a chain workgroup has LDS for one workgroup of this kernel,
+        // not two), the rest of the grid waited for the chains, and the runtime time-sliced the queues: 1.7 ms per frame instead of 13 us
+        // and barrier time-outs (profiles/round6_ab_persistent_batch.txt)
+        if (ctc && !persist) {
+            if ((rc = fork_side())) return rc;
+            if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
+        }
+        if (opt_on(kOpt_verbose)) fprintf(stderr, "[ctc_crf_hip] utterance-minor: UL %d, %d combos, tasks %d / %d, rest rows %d / %d, grid %u of %lld slots (%d per CU), %s\n", (int)w.UL, (int)ncombo,
+                                          sdv->f.ntasks, sdv->b.ntasks, sdv->f.nrest, sdv->b.nrest, G, (long long)slots, wg_cu, persist ? "one persistent launch" : "one launch per frame");
         prof_mark(1, false, stream); prof_mark(2, false, stream);
 #define CRF_BAT_UL(KERNEL, GRID, ...)                                                                        \
         switch (w.UL) {                                                                                       \
@@ -1220,6 +1227,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             }
         }
         LAUNCH_CHECK("crf_batch_frame_kernel");
+        if (ctc && persist) {
+            if ((rc = fork_side())) return rc;
+            if ((rc = launch_ctc_pair(p, lds_ctc, side, max_label_len))) return rc;
+        }
         CRF_BAT_UL(crf_batch_zsum_kernel, dim3((unsigned)((h->dev.S + 255) / 256), 1, ngrp), bp);
         hipLaunchKernelGGL(crf_batch_cost_kernel, dim3((unsigned)B), dim3(kBatThreads), 0, stream, bp);
         prof_mark(1, true, stream); prof_mark(2, true, stream);

@@ -112,11 +112,11 @@ def test_fuzz_fused_log_softmax_vs_oracle(crf, tmp_path, seed):
 
 
 @pytest.mark.parametrize("H,d,B,T,sigma,kern", [(2304, 24, 3, 60, 2.0, "crf_fac2_pair_kernel"), (3072, 24, 2, 40, 8.0, "crf_fac2_pair_kernel"),
-                                               (6144, 24, 2, 30, 2.0, "crf_batch_frame_kernel"), (6144, 24, 2, 30, 20.0, "crf_batch_frame_kernel"),
+                                               (6144, 24, 2, 30, 2.0, "crf_batch_persist_kernel"), (6144, 24, 2, 30, 20.0, "crf_batch_persist_kernel"),
                                                (2048, 24, 4, 90, 20.0, "crf_fac_pair_kernel"), (2048, 24, 3, 200, 40.0, "crf_fac_pair_kernel")])
 def test_fuzz_graphs_of_the_benchmark_size_class(crf, tmp_path, H, d, B, T, sigma, kern):
     """... and on den_lm of the benchmark generator's size classes, each on the kernels it takes BY ITSELF (one CU per recursion, two CUs, the
-    utterance-minor launches), with peaked outputs."""
+    utterance-minor kernels -- since round 6 all frames in one persistent launch), with peaked outputs."""
     import torch
     V = 72
     g, p = small_synth(tmp_path, V, H, d, 0)

@@ -94,7 +94,7 @@ def main():
     alg = bench["roofline"]["den_fwd_bwd"]["bytes"] + bench["roofline"]["den_fwd_bwd"]["bytes_num"]
     # the denominator recursions' kernel as the library names it (crf_last_den_kernel): rocprofv3's demangled name without
     # "void crf::", blanks and the argument list -- bench.py prints `traffic` only for a call that ran THIS instantiation
-    den = [k for k in traffic if any(n in k for n in ("crf_fac_pair_kernel", "crf_fac2_pair_kernel", "crf_res_pair_kernel", "crf_batch_frame_kernel", "crf_den_pair_kernel"))]
+    den = [k for k in traffic if any(n in k for n in ("crf_fac_pair_kernel", "crf_fac2_pair_kernel", "crf_res_pair_kernel", "crf_batch_frame_kernel", "crf_batch_persist_kernel", "crf_den_pair_kernel"))]
     den_kernel = den[0].replace("void ", "").replace("crf::", "").split("(")[0].replace(" ", "") if len(den) == 1 else None
     tr = {"workload": key, "den_kernel": den_kernel, "kernels": kernels,
           "whole_path": {"pmc_bytes_per_call": total, "algorithmic_bytes": alg, "ratio": round(total / max(1, alg), 3)},
