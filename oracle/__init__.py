@@ -109,6 +109,27 @@ def ctc(logits: np.ndarray, labels: np.ndarray, lx: np.ndarray, ly: np.ndarray, 
     return grad, cc, valid
 
 
+def ctc_alpha(logits: np.ndarray, labels: np.ndarray, lx: np.ndarray, ly: np.ndarray, precision: str = "f64"):
+    """ctc() plus the forward table alpha [B,T,Smax] (Smax = 2 max(ly) + 1; NaN where an utterance has no entry), in the reference's
+    workspace layout per utterance (gpu_ctc_kernels.h:134-196)."""
+    lib = _load()
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    B, T, V = logits.shape
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    lx = np.ascontiguousarray(lx, dtype=np.int32)
+    ly = np.ascontiguousarray(ly, dtype=np.int32)
+    grad = np.zeros((B, T, V), dtype=np.float32)
+    cc = np.zeros(B, dtype=np.float64)
+    valid = np.zeros(B, dtype=np.int32)
+    smax = int(2 * ly.max() + 1) if B else 1
+    alpha = np.full((B, T, smax), np.nan, dtype=np.float64)
+    fn = getattr(lib, f"oracle_ctc_alpha_{precision}")
+    rc = fn(_p(logits, ctypes.c_float), B, T, V, _p(labels, ctypes.c_int), _p(lx, ctypes.c_int),
+            _p(ly, ctypes.c_int), _p(grad, ctypes.c_float), _p(cc, ctypes.c_double), _p(valid, ctypes.c_int), _p(alpha, ctypes.c_double), smax)
+    assert rc == 0
+    return grad, cc, valid, alpha
+
+
 def ctc_crf(g: Dict, logits: np.ndarray, labels: np.ndarray, lx: np.ndarray, ly: np.ndarray,
             lamb: float = 0.1, size_average: bool = True, precision: str = "f64",
             threads: Optional[int] = None):

@@ -11,8 +11,13 @@
  *       test fixture (src/ctc_crf/test/main.py:15-28 + test/den_lm.fst, re-created from text by
  *       tests/golden/make_golden.py) and on random tiny graphs,
  *   (2) torch's CPU ctc_loss (an unrelated implementation) for the numerator, and
- *   (3) on the GPU box, the reference's own denominator kernels compiled for gfx950 from
- *       /root/reference (oracle/Makefile target `ref` -> oracle/_ref/libden_ref.so).
+ *   (3) on the GPU box, the reference's own kernels compiled in place for gfx950 from /root/reference
+ *       (oracle/Makefile target `ref`): the denominator (oracle/_ref/libden_ref.so: alpha table entry by
+ *       entry, tests/test_gpu_parity.py::test_denominator_vs_reference_kernels) and, since round 6, the
+ *       numerator (oracle/_ref/libctc_ref.so: compute_ctc_loss's costs, gradients and alpha workspace,
+ *       ::test_numerator_vs_reference_kernels -- fp32 build of this file within 2.3e-7 of the reference's
+ *       forward table, same -inf pattern, on six cases incl. repeats, an empty label sequence and an
+ *       invalid utterance).
  *
  * Each function cites the reference file:line it restates.  The file is compiled twice:
  *   -DREAL=double -DSUF=_f64   parity oracle
@@ -181,7 +186,8 @@ static int den_one(const graph_t *g, const float *logits, int T, int V, int lx, 
  * gamma = 0 ("skip the utterance"), mirrored by the HIP path.
  * ------------------------------------------------------------------------------------------ */
 static int ctc_one(const float *probs, int T, int V, const int *lab, int L, float *grad,
-                   double *loglike, int *valid) {
+                   double *loglike, int *valid, double *alpha_out) {   /* alpha_out: NULL, or [T][2L+1], the forward table as the reference's
+                                                                          workspace holds it (gpu_ctc_kernels.h:134-196: alpha[s + t * S]) */
     const int S = 2 * L + 1, blank = 0;
     int repeats = 0;
     for (int i = 1; i < L; ++i) repeats += (lab[i] == lab[i - 1]); /* gpu_ctc.h:161-165 */
@@ -217,6 +223,7 @@ static int ctc_one(const float *probs, int T, int V, const int *lab, int L, floa
         for (int i = s0; i < s1; ++i) ll = log_plus(ll, alpha[(size_t)(T - 1) * S + i]);
     }
     *loglike = (double)ll;
+    if (alpha_out) for (size_t i = 0; i < (size_t)T * S; ++i) alpha_out[i] = (double)alpha[i];
 
     /* backward + posteriors :264-436 */
     int bstart = S > 1 ? S - 2 : 0, bend = (L + repeats < T) ? S : S - 1;
@@ -295,7 +302,28 @@ int FN(oracle_ctc)(const float *logits, int B, int T, int V, const int *labels, 
 #pragma omp parallel for schedule(dynamic, 1) reduction(| : err)
     for (int b = 0; b < B; ++b)
         err |= ctc_one(logits + (size_t)b * T * V, lx[b], V, labels + off[b], ly[b],
-                       grad_ctc + (size_t)b * T * V, costs_ctc + b, valid + b);
+                       grad_ctc + (size_t)b * T * V, costs_ctc + b, valid + b, NULL);
+    free(off);
+    return err;
+}
+
+/* ... and the forward table of every utterance, alpha [B][T][Smax] (row t of utterance b: its own 2 ly[b] + 1 entries, the rest untouched),
+ * for the entry-by-entry comparison with the reference's own kernels (tests/test_gpu_parity.py::test_numerator_vs_reference_kernels). */
+int FN(oracle_ctc_alpha)(const float *logits, int B, int T, int V, const int *labels, const int *lx,
+                         const int *ly, float *grad_ctc, double *costs_ctc, int *valid, double *alpha, int Smax) {
+    memset(grad_ctc, 0, sizeof(float) * (size_t)B * T * V);
+    int *off = malloc(sizeof(int) * (size_t)(B + 1));
+    off[0] = 0;
+    for (int b = 0; b < B; ++b) off[b + 1] = off[b] + ly[b];
+    int err = 0;
+    for (int b = 0; b < B; ++b) {
+        const int S = 2 * ly[b] + 1, Tb = lx[b];
+        double *tmp = malloc(sizeof(double) * (size_t)(Tb > 0 ? Tb : 1) * S);
+        err |= ctc_one(logits + (size_t)b * T * V, Tb, V, labels + off[b], ly[b], grad_ctc + (size_t)b * T * V, costs_ctc + b, valid + b, tmp);
+        if (valid[b] && Tb > 0 && S <= Smax)
+            for (int t = 0; t < Tb; ++t) memcpy(alpha + ((size_t)b * T + t) * Smax, tmp + (size_t)t * S, sizeof(double) * (size_t)S);
+        free(tmp);
+    }
     free(off);
     return err;
 }
