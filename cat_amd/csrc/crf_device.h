@@ -63,6 +63,9 @@ constexpr int kFlagFallback = 40;   // words [40], [41] behind the error word: u
 #ifndef CRF_X_KCLATE
 #define CRF_X_KCLATE 0      // fac_chain_body, table geometries: the first slice's row constants are requested behind the first batch of gathers (0: at the frame top)
 #endif
+#ifndef CRF_X_ADDTID
+#define CRF_X_ADDTID 0      // fac_chain_body, forward row epilogue: the four next-vector entries by ds_write_addtid_b32 (base in M0) instead of ds_write_b32 -- profiles/round6_ab_addtid.txt
+#endif
 #ifndef CRF_X_LAG
 #define CRF_X_LAG 0         // fac_chain_body (one CU per recursion): the scale of frame t+1 is worked out in the TAIL of frame t from the maximum
                             // deposited in frame t-1 -- known before barrier t, so no frame starts with an LDS round trip for its scale (0: the scale of
@@ -280,6 +283,12 @@ __device__ __forceinline__ int lds_issue_i32(const int *q) {
 }
 __device__ __forceinline__ void lds_landed(double &a, double &b, double &c, int &w) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(w));
+}
+
+// LDS store of one float per lane to (uniform byte address `base`) + 4 * lane: the base goes through M0, the instruction carries no address VGPR.
+// (1 wait state between the SALU write of M0 and the add-TID instruction; volatile asms keep their order, so the frame's sync_lds follows it.)
+__device__ __forceinline__ void lds_st_addtid(float v, unsigned base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(v), "s"(base));
 }
 
 // In-kernel phase timing for diagnosis (build with CRF_BUILD_DEFS=-DCRF_TIMING; tools/timing_probe.py):

@@ -394,10 +394,17 @@ __device__ __forceinline__ void fac_chain_body(const FacParams &p, float *lds, c
                         *(float *)((char *)Orow + r4 + 4u * (unsigned)R) = qt;
                     }
                     const float Lp = em * rv, Ap = et * qt, Up = Ap + Lp;           // a_{t+1}[main], [tail], their sum
+                    if constexpr (CRF_X_ADDTID != 0 && !K2) {
+                        // the four entries lie at (uniform base) + 4 * lane: ds_write_addtid_b32 takes the base from M0 and no address VGPR -- half the
+                        // VGPR -> LDS traffic of a ds_write_b32 and no v_add per store (M0 reaches the whole LDS: tools/addtid_probe)
+                        const unsigned mb = (unsigned)(uintptr_t)xnb + (unsigned)__builtin_amdgcn_readfirstlane((int)r4);
+                        lds_st_addtid(Up, mb); lds_st_addtid(Up, mb + dup); lds_st_addtid(Lp, mb + 4u * (unsigned)R); lds_st_addtid(Ap, mb + 8u * (unsigned)R);
+                    } else {
                     *(float *)(xnb + r4) = Up;
                     *(float *)(xnb + r4 + dup) = Up;
                     *(float *)(xnb + r4 + 4u * (unsigned)R) = Lp;
                     *(float *)(xnb + r4 + 8u * (unsigned)R) = Ap;
+                    }
                     if constexpr (K2) {           // entries rid, R + rid, 2 R + rid of the peer's vector
                         gu64 *gs = (gu64 *)((char *)slot + 2u * r4);
                         res_publish(gs, 0, tag, Up, same_l2); res_publish(gs, R, tag, Lp, same_l2); res_publish(gs, 2 * R, tag, Ap, same_l2);
