@@ -113,6 +113,7 @@ struct LossParams {
     int gd_poff[17];              //   from block gd_poff[k] on -- whose workgroups wait for their stage's counter themselves:
     const int *gd_cnt;            //   the den kernels' stage counters (FacParams::stage_cnt; fine-grained memory) ...
     int gd_target;                //   ... and the value that releases a stage (2 B: every recursion has published it)
+    int *gd_timeout_host;         //   pinned host word set when a workgroup's wait times out (the context then goes back to per-stage launches)
     int gd_fpb[16];               //   frames per workgroup in stage k: kGDFrames, or a divisor of it -- the short last stages, where a workgroup's 16 frames one after the
                                   //   other (4 - 5 us each) would BE the tail: a block is still of the stage its 16 frames make it, and split among 16 / fpb workgroups there
     int grad_den_acc;             // crf_grad_den_kernel: 1 = add to the row (the numerator half has written it) instead of writing; 2 = atomic add into a

@@ -175,6 +175,8 @@ struct DevCtx {
     hipStream_t aux{};        // a third stream that runs beside the owner's (numerator fallback chains beside the grad stages), or null
     hipEvent_t ev_a{}, ev_b{};
     int *seen = nullptr;      // pinned host word the log-domain numerator chains write the call number to (read without a sync: a hint)
+    int *hostw = nullptr;     // pinned, mapped host words: [0] = seen (when there is a third stream), [4] = the one-launch grad pass has timed out
+    bool gd_fallback = false; // ... and this context has gone back to one grad launch per stage
     int call_id = 0;
     hipEvent_t fork{}, join{}, ev[kMaxStages]{}, evb[kMaxStages]{};
     int *flags = nullptr;     // fine-grained (uncached, cross-XCD coherent) words: [0] error word, [1] start counter, [16..32) stage counters
@@ -295,6 +297,11 @@ static int get_ctx(hipStream_t owner, DevCtx **out) {
         (void)hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->evb[i], hipEventDisableTiming);
     }
+    {
+        void *hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { c->hostw = (int *)hp; for (int i = 0; i < 16; ++i) c->hostw[i] = 0; }
+        else (void)hipGetLastError();
+    }
     // The side stream: the first candidate that demonstrably runs beside the owner's stream (once per context; the owner's
     // stream is drained first so that both probe kernels start at once).  find_beside() keeps the candidates that failed
     // alive until one passes, and tries streams of other priorities (queue pools of their own) and a CU-masked stream (a
@@ -322,9 +329,7 @@ static int get_ctx(hipStream_t owner, DevCtx **out) {
         (void)hipStreamSynchronize(owner);
         int kind = 0, tries = 0;
         c->aux = find_beside(owner, c->flags, dev, &kind, &tries);
-        void *hp = nullptr;
-        if (c->aux && hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { c->seen = (int *)hp; *c->seen = 0; }
-        else (void)hipGetLastError();
+        if (c->aux && c->hostw) c->seen = c->hostw;
     }
     snprintf(c->side_desc, sizeof(c->side_desc), "%s (candidate %d)%s", kSideNames[c->side_kind], c->side_tries, c->aux ? " + third stream" : "");
     g_ctxs.push_back(c);
@@ -672,7 +677,10 @@ int crf_den_kernels(const crf_graph *g, int64_t B, int64_t T, int64_t V) {
 
 // Stage bounds of the staged grad pass (crf_loss_fwd_bwd; crf_debug_stage_plan shows them to the tests): bound[0] = 0 < bound[1] < ... < bound[nstage] = T,
 // stage k = the recursions' iterations [bound[k-1], bound[k]).  Returns nstage; *gd_piece = the length of the equal pieces.
-static int plan_grad_stages(int64_t T, bool segmode, int stages_env, int pieces, int *bound, int *gd_piece_out) {
+static int plan_grad_stages(int64_t T, bool segmode, int stages_env, int pieces, int *bound, int *gd_piece_out, int stage_launches = -1) {
+    // stage_launches: one grad launch per stage (round 4's schedule) -- the switch gd_stage_launches, or a context whose one-launch grad pass has
+    // timed out once (DevCtx::gd_fallback)
+    const bool per_stage = stage_launches >= 0 ? stage_launches != 0 : opt_on(kOpt_gd_stage_launches);
     int nstage = 1, gd_piece = 0;
     bound[0] = 0;
     bound[1] = (int)T;
@@ -686,8 +694,8 @@ static int plan_grad_stages(int64_t T, bool segmode, int stages_env, int pieces,
         } else {
             // (round 5, one grad launch for all stages: a stage costs the grad pass nothing any more and the recursions one drain + barrier;
             // pieces of 48 .. 96 iterations all give 2.71 ms where 128 gives 2.75 and round 4's per-stage launches 2.82: profiles/round5_ab_grad_one_launch.txt)
-            piece = opt_on(kOpt_gd_stage_launches) ? 128 : 80;
-            while ((kMaxStages - 4) * piece < (int)T - half && piece < (int)T) piece += opt_on(kOpt_gd_stage_launches) ? 128 : 16;   // the stage counters cover T - half
+            piece = per_stage ? 128 : 80;
+            while ((kMaxStages - 4) * piece < (int)T - half && piece < (int)T) piece += per_stage ? 128 : 16;   // the stage counters cover T - half
             const int piece_env = opt(kOpt_piece, 0);
             if (piece_env > 0) piece = (piece_env + kGDFrames - 1) / kGDFrames * kGDFrames;
             const int body = std::min((int)T - half, (kMaxStages - 2) * piece);   // (a CRF_PIECE too small for the counters)
@@ -703,7 +711,7 @@ static int plan_grad_stages(int64_t T, bool segmode, int stages_env, int pieces,
         // taper: the last stage is what is left to do when the recursions have ended; with one grad launch for all stages (its workgroups
         // wait themselves) a stage costs the grad pass nothing and the recursions one drain + barrier, so the last pieces are halved down
         // to `taper` iterations: ..., piece, piece / 2, piece / 4, ..., taper
-        const int taper = stages_env > 0 || segmode || opt_on(kOpt_gd_stage_launches) ? 0 : (opt(kOpt_taper, 32) + kGDFrames - 1) / kGDFrames * kGDFrames;
+        const int taper = stages_env > 0 || segmode || per_stage ? 0 : (opt(kOpt_taper, 32) + kGDFrames - 1) / kGDFrames * kGDFrames;
         if (taper > 0 && taper < piece && nstage >= 3) {
             int desc[kMaxStages + 8], n = 0, pos = (int)T;             // stage ends from the last one backwards
             desc[n++] = pos;
@@ -957,7 +965,18 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     int bound[kMaxStages + 1] = {0};
     int nstage = 1, gd_piece = 0;
     bound[1] = (int)T;
-    if (staged && T >= 256) nstage = plan_grad_stages(T, segmode, stages_env, pieces, bound, &gd_piece);
+    // The one-launch grad pass's workgroups wait inside the kernel for the recursions' stage counters (bounded: ~2 s of wall clock).  A time-out --
+    // a den launch that aborted, a device shared with a process whose kernels keep the recursions off their CUs -- is written to a pinned host word;
+    // a context that has seen one goes back to one grad launch per stage behind stream-level waits (round 4's schedule: nothing waits on the
+    // GPU) for good (round-5 advisor)
+    if (cx->hostw && !cx->gd_fallback && ((volatile int *)cx->hostw)[4] != 0) {
+        cx->gd_fallback = true;
+        fprintf(stderr, "[ctc_crf_hip] the one-launch grad pass timed out waiting for the denominator recursions in an earlier call (its loss was NaN): "
+                        "this context now launches the grad pass stage by stage behind stream-level waits\n");
+    }
+    const bool per_stage = opt_on(kOpt_gd_stage_launches) || cx->gd_fallback;
+    p.gd_timeout_host = cx->hostw ? cx->hostw + 4 : nullptr;
+    if (staged && T >= 256) nstage = plan_grad_stages(T, segmode, stages_env, pieces, bound, &gd_piece, per_stage ? 1 : 0);
     p.gd_nb = nstage + 1;
     for (int k = 0; k <= nstage && k < 16; ++k) p.gd_bound[k] = bound[k];
     float *fstate = (float *)(base + w.off_state), *bstate = fstate + B * w.state_stride;
@@ -1316,7 +1335,7 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
         }
         p.grad_den_acc = 1;
         // (one launch for the stages 2 ..: behind stage 1's wait -- every recursion has run half of its frames, every den workgroup is resident)
-        const bool gd_one = !segmode && nstage >= 3 && !opt_on(kOpt_gd_stage_launches);
+        const bool gd_one = !segmode && nstage >= 3 && !per_stage;
         for (int k = 0; k < nstage; ++k) {
             if (gd_one && k == 1) { if ((rc = launch_grad_den(side, 2, true))) return rc; break; }
             if (!segmode) {

@@ -307,14 +307,26 @@ __global__ __launch_bounds__(NT, WPE) void crf_grad_den_kernel(LossParams p) {
         // words are uncached in L2; an agent-scope acquire before the first row load (rows of the call before may sit in this XCD's L2).
         if (tid == 0) {
             const int *c = p.gd_cnt + stg;
+            // bounded in WALL-CLOCK time (s_memrealtime: 100 MHz, whatever the shader clock does): 2 s, far beyond any recursion; a time-out sets
+            // the error word (the call's loss becomes NaN) and a pinned host word (the context goes back to per-stage launches)
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             for (unsigned spins = 0; __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < p.gd_target; ++spins) {
-                if (spins > (1u << 21)) { __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // (~7 s)
-                if ((spins & 63u) == 63u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if ((spins & 63u) == 63u) {
+                    if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t_start > 200000000ull) {
+                        __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (p.gd_timeout_host) __hip_atomic_store(p.gd_timeout_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
                 __builtin_amdgcn_s_sleep(127);
             }
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // a workgroup that leaves on the error word must not read rows that are not there and add garbage to the gradient: the rows keep what
+        // the numerator half wrote, the loss is NaN (crf_finalize_kernel)
+        if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     }
     float erc[EPR], rwc[EPR];
     if constexpr (GDE) {

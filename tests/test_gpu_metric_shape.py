@@ -31,14 +31,17 @@ def _slice(logits, labels, lx, ly, idx):
     return logits[idx], lab.astype(np.int32), lx[idx], ly[idx]
 
 
-@pytest.mark.parametrize("H,geom,B,T", [(2048, 4, 64, 1500), (2048, 0, 64, 1500), (3072, 3, 64, 1500), (2048, 4, 96, 700), (2048, 4, 112, 400)])
+@pytest.mark.parametrize("H,geom,B,T", [(2048, 4, 64, 1500), (2048, 0, 64, 1500), (3072, 3, 64, 1500), (2048, 4, 96, 700), (2048, 4, 112, 400), (2048, 4, 144, 320)])
 def test_metric_shape_vs_oracle_poisoned(crf, tmp_path_factory, H, geom, B, T):
     """H = 2048: the benchmark graph (one CU per recursion, staged grad pass) on the 1024-thread geometry the planner picks and on the
     768-thread one of round 2.  H = 3072 (S = 6 145, 156 k arcs): the same
     shape on the factored layout over TWO CUs per recursion -- 256 workgroups = every CU of the device, the products
     handed over through L2 every frame, which only a full-size batch exercises.  B = 96: the staged schedule with the den grid on
     three quarters of the device (192 workgroups; numerator chains and grad stages share the 64 CUs left).  B = 112: between that and a full device --
-    224 workgroups: unstaged, and since round 5 with the numerator chains BEHIND the recursions, beside the den half of the grad pass."""
+    224 workgroups: unstaged, and since round 5 with the numerator chains BEHIND the recursions, beside the den half of the grad pass.
+    B = 144 (round-5 advisor): more than CUs / 2 utterances -- BY DEFAULT the two-utterance kernel on its own 512-thread layout with stage flags
+    (`crf_fac_pair2_kernel<true, 512, ...>`, 144 workgroups) and the one-launch grad pass waiting on its counters, a combination the suite had only
+    reached through forced modes."""
     from cat_amd.den_lm import synth_den_lm
     p = os.path.join(str(tmp_path_factory.mktemp("denlm")), "den_lm_v72.fst")
     g = synth_den_lm(72, H, 24, 0, path=p)
@@ -59,6 +62,8 @@ def test_metric_shape_vs_oracle_poisoned(crf, tmp_path_factory, H, geom, B, T):
             outs.append(core.loss_fwd_bwd(x, torch.tensor(lab), torch.tensor(lx), torch.tensor(ly), s, s * (1 + lamb),
                                           core.graph_for(x.device), True))
         torch.cuda.synchronize()
+        if B > 128:
+            assert core.last_den_kernel().startswith("crf_fac_pair2_kernel<true"), core.last_den_kernel()
         # numerator posteriors alone, to take the staged denominator half out of the combined gradient
         gctc = []
         for lg, lab, lx, ly in batches:
