@@ -147,15 +147,79 @@ def random_labels_from_graph(g: Dict, length: int, rng: np.random.Generator) -> 
 # ilabel = token + 1 (build_ctc_topo.py:6-11) in the tropical/log convention cost = -log p, whose language is
 # (CTC topology) o (un-smoothed n-gram LM of the training transcripts with history-state pruning).
 # ------------------------------------------------------------------------------------------------
+def _select_by_likelihood(seqs, N: int, M: int, K: int):
+    """Which histories of >= M tokens keep a state of their own: the greedy rule published for Kaldi's `chain-est-phone-lm`
+    (LanguageModelEstimator: --no-prune-ngram-order, --num-extra-lm-states; cat/utils/tool/prep_den_lm.sh:40-44 calls it).  Every seen history
+    starts as a state holding the next-token counts (0 = end of sentence) of the positions whose full history (up to N - 1 tokens) it is;
+    a state's BACK-OFF state is its history without the oldest token.  While more than K states of >= M tokens are left, the state whose
+    backing off LOSES THE LEAST training-data log-likelihood is merged into its back-off state -- only states that no remaining state backs
+    off to (leaves), so the kept set stays closed under dropping the oldest token -- where, with c / n the state's counts and total and
+    b / m its back-off state's (merged counts included),
+        loss = sum_p c_p log(c_p / n) + sum_p b_p log(b_p / m) - sum_p (c_p + b_p) log((c_p + b_p) / (n + m))   >= 0.
+    Ties: shorter history first, then token order.  Returns the kept set (all histories of < M tokens included)."""
+    import heapq
+    from collections import Counter
+    own: Dict[tuple, Counter] = {(): Counter()}
+    for s in seqs:
+        for i in range(len(s) + 1):
+            h = s[max(0, i - (N - 1)):i]
+            own.setdefault(h, Counter())[s[i] if i < len(s) else 0] += 1
+    for h in list(own):                                   # back-off states exist even where no position has exactly that history
+        for k in range(1, len(h) + 1):
+            own.setdefault(h[k:], Counter())
+    active = set(own)
+    nchild: Dict[tuple, int] = {h: 0 for h in active}
+    for h in active:
+        if h:
+            nchild[h[1:]] += 1
+
+    def loglike(c):
+        n = sum(c.values())
+        return sum(v * np.log(v / n) for v in c.values()) if n else 0.0
+
+    def loss(h):
+        c, b = own[h], own[h[1:]]
+        return float(loglike(c) + loglike(b) - loglike(c + b))
+
+    def prunable(h):
+        return len(h) >= M and nchild[h] == 0
+
+    heap = [(loss(h), len(h), h) for h in active if prunable(h)]
+    heapq.heapify(heap)
+    extra = sum(1 for h in active if len(h) >= M)
+    while extra > K and heap:
+        l0, _, h = heapq.heappop(heap)
+        if h not in active or not prunable(h):
+            continue
+        l1 = loss(h)                                      # (its back-off state may have received counts since the entry was made)
+        if l1 > l0 + 1e-12:
+            heapq.heappush(heap, (l1, len(h), h))
+            continue
+        par = h[1:]
+        own[par] = own[par] + own[h]
+        active.discard(h)
+        extra -= 1
+        nchild[par] -= 1
+        if prunable(par):
+            heapq.heappush(heap, (loss(par), len(par), par))
+    return active
+
+
 def estimate_token_lm(seqs: Iterable[Sequence[int]], vocab_size: int, ngram_order: int = 4,
-                      no_prune_ngram_order: int = 3, num_extra_states: int = 250) -> Dict:
+                      no_prune_ngram_order: int = 3, num_extra_states: int = 250, selection: str = "likelihood") -> Dict:
     """Un-smoothed n-gram LM over tokens 1..vocab_size-1 (0 = blank never occurs in transcripts), as a
     deterministic acceptor without epsilons -- the kind of LM `chain-est-phone-lm` builds for the denominator:
     a state is a history (tuple of up to ngram_order-1 previous tokens); all histories of fewer than
-    ``no_prune_ngram_order`` tokens are kept, of the longer ones the ``num_extra_states`` most frequent (plus
-    their suffixes); a position whose history is not kept is counted in its longest kept suffix.  Counts are
-    collected by running the transcripts through that automaton, so every transition a transcript takes
-    exists and every state's probabilities (tokens + end of sentence) sum to one.
+    ``no_prune_ngram_order`` tokens are kept, of the longer ones ``num_extra_states`` -- chosen by ``selection``:
+    "likelihood" (default since round 6): Kaldi's published greedy rule, the states whose backing off would lose the most
+    training-data log-likelihood (`_select_by_likelihood`), and EVERY history of fewer than ``no_prune_ngram_order`` tokens that
+    occurs anywhere in a transcript (every seen bigram history at --no-prune-ngram-order=3: up to V^2 states -- what real den_lm
+    files have); "count": the most frequent ones (rounds 1 - 5; that rule also kept a shorter history only where a transcript
+    position has exactly that history, i.e. at sentence starts: fewer, higher-in-degree states -- kept for the records and tests
+    made on such graphs) --; a position
+    whose history is not kept is counted in its longest kept suffix.  Counts are collected by running the transcripts
+    through that automaton, so every transition a transcript takes exists and every state's probabilities (tokens + end
+    of sentence) sum to one.
 
     Returns dict(num_states, start, tok_in[g] (-1 for the start state), arcs[g] = [(token, next, logp)], final[g])."""
     seqs = [tuple(int(t) for t in s) for s in seqs]
@@ -173,11 +237,16 @@ def estimate_token_lm(seqs: Iterable[Sequence[int]], vocab_size: int, ngram_orde
     for h in hist_count:
         if len(h) < max(1, no_prune_ngram_order):
             keep.add(h)
-    extra = sorted((h for h in hist_count if len(h) >= max(1, no_prune_ngram_order)),
-                   key=lambda h: (-hist_count[h], h))[:max(0, num_extra_states)]
-    for h in extra:
-        for k in range(len(h) + 1):                      # suffix-closed
-            keep.add(h[k:])
+    if selection == "likelihood":
+        keep |= _select_by_likelihood(seqs, N, max(1, no_prune_ngram_order), max(0, num_extra_states))
+    elif selection == "count":
+        extra = sorted((h for h in hist_count if len(h) >= max(1, no_prune_ngram_order)),
+                       key=lambda h: (-hist_count[h], h))[:max(0, num_extra_states)]
+        for h in extra:
+            for k in range(len(h) + 1):                  # suffix-closed
+                keep.add(h[k:])
+    else:
+        raise ValueError("selection must be 'likelihood' or 'count'")
 
     def lks(h):                                           # longest kept suffix
         h = h[max(0, len(h) - (N - 1)):]
@@ -267,9 +336,9 @@ def compose_ctc_topo(lm: Dict, vocab_size: int, path: Optional[str] = None) -> D
 
 
 def prep_den_lm(seqs: Iterable[Sequence[int]], vocab_size: int, path: str, ngram_order: int = 4,
-                no_prune_ngram_order: int = 3, num_extra_states: int = 250) -> Dict:
+                no_prune_ngram_order: int = 3, num_extra_states: int = 250, selection: str = "likelihood") -> Dict:
     """text (token ids) -> den_lm.fst: the whole of cat/utils/tool/prep_den_lm.sh without Kaldi/OpenFst."""
-    lm = estimate_token_lm(seqs, vocab_size, ngram_order, no_prune_ngram_order, num_extra_states)
+    lm = estimate_token_lm(seqs, vocab_size, ngram_order, no_prune_ngram_order, num_extra_states, selection)
     return compose_ctc_topo(lm, vocab_size, path)
 
 
@@ -284,6 +353,8 @@ def _main(argv=None):
     ap.add_argument("--ngram-order", type=int, default=4)
     ap.add_argument("--no-prune-ngram-order", type=int, default=3)
     ap.add_argument("--num-extra-lm-states", type=int, default=250)
+    ap.add_argument("--state-selection", choices=["likelihood", "count"], default="likelihood",
+                    help="which longer histories keep a state: by training-data log-likelihood (Kaldi's published rule) or by frequency")
     a = ap.parse_args(argv)
     import sys
     fh = sys.stdin if a.r_specifier == "-" else open(a.r_specifier)
@@ -294,7 +365,7 @@ def _main(argv=None):
             f = f[1:]
         if f:
             seqs.append([int(x) for x in f])
-    g = prep_den_lm(seqs, a.vocab_size, a.w_specifier, a.ngram_order, a.no_prune_ngram_order, a.num_extra_lm_states)
+    g = prep_den_lm(seqs, a.vocab_size, a.w_specifier, a.ngram_order, a.no_prune_ngram_order, a.num_extra_lm_states, a.state_selection)
     print(f"{a.w_specifier}: {g['S']} states, {g['A']} arcs from {len(seqs)} transcripts")
 
 

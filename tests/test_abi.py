@@ -137,7 +137,7 @@ def test_factored_layout_takes_an_estimated_ngram_graph(tmp_path):
             c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
         seqs.append(sq)
     p = os.path.join(str(tmp_path), "est.fst")
-    g = den_lm.prep_den_lm(seqs, V, p, 4, 3, 150)
+    g = den_lm.prep_den_lm(seqs, V, p, 4, 3, 150, selection="count")
     h = core.compile_graph_host_only(p)
     st = core.graph_stats(h)
     core._lib.crf_graph_destroy(ctypes.c_void_p(h))
@@ -233,7 +233,7 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
             c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
         seqs.append(sq)
     est = os.path.join(str(tmp_path), "est.fst")
-    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150)
+    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150, selection="count")
     # the planner's own choice: 1024 threads x 15 chunks (geometry 4) unless MOST of a LARGE graph's arcs sit in rows longer than a
     # lane (more than a fifth and more than 20 000 of them: a den_lm estimated from a large corpus), which keeps the 768-thread table
     # geometry -- measured in round 4: S = 3 006 (14.9 k such arcs) faster on 1024 threads, S = 6 836 (27.3 k) slower
@@ -251,7 +251,7 @@ def test_factored_layouts_emulated_on_the_host(tmp_path, golden_dir):
         return out
 
     big = os.path.join(str(tmp_path), "est_big.fst")
-    den_lm.prep_den_lm(corpus(72, 40000, 0), 72, big, 4, 3, 2000)
+    den_lm.prep_den_lm(corpus(72, 40000, 0), 72, big, 4, 3, 2000, selection="count")
     g, r = emu(big, T=3)
     assert g == 1 and agree(r)                                    # tens of thousands of arcs in multi-lane rows: 768 threads, table geometry
     for path in (small, os.path.join(golden_dir, "den_lm_fixture.fst"), est):
@@ -338,7 +338,7 @@ def test_second_layout_for_two_utterances_emulated_on_the_host(tmp_path, golden_
             c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
         seqs.append(sq)
     est = os.path.join(str(tmp_path), "est.fst")
-    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150)                   # multi-lane rows
+    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150, selection="count")                   # multi-lane rows
     for path in (small, os.path.join(golden_dir, "den_lm_fixture.fst"), bench, v217, est):
         st, r = emu(path, T=3 if path in (bench, v217) else 4)
         assert st["fac_geom"] == 4 and st["facp"] == 1 and agree(r), (path, st["fac_geom"], st["facp"], r)
@@ -396,7 +396,7 @@ def test_generic_resident_layout_emulated_on_the_host(tmp_path, golden_dir):
             c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
         seqs.append(sq)
     est = os.path.join(str(tmp_path), "est.fst")
-    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150)
+    den_lm.prep_den_lm(seqs, V, est, 4, 3, 150, selection="count")
     K, r = emu(est)
     assert K >= 1 and agree(r), (K, r)
     bench = os.path.join(str(tmp_path), "bench.fst")

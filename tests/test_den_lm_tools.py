@@ -246,7 +246,7 @@ def test_arc_streams_of_the_utterance_minor_kernels(tmp_path, golden_dir, UL):
             a, b = b, c
         seqs.append(sq)
     q = str(tmp_path / "est.fst")
-    den_lm.prep_den_lm(seqs, V, q, 4, 3, 150)
+    den_lm.prep_den_lm(seqs, V, q, 4, 3, 150, selection="count")
     st, r = check(q, 16)
     assert 2 * st["A"] - st["max_out_deg"] <= r["arc_records"] <= 2 * st["A"] and st["max_in_deg"] > 64
     for c in json.load(open(os.path.join(golden_dir, "kat_random.json"))):
@@ -265,7 +265,7 @@ def test_estimator_on_a_hand_worked_count_table():
 
     1. Histories (up to N - 1 = 2 tokens) in front of every position, the end included, with their frequencies
          ():6  (1):4  (2):2  (3):1  (1,2):4  (2,3):4  (2,1):2  (3,1):1
-    2. Kept states: every history shorter than M = 2 tokens -- (), (1), (2), (3) -- plus the K = 2 most frequent longer ones
+    2. Kept states (selection="count"; the default rule is pinned by the next test): every history shorter than M = 2 tokens -- (), (1), (2), (3) -- plus the K = 2 most frequent longer ones
        (ties in lexicographic order): (1,2) and (2,3); suffix-closed already.  (2,1) and (3,1) fall back to their longest kept
        suffix (1).
     3. Counts collected by running the transcripts through that automaton (0 = end of sentence):
@@ -278,7 +278,7 @@ def test_estimator_on_a_hand_worked_count_table():
     4. Maximum-likelihood probabilities, no smoothing, no back-off arcs; a token leads to the longest kept suffix of
        (history + token): 1 after (1,2) -> (2,1) is not kept -> state (1); 3 after (1,2) -> (2,3)."""
     seqs = [(1, 2, 3), (1, 2, 3), (1, 2, 1), (2, 3), (3, 1, 2, 3), (2, 1)]
-    lm = den_lm.estimate_token_lm(seqs, 4, ngram_order=3, no_prune_ngram_order=2, num_extra_states=2)
+    lm = den_lm.estimate_token_lm(seqs, 4, ngram_order=3, no_prune_ngram_order=2, num_extra_states=2, selection="count")   # (the frequency rule of rounds 1 - 5)
     assert lm["histories"] == [(), (1,), (2,), (3,), (1, 2), (2, 3)] and lm["start"] == 0 and lm["num_states"] == 6
     L = math.log
     want_arcs = [
@@ -302,3 +302,63 @@ def test_estimator_on_a_hand_worked_count_table():
             (nxt, w), = [(n, w) for tt, n, w in lm["arcs"][st] if tt == t]
             st, lp = nxt, lp + w
         assert math.isfinite(lp + lm["final"][st])
+
+
+def test_estimator_selects_states_by_likelihood_like_kaldi():
+    """The DEFAULT state selection since round 6: Kaldi's published greedy rule for `chain-est-phone-lm
+    --no-prune-ngram-order=M --num-extra-lm-states=K` (cat/utils/tool/prep_den_lm.sh:40-44) -- of the histories of >= M tokens, back off the one
+    whose merging into its back-off state (the history without its oldest token) loses the LEAST training-data log-likelihood, until K are left --
+    on a table worked by hand on which it DIFFERS from the frequency rule.  (No Kaldi binary or source is in this image: this pins the published
+    rule as implemented here, not equality with a Kaldi run.)  order N = 3, M = 2, tokens {1, 2, 3, 4}:
+
+        transcripts     1 2 4  (x 4)   |   3 2 1  (x 2)   |   2 4  (x 3)
+
+    1. Next-token counts by FULL history (up to two tokens; 0 = end of sentence):
+         ():    1 x4, 3 x2, 2 x3          (1): 2 x4        (2): 4 x3  (only "2 4" has a position whose whole history is (2))        (3): 2 x2
+         (4):   none (4 never starts a transcript; the state exists as the back-off state of (2,4))
+         (1,2): 4 x4        (3,2): 1 x2        (2,4): end x7        (2,1): end x2
+    2. Frequency rule: the two-token histories by count -- (2,4): 7, (1,2): 4, (2,1): 2, (3,2): 2 -- K = 1 keeps (2,4), K = 2 keeps (2,4) and (1,2).
+    3. Likelihood rule, loss of backing off c (total n) into b (total m) = sum c log(c/n) + sum b log(b/m) - sum (c+b) log((c+b)/(n+m)):
+         (1,2) {4: 4} into (2) {4: 3}:       both distributions are "always 4": loss 0
+         (2,4) {end: 7} into (4) {}:          an empty back-off state takes the counts as they are: loss 0
+         (3,2) {1: 2} into (2) {4: 3}:        -(3 log(3/5) + 2 log(2/5)) = 3.365
+         (2,1) {end: 2} into (1) {2: 4}:      -(4 log(4/6) + 2 log(2/6)) = 3.819
+       Four states, K = 1: three are backed off, cheapest first: (1,2) and (2,4) at loss 0 -- now (2) = {4: 7}, (4) = {end: 7} -- then (3,2) costs
+       -(7 log(7/9) + 2 log(2/9)) = 4.767 against (2,1)'s 3.819: (2,1) goes, (3,2) STAYS.  K = 2 stops one step earlier: (2,1) and (3,2) stay.
+       The frequent histories are the ones whose predictions their suffix makes just as well; the rare (3,2) is the one that changes a prediction.
+    4. K = 1: states (), (1), (2), (3), (4), (3,2); counts by running the transcripts through that automaton:
+         ():    1 x4, 2 x3, 3 x2  (9)     (1): 2 x4, end x2  (6: "3 2 1" arrives in (1) from (3,2) and ends)     (2): 4 x7  ("1 2 4": (1,2) is not kept)
+         (3):   2 x2 -> (3,2)             (4): end x7                                                         (3,2): 1 x2 -> (1)"""
+    seqs = [(1, 2, 4)] * 4 + [(3, 2, 1)] * 2 + [(2, 4)] * 3
+    kept = lambda K, sel: den_lm.estimate_token_lm(seqs, 5, ngram_order=3, no_prune_ngram_order=2, num_extra_states=K, selection=sel)["histories"]
+    assert kept(1, "count") == [(), (1,), (2,), (3,), (2, 4)] and kept(2, "count") == [(), (1,), (2,), (3,), (1, 2), (2, 4)]
+    assert kept(1, "likelihood") == [(), (1,), (2,), (3,), (4,), (3, 2)] and kept(2, "likelihood") == [(), (1,), (2,), (3,), (4,), (2, 1), (3, 2)]
+    # the losses of step 3, through the function the estimator uses
+    L = math.log
+    assert abs(-(3 * L(3 / 5) + 2 * L(2 / 5)) - 3.365) < 1e-3 and abs(-(4 * L(4 / 6) + 2 * L(2 / 6)) - 3.819) < 1e-3 and abs(-(7 * L(7 / 9) + 2 * L(2 / 9)) - 4.767) < 1e-3
+    lm = den_lm.estimate_token_lm(seqs, 5, ngram_order=3, no_prune_ngram_order=2, num_extra_states=1)      # the default IS the likelihood rule
+    assert lm["histories"] == [(), (1,), (2,), (3,), (4,), (3, 2)]
+    want_arcs = [
+        [(1, 1, L(4 / 9)), (2, 2, L(3 / 9)), (3, 3, L(2 / 9))],     # ()
+        [(2, 2, L(4 / 6))],                                         # (1)
+        [(4, 4, 0.0)],                                              # (2)
+        [(2, 5, 0.0)],                                              # (3)
+        [],                                                         # (4)
+        [(1, 1, 0.0)],                                              # (3,2)
+    ]
+    want_final = [-math.inf, L(2 / 6), -math.inf, -math.inf, 0.0, -math.inf]
+    for got, want in zip(lm["arcs"], want_arcs):
+        assert [(t, n) for t, n, _ in got] == [(t, n) for t, n, _ in want]
+        assert np.allclose([w for _, _, w in got], [w for _, _, w in want], rtol=0, atol=1e-12)
+    assert np.allclose(lm["final"], want_final, rtol=0, atol=1e-12)
+    # both rules: normalised, deterministic, every transcript accepted (the contract the loss relies on)
+    for sel in ("likelihood", "count"):
+        m = den_lm.estimate_token_lm(seqs, 5, 3, 2, 2, selection=sel)
+        for g in range(m["num_states"]):
+            tot = sum(math.exp(w) for _, _, w in m["arcs"][g]) + (math.exp(m["final"][g]) if math.isfinite(m["final"][g]) else 0.0)
+            assert abs(tot - 1.0) < 1e-12 and len({t for t, _, _ in m["arcs"][g]}) == len(m["arcs"][g])
+        for sq in seqs:
+            st = m["start"]
+            for t in sq:
+                (st,) = [n for tt, n, _ in m["arcs"][st] if tt == t]
+            assert math.isfinite(m["final"][st])

@@ -176,7 +176,7 @@ def test_recipe_shaped_point_v217(crf, tmp_path):
             s.append(int(rng.choice(succ[s[-1]])) if rng.random() < 0.8 else int(rng.integers(1, V)))
         sents.append(s)
     p = os.path.join(str(tmp_path), "den_lm_v217.fst")
-    den_lm.prep_den_lm(sents, V, p, ngram_order=4, no_prune_ngram_order=2, num_extra_states=300)
+    den_lm.prep_den_lm(sents, V, p, ngram_order=4, no_prune_ngram_order=2, num_extra_states=300, selection="count")
     gref = fst_io.read_fst(p)
     B, T, lamb = 6, 120, 0.01
     logits = np.log(np.random.default_rng(3).dirichlet(np.ones(V) * 0.3, size=(B, T)).astype(np.float64) + 1e-12)

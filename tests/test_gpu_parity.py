@@ -295,7 +295,7 @@ def test_batch_kernels_factored_streams_estimated_graph(crf, tmp_path, ul):
             c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
         seqs.append(sq)
     p = str(tmp_path / "den_est.fst")
-    den_lm.prep_den_lm(seqs, V, p, 4, 3, 150)
+    den_lm.prep_den_lm(seqs, V, p, 4, 3, 150, selection="count")
     g = fst_io.read_fst(p)
     hh = crf._C.compile_graph_host_only(p)
     chk = crf._C.debug_facbatch_check(hh)
@@ -366,7 +366,7 @@ def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
             c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
         seqs.append(sq)
     p = str(tmp_path / "den_est.fst")
-    den_lm.prep_den_lm(seqs, V, p, 4, 3, 150)
+    den_lm.prep_den_lm(seqs, V, p, 4, 3, 150, selection="count")
     g = fst_io.read_fst(p)
     indeg = np.bincount(g["dst"], minlength=g["S"]).max()
     assert indeg > 100                                        # longer than one lane's 80 arcs
@@ -391,6 +391,45 @@ def test_estimated_den_lm_with_long_rows(crf, tmp_path, mode, V):
     assert rel_err(grad, ref["grad"]) <= TOL
 
 
+@pytest.mark.parametrize("V,nsent", [(40, 1500), (72, 6000)])
+def test_estimated_den_lm_default_rule(crf, tmp_path, V, nsent):
+    """A den_lm made by the DEFAULT rule of `prep_den_lm` since round 6 -- Kaldi's published selection by log-likelihood, every seen history of
+    fewer than --no-prune-ngram-order tokens kept (tests/test_den_lm_tools.py::test_estimator_selects_states_by_likelihood_like_kaldi) -- i.e.
+    with the shape real den_lm files have: about one LM state per seen bigram, in-degrees of tens instead of hundreds.  On the kernel family
+    the graph takes BY ITSELF, against the fp64 oracle."""
+    from cat_amd import den_lm
+    rng = np.random.default_rng(17)
+    trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+    seqs = []
+    for _ in range(nsent):
+        L, sq, a, b = int(rng.integers(8, 30)), [], 0, 0
+        for _ in range(L):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
+        seqs.append(sq)
+    p = str(tmp_path / "den_kaldi_rule.fst")
+    den_lm.prep_den_lm(seqs, V, p, 4, 3, 250)
+    g = fst_io.read_fst(p)
+    B, T = 4, 72
+    logits = rng.normal(size=(B, T, V)).astype(np.float32) * 2.0
+    logits = logits - np.log(np.exp(logits).sum(-1, keepdims=True))
+    lx = np.array([72, 60, 47, 33], dtype=np.int32)
+    labels, ly = [], []
+    for b in range(B):
+        lab = seqs[b][:max(1, int(lx[b]) // 6)]
+        labels += lab; ly.append(len(lab))
+    ref = oracle.ctc_crf(g, logits, np.array(labels, dtype=np.int32), lx, np.array(ly, dtype=np.int32), lamb=0.1)
+    ctx = crf.CRFContext(p, 0)
+    x = torch.tensor(logits, device="cuda:0", requires_grad=True)
+    loss = crf.CTC_CRF_LOSS(lamb=0.1)(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx), torch.tensor(ly, dtype=torch.int32))
+    loss.backward()
+    st = crf._C.graph_stats(crf._C.graph_for(torch.device("cuda", 0)))
+    print(f"V={V}: S={g['S']} A={len(g['src'])} max in-degree {np.bincount(g['dst'], minlength=g['S']).max()} kernel {crf._C.last_den_kernel()} fac={st['fac']} geom={st.get('fac_geom')}")
+    del ctx
+    assert abs(loss.item() - ref["loss"]) <= TOL * abs(ref["loss"])
+    for b in range(B):
+        assert rel_err(x.grad[b].cpu().numpy(), ref["grad"][b]) <= TOL, b
+
+
 def test_estimated_den_lm_with_many_rows(crf, tmp_path):
     """The den_lm of tools/bench_fst.py's largest point (40 000 sentences, 72 tokens: S = 6 836, 100 k arcs, in-degree up to
     970): 71 slices of forward rows -- more than the three per wave whose constants fit registers -- so the compiler
@@ -407,7 +446,7 @@ def test_estimated_den_lm_with_many_rows(crf, tmp_path):
             c = 1 + int(rng.choice(V - 1, p=trans[a, b])); sq.append(c); a, b = b, c
         seqs.append(sq)
     p = str(tmp_path / "den_est_big.fst")
-    den_lm.prep_den_lm(seqs, V, p, 4, 3, 2000)
+    den_lm.prep_den_lm(seqs, V, p, 4, 3, 2000, selection="count")
     g = fst_io.read_fst(p)
     assert g["S"] > 6000
     B, T = 4, 48

@@ -23,7 +23,7 @@ for _ in range(nsent):
         c = 1 + int(rng.choice(V - 1, p=trans[a, b])); s.append(c); a, b = b, c
     seqs.append(s)
 fst = os.path.join(tempfile.mkdtemp(), "den_lm.fst")
-g = den_lm.prep_den_lm(seqs, V, fst, 4, 3, extra)
+g = den_lm.prep_den_lm(seqs, V, fst, 4, 3, extra, selection=os.environ.get("DEN_LM_SELECTION", "count"))   # ("count": the graphs of rounds 1 - 5' records; "likelihood": the default rule since round 6)
 ctx = ctc_crf.CRFContext(fst, 0)
 st = ctc_crf._C.graph_stats(ctc_crf._C.graph_for(torch.device("cuda", 0)))
 kind = f"factored (geometry {st['fac_geom']})" if st["fac"] else f"resident K={st['res_K']}" if st["res_K"] else "streaming"

@@ -80,7 +80,7 @@ def main():
             c = 1 + int(rng.choice(V - 1, p=trans[a, b])); s.append(c); a, b = b, c
         seqs.append(s)
     p2 = os.path.join(tmp, "est.fst")
-    den_lm.prep_den_lm(seqs, V, p2, 4, 3, 6000)
+    den_lm.prep_den_lm(seqs, V, p2, 4, 3, 6000, selection="count")
     report("den_lm estimated from 120 000 sentences", p2)
 
 
