@@ -10,8 +10,8 @@ import pytest
 
 import oracle
 from oracle import fst_io
-from tests.test_gpu_parity import MODES, TOL, run_hip
-from tests.util import make_batch, rel_err, small_synth
+from tests.test_gpu_parity import MODES, TOL, _mode, run_hip
+from tests.util import make_batch, post_err, rel_err, small_synth
 
 pytestmark = pytest.mark.gpu
 
@@ -72,6 +72,26 @@ def test_fuzz_vs_oracle(crf, tmp_path, seed):
         if lx[b] > 0:
             assert rel_err(grad[b], ref["grad"][b]) <= tol, (b, what)
         assert np.all(grad[b, lx[b]:] == 0.0), (b, what)
+    # ENTRY-WISE on the two posterior matrices (round 6): the combined gradient is a difference of two O(1) posteriors and can only
+    # be judged norm-wise (tests/util.py rel_err); gamma_den and gamma_ctc themselves are non-negative, no cancellation: every entry >= 1e-3 within 1e-4
+    # relative of the oracle's, in the same kernel family
+    import torch
+    core = crf._C
+    gden_ref = oracle.den(fst_io.read_fst(p), logits, lx)[0]
+    gctc_ref, _, valid = oracle.ctc(logits, labels, lx, ly)
+    with _mode(mode):
+        ctx = crf.CRFContext(p, 0)
+        x = torch.tensor(logits, device="cuda:0")
+        tl, tx, ty = torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32), torch.tensor(ly, dtype=torch.int32)
+        gden = core.loss_fwd_bwd(x, None, tx, None, 1.0, 0.0, core.graph_for(x.device), True)[1].cpu().numpy()
+        gctc = core.loss_fwd_bwd(x, tl, tx, ty, 0.0, -1.0, None, True)[1].cpu().numpy()
+        del ctx
+    for b in range(B):
+        n = int(lx[b])
+        if n > 0:
+            assert post_err(gden[b, :n], gden_ref[b, :n]) <= TOL, ("gamma_den", b, what)
+            if valid[b]:
+                assert post_err(gctc[b, :n], gctc_ref[b, :n]) <= TOL, ("gamma_ctc", b, what)
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -133,3 +153,95 @@ def test_fuzz_graphs_of_the_benchmark_size_class(crf, tmp_path, H, d, B, T, sigm
     assert np.isfinite(grad).all() and abs(loss.item() - ref["loss"]) <= TOL * abs(ref["loss"])
     for b in range(B):
         assert rel_err(grad[b], ref["grad"][b]) <= TOL, b
+
+
+@pytest.fixture(scope="module")
+def size_class_graphs(tmp_path_factory):
+    """The benchmark generator's graphs the long-utterance fuzz runs on: H = 2048 (the metric graph: one CU per recursion, 1024 threads) and
+    H = 3072 (two CUs per recursion), built once."""
+    d = tmp_path_factory.mktemp("fuzz_graphs")
+    out = {}
+    for H in (2048, 3072):
+        g, p = small_synth(d, 72, H, 24, 0)
+        out[H] = (g, p)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_long_utterances_metric_size_class(crf, size_class_graphs, seed):
+    """40 more seeds where the first 168 are thin: T = 400 ... 1 500 on the metric graph's size class (even seeds: S = 4 097, one CU per
+    recursion, the staged schedule with the one-launch grad pass from T >= 256 on) and on the two-CU layout (odd seeds: S = 6 145), network outputs from
+    diffuse to a hundred nats apart, ragged pairs, each on the kernels the graph takes by itself; loss and every utterance's gradient within 1e-4 of the fp64 oracle."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    H = 2048 if seed % 2 == 0 else 3072
+    g, p = size_class_graphs[H]
+    B = int(rng.integers(1, 3))
+    T = int(rng.integers(400, 1501))
+    sigma = float(SIGMAS[seed % len(SIGMAS)])
+    lamb = float([0.0, 0.01, 0.1, 1.0][(seed // 2) % 4])
+    logits, labels, lx, ly = make_batch(g, B, T, 72, seed=seed, ragged=True, scale=sigma, label_frac=int([3, 6, 12][seed % 3]))
+    ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=lamb)
+    if not np.isfinite(ref["loss"]):
+        pytest.skip("the oracle itself is not finite for this draw")
+    ctx = crf.CRFContext(p, 0)
+    x = torch.tensor(logits, device="cuda:0", requires_grad=True)
+    loss = crf.CTC_CRF_LOSS(lamb=lamb)(x, torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32), torch.tensor(ly, dtype=torch.int32))
+    loss.backward()
+    k = crf._C.last_den_kernel()
+    grad = x.grad.cpu().numpy()
+    del ctx
+    what = dict(H=H, B=B, T=T, sigma=sigma, lamb=lamb, lx=list(map(int, lx)), kernel=k)
+    assert k.startswith("crf_fac_pair_kernel" if H == 2048 else "crf_fac2_pair_kernel"), what
+    assert np.isfinite(loss.item()) and np.isfinite(grad).all(), what
+    assert abs(loss.item() - ref["loss"]) <= TOL * max(1.0, abs(ref["loss"])), (loss.item(), ref["loss"], what)
+    for b in range(B):
+        assert rel_err(grad[b, :lx[b]], ref["grad"][b, :lx[b]]) <= TOL, (b, what)
+        assert np.all(grad[b, lx[b]:] == 0.0), (b, what)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_dominant_path_dropped_in_both_directions(crf, tmp_path, mode):
+    """The residual blind spot DESIGN section 5 admitted, CONSTRUCTED: the forward / backward consistency check compares two log Z, so a
+    path that BOTH directions drop leaves them agreeing on the same wrong value.  Three disjoint chains over tokens 1, 2, 3 (an LM of three sentences "1 1 1 ...",
+    "2 2 2 ...", "3 3 3 ..."), 30 frames in three segments of 10, log-probs per frame:
+                      head            middle          tail            total
+        chain A (1)    0               -16             -16             -320      leads the forward recursion: after the head B is 120, C 160 nats behind
+        chain B (2)   -12               0              -12             -240      DOMINANT by 80 nats -- and 2^-173 behind the frame's best after the head in the
+        chain C (3)   -16              -16               0             -320      forward direction, after the tail in the backward one: flushed from the scaled fp32
+    vectors in both (below even the denormals).  Forward log Z = -320 (A alone), backward log Z = -320 (C alone): crf_den_check_kernel sees nothing.  What catches
+    it is the grad pass's frame mass: q lives on A's pairs, b on C's, every product q * b of a frame is zero -- not a normal float -- the utterance is flagged
+    and the log-domain fallback redoes it (log Z = -240 + ..., posteriors on token 2).  Two paths cannot produce the hole at all (dropping B forward AND backward
+    with a survivor in each direction needs B behind by > 101 nats at both ends and ahead in total: the middle would have to make up > 202 nats while staying within 101
+    of the survivor on either side); with three, the survivors of the two directions are different chains, i.e. different states, and the frame mass is exactly zero.
+    The test pins that: every kernel family returns the oracle's loss and gradient, and the denominator fallback has fired."""
+    import math
+    import torch
+    from cat_amd import den_lm
+    V, Tn = 4, 30
+    L3, L2 = math.log(1 / 3), math.log(0.5)
+    lm = dict(num_states=4, start=0, tok_in=[-1, 1, 2, 3], arcs=[[(1, 1, L3), (2, 2, L3), (3, 3, L3)], [(1, 1, L2)], [(2, 2, L2)], [(3, 3, L2)]],
+              final=[-math.inf, L2, L2, L2])
+    p = str(tmp_path / "three_chains.fst")
+    den_lm.compose_ctc_topo(lm, V, p)
+    lp = np.full((1, Tn, V), -60.0, dtype=np.float32)                   # (the blank far away: paths with blanks do not matter)
+    for t in range(Tn):
+        seg = t // 10
+        lp[0, t, 1] = 0.0 if seg == 0 else -16.0
+        lp[0, t, 2] = 0.0 if seg == 1 else -12.0
+        lp[0, t, 3] = 0.0 if seg == 2 else -16.0
+    labels, lx, ly = np.array([2], dtype=np.int32), np.array([Tn], dtype=np.int32), np.array([1], dtype=np.int32)
+    ref = oracle.ctc_crf(fst_io.read_fst(p), lp, labels, lx, ly, lamb=0.1)
+    cden = oracle.den(fst_io.read_fst(p), lp, lx)[1][0]
+    assert abs(cden - (-240.0 + L3 + L2)) < 1e-6                        # the dominant chain alone: the others are e^-80 of it
+    with _mode(mode):
+        ctx = crf.CRFContext(p, 0)
+        x = torch.tensor(lp, device="cuda:0", requires_grad=True)
+        loss = crf.CTC_CRF_LOSS(lamb=0.1)(x, torch.tensor(labels), torch.tensor(lx), torch.tensor(ly))
+        loss.backward()
+        nden, _ = crf._C.last_fallback_counts(torch.cuda.current_stream().cuda_stream)
+        grad = x.grad.cpu().numpy()
+        del ctx
+    assert abs(loss.item() - ref["loss"]) <= TOL * abs(ref["loss"]), (loss.item(), ref["loss"])
+    assert rel_err(grad[0], ref["grad"][0]) <= TOL
+    assert nden == 1, "the fast kernels cannot carry this input: the utterance must have gone through the log-domain fallback"
