@@ -928,7 +928,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
     const int gnc = den ? (fac ? FX->NC : res ? h->dev.res.NC : h->dev.NC) : 0;
     const int gcap = fac ? FX->chunk_cap : kChunk;       // entries per chunk of the grad pass's pair lists
     const bool gd_wide = den && (w.Rq > 4 * kGDRowRegs * kGDThreads || w.Rb > 4 * kGDRowRegs * kGDThreads);   // 512-thread grad workgroups
-    const bool fast_den = den && w.Rq <= 8 * kGDRowRegs * kGDThreads && w.Rb <= 8 * kGDRowRegs * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 &&
+    // (rows of up to 12 288 floats since round 6 -- 512 threads x 6 row registers: a den_lm with a state per seen bigram history has ~5.3 k forward rows
+    // at 72 tokens, Rq = Rb = 10 752, 5 % beyond the 10 240 of five registers, and took the generic grad kernel: 10.8 ms of a 17.5 ms step)
+    const bool gd_wide6 = den && (w.Rq > 8 * kGDRowRegs * kGDThreads || w.Rb > 8 * kGDRowRegs * kGDThreads);
+    const bool fast_den = den && w.Rq <= 8 * 6 * kGDThreads && w.Rb <= 8 * 6 * kGDThreads && w.Rq % 4 == 0 && w.Rb % 4 == 0 && (!gd_wide6 || (gnc <= 2 * kGDThreads && gcap != 8)) &&
                           gnc <= 4 * kGDThreads && V <= kGDEpRegs * kGDThreads && !opt_on(kOpt_no_fast_grad);
     // numerator half of the grad pass: streaming kernel when the vocabulary fits its registers
     const bool fast_ctc = ctc && V <= kGCVRegs * kGCThreads && 2 * max_label_len + 1 <= kGCRegs * kGCThreads &&
@@ -1013,6 +1016,10 @@ static int loss_impl(const crf_graph *g, const float *logp, int fused, int in_dt
             static LdsMark set6;
             if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<2, 2, 2 * kGDThreads>, l, set6, "grad den"))) return r2;
             hipLaunchKernelGGL((crf_grad_den_kernel<2, 2, 2 * kGDThreads>), gg, dim3(2 * kGDThreads), l, st, p);
+        } else if (gd_wide6) {        // rows of 10 241 .. 12 288 floats: 512 threads with six row registers each
+            static LdsMark set9;
+            if ((r2 = ensure_lds((const void *)crf_grad_den_kernel<1, 2, 2 * kGDThreads, kChunk, 6, 1>, l, set9, "grad den"))) return r2;
+            hipLaunchKernelGGL((crf_grad_den_kernel<1, 2, 2 * kGDThreads, kChunk, 6, 1>), gg, dim3(2 * kGDThreads), l, st, p);
         } else if (gd_wide && CRF_X_GDW2 && w.Rq <= 32 * kGDThreads && w.Rb <= 32 * kGDThreads) {
             // rows of 5121 .. 8192 floats: 512 threads with four row registers each, held to 128 VGPRs so that a CU takes TWO workgroups (the
             // five-register form below compiles to 148 VGPRs: one workgroup, eight waves, per CU -- the estimated S = 6836 graph ran on that)

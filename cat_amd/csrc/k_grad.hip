@@ -683,6 +683,7 @@ template __global__ void crf_grad_den_kernel<1, 4, 256, 32, 5, 1>(LossParams);
 template __global__ void crf_grad_den_kernel<2, 4, 256, 32, 5, 1>(LossParams);
 template __global__ void crf_grad_den_kernel<1, 2, 512, 32, 5, 1>(LossParams);
 template __global__ void crf_grad_den_kernel<1, 2, 512, 32, 4, 4>(LossParams);
+template __global__ void crf_grad_den_kernel<1, 2, 512, 32, 6, 1>(LossParams);
 template __global__ void crf_grad_den_kernel<2, 2, 512, 32, 5, 1>(LossParams);
 template __global__ void crf_grad_den_kernel<2, 2, 512, 8, 5, 1>(LossParams);
 template __global__ void crf_grad_ctc_kernel<2>(LossParams);

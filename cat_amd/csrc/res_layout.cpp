@@ -1483,6 +1483,12 @@ static int build_factored_impl(HostGraph *h, int S, int P, const std::vector<int
             if (!f_ok && !no_dupf) m &= ~1;
             if (!b_ok && !no_dupb) m &= ~2;
             if (m != dup_mask) { *new_mask = m; return CRF_OK; }
+            // (one CU per recursion: the table of ALL rows beside the two vectors -- a den_lm with a state per seen bigram history, S ~ 10 k at
+            // 72 tokens, has few arcs per row and fails HERE, not on the arc slots; with two CUs per recursion a CU's table holds its own rows
+            // only: let the planner go on to that geometry instead of leaving the graph to the generic layout -- round 6: S = 10 608 / A = 78 k
+            // ran on the generic K = 2 layout at 7.1 ms of recursions, S = 10 632 / A = 111 k on generic K = 4 at 13.6 ms, where the factored
+            // two-CU layout takes S = 10 636 / A = 147 k at 6.4 ms)
+            if (K == 1 && allow3 && retry_next) { if (verbose) fprintf(stderr, "[fac_layout] one CU per recursion: state vectors and row constants exceed the LDS\n"); *retry_next = true; return CRF_OK; }
             return give_up("state vectors and row constants exceed the LDS");
         }
     }
