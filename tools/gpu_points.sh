@@ -35,3 +35,5 @@ run large --histories 8192 --fanout 32 --steps 3 --warmup 1
 [ -z "$SKIP_C5" ] && run c5 --B 8 --T 3000 --V 5000 --histories 32768 --fanout 64 --steps 2 --warmup 1
 # estimated n-gram den_lm graphs (cat_amd.den_lm.prep_den_lm on a synthetic corpus): in-degree profile of a real LM
 for a in "4000 250" "12000 800" "40000 2000"; do timeout 600 python tools/bench_fst.py $a 2>/dev/null | tail -3; done | tee $OUT/pt_${TAG}_estimated.txt
+# ... and with the estimator's DEFAULT rule since round 6 (Kaldi's: a state per seen bigram history, extra states by log-likelihood): the shape real den_lm files have
+for a in "4000 250" "12000 250" "40000 250"; do DEN_LM_SELECTION=likelihood timeout 600 python tools/bench_fst.py $a 2>/dev/null | tail -3; done | tee $OUT/pt_${TAG}_estimated_kaldi_rule.txt

@@ -1,8 +1,9 @@
 #!/bin/bash
-# tools/gpu_round4.sh TAG [quick] -- round 4, evidence run on ONE box for the build in the tree: the GPU suite, the bench line (with the CPU
+# tools/gpu_round.sh TAG [quick] -- the evidence run of a round on ONE box for the build in the tree (one parametrised script; the one-off
+# lease scripts of round 5, tools/gpu_r5[a-v].sh, are gone: an A/B is `tools/build_ab.sh name:"-Dswitch"` + `tools/gpu_ab3.sh default name@name`): the GPU suite, the bench line (with the CPU
 # baseline), rocprofv3 kernel stats + PMC passes (separate runs), the 1-rank torchrun line (RCCL initialised, DDP head), the other points of
 # SURVEY 8(d), soak.  `quick`: without the GPU suite, the points and the soak.  tools/pmc_summary.py TAG condenses it into profiles/.
-TAG=${1:-r4}; QUICK=$2
+TAG=${1:-r6}; QUICK=$2
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 if [ -z "$QUICK" ]; then
   timeout 2400 python -m pytest tests -m gpu -q -x --timeout 1500 > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_$TAG.log; tail -4 $OUT/pytest_$TAG.log

@@ -1,4 +1,4 @@
-"""tools/pmc_summary.py TAG [ROUND] -- condense the rocprofv3 outputs of tools/gpu_round4.sh (gpu_prof.sh)
+"""tools/pmc_summary.py TAG [ROUND] -- condense the rocprofv3 outputs of tools/gpu_round.sh (gpu_prof.sh)
 (gpurun_out/) into the small summaries kept under profiles/ (ROUND: file name prefix, default "round4"):
 
     profiles/<ROUND>_<TAG>_bench.json          the bench line (with cpu_baseline)
