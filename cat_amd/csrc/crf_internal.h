@@ -190,6 +190,7 @@ __host__ __device__ inline void bat_decode(int block, int grid, int ncombo, int 
 
 // bundles per task at most: 8; factored streams of groups of 16 / 8 utterances 4 / 2 (three descriptor words for each of the
 // 16 / 32 rows of a bundle: the wave's slice of LDS)
+constexpr int kBatEpiDefault = 0;   // (switch bat_epi)
 __host__ __device__ constexpr int stream_max_bundles(int UL, bool fac) { return !fac || UL >= 32 ? 8 : UL == 16 ? 4 : 2; }
 struct StreamDirDev {
     const int4 *tasks;       // [ntasks] {first batch, batches, first bundle, bundles}
@@ -338,6 +339,7 @@ void set_error(const std::string &msg);
     X(bat_task,         "C  utterance-minor kernels: steps per task")                                                        \
     X(bat_ul,           "C  utterance-minor kernels: utterances per group (8, 16, 32, 64)")                                  \
     X(bat_fill,         "C  utterance-minor kernels: percent of the device's workgroup slots a launch takes (default 70)")   \
+    X(bat_epi,          "GC utterance-minor kernels: what a bundle's row epilogues count for when the arc streams are cut into tasks, in batches of 4 steps") \
     X(bat_persist,      "C  utterance-minor kernels: 1 = all frames in ONE persistent launch with a grid barrier per frame (default when the grid is co-resident), 0 = one launch per frame") \
     X(force_batch,      "C  utterance-minor kernels for every graph")                                                        \
     X(no_batch,         "C  streaming kernels instead of the utterance-minor ones")                                          \

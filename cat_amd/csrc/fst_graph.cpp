@@ -283,6 +283,10 @@ static int build_stream_rows(int AL, int UL, int task_steps, int maxb, int NM, c
     std::vector<int4> tasks, meta;
     std::vector<int2> recs;
     const int nbund = ((int)srows.size() + AL - 1) / AL;
+    // what a bundle costs a task besides its gather batches: its row epilogues (stores, ring refill), in batches of 4 steps -- the last tasks of a combo hold the
+    // shortest rows, i.e. the most bundles per gather step, and were the last to reach the frame's end (profiles/round6_ab_persistent_batch.txt: 15 us where
+    // the first tasks take 10); switch bat_epi, default kBatEpiDefault
+    const int epi = std::max(0, opt(kOpt_bat_epi, kBatEpiDefault)) * kB;
     int task_b0 = 0, task_batch0 = 0, task_steps_now = 0;
     auto close_task = [&](int b1) {
         if (b1 == task_b0) return;
@@ -297,7 +301,7 @@ static int build_stream_rows(int AL, int UL, int task_steps, int maxb, int NM, c
             if (i < (int)srows.size()) len = std::max(len, srows[(size_t)i].n);
         }
         const int nbat = (len + kB - 1) / kB;             // every row of the bundle padded to whole batches
-        if (task_steps_now > 0 && (task_steps_now + nbat * kB > task_steps || b - task_b0 >= maxb)) close_task(b);
+        if (task_steps_now > 0 && (task_steps_now + nbat * kB + epi > task_steps || b - task_b0 >= maxb)) close_task(b);
         for (int aj = 0; aj < AL; ++aj) {
             const int i = b * AL + aj;
             for (int q = 0; q < NM; ++q) meta.push_back(i < (int)srows.size() ? srows[(size_t)i].m[q] : int4{-1, 0, 0, 0});   // (padding row: state -1)
@@ -316,7 +320,7 @@ static int build_stream_rows(int AL, int UL, int task_steps, int maxb, int NM, c
                     if (k == 0 && bt == nbat - 1) rcd.x |= (int)0x80000000u;   // the bundle ends with this batch
                     recs.push_back(rcd);
                 }
-        task_steps_now += nbat * kB;
+        task_steps_now += nbat * kB + epi;
     }
     close_task(nbund);
     for (int k = 0; k < 1024; ++k) recs.push_back(int2{0, 0});            // the kernels stage whole 4 KB chunks, one chunk ahead
@@ -623,14 +627,15 @@ int debug_check_facbatch(const HostGraph *h, int64_t *out4) {
 
 // steps per task: the longer direction's steps (rows padded to whole batches of 4) over the tasks wanted; CRF_BAT_TASK overrides
 static int stream_task_steps(const HostGraph *h, int AL, int want, bool fac = false) {
+    const int epi = std::max(0, opt(kOpt_bat_epi, kBatEpiDefault)) * 4;   // (build_stream_rows: what a bundle's row epilogues cost, in steps)
     auto steps_of = [&](const std::vector<int4> &rows) {
         int64_t n = 0;
-        for (const int4 &d : rows) if ((d.w & 0x40000000) && d.y > d.x) n += (d.y - d.x + 3) / 4 * 4;
+        for (const int4 &d : rows) if ((d.w & 0x40000000) && d.y > d.x) n += (d.y - d.x + 3) / 4 * 4 + epi;
         return (n + AL - 1) / AL;                         // (rows of a bundle have about the same length)
     };
     auto steps_fac = [&](const std::vector<FacRowH> &rows) {
         int64_t n = 0;
-        for (const FacRowH &r : rows) n += ((int64_t)r.recs.size() + 3) / 4 * 4;
+        for (const FacRowH &r : rows) n += ((int64_t)r.recs.size() + 3) / 4 * 4 + epi;
         return (n + AL - 1) / AL;
     };
     const int64_t steps = fac ? std::max(steps_fac(h->fb.frows), steps_fac(h->fb.brows)) : std::max(steps_of(h->hb_frow), steps_of(h->hb_brow));
