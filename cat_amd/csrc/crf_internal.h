@@ -190,7 +190,7 @@ __host__ __device__ inline void bat_decode(int block, int grid, int ncombo, int 
 
 // bundles per task at most: 8; factored streams of groups of 16 / 8 utterances 4 / 2 (three descriptor words for each of the
 // 16 / 32 rows of a bundle: the wave's slice of LDS)
-constexpr int kBatEpiDefault = 0;   // (switch bat_epi)
+constexpr int kBatEpiDefault = 2;   // (switch bat_epi; 0 / 1 / 2 / 4 -> S = 16 385 recursions 25.03 / 24.91 / 24.57 / 25.06 ms, S = 12 289 19.58 / 19.60 / 19.41 / 19.67: one box, round 6)
 __host__ __device__ constexpr int stream_max_bundles(int UL, bool fac) { return !fac || UL >= 32 ? 8 : UL == 16 ? 4 : 2; }
 struct StreamDirDev {
     const int4 *tasks;       // [ntasks] {first batch, batches, first bundle, bundles}
