@@ -356,7 +356,7 @@ void set_error(const std::string &msg);
     X(gd_full_grid,     "C  stage launches of the grad pass as full grids")                                                  \
     X(gd_stage_launches,"C  one grad launch per stage behind stream-level waits (round 4) instead of ONE launch whose workgroups wait") \
     X(no_fin_fold,      "C  crf_finalize_kernel as a launch of its own (round 4) instead of in the last fallback launch")                \
-    X(gd_sub,           "C  frames per grad workgroup in the short last stages of the one-launch grad pass (default 4; 16 = whole blocks)") \
+    X(gd_sub,           "C  frames per grad workgroup in the short last stages of the one-launch grad pass (default 16 = whole blocks; 8 / 4 / 2 split them: measured not better)") \
     X(taper,            "C  the last grad stages get shorter: pieces of piece/2, piece/4, ... down to this many iterations (0 = equal pieces)") \
     X(ctc_after,        "C  0 / 1: numerator chains beside / after the denominator recursions")                              \
     X(serial_chains,    "C  everything on the caller's stream")                                                              \

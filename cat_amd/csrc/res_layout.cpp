@@ -1575,6 +1575,7 @@ int build_factored(HostGraph *h, int S, int P, const std::vector<int> &pair_dst,
             if (rc != CRF_OK || retry || nm == mask) break;
             mask = nm;
         }
+        if (rc != CRF_OK) { h->facp = FacDev{}; rc = CRF_OK; }   // (the second layout is optional: a failure while building it must not fail a graph whose main layout stands)
         if (opt_on(kOpt_verbose)) fprintf(stderr, "[fac_layout] second layout (two utterances per workgroup, 512 x 30): %s\n", h->facp.ok ? "built" : "not available");
     }
     return rc;

@@ -111,15 +111,18 @@ def last_fallback_counts(stream: int = 0):
 
 
 _SERIAL_WARNED = False
+_SIDE_STREAM_SEEN = set()      # (device, stream) contexts whose side stream has been looked at: the check costs one set lookup per step afterwards
 
 
-def _warn_if_serial() -> None:
+def _warn_if_serial(key=None) -> None:
     """The library found no stream that runs beside the caller's: every kernel of the loss runs one after the other on the caller's
     stream -- same results, about 1.6 x the step time at the benchmark shape.  The C library says so on stderr (once per context); a
     training script sees it here, once per process, where Python's warning filters and loggers can pick it up."""
     global _SERIAL_WARNED
-    if _SERIAL_WARNED:
+    if _SERIAL_WARNED or key in _SIDE_STREAM_SEEN:
         return
+    if key is not None:
+        _SIDE_STREAM_SEEN.add(key)
     desc = _lib.crf_last_side_stream().decode()
     if desc.startswith("none"):
         _SERIAL_WARNED = True
@@ -468,7 +471,7 @@ def loss_fwd_bwd(logits: torch.Tensor, labels: Optional[torch.Tensor], lx: torch
                                        _ptr(c_beta), _ptr(c_ctc_t), _ptr(invalid), _ptr(ws), ws_bytes, _vp(stream))
     _check(rc)
     if c_den != 0.0 and c_ctc != 0.0:
-        _warn_if_serial()
+        _warn_if_serial((dev.index, int(stream)))
     del meta
     extras = dict(costs_alpha=c_alpha, costs_beta=c_beta, costs_ctc=c_ctc_t, invalid=invalid) if want_costs else {}
     return loss, grad, extras

@@ -188,8 +188,11 @@ const char *crf_last_side_stream(void);
 /* How many utterances of this thread's last call were redone by a fallback: out2[0] = denominator (crf_robust_den_kernel: the scaled fp32
  * recursions lost the utterance's mass, or -- lagged scale -- a frame shrank the vector by more than 2^90), out2[1] = numerator
  * (crf_robust_ctc_kernel: frames outside the fp64 range of the rescaled chains).  Synchronises `stream` (the stream of that call) and
- * copies two words: a diagnostic for benchmarks and tests, not for the training loop.  The reference has no fallback: its log-domain
- * kernels (den_calculate.cu:29-35) pay exp + log1p on every arc instead. */
+ * copies two words: a diagnostic for benchmarks and tests, not for the training loop.  LIFETIME: the words live in that call's workspace
+ * (or, with fine-grained flag words, in the buffer of its (device, stream) context): ask right after the call, before the workspace is
+ * freed or handed to another call and before another thread calls on the same device and stream -- later the counts are another call's
+ * or the pointer dangles.  The reference has no fallback: its log-domain kernels (den_calculate.cu:29-35) pay exp + log1p on every arc
+ * instead. */
 int crf_last_fallback_counts(int32_t *out2, void *stream);
 /* The build-time A/B switches of the frame loops this library was compiled with, e.g. "LAG=1 KCLATE=0 PRIO=2 EARLY=1 ..." (crf_kernels.hip,
  * CRF_X_*: the defaults are the measured best; tools build variants with CRF_BUILD_DEFS=-DCRF_X_...=n and tests ask which one they run). */

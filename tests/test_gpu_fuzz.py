@@ -5,6 +5,8 @@ rescaled fp32 recursions, the fp64 numerator chains, the grad kernels' descaling
 must meet the next one's.  The reference has one arithmetic for all of it (log-domain fp32: den_calculate.cu:29-35,
 gpu_ctc_kernels.h:87-458); here every case is checked in the kernel family a seeded choice picks, through the C ABI, against
 oracle/crf_oracle.c in fp64: loss and every utterance's gradient within 1e-4, no NaN / inf anywhere."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,12 +27,16 @@ def crf():
     return ctc_crf
 
 
+# An EXTENDED campaign draws fresh cases with the same coverage structure: CRF_FUZZ_CAMPAIGN=n shifts every random draw (graph, batch, shape) by n * 100 000
+# (tools/gpu_fuzz_campaign.sh; the suite itself runs campaign 0).
+CAMPAIGN = int(os.environ.get("CRF_FUZZ_CAMPAIGN", "0")) * 100000
+
 VS = [2, 3, 9, 24, 40, 63, 64, 65, 72, 128, 129, 200, 256, 257]
 SIGMAS = [0.5, 2.0, 8.0, 20.0, 40.0]
 
 
 def _case(seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + CAMPAIGN)
     V = int(VS[seed % len(VS)])
     H = int(max(V - 1, rng.integers(V - 1, 4 * V + 8)))
     d = int(rng.integers(1, min(V - 1, 12) + 1))
@@ -46,9 +52,9 @@ def _case(seed):
 @pytest.mark.parametrize("seed", range(168))
 def test_fuzz_vs_oracle(crf, tmp_path, seed):
     V, H, d, B, T, sigma, lamb, mode, frac = _case(seed)
-    g, p = small_synth(tmp_path, V, H, d, seed)
-    logits, labels, lx, ly = make_batch(g, B, T, V, seed=seed, ragged=True, scale=sigma, label_frac=frac, min_len=0)
-    rng = np.random.default_rng(seed)
+    g, p = small_synth(tmp_path, V, H, d, seed + CAMPAIGN)
+    logits, labels, lx, ly = make_batch(g, B, T, V, seed=seed + CAMPAIGN, ragged=True, scale=sigma, label_frac=frac, min_len=0)
+    rng = np.random.default_rng(seed + CAMPAIGN)
     if B >= 3 and seed % 3 == 0:                        # an empty utterance / a one-frame utterance somewhere in the batch
         lab = [list(labels[sum(ly[:i]):sum(ly[:i + 1])]) for i in range(B)]
         k = int(rng.integers(1, B))
@@ -101,9 +107,9 @@ def test_fuzz_fused_log_softmax_vs_oracle(crf, tmp_path, seed):
     import torch
     from tests.test_gpu_parity import _mode
     V, H, d, B, T, sigma, lamb, mode, frac = _case(300 + seed)
-    g, p = small_synth(tmp_path, V, H, d, seed)
-    _, labels, lx, ly = make_batch(g, B, T, V, seed=seed, ragged=True, scale=1.0, label_frac=frac, min_len=0)
-    rng = np.random.default_rng(7000 + seed)
+    g, p = small_synth(tmp_path, V, H, d, seed + CAMPAIGN)
+    _, labels, lx, ly = make_batch(g, B, T, V, seed=seed + CAMPAIGN, ragged=True, scale=1.0, label_frac=frac, min_len=0)
+    rng = np.random.default_rng(7000 + seed + CAMPAIGN)
     raw = (rng.normal(size=(B, T, V)) * sigma).astype(np.float32)
     x64 = raw.astype(np.float64)
     m = x64.max(-1, keepdims=True)
@@ -173,14 +179,14 @@ def test_fuzz_long_utterances_metric_size_class(crf, size_class_graphs, seed):
     recursion, the staged schedule with the one-launch grad pass from T >= 256 on) and on the two-CU layout (odd seeds: S = 6 145), network outputs from
     diffuse to a hundred nats apart, ragged pairs, each on the kernels the graph takes by itself; loss and every utterance's gradient within 1e-4 of the fp64 oracle."""
     import torch
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + CAMPAIGN)
     H = 2048 if seed % 2 == 0 else 3072
     g, p = size_class_graphs[H]
     B = int(rng.integers(1, 3))
     T = int(rng.integers(400, 1501))
     sigma = float(SIGMAS[seed % len(SIGMAS)])
     lamb = float([0.0, 0.01, 0.1, 1.0][(seed // 2) % 4])
-    logits, labels, lx, ly = make_batch(g, B, T, 72, seed=seed, ragged=True, scale=sigma, label_frac=int([3, 6, 12][seed % 3]))
+    logits, labels, lx, ly = make_batch(g, B, T, 72, seed=seed + CAMPAIGN, ragged=True, scale=sigma, label_frac=int([3, 6, 12][seed % 3]))
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=lamb)
     if not np.isfinite(ref["loss"]):
         pytest.skip("the oracle itself is not finite for this draw")
