@@ -33,6 +33,13 @@ __device__ __forceinline__ double block_max_d(double v, double *red, int tid) { 
     for (int i = 1; i < kChainWaves; ++i) m = fmax(m, red[i]);
     return m;
 }
+// The fallback's ROWS (ln q_t[p], ln b_{t+1}[dst_p]) in the workspace's 32-bit row entries: FIXED-POINT relative to the row's maximum, q = round((x - M) / step) with
+// step = max(M - min finite x, 1) * 2^-30 kept per frame in the exponent words EQ / EB (which the redone utterance's fast rows no longer need) -- an absolute
+// error of step / 2 on a logarithm whatever its distance from the maximum (3e-6 for a row spanning 3 000 nats).  Rounds 5 / 6 stored (float)(x - M): 6e-8 * |x - M|, and a
+// pair 800 nats below its row's forward maximum that the backward row makes the frame's dominant one came out 1.2e-4 off (fuzz campaign 3, seed 116: sigma 20, T = 195).
+__device__ __forceinline__ float robust_step(double mx, double mn) { return (float)(fmax(mx > -INFINITY ? mx - mn : 0.0, 1.0) * 0x1p-30); }
+__device__ __forceinline__ int robust_enc(double x, double M, float step) { return x > -INFINITY ? (int)rint((x - M) / (double)step) : (int)0x80000000; }
+__device__ __forceinline__ double robust_dec(int q, float step) { return q != (int)0x80000000 ? (double)q * (double)step : -INFINITY; }
 __device__ __forceinline__ void load_drow(const LossParams &p, int64_t frame, double *Dv, int tid) {
     const double mx = (double)p.mx[frame];
     for (int v = tid; v < p.V; v += kChainThreads) Dv[v] = (double)ld_x(p, frame * p.V + v) - mx;
@@ -97,8 +104,8 @@ __device__ __forceinline__ void den_forward_robust(const LossParams &p, int b, f
         const double *Xc = X + (size_t)(t & 1) * Sp;
         double *Xn = X + (size_t)((t + 1) & 1) * Sp;
         load_drow(p, bt0 + t, Dv, tid);
-        float *Qrow = p.Q + (bt0 + t) * p.Rq;
-        double smax = -INFINITY;
+        int *Qrow = (int *)(p.Q + (bt0 + t) * p.Rq);
+        double smax = -INFINITY, smin = INFINITY;
         for (int i = sl0; i < sl1; ++i) {
             const int j = __builtin_amdgcn_readfirstlane(g.fwd.wave_slices[i]);
             const int o = __builtin_amdgcn_readfirstlane(g.fwd.slice_off[j]);
@@ -107,9 +114,12 @@ __device__ __forceinline__ void den_forward_robust(const LossParams &p, int b, f
             const double lq = g.pair_meta[r].x >= 0 ? ell_row_lse(g.fwd.arcs + o + lane, w2, Xc) : -INFINITY;
             Ql[r] = lq;
             smax = fmax(smax, lq);
+            if (lq > -INFINITY) smin = fmin(smin, lq);
         }
         const double M = block_max_d(smax, red, tid);       // (its barriers also publish Ql and Dv)
-        for (int r = tid; r < Pr; r += kChainThreads) Qrow[r] = Ql[r] > -INFINITY ? (float)(Ql[r] - M) : -INFINITY;
+        const float step = robust_step(M, -block_max_d(-smin, red, tid));
+        if (tid == 0) p.EQ[bt0 + t] = __float_as_int(step);
+        for (int r = tid; r < Pr; r += kChainThreads) Qrow[r] = robust_enc(Ql[r], M, step);
         for (int s2 = tid; s2 < S; s2 += kChainThreads) {   // every state from the pairs that enter it (one, in T o LM)
             double m = -INFINITY;
             float sm = 0.f;
@@ -148,18 +158,21 @@ __device__ __forceinline__ void den_backward_robust(const LossParams &p, int b, 
     for (int t = 0; t < lx; ++t) off += (double)p.moff[bt0 + t];   // (every thread: lx <= T adds, once per redone utterance)
     __syncthreads();
     {   // z_{lx-1}[p] = logp_{lx-1}[lab_p] + ln end[dst_p];  BP[lx-1][p] = ln end[dst_p]
-        float *BProw = p.BP + (bt0 + lx - 1) * p.Rb;
-        double smax = -INFINITY;
+        int *BProw = (int *)(p.BP + (bt0 + lx - 1) * p.Rb);
+        double smax = -INFINITY, smin = INFINITY;
         for (int r = tid; r < Pr; r += kChainThreads) {
             const int2 meta = g.pair_meta[r];
             const double lb = (meta.x >= 0 && g.end_lin[meta.x] > 0.f) ? log((double)g.end_lin[meta.x]) : -INFINITY;
             BPst[Pr + r] = lb;
             smax = fmax(smax, lb);
+            if (lb > -INFINITY) smin = fmin(smin, lb);
         }
         const double M = block_max_d(smax, red, tid);
+        const float step = robust_step(M, -block_max_d(-smin, red, tid));
+        if (tid == 0) p.EB[bt0 + lx - 1] = __float_as_int(step);
         for (int r = tid; r < Pr; r += kChainThreads) {
             const double lb = BPst[Pr + r];
-            BProw[r] = lb > -INFINITY ? (float)(lb - M) : -INFINITY;
+            BProw[r] = robust_enc(lb, M, step);
             Z[r] = lb > -INFINITY ? Dv[g.pair_meta[r].y & 0xffff] + lb : -INFINITY;
         }
     }
@@ -167,6 +180,7 @@ __device__ __forceinline__ void den_backward_robust(const LossParams &p, int b, 
     double zm = -INFINITY;
     float zs = 0.f;
     double Mprev = 0.0;
+    float step_prev = 1.f;
     const int sl0 = g.bwd.wave_off[wave], sl1 = g.bwd.wave_off[wave + 1];
     for (int i = 0; i < lx; ++i) {
         const int t = lx - 1 - i;
@@ -176,12 +190,13 @@ __device__ __forceinline__ void den_backward_robust(const LossParams &p, int b, 
         if (t >= 1) load_drow(p, bt0 + t - 1, Dv, tid);      // (its last readers are behind the previous iteration's closing barrier)
         if (i > 0) {  // log b_{t+1}[dst_p], staged by the previous iteration -> BP[b][t]
             const double *BPp = BPst + (size_t)((i - 1) & 1) * Pr;
-            float *BProw = p.BP + (bt0 + t) * p.Rb;
-            for (int r = tid; r < Pr; r += kChainThreads) BProw[r] = BPp[r] > -INFINITY ? (float)(BPp[r] - Mprev) : -INFINITY;
+            int *BProw = (int *)(p.BP + (bt0 + t) * p.Rb);
+            if (tid == 0) p.EB[bt0 + t] = __float_as_int(step_prev);
+            for (int r = tid; r < Pr; r += kChainThreads) BProw[r] = robust_enc(BPp[r], Mprev, step_prev);
         }
         for (int r = tid; r < Pr; r += kChainThreads) BPc[r] = -INFINITY;   // (pairs into states without a backward row)
         __syncthreads();
-        double smax = -INFINITY;
+        double smax = -INFINITY, smin = INFINITY;
         for (int ii = sl0; ii < sl1; ++ii) {
             const int j = __builtin_amdgcn_readfirstlane(g.bwd.wave_slices[ii]);
             const int o = __builtin_amdgcn_readfirstlane(g.bwd.slice_off[j]);
@@ -193,12 +208,14 @@ __device__ __forceinline__ void den_backward_robust(const LossParams &p, int b, 
             if (t == 0) { if (g.start_lin[s2] > 0.f) lse_add(zm, zs, log((double)g.start_lin[s2]) + lb); }
             else {
                 smax = fmax(smax, lb);
+                if (lb > -INFINITY) smin = fmin(smin, lb);
                 if (meta.y == 1) BPc[meta.z] = lb;
                 else for (int pi = g.st_pair_off[s2]; pi < g.st_pair_off[s2 + 1]; ++pi) BPc[g.st_pairs[pi]] = lb;
             }
         }
         if (t >= 1) {
             Mprev = block_max_d(smax, red, tid);            // (barriers: BPc complete)
+            step_prev = robust_step(Mprev, -block_max_d(-smin, red, tid));
             for (int r = tid; r < Pr; r += kChainThreads) Zn[r] = BPc[r] > -INFINITY ? Dv[g.pair_meta[r].y & 0xffff] + BPc[r] : -INFINITY;
         }
         __syncthreads();
@@ -290,12 +307,22 @@ __device__ __forceinline__ void robust_grad_body(const LossParams &p) {
             for (int v = tid; v < V; v += kGradThreads) row[v] = 0.f;
             continue;
         }
-        const float *Qr = p.Q + (bt0 + t) * p.Rq, *Br = p.BP + (bt0 + t) * p.Rb;   // ln q_t[p], ln b_{t+1}[dst_p] relative to the frame's maxima
-        for (int c = tid; c < NC; c += kGradThreads) {
+        const int *Qr = (const int *)(p.Q + (bt0 + t) * p.Rq), *Br = (const int *)(p.BP + (bt0 + t) * p.Rb);   // ln q_t[p], ln b_{t+1}[dst_p]: fixed-point relative to the frame's maxima (robust_enc)
+        const float sq = __int_as_float(p.EQ[bt0 + t]), sb = __int_as_float(p.EB[bt0 + t]);
+        auto chunk_lse = [&](int c) {
             double m = -INFINITY;
             float sm = 0.f;
-            for (int j = g.chunk_off[c]; j < g.chunk_off[c + 1]; ++j) { const int r = g.perm[j]; lse_add(m, sm, (double)Qr[r] + (double)Br[r]); }
-            csum[c] = (float)lse_value(m, sm);              // (<= 0 up to the rows' rounding: fp32 keeps 1e-7 absolute near 0, where it matters)
+            for (int j = g.chunk_off[c]; j < g.chunk_off[c + 1]; ++j) { const int r = g.perm[j]; lse_add(m, sm, robust_dec(Qr[r], sq) + robust_dec(Br[r], sb)); }
+            return lse_value(m, sm);
+        };
+        // the chunks' sums relative to the LARGEST of them, so that the float in the LDS is near 0 -- 1e-7 absolute -- where it matters (relative to the rows' two
+        // maxima the frame's dominant pair itself can sit hundreds of nats down: fp32 then keeps 6e-5).  Two passes over the rows: this is the fallback.
+        double cmx = -INFINITY;
+        for (int c = tid; c < NC; c += kGradThreads) cmx = fmax(cmx, chunk_lse(c));
+        cmx = bmax(cmx);
+        for (int c = tid; c < NC; c += kGradThreads) {
+            const double v = chunk_lse(c);
+            csum[c] = v > -INFINITY ? (float)(v - cmx) : -INFINITY;
         }
         for (int v = tid; v < V; v += kGradThreads) gc[v] = 0.f;
         __syncthreads();

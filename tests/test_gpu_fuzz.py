@@ -74,9 +74,10 @@ def test_fuzz_vs_oracle(crf, tmp_path, seed):
     # scores thousands of nats apart): forward / backward consistency checks, per-frame mass checks and the emission-weighted lost-term
     # bound hand such utterances to the log-domain fp64 fallbacks, which carry any input (1.5e-6 at sigma 40, T 300).
     tol = TOL
+    floor = 0.05 * (1.0 / B if size_average else 1.0)     # (tests/util.py rel_err: an utterance whose whole gradient is the cancellation of two equal posteriors)
     for b in range(B):
         if lx[b] > 0:
-            assert rel_err(grad[b], ref["grad"][b]) <= tol, (b, what)
+            assert rel_err(grad[b], ref["grad"][b], floor) <= tol, (b, what)
         assert np.all(grad[b, lx[b]:] == 0.0), (b, what)
     # ENTRY-WISE on the two posterior matrices (round 6): the combined gradient is a difference of two O(1) posteriors and can only
     # be judged norm-wise (tests/util.py rel_err); gamma_den and gamma_ctc themselves are non-negative, no cancellation: every entry >= 1e-3 within 1e-4
@@ -134,7 +135,7 @@ def test_fuzz_fused_log_softmax_vs_oracle(crf, tmp_path, seed):
     assert abs(loss - ref["loss"]) <= TOL * max(1.0, abs(ref["loss"])), (loss, ref["loss"], what)
     for b in range(B):
         if lx[b] > 0 and np.abs(gx[b]).max() > 0:
-            assert rel_err(grad[b], gx[b]) <= 2 * TOL, (b, what)     # (the oracle's own d loss / d log_probs is fp32: two roundings meet in the chain rule)
+            assert rel_err(grad[b], gx[b], 0.05 * (1.0 / B if size_average else 1.0)) <= 2 * TOL, (b, what)     # (the oracle's own d loss / d log_probs is fp32: two roundings meet in the chain rule)
 
 
 @pytest.mark.parametrize("H,d,B,T,sigma,kern", [(2304, 24, 3, 60, 2.0, "crf_fac2_pair_kernel"), (3072, 24, 2, 40, 8.0, "crf_fac2_pair_kernel"),
@@ -202,7 +203,7 @@ def test_fuzz_long_utterances_metric_size_class(crf, size_class_graphs, seed):
     assert np.isfinite(loss.item()) and np.isfinite(grad).all(), what
     assert abs(loss.item() - ref["loss"]) <= TOL * max(1.0, abs(ref["loss"])), (loss.item(), ref["loss"], what)
     for b in range(B):
-        assert rel_err(grad[b, :lx[b]], ref["grad"][b, :lx[b]]) <= TOL, (b, what)
+        assert rel_err(grad[b, :lx[b]], ref["grad"][b, :lx[b]], 0.05 / B) <= TOL, (b, what)
         assert np.all(grad[b, lx[b]:] == 0.0), (b, what)
 
 

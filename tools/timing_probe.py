@@ -26,9 +26,25 @@ def main():
     dev = torch.device("cuda:0")
     B, T, V = 64, 1500, 72
     fst = os.path.join(tempfile.mkdtemp(prefix="crfprobe_"), "den_lm.fst")
-    H, D = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2048, 24)   # histories, fan-out of the synthetic den_lm
-    g = synth_den_lm(V, H, D, seed=0, path=fst)
-    print(f"den_lm H={H} d={D}: S={g['S']} A={g['A']}")
+    if len(sys.argv) > 2 and sys.argv[1] == "est":   # `est <sentences>`: a den_lm ESTIMATED with the default (Kaldi's) rule, as tools/bench_fst.py makes it
+        import numpy as np
+        from cat_amd import den_lm
+        from oracle import fst_io
+        rng = np.random.default_rng(0)
+        trans = rng.dirichlet(np.ones(V - 1) * 0.05, size=(V, V))
+        seqs = []
+        for _ in range(int(sys.argv[2])):
+            s, a, b = [], 0, 0
+            for _ in range(int(rng.integers(10, 40))):
+                c = 1 + int(rng.choice(V - 1, p=trans[a, b])); s.append(c); a, b = b, c
+            seqs.append(s)
+        den_lm.prep_den_lm(seqs, V, fst, 4, 3, 250, selection="likelihood")
+        g = fst_io.read_fst(fst)
+        print(f"estimated den_lm from {sys.argv[2]} sentences: S={g['S']} A={g['A']}")
+    else:
+        H, D = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2048, 24)   # histories, fan-out of the synthetic den_lm
+        g = synth_den_lm(V, H, D, seed=0, path=fst)
+        print(f"den_lm H={H} d={D}: S={g['S']} A={g['A']}")
     ctx = ctc_crf.CRFContext(fst, 0)  # noqa: F841
     logits, labels, lx, ly = make_batch(g, B, T, V, seed=0, ragged=False)
     x = torch.tensor(logits, device=dev, requires_grad=True)
