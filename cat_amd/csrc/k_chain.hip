@@ -847,22 +847,32 @@ __global__ __launch_bounds__(256) void crf_ctc_check_kernel(LossParams p) {
     if (!(zc > 0.0)) return;
     const int64_t bt0 = (int64_t)b * p.T;
     const int Sx = 2 * p.ly[b] + 1;
-    const int e = p.ctc_ez[b] - p.ECA[bt0] - p.ECB[bt0];
     const double invc = 1.0 / zc;
-    bool bad = e + ilogb(invc) > kCtcSafeExp;
-    double part = 0.0;
-    if (!bad) {
+    // frame 0 (A_0 exact, Bx_0 the end of the backward chain, Z the end of the forward chain) and -- round 6 -- the quarter points: at frame t the sum pairs the
+    // forward chain's first t frames with the backward chain's last lx - t, so a set of alignments that BOTH chains drop (the forward one before t, the backward one
+    // behind it -- frame 0 then sees the same reduced mass on both sides) is missing on one side only.  A quarter point whose own products sit at the bottom of the
+    // fp64 range says nothing (ctc_frame_factor marks such frames for the per-frame fix) and is skipped; frame 0 in that state sends the utterance to the log domain.
+    bool bad = false;
+    for (int q = 0; q < 4 && !bad; ++q) {
+        const int t = (int)((int64_t)lx * q / 4);
+        if (q > 0 && t == (int)((int64_t)lx * (q - 1) / 4)) continue;
+        const int e = p.ctc_ez[b] - p.ECA[bt0 + t] - p.ECB[bt0 + t];
+        const bool unsafe = e + ilogb(invc) > kCtcSafeExp;       // (uniform)
+        if (unsafe) { bad = q == 0; continue; }
         const double fc = ldexp(invc, e);
-        const double *Ar = p.CA + bt0 * p.Sc, *Br = p.CB + bt0 * p.Sc;
-        for (int s = tid; s < Sx && s < 2; s += 256) part += Ar[s] * Br[s] * fc;   // (frame 0: only the first blank and the first label carry mass)
+        const double *Ar = p.CA + (bt0 + t) * p.Sc, *Br = p.CB + (bt0 + t) * p.Sc;
+        double part = 0.0;
+        for (int s = tid; s < Sx; s += 256) part += Ar[s] * Br[s] * fc;
+        part = wave_sum_d(part);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = part;
+        __syncthreads();
+        const double tot = red[0] + red[1] + red[2] + red[3];
+        // (1e-6 since round 6: two fp64 chains over the same emissions agree to ~1e-12; round 5's 1e-3 let a chain that had lost 2e-4 of the mass pass -- posterior
+        //  rows summing to 1.0002, gradient 2e-4 off: fuzz campaign 1, fused case 11, sigma 20, T = 288)
+        if (!(fabs(tot - 1.0) <= kCtcCheckTol)) bad = true;
     }
-    part = wave_sum_d(part);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    const double tot = red[0] + red[1] + red[2] + red[3];
-    // (1e-6 since round 6: two fp64 chains over the same emissions agree to ~1e-12; round 5's 1e-3 let a chain that had lost 2e-4 of the mass pass -- posterior
-    //  rows summing to 1.0002, gradient 2e-4 off: fuzz campaign 1, fused case 11, sigma 20, T = 288)
-    if (tid == 0 && (bad || !(fabs(tot - 1.0) <= kCtcCheckTol))) atomicMax(&p.redo_ctc[b], 2);
+    if (tid == 0 && bad) atomicMax(&p.redo_ctc[b], 2);
 }
 
 
