@@ -79,7 +79,7 @@ __device__ __forceinline__ double block_lse(double m, float sm, double *red, int
 // fp32 vectors of the fast kernels (and of this fallback's first form, rounds 2 - 4: linear fp32 with a per-frame shift) cannot -- their
 // entries end 2^-146 below the frame maximum, and a path that far behind at ONE frame was lost for good even if later frames made it the
 // dominant one (tests/test_gpu_fuzz.py, round 5: network outputs hundreds of nats apart over den_lm with one or two arcs per state).
-// Rows for crf_robust_grad_kernel: lq_t[p] and lb_t[p] as fp32 relative to their frame's maximum (the constants cancel in the frame's
+// Rows for crf_robust_grad_kernel: lq_t[p] and lb_t[p] as 32-bit fixed-point logarithms relative to their frame's maximum, step per frame in EQ / EB (robust_enc; the constants cancel in the frame's
 // softmax over labels), pair order, first Pr entries of the workspace rows.
 // LDS fwd: A[2][Sp] | Ql[Pr] | Dv[Vp] | red[16]   (doubles; GV: A and Ql in global memory)
 // LDS bwd: Z[2][Pr] | BPst[2][Pr] | Dv[Vp] | red[16]

@@ -207,6 +207,74 @@ def test_fuzz_long_utterances_metric_size_class(crf, size_class_graphs, seed):
         assert np.all(grad[b, lx[b]:] == 0.0), (b, what)
 
 
+@pytest.mark.parametrize("seed", range(33))
+def test_fuzz_estimated_den_lm(crf, tmp_path, seed):
+    """The fuzz on den_lm graphs ESTIMATED from text (cat_amd.den_lm.prep_den_lm: the graphs CAT trains on -- back-off arcs, in-degrees from 1 to hundreds,
+    probabilities as weights) instead of the hashed synthetic T o LM: vocabulary 4 ... 48, corpus size, n-gram order 2 ... 4, no-prune order, number of extra
+    states and BOTH selection rules drawn per seed; every kernel family in rotation (a forced family the graph does not fit falls to the next one by itself);
+    output scale sigma 0.5 ... 40; label sequences taken from the corpus, so that the numerator's paths exist in the LM.  Loss, every utterance's gradient and
+    both posterior matrices entry-wise within 1e-4 of the fp64 oracle."""
+    import torch
+    from cat_amd import den_lm
+    rng = np.random.default_rng(9000 + seed + CAMPAIGN)
+    V = int([4, 6, 9, 16, 24, 33, 48][seed % 7])
+    order = int([2, 3, 4][(seed // 7) % 3])
+    noprune = int(min(order, [1, 2, 3][seed % 3]))
+    extra = int(rng.integers(0, 60))
+    nsent = int(rng.integers(20, 600))
+    conc = float([0.05, 0.3, 2.0][(seed // 2) % 3])                 # sparse ... dense second-order source
+    trans = rng.dirichlet(np.ones(V - 1) * conc, size=(V, V))
+    seqs = []
+    for _ in range(nsent):
+        sq, a, b_ = [], 0, 0
+        for _ in range(int(rng.integers(3, 25))):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b_])); sq.append(c); a, b_ = b_, c
+        seqs.append(sq)
+    p = str(tmp_path / "est.fst")
+    den_lm.prep_den_lm(seqs, V, p, order, noprune, extra, selection=["likelihood", "count"][seed % 2])
+    g = fst_io.read_fst(p)
+    B = int(rng.integers(1, 7))
+    T = int(rng.integers(4, 160))
+    sigma = float(SIGMAS[(seed // 3) % len(SIGMAS)])
+    lamb = float([0.0, 0.01, 0.1, 1.0][seed % 4])
+    mode = MODES[(seed * 5 + seed // 3) % len(MODES)]
+    logits = (rng.normal(size=(B, T, V)) * sigma).astype(np.float32)
+    x64 = logits.astype(np.float64)
+    logits = (x64 - (x64.max(-1, keepdims=True) + np.log(np.exp(x64 - x64.max(-1, keepdims=True)).sum(-1, keepdims=True)))).astype(np.float32)
+    lx = np.sort(rng.integers(1, T + 1, size=B))[::-1].astype(np.int32); lx[0] = T
+    labels, ly = [], []
+    for b in range(B):
+        sq = seqs[int(rng.integers(0, nsent))]
+        lab = sq[:max(1, min(len(sq), int(lx[b]) // int([2, 3, 6][seed % 3])))]
+        labels += lab; ly.append(len(lab))
+    labels, ly = np.array(labels, dtype=np.int32), np.array(ly, dtype=np.int32)
+    ref = oracle.ctc_crf(g, logits, labels, lx, ly, lamb=lamb)
+    if not np.isfinite(ref["loss"]):
+        pytest.skip("the oracle itself is not finite for this draw (an utterance without a valid alignment)")
+    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=lamb, mode=mode)
+    what = dict(V=V, order=order, noprune=noprune, extra=extra, nsent=nsent, S=int(g["S"]), A=len(g["src"]), B=B, T=T, sigma=sigma, lamb=lamb, mode=mode, lx=list(map(int, lx)), ly=list(map(int, ly)))
+    assert np.isfinite(loss) and np.isfinite(grad).all(), what
+    assert abs(loss - ref["loss"]) <= TOL * max(1.0, abs(ref["loss"])), (loss, ref["loss"], what)
+    for b in range(B):
+        assert rel_err(grad[b, :lx[b]], ref["grad"][b, :lx[b]], 0.05 / B) <= TOL, (b, what)
+        assert np.all(grad[b, lx[b]:] == 0.0), (b, what)
+    core = crf._C
+    gden_ref = oracle.den(g, logits, lx)[0]
+    gctc_ref, _, valid = oracle.ctc(logits, labels, lx, ly)
+    with _mode(mode):
+        ctx = crf.CRFContext(p, 0)
+        x = torch.tensor(logits, device="cuda:0")
+        tl, tx, ty = torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32), torch.tensor(ly, dtype=torch.int32)
+        gden = core.loss_fwd_bwd(x, None, tx, None, 1.0, 0.0, core.graph_for(x.device), True)[1].cpu().numpy()
+        gctc = core.loss_fwd_bwd(x, tl, tx, ty, 0.0, -1.0, None, True)[1].cpu().numpy()
+        del ctx
+    for b in range(B):
+        n = int(lx[b])
+        assert post_err(gden[b, :n], gden_ref[b, :n]) <= TOL, ("gamma_den", b, what)
+        if valid[b]:
+            assert post_err(gctc[b, :n], gctc_ref[b, :n]) <= TOL, ("gamma_ctc", b, what)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_dominant_path_dropped_in_both_directions(crf, tmp_path, mode):
     """The residual blind spot DESIGN section 5 admitted, CONSTRUCTED: the forward / backward consistency check compares two log Z, so a
