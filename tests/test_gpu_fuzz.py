@@ -13,7 +13,7 @@ import pytest
 import oracle
 from oracle import fst_io
 from tests.test_gpu_parity import MODES, TOL, _mode, run_hip
-from tests.util import make_batch, post_err, rel_err, small_synth
+from tests.util import crf_env, make_batch, post_err, rel_err, small_synth
 
 pytestmark = pytest.mark.gpu
 
@@ -66,8 +66,11 @@ def test_fuzz_vs_oracle(crf, tmp_path, seed):
     ref = oracle.ctc_crf(fst_io.read_fst(p), logits, labels, lx, ly, lamb=lamb, size_average=size_average)
     if not np.isfinite(ref["loss"]):
         pytest.skip("the oracle itself is not finite for this draw (an utterance without a valid alignment)")
-    loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=lamb, size_average=size_average, mode=mode)
-    what = dict(V=V, H=H, d=d, B=B, T=T, sigma=sigma, lamb=lamb, mode=mode, frac=frac, lx=list(map(int, lx)))
+    # (utterance-minor modes: the group width drawn too -- 8 / 16 are what these batch sizes take by themselves, 32 / 64 what B > 16 / 32 does)
+    ul = int([8, 16, 32, 64][(seed // 11) % 4]) if mode.startswith("batch") else 0
+    with crf_env(CRF_BAT_UL=ul):
+        loss, grad = run_hip(crf, p, logits, labels, lx, ly, lamb=lamb, size_average=size_average, mode=mode)
+    what = dict(V=V, H=H, d=d, B=B, T=T, sigma=sigma, lamb=lamb, mode=mode, frac=frac, lx=list(map(int, lx)), ul=ul)
     assert np.isfinite(loss) and np.isfinite(grad).all(), what
     assert abs(loss - ref["loss"]) <= TOL * max(1.0, abs(ref["loss"])), (loss, ref["loss"], what)
     # 1e-4 in EVERY regime since round 5 -- also where the fast kernels cannot go (network outputs a hundred nats apart per frame, path
@@ -86,7 +89,7 @@ def test_fuzz_vs_oracle(crf, tmp_path, seed):
     core = crf._C
     gden_ref = oracle.den(fst_io.read_fst(p), logits, lx)[0]
     gctc_ref, _, valid = oracle.ctc(logits, labels, lx, ly)
-    with _mode(mode):
+    with _mode(mode), crf_env(CRF_BAT_UL=ul):
         ctx = crf.CRFContext(p, 0)
         x = torch.tensor(logits, device="cuda:0")
         tl, tx, ty = torch.tensor(labels, dtype=torch.int32), torch.tensor(lx, dtype=torch.int32), torch.tensor(ly, dtype=torch.int32)
