@@ -169,17 +169,19 @@ def _select_by_likelihood(seqs, N: int, M: int, K: int):
             own.setdefault(h[k:], Counter())
     active = set(own)
     nchild: Dict[tuple, int] = {h: 0 for h in active}
+    kids: Dict[tuple, list] = {h: [] for h in active}
     for h in active:
         if h:
             nchild[h[1:]] += 1
+            kids[h[1:]].append(h)
 
     def loglike(c):
         n = sum(c.values())
         return sum(v * np.log(v / n) for v in c.values()) if n else 0.0
 
-    def loss(h):
+    def loss(h):                                          # (rounded to 1e-9: equal losses computed along different paths must TIE, so that the documented order decides)
         c, b = own[h], own[h[1:]]
-        return float(loglike(c) + loglike(b) - loglike(c + b))
+        return round(float(loglike(c) + loglike(b) - loglike(c + b)), 9)
 
     def prunable(h):
         return len(h) >= M and nchild[h] == 0
@@ -202,6 +204,12 @@ def _select_by_likelihood(seqs, N: int, M: int, K: int):
         nchild[par] -= 1
         if prunable(par):
             heapq.heappush(heap, (loss(par), len(par), par))
+        # the merged counts change what backing off into `par` costs its OTHER children -- and it can get CHEAPER (the back-off state's distribution has moved
+        # towards theirs): fresh entries, so that the smallest CURRENT loss is always on top (an entry that has become too small is refreshed above when it is
+        # popped; one that has become too large would otherwise sit behind states that cost more -- found by tests/test_den_lm_tools.py's naive restatement)
+        for c in kids[par]:
+            if c in active and prunable(c):
+                heapq.heappush(heap, (loss(c), len(c), c))
     return active
 
 

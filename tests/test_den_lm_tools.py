@@ -362,3 +362,58 @@ def test_estimator_selects_states_by_likelihood_like_kaldi():
             for t in sq:
                 (st,) = [n for tt, n, _ in m["arcs"][st] if tt == t]
             assert math.isfinite(m["final"][st])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_likelihood_selection_against_a_naive_greedy(seed):
+    """`_select_by_likelihood` keeps a heap with lazily refreshed losses; here the same published rule restated the slow way -- after every merge recompute the loss of
+    EVERY remaining leaf from scratch and take the smallest (ties: shorter history, then token order) -- on random corpora, for every budget K from all states
+    down to none.  The two must keep the same set at every K; the sets are nested (K - 1 is K minus one state); and the training-data log-likelihood of the
+    estimated LM never rises when a state is taken away."""
+    from collections import Counter
+    rng = np.random.default_rng(100 + seed)
+    V, N, M = int(rng.integers(3, 7)), int(rng.integers(3, 5)), int(rng.integers(1, 3))
+    trans = rng.dirichlet(np.ones(V - 1) * 0.4, size=(V, V))
+    seqs = []
+    for _ in range(int(rng.integers(15, 60))):
+        s, a, b = [], 0, 0
+        for _ in range(int(rng.integers(1, 9))):
+            c = 1 + int(rng.choice(V - 1, p=trans[a, b])); s.append(c); a, b = b, c
+        seqs.append(tuple(s))
+
+    def ll(c):
+        n = sum(c.values())
+        return sum(v * math.log(v / n) for v in c.values()) if n else 0.0
+
+    def naive(K):
+        own = {(): Counter()}
+        for s in seqs:
+            for i in range(len(s) + 1):
+                own.setdefault(s[max(0, i - (N - 1)):i], Counter())[s[i] if i < len(s) else 0] += 1
+        for h in list(own):
+            for k in range(1, len(h) + 1):
+                own.setdefault(h[k:], Counter())
+        active = set(own)
+        while sum(len(h) >= M for h in active) > K:
+            leaves = [h for h in active if len(h) >= M and not any(g[1:] == h for g in active if g)]
+            h = min(leaves, key=lambda h: (round(ll(own[h]) + ll(own[h[1:]]) - ll(own[h] + own[h[1:]]), 9), len(h), h))
+            own[h[1:]] = own[h[1:]] + own[h]
+            active.discard(h)
+        return active
+
+    total = len(naive(10 ** 9))
+    n_long = sum(len(h) >= M for h in naive(10 ** 9))
+    prev, prev_ll = None, None
+    for K in range(n_long, -1, -1):
+        want = naive(K)
+        got = den_lm._select_by_likelihood(seqs, N, M, K)
+        assert got == want, (K, sorted(got ^ want))
+        assert sum(len(h) >= M for h in got) == K
+        if prev is not None:
+            assert got < prev and len(prev) - len(got) == 1
+        prev = got
+        lm = den_lm.estimate_token_lm(seqs, V, N, M, K)
+        cur = sum(_walk(lm, s) for s in seqs)
+        assert math.isfinite(cur) and (prev_ll is None or cur <= prev_ll + 1e-9)
+        prev_ll = cur
+    assert total >= n_long
