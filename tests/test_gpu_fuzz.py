@@ -7,7 +7,7 @@ gpu_ctc_kernels.h:87-458); here every case is checked in the kernel family a see
 oracle/crf_oracle.c in fp64: loss and every utterance's gradient within 1e-4, no NaN / inf anywhere.
 Round 6: both posterior matrices entry-wise; long utterances on the metric graph's size class; den_lm graphs ESTIMATED from text; the group width of the
 utterance-minor kernels; a constructed case for the one blind spot of the forward / backward check; and CAMPAIGNS -- the same cases re-drawn with fresh seeds
-(CRF_FUZZ_CAMPAIGN, tools/gpu_fuzz_campaign.sh): 32 of them in round 6 found two more precision holes (profiles/round6_fuzz_campaigns.txt)."""
+(CRF_FUZZ_CAMPAIGN, tools/gpu_fuzz_campaign.sh): 36 of them in round 6 found two more precision holes (profiles/round6_fuzz_campaigns.txt)."""
 import os
 
 import numpy as np
